@@ -1,0 +1,123 @@
+"""ctypes binding of libcfn_hip.so (the gfx950 kernels; C ABI declared in include/cfn_hip.h).
+
+The product path has no CPU fallback: if the library is missing, or a tensor is not a contiguous
+fp32 CUDA(HIP) tensor, the ops raise.  Prototypes are generated from the header so that the header
+stays the single source of truth for the ABI.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+LIB_PATH = os.path.join(_HERE, 'libcfn_hip.so')
+HEADER = os.path.join(_ROOT, 'include', 'cfn_hip.h')
+
+ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+FAMILIES = {'dwconv_fwd': 0, 'dwconv_bwd': 1, 'pwconv_fwd': 2, 'pwconv_bwd': 3, 'gridpool': 4, 'elementwise': 5,
+            'stem': 6, 'fusion': 7}
+
+_lib = None
+_protos = None
+
+
+def header_prototypes(path=HEADER):
+    """{name: (restype, [argtype, ...])} parsed from the C header."""
+    txt = open(path).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    out = {}
+    for m in re.finditer(r'(const\s+char\s*\*|int)\s+(cfn_\w+)\s*\(([^)]*)\)\s*;', txt):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        at = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                if '*' in a:
+                    at.append(ctypes.c_void_p)
+                elif a.startswith('long'):
+                    at.append(ctypes.c_long)
+                elif a.startswith('int'):
+                    at.append(ctypes.c_int)
+                else:
+                    raise ValueError('unhandled C type in %s: %r' % (name, a))
+        out[name] = (ctypes.c_char_p if 'char' in ret else ctypes.c_int, at)
+    return out
+
+
+def load():
+    """Load the library (once) and attach the prototypes; raises if anything is missing."""
+    global _lib, _protos
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('libcfn_hip.so not found at %s -- run `python __graft_entry__.py` (hipcc, gfx950) first; '
+                           'there is no CPU fallback for the Coarse-Fine HIP ops' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    protos = header_prototypes()
+    for name, (ret, at) in protos.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise RuntimeError('libcfn_hip.so does not export %s declared in include/cfn_hip.h' % name)
+        fn.restype = ret
+        fn.argtypes = at
+    _lib, _protos = lib, protos
+    return lib
+
+
+def last_error():
+    return load().cfn_last_error().decode()
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('cfn_hip ops need device tensors (got %s); there is no CPU path' % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError('cfn_hip ops need contiguous tensors')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke one C entry point: tensors -> device pointers, appends the current HIP stream."""
+    lib = load()
+    conv = [(_ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a) for a in args]
+    rc = getattr(lib, name)(*conv, stream())
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (name, rc, last_error()))
+
+
+def check(t, dtype=torch.float32):
+    if t is not None and t.dtype != dtype:
+        raise RuntimeError('expected %s tensor, got %s' % (dtype, t.dtype))
+    return t
+
+
+def prof_enable(family, on=True):
+    rc = load().cfn_prof_enable(FAMILIES[family], 1 if on else 0)
+    if rc:
+        raise RuntimeError(last_error())
+
+
+def prof_collect(family):
+    ms, n, by = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
+    rc = load().cfn_prof_collect(FAMILIES[family], ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by))
+    if rc:
+        raise RuntimeError(last_error())
+    return ms.value, n.value, by.value
+
+
+def device_info():
+    cus, lds = ctypes.c_int(), ctypes.c_int()
+    name = ctypes.create_string_buffer(64)
+    rc = load().cfn_device_info(ctypes.byref(cus), ctypes.byref(lds), name, 64)
+    if rc:
+        raise RuntimeError(last_error())
+    return {'cus': cus.value, 'lds_per_cu': lds.value, 'arch': name.value.decode()}

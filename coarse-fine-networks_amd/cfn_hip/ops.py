@@ -1,0 +1,441 @@
+"""torch.autograd glue over the C ABI: each Function allocates outputs with torch (device memory,
+caching allocator, current stream) and hands raw pointers to libcfn_hip.so.  No op here has a CPU
+or eager fallback.
+
+Convention shared by the conv ops: the input is read through the per-(n,c) *prologue*
+``a = act(A*x + B)`` (A, B: fp32 (N,C) or None) and the op returns the raw conv output ``y``
+together with fp64 per-(n,c) ``sum(y)`` / ``sum(y*y)``.  Batch-norm statistics, the SE squeeze and
+their gradients are then tiny (N,C) tensor expressions handled by ordinary autograd, while every
+full-size tensor is touched only inside the HIP kernels.
+"""
+import torch
+from torch.autograd import Function
+
+from . import call, check, ACT_NONE, ACT_RELU, ACT_SWISH  # noqa: F401
+
+
+def _f64(n, c, dev):
+    return torch.zeros(n, c, dtype=torch.float64, device=dev)
+
+
+def _opt(t):
+    return None if t is None else t.contiguous()
+
+
+class _PwConv(Function):
+    """1x1x1 conv (optionally spatial stride 2) on fp32 MFMA; see include/cfn_hip.h cfn_pwconv_*."""
+
+    @staticmethod
+    def forward(ctx, x, A, B, w, act, stride, want_stats):
+        x = check(x).contiguous()
+        N, Cin, T, H, W = x.shape
+        Cout = w.shape[0]
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        y = torch.empty(N, Cout, T, Ho, Wo, dtype=torch.float32, device=x.device)
+        s = q = None
+        if want_stats:
+            s, q = _f64(N, Cout, x.device), _f64(N, Cout, x.device)
+        w2 = w.reshape(Cout, Cin).contiguous()
+        A, B = _opt(A), _opt(B)
+        call('cfn_pwconv_fwd', x, A, B, act, w2, y, s, q, N, Cin, Cout, T, H, W, stride)
+        ctx.save_for_backward(x, A, B, w2, y)
+        ctx.meta = (act, stride, tuple(w.shape))
+        if not want_stats:
+            return y, None, None
+        return y, s, q
+
+    @staticmethod
+    def backward(ctx, gy, gs, gq):
+        x, A, B, w2, y = ctx.saved_tensors
+        act, stride, wshape = ctx.meta
+        N, Cin, T, H, W = x.shape
+        Cout = w2.shape[0]
+        gy = torch.zeros_like(y) if gy is None else gy.contiguous()
+        gs, gq = _opt(gs), _opt(gq)
+        gx = gA = gB = gw = None
+        if ctx.needs_input_grad[0] or (A is not None and ctx.needs_input_grad[1]):
+            gx = torch.zeros_like(x) if stride != 1 else torch.empty_like(x)
+            a64 = b64 = None
+            if A is not None:
+                a64, b64 = _f64(N, Cin, x.device), _f64(N, Cin, x.device)
+            call('cfn_pwconv_bwd_data', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, Cin, Cout, T, H, W, stride)
+            if A is not None:
+                gA, gB = a64.float(), b64.float()
+        if ctx.needs_input_grad[3]:
+            g64 = torch.zeros(Cout, Cin, dtype=torch.float64, device=x.device)
+            call('cfn_pwconv_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, Cin, Cout, T, H, W, stride)
+            gw = g64.float().view(wshape)
+        return gx, gA, gB, gw, None, None, None
+
+
+def pwconv(x, w, A=None, B=None, act=ACT_NONE, stride=1, stats=True):
+    """returns (y, sum, sumsq); sum/sumsq are None when stats=False"""
+    return _PwConv.apply(x, A, B, w, act, stride, stats)
+
+
+class _DwConv3d(Function):
+    """depthwise 3x3x3, pad 1, stride (1,s,s); see cfn_dwconv3d_*."""
+
+    @staticmethod
+    def forward(ctx, x, A, B, w, act, stride, want_stats):
+        x = check(x).contiguous()
+        N, C, T, H, W = x.shape
+        Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        y = torch.empty(N, C, T, Ho, Wo, dtype=torch.float32, device=x.device)
+        s = q = None
+        if want_stats:
+            s, q = _f64(N, C, x.device), _f64(N, C, x.device)
+        w2 = w.reshape(C, 27).contiguous()
+        A, B = _opt(A), _opt(B)
+        call('cfn_dwconv3d_fwd', x, A, B, act, w2, y, s, q, N, C, T, H, W, stride)
+        ctx.save_for_backward(x, A, B, w2, y)
+        ctx.meta = (act, stride, tuple(w.shape))
+        if not want_stats:
+            return y, None, None
+        return y, s, q
+
+    @staticmethod
+    def backward(ctx, gy, gs, gq):
+        x, A, B, w2, y = ctx.saved_tensors
+        act, stride, wshape = ctx.meta
+        N, C, T, H, W = x.shape
+        gy = torch.zeros_like(y) if gy is None else gy.contiguous()
+        gs, gq = _opt(gs), _opt(gq)
+        gx = gA = gB = gw = None
+        if ctx.needs_input_grad[0] or (A is not None and ctx.needs_input_grad[1]):
+            gx = torch.empty_like(x)
+            a64 = b64 = None
+            if A is not None:
+                a64, b64 = _f64(N, C, x.device), _f64(N, C, x.device)
+            call('cfn_dwconv3d_bwd_data', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, C, T, H, W, stride)
+            if A is not None:
+                gA, gB = a64.float(), b64.float()
+        if ctx.needs_input_grad[3]:
+            g64 = torch.zeros(C, 27, dtype=torch.float64, device=x.device)
+            call('cfn_dwconv3d_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, C, T, H, W, stride)
+            gw = g64.float().view(wshape)
+        return gx, gA, gB, gw, None, None, None
+
+
+def dwconv3d(x, w, A=None, B=None, act=ACT_NONE, stride=1, stats=True):
+    return _DwConv3d.apply(x, A, B, w, act, stride, stats)
+
+
+class _DwConvT5(Function):
+    """depthwise 5x1x1 temporal conv of the stem; see cfn_dwconv_t5_*."""
+
+    @staticmethod
+    def forward(ctx, x, w, want_stats):
+        x = check(x).contiguous()
+        N, C, T, H, W = x.shape
+        y = torch.empty_like(x)
+        s = q = None
+        if want_stats:
+            s, q = _f64(N, C, x.device), _f64(N, C, x.device)
+        w2 = w.reshape(C, 5).contiguous()
+        call('cfn_dwconv_t5_fwd', x, w2, y, s, q, N, C, T, H * W)
+        ctx.save_for_backward(x, w2, y)
+        ctx.wshape = tuple(w.shape)
+        if not want_stats:
+            return y, None, None
+        return y, s, q
+
+    @staticmethod
+    def backward(ctx, gy, gs, gq):
+        x, w2, y = ctx.saved_tensors
+        N, C, T, H, W = x.shape
+        gy = torch.zeros_like(y) if gy is None else gy.contiguous()
+        gs, gq = _opt(gs), _opt(gq)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            call('cfn_dwconv_t5_bwd_data', gy, y, gs, gq, w2, gx, N, C, T, H * W)
+        if ctx.needs_input_grad[1]:
+            g64 = torch.zeros(C, 5, dtype=torch.float64, device=x.device)
+            call('cfn_dwconv_t5_bwd_weight', gy, y, gs, gq, x, g64, N, C, T, H * W)
+            gw = g64.float().view(ctx.wshape)
+        return gx, gw, None
+
+
+def dwconv_t5(x, w, stats=True):
+    return _DwConvT5.apply(x, w, stats)
+
+
+class _StemConv(Function):
+    """conv1_s: dense 1x3x3 stride (1,2,2) pad (0,1,1); the clip gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x = check(x).contiguous()
+        N, Ci, T, H, W = x.shape
+        Co = w.shape[0]
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        y = torch.empty(N, Co, T, Ho, Wo, dtype=torch.float32, device=x.device)
+        w2 = w.reshape(Co, Ci * 9).contiguous()
+        call('cfn_stem_conv_fwd', x, w2, y, N, Ci, Co, T, H, W)
+        ctx.save_for_backward(x)
+        ctx.wshape = tuple(w.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        N, Ci, T, H, W = x.shape
+        Co = ctx.wshape[0]
+        gw = None
+        if ctx.needs_input_grad[1]:
+            g64 = torch.zeros(Co, Ci * 9, dtype=torch.float64, device=x.device)
+            call('cfn_stem_conv_bwd_weight', gy.contiguous(), x, g64, N, Ci, Co, T, H, W)
+            gw = g64.float().view(ctx.wshape)
+        return None, gw
+
+
+def stem_conv(x, w):
+    return _StemConv.apply(x, w)
+
+
+class _BnAddRelu(Function):
+    """out = relu(A*y + B + (Ar*res + Br)); Ar/Br None = plain residual."""
+
+    @staticmethod
+    def forward(ctx, y, A, B, res, Ar, Br):
+        y, res = check(y).contiguous(), check(res).contiguous()
+        N, C = y.shape[:2]
+        vol = y[0, 0].numel()
+        out = torch.empty_like(y)
+        A, B, Ar, Br = A.contiguous(), B.contiguous(), _opt(Ar), _opt(Br)
+        call('cfn_bn_add_relu_fwd', y, A, B, res, Ar, Br, out, N * C, vol)
+        ctx.save_for_backward(y, A, res, Ar, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        y, A, res, Ar, out = ctx.saved_tensors
+        N, C = y.shape[:2]
+        vol = y[0, 0].numel()
+        gy, gres = torch.empty_like(y), torch.empty_like(res)
+        a64, b64 = _f64(N, C, y.device), _f64(N, C, y.device)
+        r64 = _f64(N, C, y.device) if Ar is not None else None
+        call('cfn_bn_add_relu_bwd', gout.contiguous(), out, y, A, res, Ar, gy, gres, a64, b64, r64, N * C, vol)
+        gA, gB = a64.float(), b64.float()
+        gAr = r64.float() if Ar is not None else None
+        gBr = gB if Ar is not None else None
+        return gy, gA, gB, gres, gAr, gBr
+
+
+def bn_add_relu(y, A, B, res, Ar=None, Br=None):
+    return _BnAddRelu.apply(y, A, B, res, Ar, Br)
+
+
+class _AffineAct(Function):
+    @staticmethod
+    def forward(ctx, x, A, B, act):
+        x = check(x).contiguous()
+        N, C = x.shape[:2]
+        out = torch.empty_like(x)
+        A, B = A.contiguous(), B.contiguous()
+        call('cfn_affine_act_fwd', x, A, B, act, out, N * C, x[0, 0].numel())
+        ctx.save_for_backward(x, A, B)
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, A, B = ctx.saved_tensors
+        N, C = x.shape[:2]
+        gx = torch.empty_like(x)
+        a64, b64 = _f64(N, C, x.device), _f64(N, C, x.device)
+        call('cfn_affine_act_bwd', gout.contiguous(), x, A, B, ctx.act, gx, a64, b64, N * C, x[0, 0].numel())
+        return gx, a64.float(), b64.float(), None
+
+
+def affine_act(x, A, B, act=ACT_NONE):
+    return _AffineAct.apply(x, A, B, act)
+
+
+class _ChannelStats(Function):
+    """per-(n,c) sum / sumsq (fp64) of a tensor; backward = broadcast (gs + 2 x gq)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = check(x).contiguous()
+        N, C = x.shape[:2]
+        s, q = _f64(N, C, x.device), _f64(N, C, x.device)
+        call('cfn_channel_stats', x, s, q, N * C, x[0, 0].numel())
+        ctx.save_for_backward(x)
+        return s, q
+
+    @staticmethod
+    def backward(ctx, gs, gq):
+        (x,) = ctx.saved_tensors
+        N, C = x.shape[:2]
+        gx = torch.zeros_like(x)
+        shp = (N, C) + (1,) * (x.dim() - 2)
+        if gs is not None:
+            gx = gx + gs.float().view(shp)
+        if gq is not None:
+            gx = gx + 2.0 * gq.float().view(shp) * x
+        return gx
+
+
+def channel_stats(x):
+    return _ChannelStats.apply(x)
+
+
+class _PoolHW(Function):
+    """adaptive (OH,OW) spatial mean of act(A*x+B); see cfn_pool_hw_*."""
+
+    @staticmethod
+    def forward(ctx, x, A, B, act, OH, OW):
+        x = check(x).contiguous()
+        N, C, T, H, W = x.shape
+        out = torch.empty(N, C, T, OH, OW, dtype=torch.float32, device=x.device)
+        A, B = _opt(A), _opt(B)
+        call('cfn_pool_hw_fwd', x, A, B, act, out, N * C, T, H, W, OH, OW)
+        ctx.save_for_backward(x, A, B)
+        ctx.meta = (act, OH, OW)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, A, B = ctx.saved_tensors
+        act, OH, OW = ctx.meta
+        N, C, T, H, W = x.shape
+        gx = torch.empty_like(x)
+        a64 = b64 = None
+        if A is not None:
+            a64, b64 = _f64(N, C, x.device), _f64(N, C, x.device)
+        call('cfn_pool_hw_bwd', gout.contiguous(), x, A, B, act, gx, a64, b64, N * C, T, H, W, OH, OW)
+        if A is None:
+            return gx, None, None, None, None, None
+        return gx, a64.float(), b64.float(), None, None, None
+
+
+def pool_hw(x, OH, OW, A=None, B=None, act=ACT_NONE):
+    return _PoolHW.apply(x, A, B, act, OH, OW)
+
+
+class _Film(Function):
+    """out = x * m + c with m, c constant over f x f spatial blocks ((N,C,T,H/f,W/f))."""
+
+    @staticmethod
+    def forward(ctx, x, m, c, f):
+        x, m, c = check(x).contiguous(), check(m).contiguous(), check(c).contiguous()
+        N, C, T, H, W = x.shape
+        out = torch.empty_like(x)
+        call('cfn_film_fwd', x, m, c, out, N * C, T, H, W, f)
+        ctx.save_for_backward(x, m)
+        ctx.f = f
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, m = ctx.saved_tensors
+        N, C, T, H, W = x.shape
+        gx, gm, gc = torch.empty_like(x), torch.empty_like(m), torch.empty_like(m)
+        call('cfn_film_bwd', g.contiguous(), x, m, gx, gm, gc, N * C, T, H, W, ctx.f)
+        return gx, gm, gc, None
+
+
+def film(x, m, c, f):
+    return _Film.apply(x, m, c, f)
+
+
+class _TimeSample(Function):
+    """Grid Pool / Unpool resampler: x (B,C,Tin,*) , cdf (B,K) -> (B,C,K,*) ; see cfn_time_sample_*."""
+
+    @staticmethod
+    def forward(ctx, x, cdf):
+        x, cdf = check(x).contiguous(), check(cdf).contiguous()
+        B, C, Tin = x.shape[:3]
+        K = cdf.shape[1]
+        P = x[0, 0, 0].numel()
+        out = torch.empty((B, C, K) + tuple(x.shape[3:]), dtype=torch.float32, device=x.device)
+        call('cfn_time_sample_fwd', x, cdf, out, B, C, Tin, K, P)
+        ctx.save_for_backward(x, cdf)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, cdf = ctx.saved_tensors
+        B, C, Tin = x.shape[:3]
+        K = cdf.shape[1]
+        P = x[0, 0, 0].numel()
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        g64 = torch.zeros(B, K, dtype=torch.float64, device=x.device) if ctx.needs_input_grad[1] else None
+        call('cfn_time_sample_bwd', g.contiguous(), x, cdf, gx, g64, B, C, Tin, K, P)
+        return gx, (g64.float() if g64 is not None else None)
+
+
+def time_sample(x, cdf):
+    return _TimeSample.apply(x, cdf)
+
+
+def grid_time_index(cdf, Tin):
+    """(i0 int32, w1 fp32) the resampler derives from a CDF (bit-exact ATen index arithmetic)."""
+    cdf = check(cdf).contiguous()
+    i0 = torch.empty(cdf.shape, dtype=torch.int32, device=cdf.device)
+    w1 = torch.empty(cdf.shape, dtype=torch.float32, device=cdf.device)
+    call('cfn_grid_time_index', cdf, cdf.numel(), Tin, i0, w1)
+    return i0, w1
+
+
+class _Interp1d(Function):
+    @staticmethod
+    def forward(ctx, x, y, xnew):
+        x, y, xnew = check(x).contiguous(), check(y).contiguous(), check(xnew).contiguous()
+        B = max(x.shape[0], y.shape[0], xnew.shape[0])
+        N, Pq = x.shape[1], xnew.shape[1]
+        rows = (int(x.shape[0] > 1), int(y.shape[0] > 1), int(xnew.shape[0] > 1))
+        ynew = torch.empty(B, Pq, dtype=torch.float32, device=x.device)
+        ind = torch.empty(B, Pq, dtype=torch.int64, device=x.device)
+        call('cfn_interp1d_fwd', x, y, xnew, ynew, ind, B, N, Pq, *rows)
+        ctx.save_for_backward(x, y, xnew, ind)
+        ctx.rows = rows
+        ctx.mark_non_differentiable(ind)
+        return ynew, ind
+
+    @staticmethod
+    def backward(ctx, g, _gind):
+        x, y, xnew, ind = ctx.saved_tensors
+        B, Pq = ind.shape
+        N = x.shape[1]
+        gx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.zeros_like(y) if ctx.needs_input_grad[1] else None
+        gq = torch.zeros_like(xnew) if ctx.needs_input_grad[2] else None
+        call('cfn_interp1d_bwd', g.contiguous(), x, y, xnew, ind, gx, gy, gq, B, N, Pq, *ctx.rows)
+        return gx, gy, gq
+
+
+def interp1d(x, y, xnew):
+    """2-D inputs (rows broadcast when a tensor has a single row) -> (ynew, ind)."""
+    return _Interp1d.apply(x, y, xnew)
+
+
+class _TimeResize(Function):
+    """linear resize along dim 2, align_corners=True."""
+
+    @staticmethod
+    def forward(ctx, x, L):
+        x = check(x).contiguous()
+        BC = x.shape[0] * x.shape[1]
+        Kin = x.shape[2]
+        P = x[0, 0, 0].numel()
+        out = torch.empty(tuple(x.shape[:2]) + (L,) + tuple(x.shape[3:]), dtype=torch.float32, device=x.device)
+        call('cfn_time_resize_fwd', x, out, BC, Kin, L, P)
+        ctx.meta = (tuple(x.shape), L)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, L = ctx.meta
+        gx = torch.empty(shape, dtype=torch.float32, device=g.device)
+        P = 1
+        for d in shape[3:]:
+            P *= d
+        call('cfn_time_resize_bwd', g.contiguous(), gx, shape[0] * shape[1], shape[2], L, P)
+        return gx, None
+
+
+def time_resize(x, L):
+    return _TimeResize.apply(x, L)

@@ -1,0 +1,80 @@
+// Shared device/host helpers for the Coarse-Fine HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#define CFN_OK 0
+#define CFN_ERR_ARG 1
+#define CFN_ERR_LAUNCH 2
+#define CFN_ERR_UNSUPPORTED 3
+
+// activation codes of the load-time prologue  a = act(A[n,c] * x + B[n,c])
+enum { CFN_ACT_NONE = 0, CFN_ACT_RELU = 1, CFN_ACT_SWISH = 2 };
+
+extern "C" const char* cfn_last_error(void);
+int cfn_fail(int code, const char* fmt, ...);  // records the message, returns code
+int cfn_check_launch(const char* what);        // hipGetLastError -> CFN_ERR_LAUNCH
+
+#define CFN_REQUIRE(cond, ...) \
+    do { if (!(cond)) return cfn_fail(CFN_ERR_ARG, __VA_ARGS__); } while (0)
+
+// optional per-kernel-family HIP-event timing (bench.py roofline leg); see capi.hip
+enum { CFN_K_DWCONV_FWD = 0, CFN_K_DWCONV_BWD = 1, CFN_K_PWCONV_FWD = 2, CFN_K_PWCONV_BWD = 3,
+       CFN_K_GRIDPOOL = 4, CFN_K_ELEMWISE = 5, CFN_K_STEM = 6, CFN_K_FUSION = 7, CFN_K_COUNT = 8 };
+struct CfnProfScope {
+    int fam; hipStream_t s; hipEvent_t e0; bool on;
+    CfnProfScope(int family, hipStream_t stream, double bytes);
+    ~CfnProfScope();
+};
+
+static inline int cfn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cfn_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+template <int ACT>
+__device__ __forceinline__ float cfn_act(float z) {
+    if (ACT == CFN_ACT_RELU) return fmaxf(z, 0.0f);
+    if (ACT == CFN_ACT_SWISH) return z * cfn_sigmoid(z);
+    return z;
+}
+// d act(z) / dz ; Swish derivative as in SwishEfficient.backward (x3d_fine.py:82-86)
+template <int ACT>
+__device__ __forceinline__ float cfn_act_grad(float z) {
+    if (ACT == CFN_ACT_RELU) return z > 0.0f ? 1.0f : 0.0f;
+    if (ACT == CFN_ACT_SWISH) { float s = cfn_sigmoid(z); return s * (1.0f + z * (1.0f - s)); }
+    return 1.0f;
+}
+__device__ __forceinline__ float cfn_act_rt(float z, int act) {
+    return act == CFN_ACT_RELU ? fmaxf(z, 0.0f) : (act == CFN_ACT_SWISH ? z * cfn_sigmoid(z) : z);
+}
+__device__ __forceinline__ float cfn_act_grad_rt(float z, int act) {
+    if (act == CFN_ACT_RELU) return z > 0.0f ? 1.0f : 0.0f;
+    if (act == CFN_ACT_SWISH) { float s = cfn_sigmoid(z); return s * (1.0f + z * (1.0f - s)); }
+    return 1.0f;
+}
+
+// wave64 all-lane sum (DPP/bpermute through __shfl_xor)
+__device__ __forceinline__ float cfn_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double cfn_wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Bijective XCD-aware remap: hardware places block b on XCD (b % 8); give each XCD one contiguous
+// run of logical ids so neighbouring logical blocks (which share halo frames / operand panels)
+// hit the same private L2.  Placement only affects speed, never results.
+__device__ __forceinline__ unsigned cfn_xcd_remap(unsigned b, unsigned total) {
+    const unsigned q = total >> 3, r = total & 7u;
+    const unsigned xcd = b & 7u, i = b >> 3;
+    return xcd * q + (xcd < r ? xcd : r) + i;
+}

@@ -1,0 +1,538 @@
+// Depthwise 3x3x3 convolution (X3D bottleneck conv2; x3d_fine.py:89-97, used at :117) for gfx950.
+//
+// One streaming skeleton, three modes:
+//   DW_FWD    y = dwconv( act(A*x+B) ) , epilogue per-(n,c) sum / sum-of-squares of y
+//   DW_DGRAD  (stride 1) da = dwconv_flipped( gy + gs + 2*y*gq ), gx = da*act'(A*x+B)*A,
+//             epilogue per-(n,c) sum(dz*x), sum(dz)
+//   DW_WGRAD  gw[c][27] += sum over outputs of (gy + gs + 2*y*gq) * act(A*x+B)[tap]
+//
+// Data layout: NCDHW fp32, each (n,c) volume is T contiguous H*W planes.
+// A workgroup owns CG channels x one band of output rows x one chunk of TT output frames and
+// marches along t: every input frame is read from HBM once (coalesced float4 over the
+// contiguous plane), transformed by the load-time prologue, staged in LDS with a zero halo, and
+// consumed by every thread for HS vertically adjacent outputs at one column (lanes run along w
+// => conflict-free LDS reads, coalesced stores).  Three rolling accumulator sets carry the
+// temporal taps, so each output frame is written once.  The next frame's global loads are in
+// flight while the current one is computed (register prefetch, single LDS buffer).
+// blockIdx is remapped so that the t-chunks / bands of one (n, channel group) run on one XCD and
+// find their halo frames in that XCD's L2.
+#include "cfn_common.h"
+
+enum { DW_FWD = 0, DW_DGRAD = 1, DW_WGRAD = 2 };
+
+struct DwArgs {
+    const float* src;    // FWD/WGRAD: x raw (N,C,T,Hi,Wi)      DGRAD: gy (N,C,T,H,W)
+    const float* src2;   // DGRAD: y (raw conv output) for the 2*y*gq term, may be null
+    const float* A;      // per-(n,c) prologue scale of the forward input (null = identity)
+    const float* B;
+    const double* gs;    // DGRAD/WGRAD: d loss / d sum(y)   per (n,c), may be null
+    const double* gq;    // DGRAD/WGRAD: d loss / d sum(y^2) per (n,c), may be null
+    const float* w;      // (C,27)
+    float* dst;          // FWD: y     DGRAD: gx
+    const float* xin;    // DGRAD: forward input x raw (for act' and the A/B gradients)
+    const float* gy;     // WGRAD: upstream gradient at output resolution
+    const float* yout;   // WGRAD: raw conv output (for the 2*y*gq term), may be null
+    double* s1;          // FWD: sum(y)      DGRAD: sum(dz*x)     WGRAD: gw (C,27) accumulators
+    double* s2;          // FWD: sum(y*y)    DGRAD: sum(dz)
+    int N, C, T, Hi, Wi, Ho, Wo, act;
+    int TT, nchunks, CG, ngroups, GB, nbands, IPCb, RIN, WP, XO;
+};
+
+// contiguous-segment sum inside a wave: lanes with equal key form runs; the first lane of each
+// run ends up with the run total.
+__device__ __forceinline__ float seg_wave_sum(float v, int key, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float ov = __shfl_down(v, o, 64);
+        const int ok = __shfl_down(key, o, 64);
+        if (lane + o < 64 && ok == key) v += ov;
+    }
+    return v;
+}
+
+template <int MODE, int S, int HS, int VEC, int MAXLD>
+__global__ __launch_bounds__(512) void dw3d_kernel(const DwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HSIN = (HS - 1) * S + 3;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+
+    unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    const int chunk = L % a.nchunks; L /= a.nchunks;
+    const int band = L % a.nbands;   L /= a.nbands;
+    const int grp = L % a.ngroups;
+    const int n = L / a.ngroups;
+    const int c0 = grp * a.CG;
+    const int ncg = min(a.CG, a.C - c0);
+    const int t0 = chunk * a.TT, t1 = min(t0 + a.TT, a.T);
+    const int RIN = a.RIN, WP = a.WP, XO = a.XO;
+    const int Hi = a.Hi, Wi = a.Wi, Ho = a.Ho, Wo = a.Wo, T = a.T, C = a.C;
+    const int hin0 = band * a.GB * HS * S - 1;                 // input row held by LDS row 0
+    const int row_lo = max(hin0, 0), row_hi = min(hin0 + RIN, Hi);
+    const int per_ch = (row_hi - row_lo) * Wi;                 // floats per channel per frame
+    const int total_ld = ncg * per_ch;
+    const long plane_i = (long)Hi * Wi, plane_o = (long)Ho * Wo;
+
+    float* buf = smem;
+    float* sA = buf + a.CG * RIN * WP;
+    float* sB = sA + a.CG;
+    float* sR = sB + a.CG;                                     // reduction scratch: 27*CG floats
+
+    for (int i = tid; i < a.CG * RIN * WP; i += nthr) buf[i] = 0.0f;
+    for (int i = tid; i < a.CG * 27; i += nthr) sR[i] = 0.0f;
+    if (tid < a.CG) {
+        if (MODE == DW_DGRAD) {   // staged tensor is gy + gs + y * 2gq
+            const bool ok = tid < ncg;
+            sA[tid] = (ok && a.gs) ? (float)a.gs[(long)n * C + c0 + tid] : 0.0f;
+            sB[tid] = (ok && a.gq && a.src2) ? 2.0f * (float)a.gq[(long)n * C + c0 + tid] : 0.0f;
+        } else {                  // staged tensor is act(A * x + B)
+            const bool ok = tid < ncg && a.A != nullptr;
+            sA[tid] = ok ? a.A[(long)n * C + c0 + tid] : 1.0f;
+            sB[tid] = ok ? a.B[(long)n * C + c0 + tid] : 0.0f;
+        }
+    }
+
+    // ---- loader bookkeeping (frame invariant) -------------------------------------------------
+    int rel[MAXLD];      // element offset from the (n, c0, frame) base, -1 = nothing to load
+    int lofs[MAXLD];     // (channel_local << 16) | LDS float offset
+#pragma unroll
+    for (int k = 0; k < MAXLD; ++k) {
+        const int e = (k * nthr + tid) * VEC;
+        if (e < total_ld) {
+            const int cl = e / per_ch, off = e - cl * per_ch;
+            const int r = off / Wi, col = off - r * Wi;
+            rel[k] = (int)((long)cl * T * plane_i) + row_lo * Wi + off;
+            lofs[k] = (cl << 16) | ((cl * RIN + (row_lo - hin0) + r) * WP + XO + col);
+        } else {
+            rel[k] = -1;
+            lofs[k] = 0;
+        }
+    }
+
+    // ---- compute-thread identity ----------------------------------------------------------------
+    const int IPCb = a.IPCb;
+    const bool active = tid < ncg * IPCb;
+    const int c_local = active ? tid / IPCb : 0;
+    const int item = tid - c_local * IPCb;
+    const int gl = active ? item / Wo : 0;
+    const int wo = active ? item - gl * Wo : 0;
+    const int c = c0 + c_local;
+    const int hrow0 = (band * a.GB + gl) * HS;                 // first output row of this thread
+    const float* tb = buf + (c_local * RIN + gl * HS * S) * WP + (XO - 1) + wo * S;
+    const long nc = (long)n * C + c;
+
+    float wr[27];
+    if (MODE != DW_WGRAD) {
+#pragma unroll
+        for (int j = 0; j < 27; ++j) wr[j] = active ? a.w[(long)c * 27 + (MODE == DW_DGRAD ? 26 - j : j)] : 0.0f;
+    }
+    // stats-gradient terms of the incoming gradient (DGRAD: on the LDS-staged tensor; WGRAD: on gy)
+    float gs_c = 0.0f, gq2_c = 0.0f;
+    if (MODE == DW_WGRAD && active) {
+        if (a.gs) gs_c = (float)a.gs[nc];
+        if (a.gq) gq2_c = 2.0f * (float)a.gq[nc];
+    }
+    // DGRAD epilogue coefficients (prologue of the forward input)
+    float eA = 1.0f, eB = 0.0f;
+    if (MODE == DW_DGRAD && active && a.A) { eA = a.A[nc]; eB = a.B[nc]; }
+
+    float acc[3][HS];      // FWD/DGRAD rolling accumulators: [0]=frame+1, [1]=frame, [2]=frame-1
+    float dwa[27];         // WGRAD partial weight gradients
+    float gro[3][HS];      // WGRAD rolling gradients: [0]=g(frame+1) [1]=g(frame) [2]=g(frame-1)
+    float gnn[HS];         // WGRAD prefetch g(frame+2)
+#pragma unroll
+    for (int i = 0; i < HS; ++i) { acc[0][i] = acc[1][i] = acc[2][i] = 0.0f; gro[0][i] = gro[1][i] = gro[2][i] = 0.0f; gnn[i] = 0.0f; }
+#pragma unroll
+    for (int j = 0; j < 27; ++j) dwa[j] = 0.0f;
+    float st1 = 0.0f, st2 = 0.0f;
+
+    typedef float __attribute__((ext_vector_type(4))) f4;
+    f4 pf[MAXLD], pf2[MAXLD];
+    const bool two_src = (MODE == DW_DGRAD) && a.src2 != nullptr;
+
+    auto frame_valid = [&](int f) { return f >= 0 && f < T; };
+    auto prefetch = [&](int f) {
+        const long base = (((long)n * C + c0) * T + f) * plane_i;
+#pragma unroll
+        for (int k = 0; k < MAXLD; ++k) {
+            if (rel[k] >= 0) {
+                if (VEC == 4) {
+                    pf[k] = *reinterpret_cast<const f4*>(a.src + base + rel[k]);
+                    if (MODE == DW_DGRAD && two_src) pf2[k] = *reinterpret_cast<const f4*>(a.src2 + base + rel[k]);
+                } else {
+                    pf[k].x = a.src[base + rel[k]];
+                    if (MODE == DW_DGRAD && two_src) pf2[k].x = a.src2[base + rel[k]];
+                }
+            }
+        }
+    };
+    auto stage = [&]() {   // registers -> LDS with the load-time prologue
+#pragma unroll
+        for (int k = 0; k < MAXLD; ++k) {
+            if (rel[k] >= 0) {
+                const int cl = lofs[k] >> 16, lo = lofs[k] & 0xffff;
+                f4 v = pf[k];
+                const float pa = sA[cl], pb = sB[cl];
+                if (MODE == DW_DGRAD) {
+                    if (two_src) {
+                        v.x = fmaf(pf2[k].x, pb, v.x + pa);
+                        if (VEC == 4) {
+                            v.y = fmaf(pf2[k].y, pb, v.y + pa);
+                            v.z = fmaf(pf2[k].z, pb, v.z + pa);
+                            v.w = fmaf(pf2[k].w, pb, v.w + pa);
+                        }
+                    } else {
+                        v.x += pa;
+                        if (VEC == 4) { v.y += pa; v.z += pa; v.w += pa; }
+                    }
+                } else {
+                    v.x = cfn_act_rt(fmaf(v.x, pa, pb), a.act);
+                    if (VEC == 4) {
+                        v.y = cfn_act_rt(fmaf(v.y, pa, pb), a.act);
+                        v.z = cfn_act_rt(fmaf(v.z, pa, pb), a.act);
+                        v.w = cfn_act_rt(fmaf(v.w, pa, pb), a.act);
+                    }
+                }
+                if (VEC == 4) *reinterpret_cast<f4*>(buf + lo) = v;
+                else buf[lo] = v.x;
+            }
+        }
+    };
+    // WGRAD: effective upstream gradient of output frame t for this thread's HS outputs
+    auto load_g = [&](int t, float (&g)[HS]) {
+        if (t >= t0 && t < t1 && active) {
+            const long o = (nc * T + t) * plane_o + (long)hrow0 * Wo + wo;
+#pragma unroll
+            for (int i = 0; i < HS; ++i) {
+                float v = a.gy[o + (long)i * Wo] + gs_c;
+                if (a.yout) v = fmaf(a.yout[o + (long)i * Wo], gq2_c, v);
+                g[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < HS; ++i) g[i] = 0.0f;
+        }
+    };
+
+    __syncthreads();   // zero fill + sA/sB visible
+
+    const int f_first = t0 - 1, f_last = t1;   // input frames t0-1 .. t1 (inclusive)
+    if (frame_valid(f_first)) prefetch(f_first);
+    if (MODE == DW_WGRAD) { load_g(t0, gro[0]); load_g(t0 + 1, gnn); }
+
+    for (int f = f_first; f <= f_last; ++f) {
+        const bool fv = frame_valid(f);
+        if (f != f_first) __syncthreads();         // everyone finished reading the previous frame
+        if (fv) stage();
+        __syncthreads();
+        if (f + 1 <= f_last && frame_valid(f + 1)) prefetch(f + 1);
+
+        // DGRAD epilogue operand for the frame that completes in this step
+        const int to = f - 1;
+        const bool emit = (to >= t0 && to < t1) && active;
+        float xe[HS];
+        if (MODE == DW_DGRAD && emit && a.A) {
+            const long o = (nc * T + to) * plane_o + (long)hrow0 * Wo + wo;
+#pragma unroll
+            for (int i = 0; i < HS; ++i) xe[i] = a.xin[o + (long)i * Wo];
+        }
+
+        if (fv && active) {
+#pragma unroll
+            for (int r = 0; r < HSIN; ++r) {
+                const float v0 = tb[r * WP], v1 = tb[r * WP + 1], v2 = tb[r * WP + 2];
+#pragma unroll
+                for (int i = 0; i < HS; ++i) {
+                    const int kh = r - i * S;
+                    if (kh >= 0 && kh < 3) {
+                        if (MODE == DW_WGRAD) {
+#pragma unroll
+                            for (int kt = 0; kt < 3; ++kt) {
+                                dwa[kt * 9 + kh * 3 + 0] = fmaf(gro[kt][i], v0, dwa[kt * 9 + kh * 3 + 0]);
+                                dwa[kt * 9 + kh * 3 + 1] = fmaf(gro[kt][i], v1, dwa[kt * 9 + kh * 3 + 1]);
+                                dwa[kt * 9 + kh * 3 + 2] = fmaf(gro[kt][i], v2, dwa[kt * 9 + kh * 3 + 2]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int kt = 0; kt < 3; ++kt)
+                                acc[kt][i] = fmaf(wr[kt * 9 + kh * 3 + 0], v0,
+                                             fmaf(wr[kt * 9 + kh * 3 + 1], v1,
+                                             fmaf(wr[kt * 9 + kh * 3 + 2], v2, acc[kt][i])));
+                        }
+                    }
+                }
+            }
+        }
+
+        if (MODE == DW_WGRAD) {
+#pragma unroll
+            for (int i = 0; i < HS; ++i) { gro[2][i] = gro[1][i]; gro[1][i] = gro[0][i]; gro[0][i] = gnn[i]; }
+            load_g(f + 3, gnn);
+        } else {
+            if (emit) {
+                const long o = (nc * T + to) * plane_o + (long)hrow0 * Wo + wo;
+#pragma unroll
+                for (int i = 0; i < HS; ++i) {
+                    float v = acc[2][i];
+                    if (MODE == DW_FWD) {
+                        st1 += v;
+                        st2 = fmaf(v, v, st2);
+                    } else if (a.A) {
+                        const float z = fmaf(xe[i], eA, eB);
+                        const float dz = v * cfn_act_grad_rt(z, a.act);
+                        st1 = fmaf(dz, xe[i], st1);
+                        st2 += dz;
+                        v = dz * eA;
+                    }
+                    a.dst[o + (long)i * Wo] = v;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < HS; ++i) { acc[2][i] = acc[1][i]; acc[1][i] = acc[0][i]; acc[0][i] = 0.0f; }
+        }
+    }
+
+    // ---- block reductions -> one fp64 atomic per (channel, value) per block -----------------
+    const int key = active ? c_local : -1 - (tid >> 6);
+    const bool head = active && (lane == 0 || __shfl_up(key, 1, 64) != key);
+    if (MODE == DW_WGRAD) {
+#pragma unroll
+        for (int j = 0; j < 27; ++j) {
+            const float r = seg_wave_sum(dwa[j], key, lane);
+            if (head) atomicAdd(&sR[c_local * 27 + j], r);
+        }
+        __syncthreads();
+        for (int i = tid; i < ncg * 27; i += nthr) atomicAdd(&a.s1[(long)c0 * 27 + i], (double)sR[i]);
+    } else if (a.s1 != nullptr) {
+        const float r1 = seg_wave_sum(st1, key, lane);
+        const float r2 = seg_wave_sum(st2, key, lane);
+        if (head) { atomicAdd(&sR[c_local * 2], r1); atomicAdd(&sR[c_local * 2 + 1], r2); }
+        __syncthreads();
+        if (tid < ncg) {
+            atomicAdd(&a.s1[(long)n * C + c0 + tid], (double)sR[tid * 2]);
+            atomicAdd(&a.s2[(long)n * C + c0 + tid], (double)sR[tid * 2 + 1]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stride-2 data gradient (4 of the 26 layers): gather form, one thread per input element.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                            const double* __restrict__ gs, const double* __restrict__ gq,
+                                                            const float* __restrict__ w, const float* __restrict__ x,
+                                                            const float* __restrict__ A, const float* __restrict__ B, int act,
+                                                            float* __restrict__ gx, double* __restrict__ gA, double* __restrict__ gB,
+                                                            int C, int T, int Hi, int Wi, int Ho, int Wo) {
+    // grid: (ceil(Hi*Wi/256), T, N*C)
+    const int nc = blockIdx.z, t = blockIdx.y, c = nc % C;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = p < Hi * Wi;
+    const int h = ok ? p / Wi : 0, wq = ok ? p - h * Wi : 0;
+    const float gsv = gs ? (float)gs[nc] : 0.0f;
+    const float gqv = (gq && y) ? 2.0f * (float)gq[nc] : 0.0f;
+    float da = 0.0f;
+    if (ok) {
+        for (int kt = 0; kt < 3; ++kt) {
+            const int to = t + 1 - kt;
+            if (to < 0 || to >= T) continue;
+            for (int kh = 0; kh < 3; ++kh) {
+                const int hh = h + 1 - kh;
+                if (hh < 0 || (hh & 1)) continue;
+                const int oh = hh >> 1;
+                if (oh >= Ho) continue;
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ww = wq + 1 - kw;
+                    if (ww < 0 || (ww & 1)) continue;
+                    const int ow = ww >> 1;
+                    if (ow >= Wo) continue;
+                    const long o = (((long)nc * T + to) * Ho + oh) * Wo + ow;
+                    float g = gy[o] + gsv;
+                    if (y) g = fmaf(y[o], gqv, g);
+                    da = fmaf(w[c * 27 + kt * 9 + kh * 3 + kw], g, da);
+                }
+            }
+        }
+    }
+    float s1 = 0.0f, s2 = 0.0f;
+    if (ok) {
+        const long o = ((long)nc * T + t) * Hi * Wi + p;
+        if (A) {
+            const float xa = A[nc], xb = B[nc], xv = x[o];
+            const float dz = da * cfn_act_grad_rt(fmaf(xv, xa, xb), act);
+            s1 = dz * xv; s2 = dz;
+            gx[o] = dz * xa;
+        } else {
+            gx[o] = da;
+        }
+    }
+    if (A && gA) {
+        s1 = cfn_wave_sum(s1); s2 = cfn_wave_sum(s2);
+        __shared__ float r1[4], r2[4];
+        if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&gA[nc], (double)(r1[0] + r1[1] + r1[2] + r1[3]));
+            atomicAdd(&gB[nc], (double)(r2[0] + r2[1] + r2[2] + r2[3]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: geometry heuristics + dispatch
+// ---------------------------------------------------------------------------------------------
+struct DwPlan { int HS, VEC, MAXLD, threads; size_t lds; unsigned blocks; };
+
+static int pick_hs(int Ho) {
+    if (Ho % 7 == 0) return 7;
+    if (Ho % 4 == 0) return 4;
+    return 1;
+}
+
+static int dw_plan(DwArgs& a, int S, int mode, DwPlan& pl) {
+    a.Ho = (a.Hi + 2 - 3) / S + 1;
+    a.Wo = (a.Wi + 2 - 3) / S + 1;
+    const int HS = pick_hs(a.Ho);
+    const int G = a.Ho / HS;
+    if (a.Wo > 512) return cfn_fail(CFN_ERR_UNSUPPORTED, "dwconv3d: output width %d > 512 not supported", a.Wo);
+    const int VEC = (a.Wi % 4 == 0) ? 4 : 1;
+    a.XO = VEC == 4 ? 4 : 1;
+    a.WP = VEC == 4 ? a.Wi + 8 : a.Wi + 2;
+    // rows per band: largest divisor GB of G with GB*Wo <= 512 threads, LDS <= 64 KiB, loader capacity
+    int GB = G;
+    for (;; ) {
+        while (G % GB) --GB;
+        const int rin = (GB * HS - 1) * S + 3;
+        const long ipcb = (long)GB * a.Wo;
+        const long thr = (ipcb + 63) / 64 * 64;
+        const bool fits = ipcb <= 512 && (long)rin * a.WP * 4 <= 60 * 1024 && (long)rin * a.Wi <= (long)VEC * 8 * thr;
+        if (fits || GB == 1) break;
+        --GB;
+    }
+    a.GB = GB;
+    a.nbands = G / GB;
+    a.RIN = (GB * HS - 1) * S + 3;
+    a.IPCb = GB * a.Wo;
+    if (a.IPCb > 512 || (long)a.RIN * a.WP * 4 > 150 * 1024)
+        return cfn_fail(CFN_ERR_UNSUPPORTED, "dwconv3d: plane %dx%d does not fit the LDS band scheme", a.Hi, a.Wi);
+    int CG = 512 / a.IPCb;
+    if (CG > a.C) CG = a.C;
+    if (CG > 128) CG = 128;
+    while (CG > 1 && ((long)CG * a.RIN * a.WP * 4 > 48 * 1024)) --CG;
+    int threads;
+    for (;; --CG) {   // loader capacity: VEC*8 elements per thread per frame
+        threads = (CG * a.IPCb + 63) / 64 * 64;
+        if ((long)CG * a.RIN * a.Wi <= (long)VEC * 8 * threads || CG == 1) break;
+    }
+    if ((long)CG * a.RIN * a.Wi > (long)VEC * 8 * threads)
+        return cfn_fail(CFN_ERR_UNSUPPORTED, "dwconv3d: loader capacity exceeded for plane %dx%d", a.Hi, a.Wi);
+    a.CG = CG;
+    a.ngroups = cfn_cdiv(a.C, CG);
+    const long per_thread = ((long)CG * a.RIN * a.Wi + (long)VEC * threads - 1) / ((long)VEC * threads);
+    const int MAXLD = (VEC == 4 && per_thread <= 2) ? 2 : 8;
+    // frames per chunk: as long as possible while keeping >= ~6 workgroups per CU in the grid
+    const long planes = (long)a.N * a.ngroups * a.nbands;
+    int TT = 32;
+    while (TT > 8 && planes * cfn_cdiv(a.T, TT) < 1536) TT >>= 1;
+    if (TT > a.T) TT = a.T;
+    a.TT = TT;
+    a.nchunks = cfn_cdiv(a.T, TT);
+    pl.HS = HS; pl.VEC = VEC; pl.MAXLD = MAXLD; pl.threads = threads;
+    pl.lds = ((size_t)CG * a.RIN * a.WP + 2 * CG + 27 * CG) * sizeof(float);
+    pl.blocks = (unsigned)(planes * a.nchunks);
+    return CFN_OK;
+}
+
+template <int MODE, int S, int HS>
+static int dw_launch_hs(const DwArgs& a, const DwPlan& pl, hipStream_t st) {
+#define CFN_DW_GO(VEC, MAXLD)                                                                                          \
+    do {                                                                                                               \
+        auto k = dw3d_kernel<MODE, S, HS, VEC, MAXLD>;                                                                 \
+        if (pl.lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
+        hipLaunchKernelGGL(k, dim3(pl.blocks), dim3(pl.threads), pl.lds, st, a);                                       \
+    } while (0)
+    if (pl.VEC == 4 && pl.MAXLD == 2) CFN_DW_GO(4, 2);
+    else if (pl.VEC == 4) CFN_DW_GO(4, 8);
+    else CFN_DW_GO(1, 8);
+#undef CFN_DW_GO
+    return cfn_check_launch("dwconv3d");
+}
+
+template <int MODE, int S>
+static int dw_launch(const DwArgs& a, const DwPlan& pl, hipStream_t st) {
+    switch (pl.HS) {
+        case 7: return dw_launch_hs<MODE, S, 7>(a, pl, st);
+        case 4: return dw_launch_hs<MODE, S, 4>(a, pl, st);
+        default: return dw_launch_hs<MODE, S, 1>(a, pl, st);
+    }
+}
+
+static double dw_bytes(const DwArgs& a, int tensors_in, int tensors_out) {
+    return 4.0 * a.N * a.C * a.T * ((double)tensors_in * a.Hi * a.Wi + (double)tensors_out * a.Ho * a.Wo);
+}
+
+extern "C" int cfn_dwconv3d_fwd(const float* x, const float* A, const float* B, int act, const float* w, float* y,
+                                double* sum, double* sumsq, int N, int C, int T, int Hi, int Wi, int stride,
+                                void* stream) {
+    CFN_REQUIRE(x && w && y, "cfn_dwconv3d_fwd: null tensor");
+    CFN_REQUIRE(N > 0 && C > 0 && T > 0 && Hi > 0 && Wi > 0, "cfn_dwconv3d_fwd: bad shape");
+    CFN_REQUIRE(stride == 1 || stride == 2, "cfn_dwconv3d_fwd: stride must be 1 or 2 (got %d)", stride);
+    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_dwconv3d_fwd: A and B must both be given or both null");
+    CFN_REQUIRE((sum == nullptr) == (sumsq == nullptr), "cfn_dwconv3d_fwd: sum and sumsq go together");
+    DwArgs a = {};
+    a.src = x; a.A = A; a.B = B; a.act = act; a.w = w; a.dst = y; a.s1 = sum; a.s2 = sumsq;
+    a.N = N; a.C = C; a.T = T; a.Hi = Hi; a.Wi = Wi;
+    DwPlan pl;
+    int rc = dw_plan(a, stride, DW_FWD, pl);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DWCONV_FWD, st, 4.0 * N * C * T * ((double)Hi * Wi + (double)a.Ho * a.Wo) + 4.0 * C * 27);
+    return stride == 1 ? dw_launch<DW_FWD, 1>(a, pl, st) : dw_launch<DW_FWD, 2>(a, pl, st);
+}
+
+extern "C" int cfn_dwconv3d_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq,
+                                     const float* w, const float* x, const float* A, const float* B, int act,
+                                     float* gx, double* gA, double* gB, int N, int C, int T, int Hi, int Wi,
+                                     int stride, void* stream) {
+    CFN_REQUIRE(gy && w && gx, "cfn_dwconv3d_bwd_data: null tensor");
+    CFN_REQUIRE(stride == 1 || stride == 2, "cfn_dwconv3d_bwd_data: stride must be 1 or 2");
+    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_dwconv3d_bwd_data: A/B mismatch");
+    CFN_REQUIRE(A == nullptr || (x != nullptr && gA != nullptr && gB != nullptr), "cfn_dwconv3d_bwd_data: prologue needs x, gA, gB");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv3d_bwd_data: gsumsq needs y");
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = (Hi + 2 - 3) / stride + 1, Wo = (Wi + 2 - 3) / stride + 1;
+    CfnProfScope prof(CFN_K_DWCONV_BWD, st, 4.0 * N * C * T * ((double)Hi * Wi * (A ? 2 : 1) + (double)Ho * Wo * (y ? 2 : 1)));
+    if (stride == 2) {
+        dim3 grid(cfn_cdiv((long)Hi * Wi, 256), T, N * C);
+        CFN_REQUIRE((long)N * C <= 65535 && T <= 65535, "cfn_dwconv3d_bwd_data: grid too large");
+        hipLaunchKernelGGL(dw3d_dgrad_s2_kernel, grid, dim3(256), 0, st, gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB,
+                           C, T, Hi, Wi, Ho, Wo);
+        return cfn_check_launch("dwconv3d_bwd_data_s2");
+    }
+    DwArgs a = {};
+    a.src = gy; a.src2 = y; a.gs = gsum; a.gq = gsumsq; a.w = w; a.xin = x; a.A = A; a.B = B; a.act = act;
+    a.dst = gx; a.s1 = A ? gA : nullptr; a.s2 = A ? gB : nullptr;
+    a.N = N; a.C = C; a.T = T; a.Hi = Hi; a.Wi = Wi;
+    DwPlan pl;
+    int rc = dw_plan(a, 1, DW_DGRAD, pl);
+    if (rc) return rc;
+    return dw_launch<DW_DGRAD, 1>(a, pl, st);
+}
+
+extern "C" int cfn_dwconv3d_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq,
+                                       const float* x, const float* A, const float* B, int act, double* gw, int N,
+                                       int C, int T, int Hi, int Wi, int stride, void* stream) {
+    CFN_REQUIRE(gy && x && gw, "cfn_dwconv3d_bwd_weight: null tensor");
+    CFN_REQUIRE(stride == 1 || stride == 2, "cfn_dwconv3d_bwd_weight: stride must be 1 or 2");
+    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_dwconv3d_bwd_weight: A/B mismatch");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv3d_bwd_weight: gsumsq needs y");
+    DwArgs a = {};
+    a.src = x; a.A = A; a.B = B; a.act = act; a.gy = gy; a.yout = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq;
+    a.s1 = gw;
+    a.N = N; a.C = C; a.T = T; a.Hi = Hi; a.Wi = Wi;
+    DwPlan pl;
+    int rc = dw_plan(a, stride, DW_WGRAD, pl);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DWCONV_BWD, st, 4.0 * N * C * T * ((double)Hi * Wi + (double)a.Ho * a.Wo * (a.yout ? 2 : 1)));
+    return stride == 1 ? dw_launch<DW_WGRAD, 1>(a, pl, st) : dw_launch<DW_WGRAD, 2>(a, pl, st);
+}

@@ -1,0 +1,161 @@
+// Depthwise 5x1x1 temporal convolution of the X3D stem (conv1_t, x3d_fine.py:216-222): pure streaming.
+// A thread owns 4 consecutive positions of one (n,c) plane and marches along t with a 5-frame
+// register window, so every input element is loaded exactly once per t-chunk (+4 halo frames) with
+// fully coalesced float4 accesses; no LDS.
+//   T5_FWD    y = conv(x)                       + per-(n,c) sum / sumsq of y
+//   T5_DGRAD  gx = conv_flipped(gy + gs + 2 y gq)
+//   T5_WGRAD  gw[c][kt] += sum (gy + gs + 2 y gq)[t] * x[t+kt-2]
+#include "cfn_common.h"
+
+typedef float __attribute__((ext_vector_type(4))) f4v;
+enum { T5_FWD = 0, T5_DGRAD = 1, T5_WGRAD = 2 };
+
+struct T5Args {
+    const float* src;    // FWD/WGRAD: x (N,C,T,P)    DGRAD: gy
+    const float* src2;   // DGRAD: y (for gq) or null
+    const double* gs; const double* gq;
+    const float* w;      // (C,5)
+    float* dst;
+    const float* gy;     // WGRAD
+    const float* yout;   // WGRAD: y (for gq) or null
+    double* s1; double* s2;
+    int C, T, TT, nchunks, pchunks;
+    long plane;
+};
+
+template <int MODE, int VEC>
+__global__ __launch_bounds__(256) void dwt5_kernel(const T5Args a) {
+    __shared__ float sh[20];
+    const long nc = blockIdx.y;
+    const int c = (int)(nc % a.C);
+    const int chunk = blockIdx.x % a.nchunks, pc = blockIdx.x / a.nchunks;
+    const long p = ((long)pc * 256 + threadIdx.x) * VEC;
+    const bool ok = p < a.plane;
+    const int t0 = chunk * a.TT, t1 = min(t0 + a.TT, a.T);
+    const long base = nc * a.T * a.plane + p;
+
+    float wk[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) wk[k] = a.w[c * 5 + (MODE == T5_DGRAD ? 4 - k : k)];
+    const float gsv = (MODE != T5_FWD && a.gs) ? (float)a.gs[nc] : 0.0f;
+    const float gqv = (MODE != T5_FWD && a.gq) ? 2.0f * (float)a.gq[nc] : 0.0f;
+
+    auto ld = [&](const float* ptr, int t) -> f4v {
+        f4v v = {0.f, 0.f, 0.f, 0.f};
+        if (ok && t >= 0 && t < a.T) {
+            if (VEC == 4) v = *reinterpret_cast<const f4v*>(ptr + base + (long)t * a.plane);
+            else v.x = ptr[base + (long)t * a.plane];
+        }
+        return v;
+    };
+    auto ld_src = [&](int t) -> f4v {   // staged tensor of the window
+        f4v v = ld(a.src, t);
+        if (MODE == T5_DGRAD && ok && t >= 0 && t < a.T) {
+            v += gsv;
+            if (a.src2) v += ld(a.src2, t) * gqv;
+        }
+        return v;
+    };
+
+    f4v win[5];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) win[k + 1] = ld_src(t0 - 2 + k);   // frames t0-2 .. t0+1
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float st1 = 0.f, st2 = 0.f;
+    for (int t = t0; t < t1; ++t) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) win[k] = win[k + 1];
+        win[4] = ld_src(t + 2);
+        if (MODE == T5_WGRAD) {
+            f4v g = ld(a.gy, t);
+            if (ok) {
+                g += gsv;
+                if (a.yout) g += ld(a.yout, t) * gqv;
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const f4v pr = g * win[k];
+                acc[k] += VEC == 4 ? pr.x + pr.y + pr.z + pr.w : pr.x;
+            }
+        } else {
+            f4v y = win[0] * wk[0] + win[1] * wk[1] + win[2] * wk[2] + win[3] * wk[3] + win[4] * wk[4];
+            if (ok) {
+                if (VEC == 4) *reinterpret_cast<f4v*>(a.dst + base + (long)t * a.plane) = y;
+                else a.dst[base + (long)t * a.plane] = y.x;
+                if (MODE == T5_FWD) {
+                    if (VEC == 4) { st1 += y.x + y.y + y.z + y.w; st2 += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w; }
+                    else { st1 += y.x; st2 = fmaf(y.x, y.x, st2); }
+                }
+            }
+        }
+    }
+    // block reductions
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (MODE == T5_WGRAD) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { acc[k] = cfn_wave_sum(acc[k]); if (lane == 0) sh[k * 4 + wave] = acc[k]; }
+        __syncthreads();
+        if (threadIdx.x < 5)
+            atomicAdd(&a.s1[c * 5 + threadIdx.x],
+                      (double)(sh[threadIdx.x * 4] + sh[threadIdx.x * 4 + 1] + sh[threadIdx.x * 4 + 2] + sh[threadIdx.x * 4 + 3]));
+    } else if (MODE == T5_FWD && a.s1) {
+        st1 = cfn_wave_sum(st1); st2 = cfn_wave_sum(st2);
+        if (lane == 0) { sh[wave] = st1; sh[4 + wave] = st2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&a.s1[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
+            atomicAdd(&a.s2[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
+        }
+    }
+}
+
+template <int MODE>
+static int t5_launch(T5Args& a, int N, hipStream_t st) {
+    const long NC = (long)N * a.C;
+    CFN_REQUIRE(NC <= 65535, "dwconv_t5: N*C = %ld exceeds grid.y", NC);
+    const bool v4 = a.plane % 4 == 0;
+    const int vec = v4 ? 4 : 1;
+    a.pchunks = cfn_cdiv(a.plane, 256L * vec);
+    int TT = 64;
+    while (TT > 16 && NC * a.pchunks * cfn_cdiv(a.T, TT) < 2048) TT >>= 1;
+    if (TT > a.T) TT = a.T;
+    a.TT = TT;
+    a.nchunks = cfn_cdiv(a.T, TT);
+    dim3 grid((unsigned)(a.pchunks * a.nchunks), (unsigned)NC);
+    if (v4) hipLaunchKernelGGL((dwt5_kernel<MODE, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dwt5_kernel<MODE, 1>), grid, dim3(256), 0, st, a);
+    return cfn_check_launch("dwconv_t5");
+}
+
+extern "C" int cfn_dwconv_t5_fwd(const float* x, const float* w, float* y, double* sum, double* sumsq, int N, int C, int T,
+                                 long plane, void* stream) {
+    CFN_REQUIRE(x && w && y, "cfn_dwconv_t5_fwd: null tensor");
+    CFN_REQUIRE((sum == nullptr) == (sumsq == nullptr), "cfn_dwconv_t5_fwd: sum/sumsq mismatch");
+    T5Args a = {};
+    a.src = x; a.w = w; a.dst = y; a.s1 = sum; a.s2 = sumsq; a.C = C; a.T = T; a.plane = plane;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DWCONV_FWD, st, 8.0 * N * C * T * plane);
+    return t5_launch<T5_FWD>(a, N, st);
+}
+
+extern "C" int cfn_dwconv_t5_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq,
+                                      const float* w, float* gx, int N, int C, int T, long plane, void* stream) {
+    CFN_REQUIRE(gy && w && gx, "cfn_dwconv_t5_bwd_data: null tensor");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv_t5_bwd_data: gsumsq needs y");
+    T5Args a = {};
+    a.src = gy; a.src2 = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.w = w; a.dst = gx; a.C = C; a.T = T; a.plane = plane;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DWCONV_BWD, st, 4.0 * N * C * T * plane * (a.src2 ? 3 : 2));
+    return t5_launch<T5_DGRAD>(a, N, st);
+}
+
+extern "C" int cfn_dwconv_t5_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq,
+                                        const float* x, double* gw, int N, int C, int T, long plane, void* stream) {
+    CFN_REQUIRE(gy && x && gw, "cfn_dwconv_t5_bwd_weight: null tensor");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv_t5_bwd_weight: gsumsq needs y");
+    T5Args a = {};
+    a.src = x; a.gy = gy; a.yout = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.s1 = gw; a.C = C; a.T = T; a.plane = plane;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DWCONV_BWD, st, 4.0 * N * C * T * plane * (a.yout ? 3 : 2));
+    return t5_launch<T5_WGRAD>(a, N, st);
+}

@@ -1,0 +1,394 @@
+// Streaming per-(n,c) kernels around the convolutions: everything SubBatchNorm3d / ReLU / Swish /
+// residual add / spatial average pooling does in the reference as separate eager passes
+// (x3d_fine.py:51-62, :74-86, :151, :164, :172-173, :345-366) is folded here into single passes
+// with a per-(n,c) affine  z = A[n,c]*x + B[n,c]  (A,B carry batch-norm scale/shift, the BN affine
+// and the squeeze-excite gate) and fp64 per-(n,c) reduction outputs for the backward of that affine.
+// All kernels: grid = (chunks of the (n,c) volume, N*C), float4 when the volume allows it.
+#include "cfn_common.h"
+
+typedef float __attribute__((ext_vector_type(4))) f4v;
+
+// block-wide sum of up to 4 values -> thread 0 ; 256 threads
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* sh /* [NV*4] */) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = cfn_wave_sum(v[i]);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sh[i * 4 + wave] = v[i];
+    __syncthreads();
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = sh[i * 4] + sh[i * 4 + 1] + sh[i * 4 + 2] + sh[i * 4 + 3];
+}
+
+#define EW_ITEMS 8   // float4 (or scalars) per thread
+
+// ---- out = relu( A*y + B + (Ar*res + Br) ) --------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_add_relu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ A,
+                                                              const float* __restrict__ B, const float* __restrict__ res,
+                                                              const float* __restrict__ Ar, const float* __restrict__ Br,
+                                                              float* __restrict__ out, long vol) {
+    const long nc = blockIdx.y;
+    const float a = A[nc], b = B[nc] + (Br ? Br[nc] : 0.0f), ar = Ar ? Ar[nc] : 1.0f;
+    const long base = nc * vol;
+    long i = ((long)blockIdx.x * 256 * EW_ITEMS + threadIdx.x) * VEC;
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k, i += 256 * VEC) {
+        if (i >= vol) break;
+        if (VEC == 4) {
+            const f4v yv = *reinterpret_cast<const f4v*>(y + base + i);
+            const f4v rv = *reinterpret_cast<const f4v*>(res + base + i);
+            f4v o;
+            o.x = fmaxf(fmaf(yv.x, a, fmaf(rv.x, ar, b)), 0.f); o.y = fmaxf(fmaf(yv.y, a, fmaf(rv.y, ar, b)), 0.f);
+            o.z = fmaxf(fmaf(yv.z, a, fmaf(rv.z, ar, b)), 0.f); o.w = fmaxf(fmaf(yv.w, a, fmaf(rv.w, ar, b)), 0.f);
+            *reinterpret_cast<f4v*>(out + base + i) = o;
+        } else {
+            out[base + i] = fmaxf(fmaf(y[base + i], a, fmaf(res[base + i], ar, b)), 0.f);
+        }
+    }
+}
+
+// g = gout * (out > 0);  gy = g*A;  gres = g*Ar;  gA += sum g*y;  gB += sum g;  gAr += sum g*res
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_add_relu_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ out,
+                                                              const float* __restrict__ y, const float* __restrict__ A,
+                                                              const float* __restrict__ res, const float* __restrict__ Ar,
+                                                              float* __restrict__ gy, float* __restrict__ gres,
+                                                              double* __restrict__ gA, double* __restrict__ gB,
+                                                              double* __restrict__ gAr, long vol) {
+    __shared__ float sh[12];
+    const long nc = blockIdx.y;
+    const float a = A[nc], ar = Ar ? Ar[nc] : 1.0f;
+    const long base = nc * vol;
+    float acc[3] = {0.f, 0.f, 0.f};
+    long i = ((long)blockIdx.x * 256 * EW_ITEMS + threadIdx.x) * VEC;
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k, i += 256 * VEC) {
+        if (i >= vol) break;
+        if (VEC == 4) {
+            const f4v go = *reinterpret_cast<const f4v*>(gout + base + i);
+            const f4v ov = *reinterpret_cast<const f4v*>(out + base + i);
+            const f4v yv = *reinterpret_cast<const f4v*>(y + base + i);
+            f4v g;
+            g.x = ov.x > 0.f ? go.x : 0.f; g.y = ov.y > 0.f ? go.y : 0.f;
+            g.z = ov.z > 0.f ? go.z : 0.f; g.w = ov.w > 0.f ? go.w : 0.f;
+            acc[0] += g.x * yv.x + g.y * yv.y + g.z * yv.z + g.w * yv.w;
+            acc[1] += g.x + g.y + g.z + g.w;
+            if (Ar) {
+                const f4v rv = *reinterpret_cast<const f4v*>(res + base + i);
+                acc[2] += g.x * rv.x + g.y * rv.y + g.z * rv.z + g.w * rv.w;
+            }
+            *reinterpret_cast<f4v*>(gy + base + i) = g * a;
+            *reinterpret_cast<f4v*>(gres + base + i) = g * ar;
+        } else {
+            const float g = out[base + i] > 0.f ? gout[base + i] : 0.f;
+            acc[0] = fmaf(g, y[base + i], acc[0]);
+            acc[1] += g;
+            if (Ar) acc[2] = fmaf(g, res[base + i], acc[2]);
+            gy[base + i] = g * a;
+            gres[base + i] = g * ar;
+        }
+    }
+    block_sum<3>(acc, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(&gA[nc], (double)acc[0]);
+        atomicAdd(&gB[nc], (double)acc[1]);
+        if (gAr) atomicAdd(&gAr[nc], (double)acc[2]);
+    }
+}
+
+// ---- out = act(A*x + B)   (+ optional per-(n,c) sum / sumsq of x itself: channel statistics) ----
+template <int VEC>
+__global__ __launch_bounds__(256) void affine_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ A,
+                                                             const float* __restrict__ B, int act, float* __restrict__ out,
+                                                             long vol) {
+    const long nc = blockIdx.y;
+    const float a = A[nc], b = B[nc];
+    const long base = nc * vol;
+    long i = ((long)blockIdx.x * 256 * EW_ITEMS + threadIdx.x) * VEC;
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k, i += 256 * VEC) {
+        if (i >= vol) break;
+        if (VEC == 4) {
+            const f4v v = *reinterpret_cast<const f4v*>(x + base + i);
+            f4v o;
+            o.x = cfn_act_rt(fmaf(v.x, a, b), act); o.y = cfn_act_rt(fmaf(v.y, a, b), act);
+            o.z = cfn_act_rt(fmaf(v.z, a, b), act); o.w = cfn_act_rt(fmaf(v.w, a, b), act);
+            *reinterpret_cast<f4v*>(out + base + i) = o;
+        } else {
+            out[base + i] = cfn_act_rt(fmaf(x[base + i], a, b), act);
+        }
+    }
+}
+
+// dz = gout * act'(A*x+B);  gx = dz*A;  gA += sum dz*x;  gB += sum dz
+template <int VEC>
+__global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x,
+                                                             const float* __restrict__ A, const float* __restrict__ B, int act,
+                                                             float* __restrict__ gx, double* __restrict__ gA,
+                                                             double* __restrict__ gB, long vol) {
+    __shared__ float sh[8];
+    const long nc = blockIdx.y;
+    const float a = A[nc], b = B[nc];
+    const long base = nc * vol;
+    float acc[2] = {0.f, 0.f};
+    long i = ((long)blockIdx.x * 256 * EW_ITEMS + threadIdx.x) * VEC;
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k, i += 256 * VEC) {
+        if (i >= vol) break;
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) {
+            const float xv = x[base + i + u];
+            const float dz = gout[base + i + u] * cfn_act_grad_rt(fmaf(xv, a, b), act);
+            acc[0] = fmaf(dz, xv, acc[0]);
+            acc[1] += dz;
+            gx[base + i + u] = dz * a;
+        }
+    }
+    block_sum<2>(acc, sh);
+    if (threadIdx.x == 0) { atomicAdd(&gA[nc], (double)acc[0]); atomicAdd(&gB[nc], (double)acc[1]); }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, double* __restrict__ sum,
+                                                            double* __restrict__ sumsq, long vol) {
+    __shared__ float sh[8];
+    const long nc = blockIdx.y;
+    const long base = nc * vol;
+    float acc[2] = {0.f, 0.f};
+    long i = ((long)blockIdx.x * 256 * EW_ITEMS + threadIdx.x) * VEC;
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k, i += 256 * VEC) {
+        if (i >= vol) break;
+        if (VEC == 4) {
+            const f4v v = *reinterpret_cast<const f4v*>(x + base + i);
+            acc[0] += v.x + v.y + v.z + v.w;
+            acc[1] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        } else {
+            const float v = x[base + i];
+            acc[0] += v;
+            acc[1] = fmaf(v, v, acc[1]);
+        }
+    }
+    block_sum<2>(acc, sh);
+    if (threadIdx.x == 0) { atomicAdd(&sum[nc], (double)acc[0]); atomicAdd(&sumsq[nc], (double)acc[1]); }
+}
+
+// ---- adaptive spatial average of act(A*x+B): (N,C,T,H,W) -> (N,C,T,OH,OW) -----------------------------
+// adaptive_avg_pool3d((None,1,1)) of the head (x3d_fine.py:255,366) and ((None,7,7)) of the feature tower
+// (:345-363); window of output cell o along a size-S axis: [floor(o*S/O), ceil((o+1)*S/O)) as in ATen.
+__device__ __forceinline__ int ap_start(int o, int O, int S) { return (o * S) / O; }
+__device__ __forceinline__ int ap_end(int o, int O, int S) { return ((o + 1) * S + O - 1) / O; }
+
+__global__ __launch_bounds__(256) void pool_hw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ A,
+                                                          const float* __restrict__ B, int act, float* __restrict__ out,
+                                                          int T, int H, int W, int OH, int OW) {
+    const long nc = blockIdx.y;
+    const long ovol = (long)T * OH * OW;
+    const long o = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= ovol) return;
+    const float a = A ? A[nc] : 1.0f, b = A ? B[nc] : 0.0f;
+    const int ow = (int)(o % OW), oh = (int)((o / OW) % OH), t = (int)(o / ((long)OW * OH));
+    const int h0 = ap_start(oh, OH, H), h1 = ap_end(oh, OH, H), w0 = ap_start(ow, OW, W), w1 = ap_end(ow, OW, W);
+    const float* p = x + (nc * T + t) * (long)H * W;
+    float s = 0.f;
+    for (int i = h0; i < h1; ++i)
+        for (int j = w0; j < w1; ++j) s += cfn_act_rt(fmaf(p[i * W + j], a, b), act);
+    out[nc * ovol + o] = s / (float)((h1 - h0) * (w1 - w0));
+}
+
+__global__ __launch_bounds__(256) void pool_hw_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x,
+                                                          const float* __restrict__ A, const float* __restrict__ B, int act,
+                                                          float* __restrict__ gx, double* __restrict__ gA,
+                                                          double* __restrict__ gB, int T, int H, int W, int OH, int OW) {
+    __shared__ float sh[8];
+    const long nc = blockIdx.y;
+    const long vol = (long)T * H * W;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float acc[2] = {0.f, 0.f};
+    if (i < vol) {
+        const float a = A ? A[nc] : 1.0f, b = A ? B[nc] : 0.0f;
+        const int w = (int)(i % W), h = (int)((i / W) % H), t = (int)(i / ((long)W * H));
+        const float* gp = gout + (nc * T + t) * (long)OH * OW;
+        float g = 0.f;
+        // every output window that contains (h, w); adaptive windows may overlap, OH*OW <= 49 here
+        for (int oh = 0; oh < OH; ++oh) {
+            const int hs = ap_start(oh, OH, H), he = ap_end(oh, OH, H);
+            if (h < hs || h >= he) continue;
+            for (int ow = 0; ow < OW; ++ow) {
+                const int ws = ap_start(ow, OW, W), we = ap_end(ow, OW, W);
+                if (w >= ws && w < we) g += gp[oh * OW + ow] / (float)((he - hs) * (we - ws));
+            }
+        }
+        const float xv = x[nc * vol + i];
+        const float dz = g * cfn_act_grad_rt(fmaf(xv, a, b), act);
+        acc[0] = dz * xv;
+        acc[1] = dz;
+        gx[nc * vol + i] = dz * a;
+    }
+    if (gA) {
+        block_sum<2>(acc, sh);
+        if (threadIdx.x == 0) { atomicAdd(&gA[nc], (double)acc[0]); atomicAdd(&gB[nc], (double)acc[1]); }
+    }
+}
+
+// ---- FiLM with 7x7 block-constant modulation (x3d_coarse.py:663-679 after the fusion branch has been
+// evaluated at its native 7x7 resolution): out = x * m[h/f, w/f] + c[h/f, w/f] -------------------------
+__global__ __launch_bounds__(256) void film_fwd_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                                       const float* __restrict__ c, float* __restrict__ out, int T, int H,
+                                                       int W, int f) {
+    const long nc = blockIdx.y;
+    const long vol = (long)T * H * W;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= vol) return;
+    const int Hs = H / f, Ws = W / f;
+    const int w = (int)(i % W), h = (int)((i / W) % H), t = (int)(i / ((long)W * H));
+    const long s = (nc * T + t) * (long)Hs * Ws + (long)(h / f) * Ws + w / f;
+    out[nc * vol + i] = fmaf(x[nc * vol + i], m[s], c[s]);
+}
+
+// gx = g*m ;  gm[s] = sum_window g*x ; gc[s] = sum_window g   (one thread per 7x7 cell)
+__global__ __launch_bounds__(256) void film_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                       const float* __restrict__ m, float* __restrict__ gx,
+                                                       float* __restrict__ gm, float* __restrict__ gc, int T, int H, int W,
+                                                       int f) {
+    const long nc = blockIdx.y;
+    const int Hs = H / f, Ws = W / f;
+    const long svol = (long)T * Hs * Ws;
+    const long s = (long)blockIdx.x * 256 + threadIdx.x;
+    if (s >= svol) return;
+    const int ws = (int)(s % Ws), hs = (int)((s / Ws) % Hs), t = (int)(s / ((long)Ws * Hs));
+    const long base = (nc * T + t) * (long)H * W + (long)hs * f * W + ws * f;
+    const float mv = m[nc * svol + s];
+    float a0 = 0.f, a1 = 0.f;
+    for (int i = 0; i < f; ++i)
+        for (int j = 0; j < f; ++j) {
+            const float gv = g[base + i * W + j];
+            a0 = fmaf(gv, x[base + i * W + j], a0);
+            a1 += gv;
+            gx[base + i * W + j] = gv * mv;
+        }
+    gm[nc * svol + s] = a0;
+    gc[nc * svol + s] = a1;
+}
+
+// ---------------------------------------------------------------------------------------------
+static inline dim3 ew_grid(long vol, long NC, int vec) { return dim3(cfn_cdiv(vol, 256L * EW_ITEMS * vec), (unsigned)NC); }
+static inline bool ew_vec4(long vol, const void* p0, const void* p1 = nullptr, const void* p2 = nullptr,
+                           const void* p3 = nullptr, const void* p4 = nullptr, const void* p5 = nullptr) {
+    auto al = [](const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; };
+    return vol % 4 == 0 && al(p0) && al(p1) && al(p2) && al(p3) && al(p4) && al(p5);
+}
+#define CFN_NC_CHECK(NC) CFN_REQUIRE((NC) > 0 && (NC) <= 65535, "N*C = %ld exceeds grid.y limit", (long)(NC))
+
+extern "C" int cfn_bn_add_relu_fwd(const float* y, const float* A, const float* B, const float* res, const float* Ar,
+                                   const float* Br, float* out, long NC, long vol, void* stream) {
+    CFN_REQUIRE(y && A && B && res && out, "cfn_bn_add_relu_fwd: null tensor");
+    CFN_REQUIRE((Ar == nullptr) == (Br == nullptr), "cfn_bn_add_relu_fwd: Ar/Br mismatch");
+    CFN_NC_CHECK(NC);
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_ELEMWISE, st, 12.0 * NC * vol);
+    if (ew_vec4(vol, y, res, out)) hipLaunchKernelGGL(bn_add_relu_fwd_kernel<4>, ew_grid(vol, NC, 4), dim3(256), 0, st, y, A, B, res, Ar, Br, out, vol);
+    else hipLaunchKernelGGL(bn_add_relu_fwd_kernel<1>, ew_grid(vol, NC, 1), dim3(256), 0, st, y, A, B, res, Ar, Br, out, vol);
+    return cfn_check_launch("bn_add_relu_fwd");
+}
+
+extern "C" int cfn_bn_add_relu_bwd(const float* gout, const float* out, const float* y, const float* A, const float* res,
+                                   const float* Ar, float* gy, float* gres, double* gA, double* gB, double* gAr, long NC,
+                                   long vol, void* stream) {
+    CFN_REQUIRE(gout && out && y && A && gy && gres && gA && gB, "cfn_bn_add_relu_bwd: null tensor");
+    CFN_REQUIRE(Ar == nullptr || (res != nullptr && gAr != nullptr), "cfn_bn_add_relu_bwd: Ar needs res and gAr");
+    CFN_NC_CHECK(NC);
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_ELEMWISE, st, (Ar ? 24.0 : 20.0) * NC * vol);
+    if (ew_vec4(vol, gout, out, y, res, gy, gres))
+        hipLaunchKernelGGL(bn_add_relu_bwd_kernel<4>, ew_grid(vol, NC, 4), dim3(256), 0, st, gout, out, y, A, res, Ar, gy, gres, gA, gB, gAr, vol);
+    else
+        hipLaunchKernelGGL(bn_add_relu_bwd_kernel<1>, ew_grid(vol, NC, 1), dim3(256), 0, st, gout, out, y, A, res, Ar, gy, gres, gA, gB, gAr, vol);
+    return cfn_check_launch("bn_add_relu_bwd");
+}
+
+extern "C" int cfn_affine_act_fwd(const float* x, const float* A, const float* B, int act, float* out, long NC, long vol,
+                                  void* stream) {
+    CFN_REQUIRE(x && A && B && out, "cfn_affine_act_fwd: null tensor");
+    CFN_NC_CHECK(NC);
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_ELEMWISE, st, 8.0 * NC * vol);
+    if (ew_vec4(vol, x, out)) hipLaunchKernelGGL(affine_act_fwd_kernel<4>, ew_grid(vol, NC, 4), dim3(256), 0, st, x, A, B, act, out, vol);
+    else hipLaunchKernelGGL(affine_act_fwd_kernel<1>, ew_grid(vol, NC, 1), dim3(256), 0, st, x, A, B, act, out, vol);
+    return cfn_check_launch("affine_act_fwd");
+}
+
+extern "C" int cfn_affine_act_bwd(const float* gout, const float* x, const float* A, const float* B, int act, float* gx,
+                                  double* gA, double* gB, long NC, long vol, void* stream) {
+    CFN_REQUIRE(gout && x && A && B && gx && gA && gB, "cfn_affine_act_bwd: null tensor");
+    CFN_NC_CHECK(NC);
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_ELEMWISE, st, 12.0 * NC * vol);
+    if (vol % 4 == 0) hipLaunchKernelGGL(affine_act_bwd_kernel<4>, ew_grid(vol, NC, 4), dim3(256), 0, st, gout, x, A, B, act, gx, gA, gB, vol);
+    else hipLaunchKernelGGL(affine_act_bwd_kernel<1>, ew_grid(vol, NC, 1), dim3(256), 0, st, gout, x, A, B, act, gx, gA, gB, vol);
+    return cfn_check_launch("affine_act_bwd");
+}
+
+extern "C" int cfn_channel_stats(const float* x, double* sum, double* sumsq, long NC, long vol, void* stream) {
+    CFN_REQUIRE(x && sum && sumsq, "cfn_channel_stats: null tensor");
+    CFN_NC_CHECK(NC);
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_ELEMWISE, st, 4.0 * NC * vol);
+    if (ew_vec4(vol, x)) hipLaunchKernelGGL(channel_stats_kernel<4>, ew_grid(vol, NC, 4), dim3(256), 0, st, x, sum, sumsq, vol);
+    else hipLaunchKernelGGL(channel_stats_kernel<1>, ew_grid(vol, NC, 1), dim3(256), 0, st, x, sum, sumsq, vol);
+    return cfn_check_launch("channel_stats");
+}
+
+extern "C" int cfn_pool_hw_fwd(const float* x, const float* A, const float* B, int act, float* out, long NC, int T, int H,
+                               int W, int OH, int OW, void* stream) {
+    CFN_REQUIRE(x && out, "cfn_pool_hw_fwd: null tensor");
+    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pool_hw_fwd: A/B mismatch");
+    CFN_REQUIRE(OH > 0 && OW > 0 && OH <= H && OW <= W, "cfn_pool_hw_fwd: bad output size %dx%d for %dx%d", OH, OW, H, W);
+    CFN_NC_CHECK(NC);
+    hipStream_t st = (hipStream_t)stream;
+    const long ovol = (long)T * OH * OW;
+    hipLaunchKernelGGL(pool_hw_fwd_kernel, dim3(cfn_cdiv(ovol, 256), (unsigned)NC), dim3(256), 0, st, x, A, B, act, out, T, H, W, OH, OW);
+    return cfn_check_launch("pool_hw_fwd");
+}
+
+extern "C" int cfn_pool_hw_bwd(const float* gout, const float* x, const float* A, const float* B, int act, float* gx,
+                               double* gA, double* gB, long NC, int T, int H, int W, int OH, int OW, void* stream) {
+    CFN_REQUIRE(gout && x && gx, "cfn_pool_hw_bwd: null tensor");
+    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pool_hw_bwd: A/B mismatch");
+    CFN_REQUIRE(A == nullptr || (gA && gB), "cfn_pool_hw_bwd: prologue needs gA, gB");
+    CFN_REQUIRE(OH > 0 && OW > 0 && OH <= H && OW <= W, "cfn_pool_hw_bwd: bad output size %dx%d for %dx%d", OH, OW, H, W);
+    CFN_NC_CHECK(NC);
+    hipStream_t st = (hipStream_t)stream;
+    const long vol = (long)T * H * W;
+    hipLaunchKernelGGL(pool_hw_bwd_kernel, dim3(cfn_cdiv(vol, 256), (unsigned)NC), dim3(256), 0, st, gout, x, A, B, act, gx,
+                       A ? gA : nullptr, A ? gB : nullptr, T, H, W, OH, OW);
+    return cfn_check_launch("pool_hw_bwd");
+}
+
+extern "C" int cfn_film_fwd(const float* x, const float* m, const float* c, float* out, long NC, int T, int H, int W, int f,
+                            void* stream) {
+    CFN_REQUIRE(x && m && c && out, "cfn_film_fwd: null tensor");
+    CFN_REQUIRE(f > 0 && H % f == 0 && W % f == 0, "cfn_film_fwd: factor %d does not tile %dx%d", f, H, W);
+    CFN_NC_CHECK(NC);
+    hipStream_t st = (hipStream_t)stream;
+    const long vol = (long)T * H * W;
+    CfnProfScope prof(CFN_K_FUSION, st, 8.0 * NC * vol);
+    hipLaunchKernelGGL(film_fwd_kernel, dim3(cfn_cdiv(vol, 256), (unsigned)NC), dim3(256), 0, st, x, m, c, out, T, H, W, f);
+    return cfn_check_launch("film_fwd");
+}
+
+extern "C" int cfn_film_bwd(const float* g, const float* x, const float* m, float* gx, float* gm, float* gc, long NC, int T,
+                            int H, int W, int f, void* stream) {
+    CFN_REQUIRE(g && x && m && gx && gm && gc, "cfn_film_bwd: null tensor");
+    CFN_REQUIRE(f > 0 && H % f == 0 && W % f == 0, "cfn_film_bwd: factor %d does not tile %dx%d", f, H, W);
+    CFN_NC_CHECK(NC);
+    hipStream_t st = (hipStream_t)stream;
+    const long svol = (long)T * (H / f) * (W / f);
+    CfnProfScope prof(CFN_K_FUSION, st, 12.0 * NC * T * H * W);
+    hipLaunchKernelGGL(film_bwd_kernel, dim3(cfn_cdiv(svol, 256), (unsigned)NC), dim3(256), 0, st, g, x, m, gx, gm, gc, T, H, W, f);
+    return cfn_check_launch("film_bwd");
+}

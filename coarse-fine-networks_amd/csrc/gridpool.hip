@@ -1,0 +1,259 @@
+// Grid Pool / Grid Unpool temporal resampler (x3d_coarse.py:355-451) and Interp1d (interp1d.py:8-147).
+//
+// The reference resamples with a 5-D F.grid_sample whose h/w coordinates are the pixel centres, so
+// the op is a 2-tap linear interpolation along t at  i_t = ((2(cdf-0.5)+1)/2)*(T-1)  (ATen
+// grid_sampler_unnormalize, align_corners=True, zeros padding).  The integer frame index
+// i0 = floor(i_t) is reproduced bit-exactly: same fp32 operation order, FMA contraction disabled
+// in the index helpers.  Kernels are pure streaming (two input planes -> one output plane).
+#include "cfn_common.h"
+
+typedef float __attribute__((ext_vector_type(4))) f4v;
+
+__device__ __forceinline__ void grid_time_coord(float cdf, int Tin, int& i0, float& w0, float& w1) {
+#pragma clang fp contract(off)
+    const float c = (cdf - 0.5f) * 2.0f;                       // x3d_coarse.py:394
+    const float it = ((c + 1.0f) / 2.0f) * (float)(Tin - 1);   // ATen unnormalize, align_corners
+    const float fl = floorf(it);
+    i0 = (int)fl;
+    w1 = it - fl;
+    w0 = (fl + 1.0f) - it;
+}
+
+__global__ void grid_time_index_kernel(const float* __restrict__ cdf, int n, int Tin, int* __restrict__ i0,
+                                       float* __restrict__ w1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int k; float a, b;
+    grid_time_coord(cdf[i], Tin, k, a, b);
+    i0[i] = k;
+    if (w1) w1[i] = b;
+}
+
+// out[b,c,k,p] = w0*x[b,c,i0,p] + w1*x[b,c,i0+1,p]   (frames outside [0,Tin) read as zero)
+template <int VEC>
+__global__ __launch_bounds__(256) void time_sample_fwd_kernel(const float* __restrict__ x, const float* __restrict__ cdf,
+                                                              float* __restrict__ out, int C, int Tin, int K, long P) {
+    const long bc = blockIdx.z;
+    const int k = blockIdx.y, b = (int)(bc / C);
+    int i0; float w0, w1;
+    grid_time_coord(cdf[(long)b * K + k], Tin, i0, w0, w1);
+    const bool ok0 = i0 >= 0 && i0 < Tin, ok1 = i0 + 1 >= 0 && i0 + 1 < Tin;
+    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (p >= P) return;
+    const float* x0 = x + (bc * Tin + i0) * P + p;
+    float* o = out + (bc * K + k) * P + p;
+    if (VEC == 4) {
+        f4v a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+        if (ok0) a = *reinterpret_cast<const f4v*>(x0);
+        if (ok1) c = *reinterpret_cast<const f4v*>(x0 + P);
+        *reinterpret_cast<f4v*>(o) = a * w0 + c * w1;
+    } else {
+        const float a = ok0 ? x0[0] : 0.f, c = ok1 ? x0[P] : 0.f;
+        o[0] = a * w0 + c * w1;
+    }
+}
+
+// gx[b,c,t,p] = sum_k [i0(k)==t] w0(k) g[k] + [i0(k)+1==t] w1(k) g[k]   (gather, deterministic)
+template <int VEC>
+__global__ __launch_bounds__(256) void time_sample_bwd_x_kernel(const float* __restrict__ g, const float* __restrict__ cdf,
+                                                                float* __restrict__ gx, int C, int Tin, int K, long P) {
+    const long bc = blockIdx.z;
+    const int t = blockIdx.y, b = (int)(bc / C);
+    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (p >= P) return;
+    f4v acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {
+        int i0; float w0, w1;
+        grid_time_coord(cdf[(long)b * K + k], Tin, i0, w0, w1);
+        float wsel = 0.f;
+        if (i0 == t) wsel = w0; else if (i0 + 1 == t) wsel = w1; else continue;
+        const float* gp = g + (bc * K + k) * P + p;
+        if (VEC == 4) acc += *reinterpret_cast<const f4v*>(gp) * wsel;
+        else acc.x = fmaf(gp[0], wsel, acc.x);
+    }
+    float* o = gx + (bc * Tin + t) * P + p;
+    if (VEC == 4) *reinterpret_cast<f4v*>(o) = acc; else o[0] = acc.x;
+}
+
+// gcdf[b,k] += (Tin-1) * sum_{c,p} g[b,c,k,p] * (x[i0+1] - x[i0])      (d i_t / d cdf = Tin-1)
+__global__ __launch_bounds__(256) void time_sample_bwd_cdf_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                                  const float* __restrict__ cdf, double* __restrict__ gcdf,
+                                                                  int C, int Tin, int K, long P, int cchunk) {
+    __shared__ float sh[4];
+    const int b = blockIdx.z, k = blockIdx.y;
+    int i0; float w0, w1;
+    grid_time_coord(cdf[(long)b * K + k], Tin, i0, w0, w1);
+    const bool ok0 = i0 >= 0 && i0 < Tin, ok1 = i0 + 1 >= 0 && i0 + 1 < Tin;
+    const int c_lo = blockIdx.x * cchunk, c_hi = min(c_lo + cchunk, C);
+    float acc = 0.f;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const long bc = (long)b * C + c;
+        const float* gp = g + (bc * K + k) * P;
+        const float* xp = x + (bc * Tin + i0) * P;
+        for (long p = threadIdx.x; p < P; p += 256) {
+            const float d = (ok1 ? xp[P + p] : 0.f) - (ok0 ? xp[p] : 0.f);
+            acc = fmaf(gp[p], d, acc);
+        }
+    }
+    acc = cfn_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&gcdf[(long)b * K + k], (double)(sh[0] + sh[1] + sh[2] + sh[3]) * (double)(Tin - 1));
+}
+
+// ---- Interp1d ----------------------------------------------------------------------------------
+// one thread per query: ind = clamp(#(x < q) - 1, 0, N-2)   (searchsorted 'left' - 1, interp1d.py:100-110)
+__global__ void interp1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ q,
+                                    float* __restrict__ ynew, long* __restrict__ ind, int B, int N, int Pq, int xrow,
+                                    int yrow, int qrow) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * Pq) return;
+    const int b = i / Pq, j = i - b * Pq;
+    const float* xr = x + (long)(xrow ? b : 0) * N;
+    const float* yr = y + (long)(yrow ? b : 0) * N;
+    const float qv = q[(long)(qrow ? b : 0) * Pq + j];
+    int lo = 0, hi = N;                     // first index with x[idx] >= qv
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (xr[mid] < qv) lo = mid + 1; else hi = mid; }
+    int id = lo - 1;
+    id = id < 0 ? 0 : (id > N - 2 ? N - 2 : id);
+    const float eps = 1.1920928955078125e-07f;   // torch.finfo(float32).eps, interp1d.py:37
+    const float slope = (yr[id + 1] - yr[id]) / (eps + (xr[id + 1] - xr[id]));
+    ynew[i] = yr[id] + slope * (qv - xr[id]);
+    if (ind) ind[i] = id;
+}
+
+// gradients of ynew = y0 + (y1-y0)/(eps+x1-x0) * (q-x0) with ind constant; fp32 atomics on
+// (B,N)-sized tensors (tiny)
+__global__ void interp1d_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ y,
+                                    const float* __restrict__ q, const long* __restrict__ ind, float* __restrict__ gx,
+                                    float* __restrict__ gy, float* __restrict__ gq, int B, int N, int Pq, int xrow, int yrow,
+                                    int qrow) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * Pq) return;
+    const int b = i / Pq, j = i - b * Pq;
+    const long xo = (long)(xrow ? b : 0) * N, yo = (long)(yrow ? b : 0) * N;
+    const int id = (int)ind[i];
+    const float x0 = x[xo + id], x1 = x[xo + id + 1], y0 = y[yo + id], y1 = y[yo + id + 1];
+    const float qv = q[(long)(qrow ? b : 0) * Pq + j];
+    const float den = 1.1920928955078125e-07f + (x1 - x0);
+    const float dy = y1 - y0, dq = qv - x0, slope = dy / den, gv = g[i];
+    if (gy) { atomicAdd(&gy[yo + id], gv * (1.0f - dq / den)); atomicAdd(&gy[yo + id + 1], gv * (dq / den)); }
+    if (gx) {
+        const float t = dy * dq / (den * den);
+        atomicAdd(&gx[xo + id], gv * (t - slope));
+        atomicAdd(&gx[xo + id + 1], gv * (-t));
+    }
+    if (gq) atomicAdd(&gq[(long)(qrow ? b : 0) * Pq + j], gv * slope);
+}
+
+// ---- temporal linear resize, align_corners=True (F.interpolate 'linear' x3d_coarse.py:725 and the
+// t-axis of 'trilinear' :449 when h,w keep their size) -------------------------------------------
+__device__ __forceinline__ void resize_src(int j, int Kin, int Lout, int& i0, int& i1, float& l0, float& l1) {
+#pragma clang fp contract(off)
+    const float scale = Lout > 1 ? (float)(Kin - 1) / (float)(Lout - 1) : 0.0f;   // ATen area_pixel_compute_scale
+    const float src = scale * (float)j;
+    i0 = (int)src;
+    i1 = i0 + (i0 < Kin - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.0f - l1;
+}
+
+__global__ __launch_bounds__(256) void time_resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int Kin,
+                                                              int Lout, long P) {
+    const long bc = blockIdx.z;
+    const int j = blockIdx.y;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    int i0, i1; float l0, l1;
+    resize_src(j, Kin, Lout, i0, i1, l0, l1);
+    const float* xp = x + bc * Kin * P + p;
+    out[(bc * Lout + j) * P + p] = l0 * xp[(long)i0 * P] + l1 * xp[(long)i1 * P];
+}
+
+__global__ __launch_bounds__(256) void time_resize_bwd_kernel(const float* __restrict__ g, float* __restrict__ gx, int Kin,
+                                                              int Lout, long P) {
+    const long bc = blockIdx.z;
+    const int k = blockIdx.y;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    float acc = 0.f;
+    for (int j = 0; j < Lout; ++j) {     // Lout <= a few hundred; uniform branch per block
+        int i0, i1; float l0, l1;
+        resize_src(j, Kin, Lout, i0, i1, l0, l1);
+        if (i0 != k && i1 != k) continue;
+        const float gv = g[(bc * Lout + j) * P + p];
+        if (i0 == k) acc = fmaf(gv, l0, acc);
+        if (i1 == k) acc = fmaf(gv, l1, acc);
+    }
+    gx[(bc * Kin + k) * P + p] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int cfn_grid_time_index(const float* cdf, int n, int Tin, int* i0, float* w1, void* stream) {
+    CFN_REQUIRE(cdf && i0 && n > 0 && Tin > 0, "cfn_grid_time_index: bad argument");
+    hipLaunchKernelGGL(grid_time_index_kernel, dim3(cfn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, cdf, n, Tin, i0, w1);
+    return cfn_check_launch("grid_time_index");
+}
+
+#define CFN_GRID_CHECK(BC, Y) CFN_REQUIRE((BC) > 0 && (BC) <= 65535 && (Y) > 0 && (Y) <= 65535, "grid dims exceed 65535 (%ld, %ld)", (long)(BC), (long)(Y))
+
+extern "C" int cfn_time_sample_fwd(const float* x, const float* cdf, float* out, int B, int C, int Tin, int K, long P,
+                                   void* stream) {
+    CFN_REQUIRE(x && cdf && out, "cfn_time_sample_fwd: null tensor");
+    CFN_GRID_CHECK((long)B * C, K);
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_GRIDPOOL, st, 4.0 * B * C * K * P * 3);
+    if (P % 4 == 0) hipLaunchKernelGGL(time_sample_fwd_kernel<4>, dim3(cfn_cdiv(P, 1024), K, B * C), dim3(256), 0, st, x, cdf, out, C, Tin, K, P);
+    else hipLaunchKernelGGL(time_sample_fwd_kernel<1>, dim3(cfn_cdiv(P, 256), K, B * C), dim3(256), 0, st, x, cdf, out, C, Tin, K, P);
+    return cfn_check_launch("time_sample_fwd");
+}
+
+extern "C" int cfn_time_sample_bwd(const float* g, const float* x, const float* cdf, float* gx, double* gcdf, int B, int C,
+                                   int Tin, int K, long P, void* stream) {
+    CFN_REQUIRE(g && cdf, "cfn_time_sample_bwd: null tensor");
+    CFN_GRID_CHECK((long)B * C, Tin > K ? Tin : K);
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_GRIDPOOL, st, 4.0 * B * C * P * ((double)K * 2 + Tin));
+    if (gx) {
+        if (P % 4 == 0) hipLaunchKernelGGL(time_sample_bwd_x_kernel<4>, dim3(cfn_cdiv(P, 1024), Tin, B * C), dim3(256), 0, st, g, cdf, gx, C, Tin, K, P);
+        else hipLaunchKernelGGL(time_sample_bwd_x_kernel<1>, dim3(cfn_cdiv(P, 256), Tin, B * C), dim3(256), 0, st, g, cdf, gx, C, Tin, K, P);
+    }
+    if (gcdf) {
+        CFN_REQUIRE(x != nullptr, "cfn_time_sample_bwd: gcdf needs x");
+        int cchunk = 1;
+        while ((long)cchunk * P < 16384 && cchunk < C) cchunk *= 2;
+        hipLaunchKernelGGL(time_sample_bwd_cdf_kernel, dim3(cfn_cdiv(C, cchunk), K, B), dim3(256), 0, st, g, x, cdf, gcdf, C, Tin, K, P, cchunk);
+    }
+    return cfn_check_launch("time_sample_bwd");
+}
+
+extern "C" int cfn_interp1d_fwd(const float* x, const float* y, const float* xnew, float* ynew, long* ind, int B, int N,
+                                int Pq, int xrow, int yrow, int qrow, void* stream) {
+    CFN_REQUIRE(x && y && xnew && ynew, "cfn_interp1d_fwd: null tensor");
+    CFN_REQUIRE(N >= 2, "cfn_interp1d_fwd: need at least 2 knots (got %d)", N);
+    hipLaunchKernelGGL(interp1d_fwd_kernel, dim3(cfn_cdiv((long)B * Pq, 256)), dim3(256), 0, (hipStream_t)stream, x, y, xnew, ynew, ind, B, N, Pq, xrow, yrow, qrow);
+    return cfn_check_launch("interp1d_fwd");
+}
+
+// gx / gy / gq must be zero-initialised by the caller (scatter-add); any of them may be null
+extern "C" int cfn_interp1d_bwd(const float* g, const float* x, const float* y, const float* xnew, const long* ind, float* gx,
+                                float* gy, float* gq, int B, int N, int Pq, int xrow, int yrow, int qrow, void* stream) {
+    CFN_REQUIRE(g && x && y && xnew && ind, "cfn_interp1d_bwd: null tensor");
+    hipLaunchKernelGGL(interp1d_bwd_kernel, dim3(cfn_cdiv((long)B * Pq, 256)), dim3(256), 0, (hipStream_t)stream, g, x, y, xnew, ind, gx, gy, gq, B, N, Pq, xrow, yrow, qrow);
+    return cfn_check_launch("interp1d_bwd");
+}
+
+extern "C" int cfn_time_resize_fwd(const float* x, float* out, long BC, int Kin, int Lout, long P, void* stream) {
+    CFN_REQUIRE(x && out && Kin > 0 && Lout > 0, "cfn_time_resize_fwd: bad argument");
+    CFN_GRID_CHECK(BC, Lout);
+    hipLaunchKernelGGL(time_resize_fwd_kernel, dim3(cfn_cdiv(P, 256), Lout, (unsigned)BC), dim3(256), 0, (hipStream_t)stream, x, out, Kin, Lout, P);
+    return cfn_check_launch("time_resize_fwd");
+}
+
+extern "C" int cfn_time_resize_bwd(const float* g, float* gx, long BC, int Kin, int Lout, long P, void* stream) {
+    CFN_REQUIRE(g && gx && Kin > 0 && Lout > 0, "cfn_time_resize_bwd: bad argument");
+    CFN_GRID_CHECK(BC, Kin);
+    hipLaunchKernelGGL(time_resize_bwd_kernel, dim3(cfn_cdiv(P, 256), Kin, (unsigned)BC), dim3(256), 0, (hipStream_t)stream, g, gx, Kin, Lout, P);
+    return cfn_check_launch("time_resize_bwd");
+}

@@ -1,0 +1,134 @@
+/* cfn_hip.h -- C ABI of libcfn_hip.so: the MI355X (gfx950) kernels behind the Coarse-Fine hot path.
+ *
+ * The reference (kkahatapitiya/Coarse-Fine-Networks) is pure Python/PyTorch: it has no FFI of its
+ * own, every heavy op is an ATen call.  Each entry point below therefore names the reference CALL
+ * SITE (file:line under the reference tree) whose ATen op(s) it replaces; INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers to DEVICE memory + sizes; no torch types.  Tensors are dense NCDHW fp32.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); kernels are enqueued on it and
+ *     the call returns immediately; no allocation, no synchronisation, no host<->device copy inside
+ *     (graph-capture safe).
+ *   - return 0 on success, otherwise an error code (1 bad argument, 2 launch failure, 3 unsupported
+ *     shape); cfn_last_error() returns a thread-local message.  Nothing ever aborts.
+ *   - "prologue": many ops read their input x through  a = act(A[n,c]*x + B[n,c])  where A/B (float,
+ *     N*C, may be NULL = identity) carry the folded SubBatchNorm3d scale/shift (+ BN affine + SE gate)
+ *     and act is 0 none / 1 ReLU / 2 Swish.  This is how SubBatchNorm3d.forward (x3d_fine.py:51-62),
+ *     relu_ (:151), Swish (:74-86) and the SE multiply (:163) disappear into the next conv.
+ *   - "stats": fp64 accumulators per (n,c) that the caller zero-fills; kernels atomically add
+ *     per-workgroup partial sums.  sum/sumsq of a conv output are what batch_norm (train) and the SE
+ *     average pool (x3d_fine.py:158) need; gsum/gsumsq are the gradients flowing back into them.
+ */
+#ifndef CFN_HIP_H
+#define CFN_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* cfn_last_error(void);
+const char* cfn_version(void);
+int cfn_device_info(int* cus, int* lds_per_cu, char* name, int name_len);
+
+/* opt-in HIP-event timing per kernel family (bench.py roofline leg). family: 0 dwconv fwd, 1 dwconv
+ * bwd, 2 pwconv fwd, 3 pwconv bwd, 4 gridpool, 5 elementwise, 6 stem, 7 fusion.  collect() sums and
+ * clears: total device ms between the bracketing events, launches, algorithmic bytes. */
+int cfn_prof_enable(int family, int on);
+int cfn_prof_collect(int family, double* total_ms, long* launches, double* total_bytes);
+
+/* ---- depthwise 3x3x3, pad 1, stride (1,s,s): conv3x3x3 x3d_fine.py:89-97 used at :117 / x3d_coarse.py:87-95 ----
+ * fwd   y[N,C,T,Ho,Wo] = dwconv(act(A x + B)); sum/sumsq[N*C] += sum y, sum y^2 (NULL to skip)
+ * bwd_data   g' = gy + gsum[n,c] + 2 y gsumsq[n,c];  da = dwconv^T(g');  gx = da*act'(A x+B)*A;
+ *            gA[N*C] += sum da*act'*x, gB += sum da*act'   (autograd of F.conv3d + batch_norm + relu_)
+ * bwd_weight gw[C*27] (fp64, zero-filled by caller) += sum g' * act(A x + B)[tap] */
+int cfn_dwconv3d_fwd(const float* x, const float* A, const float* B, int act, const float* w, float* y, double* sum,
+                     double* sumsq, int N, int C, int T, int Hi, int Wi, int stride, void* stream);
+int cfn_dwconv3d_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
+                          const float* x, const float* A, const float* B, int act, float* gx, double* gA, double* gB,
+                          int N, int C, int T, int Hi, int Wi, int stride, void* stream);
+int cfn_dwconv3d_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* x,
+                            const float* A, const float* B, int act, double* gw, int N, int C, int T, int Hi, int Wi,
+                            int stride, void* stream);
+
+/* ---- depthwise 5x1x1, pad (2,0,0): conv1_t x3d_fine.py:216-222 / x3d_coarse.py:502-508 ; plane = H*W ---- */
+int cfn_dwconv_t5_fwd(const float* x, const float* w, float* y, double* sum, double* sumsq, int N, int C, int T,
+                      long plane, void* stream);
+int cfn_dwconv_t5_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
+                           float* gx, int N, int C, int T, long plane, void* stream);
+int cfn_dwconv_t5_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* x,
+                             double* gw, int N, int C, int T, long plane, void* stream);
+
+/* ---- pointwise 1x1x1, spatial stride s in {1,2}: conv1x1x1 x3d_fine.py:100-105 (conv1 :115, conv3 :119,
+ * shortcut :284-287), conv5 :245-250, fc1 :256; fp32 MFMA (v_mfma_f32_32x32x2_f32).  w is (Cout,Cin).
+ * bwd_data with stride 2 writes only the strided positions: caller zero-fills gx. ---- */
+int cfn_pwconv_fwd(const float* x, const float* A, const float* B, int act, const float* w, float* y, double* sum,
+                   double* sumsq, int N, int Cin, int Cout, int T, int Hi, int Wi, int stride, void* stream);
+int cfn_pwconv_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
+                        const float* x, const float* A, const float* B, int act, float* gx, double* gA, double* gB, int N,
+                        int Cin, int Cout, int T, int Hi, int Wi, int stride, void* stream);
+int cfn_pwconv_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* x,
+                          const float* A, const float* B, int act, double* gw, int N, int Cin, int Cout, int T, int Hi,
+                          int Wi, int stride, void* stream);
+
+/* ---- stem 1x3x3 stride (1,2,2) pad (0,1,1) dense conv: conv1_s x3d_fine.py:210-215 (im2col view on MFMA);
+ * gw is fp64 (Cout, Cimg*9), zero-filled by caller.  The clip needs no gradient. ---- */
+int cfn_stem_conv_fwd(const float* x, const float* w, float* y, int N, int Cimg, int Cout, int T, int Hi, int Wi,
+                      void* stream);
+int cfn_stem_conv_bwd_weight(const float* gy, const float* x, double* gw, int N, int Cimg, int Cout, int T, int Hi, int Wi,
+                             void* stream);
+
+/* ---- block tail  out = relu(A y + B + (Ar res + Br)) : bn3 + (downsample bn) + `out += residual` + relu,
+ * x3d_fine.py:167-173.  Ar/Br NULL = identity shortcut.  vol = T*H*W, NC = N*C. ---- */
+int cfn_bn_add_relu_fwd(const float* y, const float* A, const float* B, const float* res, const float* Ar, const float* Br,
+                        float* out, long NC, long vol, void* stream);
+int cfn_bn_add_relu_bwd(const float* gout, const float* out, const float* y, const float* A, const float* res,
+                        const float* Ar, float* gy, float* gres, double* gA, double* gB, double* gAr, long NC, long vol,
+                        void* stream);
+
+/* ---- materialised prologue out = act(A x + B) (SubBatchNorm3d.forward on its own, x3d_fine.py:51-62) and
+ * per-(n,c) sum / sumsq of a tensor (batch statistics of an arbitrary input) ---- */
+int cfn_affine_act_fwd(const float* x, const float* A, const float* B, int act, float* out, long NC, long vol, void* stream);
+int cfn_affine_act_bwd(const float* gout, const float* x, const float* A, const float* B, int act, float* gx, double* gA,
+                       double* gB, long NC, long vol, void* stream);
+int cfn_channel_stats(const float* x, double* sum, double* sumsq, long NC, long vol, void* stream);
+
+/* ---- adaptive spatial mean of act(A x + B) to (OH,OW): adaptive_avg_pool3d((None,1,1)) x3d_fine.py:255/366 and
+ * ((None,7,7)) :345-363 (ATen window rule: [floor(o*S/O), ceil((o+1)*S/O)) ) ---- */
+int cfn_pool_hw_fwd(const float* x, const float* A, const float* B, int act, float* out, long NC, int T, int H, int W, int OH,
+                    int OW, void* stream);
+int cfn_pool_hw_bwd(const float* gout, const float* x, const float* A, const float* B, int act, float* gx, double* gA,
+                    double* gB, long NC, int T, int H, int W, int OH, int OW, void* stream);
+
+/* ---- FiLM x*m + c with (H/f x W/f)-block-constant m, c: `x = x * m2 + c2` x3d_coarse.py:663-679 after the
+ * fusion branch was evaluated at its native 7x7 ---- */
+int cfn_film_fwd(const float* x, const float* m, const float* c, float* out, long NC, int T, int H, int W, int f,
+                 void* stream);
+int cfn_film_bwd(const float* g, const float* x, const float* m, float* gx, float* gm, float* gc, long NC, int T, int H,
+                 int W, int f, void* stream);
+
+/* ---- Grid Pool / Unpool resampler: 5-D F.grid_sample(align_corners=True) of x3d_coarse.py:403 / :447 as a
+ * 2-tap lerp along t at i_t = ((2(cdf-0.5)+1)/2)(Tin-1).  i0 = floor(i_t) is bit-exact w.r.t. ATen.
+ * x (B,C,Tin,P), cdf (B,K) -> out (B,C,K,P).  bwd: gx (B,C,Tin,P) fully written, gcdf (B,K) fp64 zero-filled
+ * by the caller; either may be NULL. ---- */
+int cfn_grid_time_index(const float* cdf, int n, int Tin, int* i0, float* w1, void* stream);
+int cfn_time_sample_fwd(const float* x, const float* cdf, float* out, int B, int C, int Tin, int K, long P, void* stream);
+int cfn_time_sample_bwd(const float* g, const float* x, const float* cdf, float* gx, double* gcdf, int B, int C, int Tin,
+                        int K, long P, void* stream);
+
+/* ---- Interp1d.forward interp1d.py:8-147: x,y (B or 1 rows, N), xnew (B or 1 rows, Pq) -> ynew (B,Pq), ind int64
+ * (searchsorted-left - 1, clamped to [0,N-2]).  *row flags: 1 = one row per batch entry, 0 = shared row.
+ * bwd scatter-adds into zero-filled gx/gy/gq (any may be NULL). ---- */
+int cfn_interp1d_fwd(const float* x, const float* y, const float* xnew, float* ynew, long* ind, int B, int N, int Pq,
+                     int xrow, int yrow, int qrow, void* stream);
+int cfn_interp1d_bwd(const float* g, const float* x, const float* y, const float* xnew, const long* ind, float* gx, float* gy,
+                     float* gq, int B, int N, int Pq, int xrow, int yrow, int qrow, void* stream);
+
+/* ---- linear resize along t, align_corners=True: F.interpolate x3d_coarse.py:725 (and the t axis of :449).
+ * x (BC,Kin,P) -> out (BC,Lout,P) ---- */
+int cfn_time_resize_fwd(const float* x, float* out, long BC, int Kin, int Lout, long P, void* stream);
+int cfn_time_resize_bwd(const float* g, float* gx, long BC, int Kin, int Lout, long P, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,314 @@
+"""GPU parity of every HIP kernel (through the C ABI / cfn_hip.ops) against plain fp32 torch on the
+CPU computing the same op, forward and backward.  Tolerances are written per test: fp32 kernels,
+different summation order => 1e-5 .. 1e-4 relative; index outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import maxdiff, relerr, load_golden, t
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def ops():
+    from cfn_hip import ops as o
+    return o
+
+
+def act_ref(z, act):
+    if act == 1:
+        return F.relu(z)
+    if act == 2:
+        return z * torch.sigmoid(z)
+    return z
+
+
+def rnd(seed, *shape, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def prologue_ref(x, A, B, act):
+    if A is None:
+        return x
+    shp = A.shape + (1,) * (x.dim() - 2)
+    return act_ref(x * A.view(shp) + B.view(shp), act)
+
+
+def stats_ref(y):
+    d = tuple(range(2, y.dim()))
+    return y.double().sum(d), (y.double() * y.double()).sum(d)
+
+
+def check_conv(hip_fn, ref_fn, x, w, A, B, act, tol_f=2e-5, tol_g=2e-4, x_grad=True):
+    """hip_fn(x,w,A,B) -> (y,s,q) on GPU ; ref_fn(a, w) -> y on CPU with a = prologue(x)."""
+    leaves_c = [v.clone().requires_grad_(True) if v is not None else None for v in (x, w, A, B)]
+    leaves_g = [v.clone().to(DEV).requires_grad_(True) if v is not None else None for v in (x, w, A, B)]
+    if not x_grad:
+        leaves_c[0].requires_grad_(False)
+        leaves_g[0].requires_grad_(False)
+    yc = ref_fn(prologue_ref(leaves_c[0], leaves_c[2], leaves_c[3], act), leaves_c[1])
+    sc, qc = stats_ref(yc)
+    yg, sg, qg = hip_fn(*leaves_g)
+    assert relerr(yg, yc) <= tol_f, ('fwd', relerr(yg, yc))
+    assert relerr(sg, sc) <= 1e-5 and relerr(qg, qc) <= 1e-5, ('stats', relerr(sg, sc), relerr(qg, qc))
+    r, rs, rq = rnd(7, *yc.shape), rnd(8, *sc.shape).double(), rnd(9, *qc.shape).double() * 0.1
+    ((yc * r).sum() + (sc * rs).sum() + (qc * rq).sum()).backward()
+    ((yg * r.to(DEV)).sum() + (sg * rs.to(DEV)).sum() + (qg * rq.to(DEV)).sum()).backward()
+    names = ('x', 'w', 'A', 'B')
+    for nm, c, g in zip(names, leaves_c, leaves_g):
+        if c is None or not c.requires_grad:
+            continue
+        assert g.grad is not None, nm
+        assert relerr(g.grad, c.grad) <= tol_g, ('grad ' + nm, relerr(g.grad, c.grad))
+
+
+DW_CASES = [
+    # N, C, T, H, W, stride, act, with_prologue
+    (2, 6, 5, 7, 7, 1, 1, True),
+    (1, 75, 6, 7, 7, 1, 1, True),        # more channels than one workgroup takes at 7x7
+    (1, 20, 9, 14, 14, 1, 1, True),
+    (1, 8, 5, 14, 14, 2, 1, True),
+    (2, 5, 6, 28, 28, 1, 1, True),
+    (1, 4, 4, 28, 28, 2, 0, False),
+    (1, 3, 37, 56, 56, 1, 1, True),      # several t-chunks
+    (1, 2, 3, 112, 112, 2, 1, True),
+    (1, 3, 4, 40, 40, 1, 1, True),       # X3D-S sizes (HS=4 path)
+    (1, 2, 3, 80, 80, 2, 1, True),
+    (1, 3, 3, 10, 10, 1, 2, True),       # HS=1 path
+    (2, 3, 2, 5, 5, 2, 1, True),
+    (1, 2, 1, 7, 7, 1, 1, True),         # T = 1
+]
+
+
+@pytest.mark.parametrize('N,C,T,H,W,stride,act,pro', DW_CASES)
+def test_dwconv3d(N, C, T, H, W, stride, act, pro):
+    x, w = rnd(1, N, C, T, H, W), rnd(2, C, 1, 3, 3, 3, scale=0.3)
+    A = (1 + 0.2 * rnd(3, N, C)) if pro else None
+    B = 0.3 * rnd(4, N, C) if pro else None
+    check_conv(lambda x_, w_, A_, B_: ops().dwconv3d(x_, w_, A_, B_, act, stride, True),
+               lambda a, w_: F.conv3d(a, w_, stride=(1, stride, stride), padding=1, groups=C), x, w, A, B, act)
+
+
+PW_CASES = [
+    # N, Cin, Cout, T, H, W, stride, act, pro
+    (2, 24, 54, 3, 8, 8, 1, 0, False),
+    (1, 54, 24, 4, 9, 7, 1, 2, True),
+    (2, 48, 108, 2, 6, 6, 1, 1, True),
+    (1, 108, 48, 3, 5, 5, 1, 2, True),
+    (1, 96, 216, 2, 7, 7, 1, 1, True),
+    (1, 216, 96, 2, 7, 7, 1, 2, True),
+    (1, 192, 432, 3, 4, 4, 1, 0, False),
+    (1, 432, 192, 2, 3, 3, 1, 2, True),
+    (2, 24, 48, 3, 8, 8, 2, 1, True),     # shortcut conv, spatial stride 2
+    (1, 24, 24, 2, 7, 7, 2, 0, False),
+    (1, 432, 2048, 5, 1, 1, 1, 0, False),  # fc1
+    (2, 2048, 157, 3, 1, 1, 1, 1, True),   # fc2 as pointwise
+    (1, 3, 5, 40, 13, 11, 1, 1, True),     # odd everything, many position tiles
+]
+
+
+@pytest.mark.parametrize('N,Cin,Cout,T,H,W,stride,act,pro', PW_CASES)
+def test_pwconv(N, Cin, Cout, T, H, W, stride, act, pro):
+    x, w = rnd(1, N, Cin, T, H, W), rnd(2, Cout, Cin, 1, 1, 1, scale=(2.0 / Cin) ** 0.5)
+    A = (1 + 0.2 * rnd(3, N, Cin)) if pro else None
+    B = 0.3 * rnd(4, N, Cin) if pro else None
+    check_conv(lambda x_, w_, A_, B_: ops().pwconv(x_, w_, A_, B_, act, stride, True),
+               lambda a, w_: F.conv3d(a, w_, stride=(1, stride, stride)), x, w, A, B, act, tol_f=3e-5, tol_g=3e-4)
+
+
+@pytest.mark.parametrize('N,C,T,H,W', [(2, 5, 7, 6, 6), (1, 24, 40, 12, 12), (1, 3, 3, 5, 7), (1, 2, 1, 8, 8)])
+def test_dwconv_t5(N, C, T, H, W):
+    x, w = rnd(1, N, C, T, H, W), rnd(2, C, 1, 5, 1, 1, scale=0.4)
+    check_conv(lambda x_, w_, A_, B_: ops().dwconv_t5(x_, w_, True),
+               lambda a, w_: F.conv3d(a, w_, padding=(2, 0, 0), groups=C), x, w, None, None, 0)
+
+
+@pytest.mark.parametrize('N,T,H,W', [(2, 3, 16, 16), (1, 5, 30, 22), (1, 2, 17, 15)])
+def test_stem_conv(N, T, H, W):
+    x, w = rnd(1, N, 3, T, H, W), rnd(2, 24, 3, 1, 3, 3, scale=0.3)
+    wc, wg = w.clone().requires_grad_(True), w.clone().to(DEV).requires_grad_(True)
+    yc = F.conv3d(x, wc, stride=(1, 2, 2), padding=(0, 1, 1))
+    yg = ops().stem_conv(x.to(DEV), wg)
+    assert relerr(yg, yc) <= 2e-5
+    r = rnd(5, *yc.shape)
+    (yc * r).sum().backward()
+    (yg * r.to(DEV)).sum().backward()
+    assert relerr(wg.grad, wc.grad) <= 1e-4
+
+
+@pytest.mark.parametrize('affine_res', [False, True])
+@pytest.mark.parametrize('shape', [(2, 6, 3, 8, 8), (1, 5, 2, 7, 7)])
+def test_bn_add_relu(shape, affine_res):
+    N, C = shape[:2]
+    vals = dict(y=rnd(1, *shape), A=1 + 0.2 * rnd(2, N, C), B=0.2 * rnd(3, N, C), res=rnd(4, *shape))
+    if affine_res:
+        vals.update(Ar=1 + 0.3 * rnd(5, N, C), Br=0.1 * rnd(6, N, C))
+    c = {k: v.clone().requires_grad_(True) for k, v in vals.items()}
+    g = {k: v.clone().to(DEV).requires_grad_(True) for k, v in vals.items()}
+    shp = (N, C, 1, 1, 1)
+    res_c = c['res'] * c['Ar'].view(shp) + c['Br'].view(shp) if affine_res else c['res']
+    oc = F.relu(c['y'] * c['A'].view(shp) + c['B'].view(shp) + res_c)
+    og = ops().bn_add_relu(g['y'], g['A'], g['B'], g['res'], g.get('Ar'), g.get('Br'))
+    assert relerr(og, oc) <= 1e-6
+    r = rnd(9, *shape)
+    (oc * r).sum().backward()
+    (og * r.to(DEV)).sum().backward()
+    for k in vals:
+        assert relerr(g[k].grad, c[k].grad) <= 2e-5, k
+
+
+@pytest.mark.parametrize('act', [0, 1, 2])
+def test_affine_act_and_stats(act):
+    shape = (2, 5, 3, 6, 6)
+    x, A, B = rnd(1, *shape), 1 + 0.2 * rnd(2, 2, 5), 0.2 * rnd(3, 2, 5)
+    c = [v.clone().requires_grad_(True) for v in (x, A, B)]
+    g = [v.clone().to(DEV).requires_grad_(True) for v in (x, A, B)]
+    oc = prologue_ref(c[0], c[1], c[2], act)
+    og = ops().affine_act(g[0], g[1], g[2], act)
+    assert relerr(og, oc) <= 1e-6
+    sg, qg = ops().channel_stats(g[0])
+    sc, qc = stats_ref(c[0])
+    assert relerr(sg, sc) <= 1e-6 and relerr(qg, qc) <= 1e-6
+    r = rnd(9, *shape)
+    ((oc * r).sum() + (sc * 0.3).sum() + (qc * 0.1).sum()).backward()
+    ((og * r.to(DEV)).sum() + (sg * 0.3).sum() + (qg * 0.1).sum()).backward()
+    for a, b in zip(g, c):
+        assert relerr(a.grad, b.grad) <= 2e-5
+
+
+@pytest.mark.parametrize('H,W,OH,OW,pro', [(7, 7, 1, 1, True), (14, 14, 7, 7, False), (16, 16, 7, 7, False),
+                                           (8, 8, 7, 7, True), (7, 7, 7, 7, True), (56, 56, 7, 7, False)])
+def test_pool_hw(H, W, OH, OW, pro):
+    shape = (2, 4, 3, H, W)
+    x = rnd(1, *shape)
+    A = 1 + 0.2 * rnd(2, 2, 4) if pro else None
+    B = 0.2 * rnd(3, 2, 4) if pro else None
+    c = [v.clone().requires_grad_(True) if v is not None else None for v in (x, A, B)]
+    g = [v.clone().to(DEV).requires_grad_(True) if v is not None else None for v in (x, A, B)]
+    oc = F.adaptive_avg_pool3d(prologue_ref(c[0], c[1], c[2], 1), (None, OH, OW))
+    og = ops().pool_hw(g[0], OH, OW, g[1], g[2], 1 if pro else 0)
+    assert relerr(og, oc) <= 2e-6
+    r = rnd(9, *oc.shape)
+    (oc * r).sum().backward()
+    (og * r.to(DEV)).sum().backward()
+    for a, b in zip(g, c):
+        if a is not None:
+            assert relerr(a.grad, b.grad) <= 2e-5
+
+
+def test_film():
+    x, m, cc = rnd(1, 2, 3, 4, 14, 14), rnd(2, 2, 3, 4, 7, 7), rnd(3, 2, 3, 4, 7, 7)
+    c = [v.clone().requires_grad_(True) for v in (x, m, cc)]
+    g = [v.clone().to(DEV).requires_grad_(True) for v in (x, m, cc)]
+    up = lambda v: v.repeat_interleave(2, dim=3).repeat_interleave(2, dim=4)
+    oc = c[0] * up(c[1]) + up(c[2])
+    og = ops().film(g[0], g[1], g[2], 2)
+    assert relerr(og, oc) <= 1e-6
+    r = rnd(9, *oc.shape)
+    (oc * r).sum().backward()
+    (og * r.to(DEV)).sum().backward()
+    for a, b in zip(g, c):
+        assert relerr(a.grad, b.grad) <= 2e-5
+
+
+# ---- Grid Pool / Unpool / Interp1d --------------------------------------------------------------------
+def test_grid_time_index_bit_exact_on_reference_vectors():
+    """indices the reference's grid_sample used (golden, captured from the reference run)"""
+    for name, T in (('gridsample_ulp', 16), ('gridpool_d24_eval', 64), ('gridpool_d24_train', 64),
+                    ('gridpool_d4_eval', 16), ('gridpool_d4_train', 16)):
+        z = load_golden(name)
+        i0, _ = ops().grid_time_index(t(z['cdf']).to(DEV), T)
+        assert torch.equal(i0.cpu(), t(z['i0'])), name
+
+
+def test_grid_time_index_bit_exact_random_sweep():
+    from oracle import x3d_ref as R
+    g = torch.Generator().manual_seed(5)
+    for T in (16, 64, 256, 1000):
+        p = torch.rand(64, 65, generator=g) + 0.05
+        cdf = torch.cumsum((p / p.sum(1, keepdim=True)).double(), 1).float()
+        cdf = torch.cat([torch.zeros(64, 1), cdf], 1)
+        i0c, w1c = R.grid_sample_time_index(cdf, T)
+        i0g, w1g = ops().grid_time_index(cdf.to(DEV), T)
+        assert torch.equal(i0g.cpu(), i0c)
+        assert torch.equal(w1g.cpu(), w1c)
+
+
+def test_time_sample_matches_grid_sample_and_grads():
+    from oracle import x3d_ref as R
+    z = load_golden('gridsample_ulp')
+    x, cdf = t(z['x']), t(z['cdf'])
+    xc, cc = x.clone().requires_grad_(True), cdf.clone().requires_grad_(True)
+    xg, cg = x.clone().to(DEV).requires_grad_(True), cdf.clone().to(DEV).requires_grad_(True)
+    yc = R.grid_pool_resample(xc, cc)
+    yg = ops().time_sample(xg, cg)
+    # 2-tap temporal lerp vs 8-tap trilinear whose h/w coordinates are integers up to 1 ulp: 2e-5 abs
+    assert maxdiff(yg, z['y']) <= 2e-5 and maxdiff(yg, yc) <= 2e-5
+    r = rnd(3, *yc.shape)
+    (yc * r).sum().backward()
+    (yg * r.to(DEV)).sum().backward()
+    assert relerr(xg.grad, xc.grad) <= 2e-5
+    assert relerr(cg.grad, cc.grad) <= 1e-4
+
+
+def test_time_sample_large_plane_vec4():
+    from oracle import x3d_ref as R
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 3, 32, 12, 12, generator=g)
+    p = torch.rand(1, 8, generator=g) + 0.1
+    cdf = torch.cat([torch.zeros(1, 1), torch.cumsum(p / p.sum(), 1)], 1)
+    yc = R.grid_pool_resample(x, cdf)
+    yg = ops().time_sample(x.to(DEV), cdf.to(DEV))
+    assert maxdiff(yg, yc) <= 2e-5
+
+
+@pytest.mark.parametrize('k', [5, 17, 65])
+def test_interp1d_bit_exact(k):
+    z = load_golden('interp1d_k%d' % k)
+    y, ind = ops().interp1d(t(z['x']).to(DEV), t(z['mid']).to(DEV), t(z['mid']).to(DEV))
+    assert torch.equal(ind.cpu(), t(z['ind']))
+    assert torch.equal(y.cpu(), t(z['ynew']))
+    y2, ind2 = ops().interp1d(t(z['x']).to(DEV), t(z['y2']).to(DEV), t(z['q2']).to(DEV))
+    assert torch.equal(ind2.cpu(), t(z['ind2']))
+    assert maxdiff(y2, z['ynew2']) == 0.0
+
+
+def test_interp1d_grads():
+    from oracle import x3d_ref as R
+    z = load_golden('interp1d_k17')
+    vals = [t(z['x']), t(z['y2']), t(z['q2'])]
+    c = [v.clone().requires_grad_(True) for v in vals]
+    g = [v.clone().to(DEV).requires_grad_(True) for v in vals]
+    yc, _ = R.interp1d(*c)
+    yg, _ = ops().interp1d(*g)
+    r = rnd(2, *yc.shape)
+    (yc * r).sum().backward()
+    (yg * r.to(DEV)).sum().backward()
+    for a, b in zip(g, c):
+        assert relerr(a.grad, b.grad) <= 1e-5
+
+
+@pytest.mark.parametrize('shape,L', [((2, 7, 17), 64), ((1, 3, 17, 6, 6), 68), ((1, 2, 5), 16)])
+def test_time_resize(shape, L):
+    x = rnd(1, *shape)
+    xc, xg = x.clone().requires_grad_(True), x.clone().to(DEV).requires_grad_(True)
+    if len(shape) == 3:
+        yc = F.interpolate(xc, L, mode='linear', align_corners=True)
+    else:
+        yc = F.interpolate(xc, (L,) + shape[3:], mode='trilinear', align_corners=True)
+    yg = ops().time_resize(xg, L)
+    assert maxdiff(yg, yc) <= 1e-6
+    r = rnd(2, *yc.shape)
+    (yc * r).sum().backward()
+    (yg * r.to(DEV)).sum().backward()
+    assert relerr(xg.grad, xc.grad) <= 1e-5
+
+
+def test_ops_refuse_cpu_tensors():
+    """the product path has no CPU fallback"""
+    with pytest.raises(RuntimeError):
+        ops().dwconv3d(torch.zeros(1, 2, 2, 7, 7), torch.zeros(2, 1, 3, 3, 3))
