@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/sec (fwd + loss + bwd + SGD step) of x3d_fine X3D-M on synthetic
+1x3x256x224x224 clips, one process per GPU, gradients all-reduced over RCCL.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  ``value`` = clips all ranks processed / max-over-ranks wall time of the K
+timed steps (inputs already resident in HBM).  ``roofline`` is measured live: HIP events bracket every
+launch of the depthwise-conv forward kernels (the headline kernel family) on the stream they
+run on; achieved = algorithmic bytes (N_in + N_out elements x 4 B + weights, per launch) / device time.
+``cpu_baseline`` times the CPU oracle (plain torch fp32, all host cores) on a bounded sample of the same
+workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'coarse-fine-networks_amd')
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch                                     # noqa: E402
+import torch.distributed as dist                 # noqa: E402
+import torch.optim as optim                      # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
+
+
+def cpu_baseline(frames_full, sample_frames=64):
+    """CPU oracle (oracle/x3d_ref.py, stock torch CPU ops) fwd+bwd on one 3 x sample_frames x 224 x 224 clip;
+    cost is linear in T, so clips/s at T=frames_full = (1/t) * sample_frames/frames_full."""
+    from oracle import spec, x3d_ref
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    sd = spec.procedural_fill(spec.fine_keys('M', 157, 1))
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running' not in k:
+            v.requires_grad_(True)
+    x = spec.rand_input(0, (1, 3, sample_frames, 224, 224))
+    t0 = time.time()
+    y = x3d_ref.x3d_fine_forward(sd, x, 'M', training=True)
+    y.square().mean().backward()
+    dt = time.time() - t0
+    return {'value': round((1.0 / dt) * sample_frames / frames_full, 5), 'unit': 'clips/s', 'cores': threads,
+            'kind': 'port',
+            'sample': '1 clip 3x%dx224x224 fwd+bwd fp32 (%.1f s), scaled by %d/%d to T=%d clips'
+                      % (sample_frames, dt, sample_frames, frames_full, frames_full)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--frames', type=int, default=256)
+    ap.add_argument('--batch', type=int, default=1, help='clips per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-frames', type=int, default=64)
+    args = ap.parse_args()
+
+    from cfn_hip import dist as cdist
+    import cfn_hip
+    import train_fine
+    rank, world, dev = cdist.init_from_env()
+    assert torch.cuda.is_available(), 'bench.py measures the HIP path; it needs a GPU'
+    cfn_hip.load()
+
+    torch.manual_seed(0)
+    net = train_fine.build_model(dev, pretrained=None)
+    net.train(True)
+    optimizer = optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-5)
+    reducer = cdist.GradReducer(net.parameters())
+
+    B, T = args.batch, args.frames
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(B, 3, T, 224, 224, generator=g).to(dev)
+    tl = T * 10
+    labels = (torch.rand(B, 157, tl, generator=g) < 0.05).float().to(dev)
+    masks = torch.ones(B, tl, device=dev)
+
+    def step():
+        return train_fine.train_step(net, reducer, optimizer, x, labels, masks)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    cfn_hip.prof_enable('dwconv_fwd', True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    cfn_hip.prof_enable('dwconv_fwd', False)
+    ms, launches, by = cfn_hip.prof_collect('dwconv_fwd')
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+
+    if rank == 0:
+        achieved = (by / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+        out = {
+            'metric': 'clips/sec (fwd+bwd+SGD) x3d_fine X3D-M T=%dx224x224' % T,
+            'value': round(world * B * args.steps / dt, 4),
+            'unit': 'clips/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'x3d_fine X3D-M train step (fwd+loss+bwd+SGD), %dx3x%dx224x224 clips per GPU, '
+                                   'random-init weights' % (B, T),
+                       'clips_per_gpu': B, 'frames': T, 'parallelism': 'dp%d' % world},
+            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'kernel': 'dw3d_kernel<FWD> + dwt5_kernel<FWD> (depthwise conv stack forward)',
+                         'launches': launches, 'avg_launch_ms': round(ms / max(launches, 1), 4),
+                         'algorithmic_bytes_per_step': round(by / max(args.steps, 1))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(T, args.cpu_sample_frames)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

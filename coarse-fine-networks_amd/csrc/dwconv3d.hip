@@ -293,7 +293,8 @@ __global__ __launch_bounds__(512) void dw3d_kernel(const DwArgs a) {
 
     // ---- block reductions -> one fp64 atomic per (channel, value) per block -----------------
     const int key = active ? c_local : -1 - (tid >> 6);
-    const bool head = active && (lane == 0 || __shfl_up(key, 1, 64) != key);
+    const int prev_key = __shfl_up(key, 1, 64);   // all lanes take part in the shuffle
+    const bool head = active && (lane == 0 || prev_key != key);
     if (MODE == DW_WGRAD) {
 #pragma unroll
         for (int j = 0; j < 27; ++j) {

@@ -347,7 +347,7 @@ extern "C" int cfn_pool_hw_fwd(const float* x, const float* A, const float* B, i
                                int W, int OH, int OW, void* stream) {
     CFN_REQUIRE(x && out, "cfn_pool_hw_fwd: null tensor");
     CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pool_hw_fwd: A/B mismatch");
-    CFN_REQUIRE(OH > 0 && OW > 0 && OH <= H && OW <= W, "cfn_pool_hw_fwd: bad output size %dx%d for %dx%d", OH, OW, H, W);
+    CFN_REQUIRE(OH > 0 && OW > 0 && OH <= 64 && OW <= 64, "cfn_pool_hw_fwd: bad output size %dx%d", OH, OW);
     CFN_NC_CHECK(NC);
     hipStream_t st = (hipStream_t)stream;
     const long ovol = (long)T * OH * OW;
@@ -360,7 +360,7 @@ extern "C" int cfn_pool_hw_bwd(const float* gout, const float* x, const float* A
     CFN_REQUIRE(gout && x && gx, "cfn_pool_hw_bwd: null tensor");
     CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pool_hw_bwd: A/B mismatch");
     CFN_REQUIRE(A == nullptr || (gA && gB), "cfn_pool_hw_bwd: prologue needs gA, gB");
-    CFN_REQUIRE(OH > 0 && OW > 0 && OH <= H && OW <= W, "cfn_pool_hw_bwd: bad output size %dx%d for %dx%d", OH, OW, H, W);
+    CFN_REQUIRE(OH > 0 && OW > 0 && OH <= 64 && OW <= 64, "cfn_pool_hw_bwd: bad output size %dx%d", OH, OW);
     CFN_NC_CHECK(NC);
     hipStream_t st = (hipStream_t)stream;
     const long vol = (long)T * H * W;

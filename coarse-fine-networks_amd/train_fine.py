@@ -1,0 +1,205 @@
+"""train_fine -- entry point #1 of the reference (train_fine.py) on the MI355X engine.
+
+    python train_fine.py -gpu 0,1,...            one process per listed GPU is spawned (RCCL all-reduce)
+    torchrun --nproc-per-node N train_fine.py    same thing under an external launcher
+
+Same ``run()`` keyword arguments, loss, optimiser, LR schedule, phase pattern and checkpoint dict as the
+reference (train_fine.py:56-263).  The Charades JPEG pipeline is out of scope: batches come
+from ``SyntheticCharades`` which yields the same structures and shapes ``mt_collate_fn`` produces
+(charades_fine.py:201-224); plug a real loader in through ``run(dataloaders=...)``.
+
+DataParallel -> one-process-per-GPU differences that are handled explicitly:
+  * the loc-loss normaliser sum(masks) is taken over the GLOBAL batch (all-reduced scalar);
+  * BN statistics stay per replica; rank 0's running stats are broadcast before eval / checkpoints;
+  * short last batches are skipped as in the reference (train_fine.py:180-181).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+import torch.optim as optim
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import x3d_fine                                   # noqa: E402
+from cfn_hip import dist as cdist                 # noqa: E402
+from apmeter import APMeter                       # noqa: E402
+
+BS = 8
+BS_UPSCALE = 1
+INIT_LR = 0.01 * BS_UPSCALE
+X3D_VERSION = 'M'
+CHARADES_TR_SIZE = 7900
+CHARADES_VAL_SIZE = 1850
+NUM_CLASSES = 157
+
+
+class SyntheticCharades(object):
+    """Iterable of collated batches shaped like the reference loader's output for task='loc':
+    inputs (B,1,3,T,H,W) fp32, labels (B,157,TL) in {0,1}, masks (B,TL), names."""
+
+    def __init__(self, batch_size, iters, frames=64, crop=224, stride=10, seed=0, device='cpu', label_p=0.05):
+        self.bs, self.iters, self.T, self.crop, self.stride = batch_size, iters, frames, crop, stride
+        self.seed, self.device, self.p = seed, device, label_p
+
+    def __len__(self):
+        return self.iters
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed)
+        tl = self.T * self.stride
+        for i in range(self.iters):
+            x = torch.randn(self.bs, 1, 3, self.T, self.crop, self.crop, generator=g)
+            labels = (torch.rand(self.bs, NUM_CLASSES, tl, generator=g) < self.p).float()
+            masks = torch.ones(self.bs, tl)
+            yield x, labels, masks, ['synthetic_%d' % i] * self.bs
+
+
+def detection_loss(per_frame_logits, labels, masks, align_corners=True, group=None):
+    """cls + loc loss of train_fine.py:199-213 for one rank's shard.
+
+    ``loc_loss`` is normalised by the GLOBAL sum(masks) and multiplied by the world size, so that the
+    average of the ranks' gradients equals the gradient of the reference's gathered-batch loss."""
+    tl = labels.size(2)
+    logits = F.interpolate(per_frame_logits, tl, mode='linear', align_corners=align_corners)
+    probs = torch.sigmoid(logits) * masks.unsqueeze(1)
+    cls_loss = F.binary_cross_entropy(torch.max(probs, dim=2)[0], torch.max(labels, dim=2)[0])
+    world = torch.distributed.get_world_size(group) if torch.distributed.is_initialized() else 1
+    norm = cdist.global_mask_count(masks, group) * labels.shape[1]
+    loc_loss = F.binary_cross_entropy(probs, labels, reduction='sum') / norm * world
+    return cls_loss, loc_loss, probs
+
+
+def lr_warmup(init_lr, cur_steps, warmup_steps, opt):
+    start_after = 1
+    if cur_steps < warmup_steps and cur_steps > start_after:
+        lr_scale = min(1., float(cur_steps + 1) / warmup_steps)
+        for pg in opt.param_groups:
+            pg['lr'] = lr_scale * init_lr
+
+
+def build_model(device, n_classes=NUM_CLASSES, pretrained=None, dropout=0.5):
+    net = x3d_fine.generate_model(x3d_version=X3D_VERSION, n_classes=400, n_input_channels=3, task='loc',
+                                  dropout=dropout, base_bn_splits=1, t_downsample=False, extract_feat=False)
+    if pretrained and os.path.exists(pretrained):      # partial state.update as train_fine.py:104-107
+        ckpt = torch.load(pretrained, map_location='cpu')
+        state = net.state_dict()
+        state.update(ckpt['model_state_dict'])
+        net.load_state_dict(state)
+    net.replace_logits(n_classes)
+    return net.to(device)
+
+
+def train_step(net, reducer, optimizer, inputs, labels, masks, gamma_tau=5):
+    """one optimisation step on this rank's shard; returns (cls_loss, loc_loss, probs)"""
+    masks_clip = masks[:, ::gamma_tau * 2]
+    logits = net([inputs, masks_clip])
+    cls_loss, loc_loss, probs = detection_loss(logits, labels, masks, True)
+    loss = (cls_loss + loc_loss) / 2
+    loss.backward()
+    reducer.finish()
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    return cls_loss.detach(), loc_loss.detach(), probs.detach()
+
+
+def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, train_split=None,
+        batch_size=BS * BS_UPSCALE, frames=80 * 4, dataloaders=None, max_steps=None, save_model='models/fine_charades_',
+        pretrained='models/x3d_multigrid_kinetics_fb_pretrained.pt', log=print):
+    rank, world, dev = cdist.init_from_env()
+    gamma_tau = {'S': 6, 'M': 5, 'XL': 5}[X3D_VERSION]
+    crop = {'S': 160, 'M': 224, 'XL': 312}[X3D_VERSION]
+    clip_frames = frames * 2 // (gamma_tau * 2)          # 640-frame window at stride 10 -> 64 frames
+    local_bs = max(batch_size // world, 1)
+    iters = CHARADES_TR_SIZE // batch_size
+    val_bs = max(batch_size // 2 // world, 1)
+    val_iters = CHARADES_VAL_SIZE // max(batch_size // 2, 1)
+    if dataloaders is None:
+        dataloaders = {'train': SyntheticCharades(local_bs, iters, clip_frames, crop, gamma_tau * 2, seed=rank),
+                       'val': SyntheticCharades(val_bs, val_iters, clip_frames, crop, gamma_tau * 2, seed=1000 + rank)}
+    net = build_model(dev, pretrained=pretrained)
+    optimizer = optim.SGD(net.parameters(), lr=init_lr, momentum=0.9, weight_decay=1e-5)
+    lr_sched = optim.lr_scheduler.MultiStepLR(optimizer, [15, 20, 25])
+    reducer = cdist.GradReducer(net.parameters())
+    tr_apm, val_apm = APMeter(), APMeter()
+    steps, epochs = 0, 0
+    while epochs < max_epochs:
+        for phase in 4 * ['train'] + ['val']:
+            train = phase == 'train'
+            net.train(train)
+            if train:
+                epochs += 1
+            else:
+                cdist.broadcast_buffers(net)
+                net.aggregate_sub_bn_stats()
+            tot_loc = tot_cls = 0.0
+            n_it = 0
+            for inputs, labels, masks, _name in dataloaders[phase]:
+                want = local_bs if train else val_bs
+                if inputs.shape[0] != want:
+                    continue
+                b, n = inputs.shape[:2]
+                inputs = inputs.view((b * n,) + tuple(inputs.shape[2:])).to(dev, non_blocking=True)
+                labels, masks = labels.to(dev), masks.to(dev)
+                valid_t = masks.sum(1).int()
+                n_it += 1
+                if train:
+                    cls_loss, loc_loss, probs = train_step(net, reducer, optimizer, inputs, labels, masks, gamma_tau)
+                    lr_warmup(init_lr, steps, warmup_steps, optimizer)
+                    steps += 1
+                    apm = tr_apm
+                else:
+                    with torch.no_grad():
+                        logits = net([inputs, masks[:, ::gamma_tau * 2]])
+                        cls_loss, loc_loss, probs = detection_loss(logits, labels, masks, True)
+                    apm = val_apm
+                tot_cls += float(cls_loss)
+                tot_loc += float(loc_loss)
+                for i in range(labels.shape[0]):
+                    v = int(valid_t[i])
+                    apm.add(probs[i][:, :v].transpose(0, 1).cpu().numpy(), labels[i][:, :v].transpose(0, 1).cpu().numpy())
+                if train and steps % max(iters // 2, 1) == 0 and rank == 0:
+                    log(' Epoch:{} {} steps: {} Loc Loss: {:.4f} Cls Loss: {:.4f} mAP: {:.4f}'.format(
+                        epochs, phase, steps, tot_loc / n_it, tot_cls / n_it, float(np.mean(tr_apm.value()))))
+                    tr_apm.reset()
+                if train and steps % 1000 == 0 and rank == 0:
+                    os.makedirs(os.path.dirname(save_model) or '.', exist_ok=True)
+                    torch.save({'model_state_dict': net.state_dict(), 'optimizer_state_dict': optimizer.state_dict(),
+                                'scheduler_state_dict': lr_sched.state_dict()}, save_model + str(steps).zfill(6) + '.pt')
+                if max_steps is not None and steps >= max_steps:
+                    return net
+            if not train:
+                if rank == 0:
+                    log(' Epoch:{} val Loc Loss: {:.4f} Cls Loss: {:.4f} mAP: {:.4f}'.format(
+                        epochs, tot_loc / max(n_it, 1), tot_cls / max(n_it, 1), float(np.mean(val_apm.value()))))
+                val_apm.reset()
+                lr_sched.step()
+    return net
+
+
+def _spawn(gpus, argv):
+    """`-gpu 0,1,2` -> one worker process per GPU (what nn.DataParallel did with threads)."""
+    import subprocess
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES=gpus, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    n = len(gpus.split(','))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', os.environ.get('MASTER_PORT', '29511'),
+           os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser()
+    parser.add_argument('-gpu', default='0', type=str)
+    parser.add_argument('--max-steps', type=int, default=None)
+    parser.add_argument('--batch-size', type=int, default=BS * BS_UPSCALE)
+    args = parser.parse_args()
+    if 'RANK' not in os.environ and len(args.gpu.split(',')) > 1:
+        sys.exit(_spawn(args.gpu, ['--batch-size', str(args.batch_size)] +
+                        (['--max-steps', str(args.max_steps)] if args.max_steps else [])))
+    if 'RANK' not in os.environ:
+        os.environ['CUDA_VISIBLE_DEVICES'] = args.gpu
+    run(batch_size=args.batch_size, max_steps=args.max_steps)

@@ -249,3 +249,15 @@ def test_coarse_train_fwd_bwd():
     for k in ('g_fc2_bias', 'g_rw6_at2_weight', 'g_mix5_conv_at2_weight'):
         name = [n for n in gn if ('g_' + n.replace('.', '_')) == k][0]
         assert relerr(thin(sd[name].grad), z[k]) <= 1e-4, k
+
+
+def test_product_apmeter_matches_reference():
+    """coarse-fine-networks_amd/apmeter.py (host-side metric) against the reference's APMeter output"""
+    from apmeter import APMeter
+    z = load_golden('loss_ap')
+    m = APMeter()
+    for i in range(3):
+        m.add(z['ap_scores'][20 * i:20 * i + 20], z['ap_targets'][20 * i:20 * i + 20])
+    assert np.abs(m.value().numpy() - z['ap']).max() <= 1e-6
+    m.reset()
+    assert m.value() == 0
