@@ -38,6 +38,8 @@ def header_prototypes(path=HEADER):
                     at.append(ctypes.c_void_p)
                 elif a.startswith('long'):
                     at.append(ctypes.c_long)
+                elif a.startswith('double'):
+                    at.append(ctypes.c_double)
                 elif a.startswith('int'):
                     at.append(ctypes.c_int)
                 else:

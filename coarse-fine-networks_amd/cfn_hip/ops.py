@@ -194,6 +194,68 @@ def stem_conv(x, w):
     return _StemConv.apply(x, w)
 
 
+class _BnFold(Function):
+    """(sum, sumsq) of a conv output -> per-(n,c) prologue (A, B); optional fused SE gate.  cfn_bn_fold_*."""
+
+    @staticmethod
+    def forward(ctx, s, q, gamma, beta, w1, b1, w2, b2, bufs, cfg):
+        training, N, C, S, count, eps, momentum, pool_count = cfg
+        run_mean, run_var, nbt = bufs
+        dev = run_mean.device
+        Wd = w1.shape[0] if w1 is not None else 0
+        Se = S if training else 1
+        A = torch.empty(N, C, dtype=torch.float32, device=dev)
+        B = torch.empty_like(A)
+        mean = torch.empty(Se, C, dtype=torch.float64, device=dev)
+        rstd = torch.empty_like(mean)
+        A0 = B0 = gate = hbuf = pooled = None
+        w1c = w2c = None
+        if Wd:
+            A0, B0, gate, pooled = (torch.empty_like(A) for _ in range(4))
+            hbuf = torch.empty(N, Wd, dtype=torch.float32, device=dev)
+            w1c, w2c = w1.reshape(Wd, C).contiguous(), w2.reshape(C, Wd).contiguous()
+        s, q = _opt(s), _opt(q)
+        call('cfn_bn_fold_fwd', s, q, gamma, beta, run_mean, run_var, nbt if training else None, int(training), N, C, S,
+             float(count), float(eps), float(momentum), w1c, b1, w2c, b2, Wd, float(pool_count), A, B, mean, rstd,
+             A0, B0, gate, hbuf, pooled)
+        ctx.save_for_backward(s, gamma, mean, rstd, A0, B0, gate, hbuf, pooled, w1c, w2c)
+        ctx.cfg = (training, N, C, S, Wd, count, pool_count, None if w1 is None else tuple(w1.shape),
+                   None if w2 is None else tuple(w2.shape))
+        return A, B
+
+    @staticmethod
+    def backward(ctx, gA, gB):
+        s, gamma, mean, rstd, A0, B0, gate, hbuf, pooled, w1c, w2c = ctx.saved_tensors
+        training, N, C, S, Wd, count, pool_count, w1s, w2s = ctx.cfg
+        dev = mean.device
+        gA = torch.zeros(N, C, device=dev) if gA is None else gA.contiguous()
+        gB = torch.zeros(N, C, device=dev) if gB is None else gB.contiguous()
+        gs = gq = None
+        if training:
+            gs = torch.empty(N, C, dtype=torch.float64, device=dev)
+            gq = torch.empty_like(gs)
+        gg = gbt = None
+        if gamma is not None:
+            gg, gbt = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        gw1 = gb1 = gw2 = gb2 = tA = tB = None
+        if Wd:
+            gw1, gb1 = torch.zeros(Wd, C, device=dev), torch.zeros(Wd, device=dev)
+            gw2, gb2 = torch.zeros(C, Wd, device=dev), torch.zeros(C, device=dev)
+            tA, tB = torch.empty(N, C, device=dev), torch.empty(N, C, device=dev)
+        call('cfn_bn_fold_bwd', gA, gB, s, gamma, mean, rstd, A0, B0, gate, hbuf, pooled, w1c, w2c, int(training), N, C, S,
+             Wd, float(count), float(pool_count), gs, gq, gg, gbt, gw1, gb1, gw2, gb2, tA, tB)
+        if Wd:
+            gw1, gw2 = gw1.view(w1s), gw2.view(w2s)
+        return gs, gq, gg, gbt, gw1, gb1, gw2, gb2, None, None
+
+
+def bn_fold(s, q, gamma, beta, bufs, training, N, C, S, count, eps, momentum, se=None, pool_count=1.0):
+    """bufs = (running_mean, running_var, num_batches_tracked) of split_bn (training) or bn (eval);
+    se = (fc1.weight, fc1.bias, fc2.weight, fc2.bias) or None."""
+    w1, b1, w2, b2 = se if se is not None else (None, None, None, None)
+    return _BnFold.apply(s, q, gamma, beta, w1, b1, w2, b2, bufs, (training, N, C, S, count, eps, momentum, pool_count))
+
+
 class _BnAddRelu(Function):
     """out = relu(A*y + B + (Ar*res + Br)); Ar/Br None = plain residual."""
 

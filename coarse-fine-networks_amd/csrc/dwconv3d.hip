@@ -316,64 +316,101 @@ __global__ __launch_bounds__(512) void dw3d_kernel(const DwArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// stride-2 data gradient (4 of the 26 layers): gather form, one thread per input element.
+// stride-2 data gradient (first block of every stage).  A thread owns one position (i,j) of the
+// (Ho x Wo) gradient plane = the 2x2 input block (2i..2i+1, 2j..2j+1) and marches along t holding
+// the 2x2 neighbourhood g'[f][i..i+1][j..j+1] of three consecutive gradient frames in registers,
+// so every gradient element is fetched once per thread (neighbours come from L1), x is read once
+// and gx written once with 8-byte accesses.  Tap parity: even input row <- kh=1 only, odd row <-
+// kh in {0,2}; same along w  =>  27 FMAs per 2x2 block per frame.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const float* __restrict__ gy, const float* __restrict__ y,
-                                                            const double* __restrict__ gs, const double* __restrict__ gq,
-                                                            const float* __restrict__ w, const float* __restrict__ x,
-                                                            const float* __restrict__ A, const float* __restrict__ B, int act,
-                                                            float* __restrict__ gx, double* __restrict__ gA, double* __restrict__ gB,
-                                                            int C, int T, int Hi, int Wi, int Ho, int Wo) {
-    // grid: (ceil(Hi*Wi/256), T, N*C)
-    const int nc = blockIdx.z, t = blockIdx.y, c = nc % C;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const bool ok = p < Hi * Wi;
-    const int h = ok ? p / Wi : 0, wq = ok ? p - h * Wi : 0;
-    const float gsv = gs ? (float)gs[nc] : 0.0f;
-    const float gqv = (gq && y) ? 2.0f * (float)gq[nc] : 0.0f;
-    float da = 0.0f;
-    if (ok) {
+struct DwS2Args {
+    const float* gy; const float* y; const double* gs; const double* gq; const float* w;
+    const float* x; const float* A; const float* B; float* gx; double* gA; double* gB;
+    int C, T, Hi, Wi, Ho, Wo, act, TT, nchunks, pblocks;
+};
+
+__global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
+    __shared__ float sh[8];
+    const int nc = blockIdx.y, c = nc % a.C;
+    const int chunk = blockIdx.x % a.nchunks, pb = blockIdx.x / a.nchunks;
+    const int p = pb * 256 + threadIdx.x;
+    const int Ho = a.Ho, Wo = a.Wo, Hi = a.Hi, Wi = a.Wi, T = a.T;
+    const bool ok = p < Ho * Wo;
+    const int i = ok ? p / Wo : 0, j = ok ? p - i * Wo : 0;
+    const bool i1 = i + 1 < Ho, j1 = j + 1 < Wo;              // neighbours inside the gradient plane
+    const bool r1 = 2 * i + 1 < Hi, c1 = 2 * j + 1 < Wi;      // odd row / column inside the input plane
+    const float gsv = a.gs ? (float)a.gs[nc] : 0.0f;
+    const float gqv = (a.gq && a.y) ? 2.0f * (float)a.gq[nc] : 0.0f;
+    float w[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) w[k] = a.w[c * 27 + k];
+    const float pa = a.A ? a.A[nc] : 1.0f, pb2 = a.A ? a.B[nc] : 0.0f;
+    const long po = (long)Ho * Wo, pi = (long)Hi * Wi;
+    const float* gyb = a.gy + (long)nc * T * po + (long)i * Wo + j;
+    const float* yb = a.y ? a.y + (long)nc * T * po + (long)i * Wo + j : nullptr;
+
+    auto ldg = [&](int f, float (&g)[4]) {     // g'[f] at (i,j) (i,j+1) (i+1,j) (i+1,j+1), zero outside
+        g[0] = g[1] = g[2] = g[3] = 0.0f;
+        if (ok && f >= 0 && f < T) {
+            const long o = (long)f * po;
+            g[0] = gyb[o] + gsv;
+            if (j1) g[1] = gyb[o + 1] + gsv;
+            if (i1) g[2] = gyb[o + Wo] + gsv;
+            if (i1 && j1) g[3] = gyb[o + Wo + 1] + gsv;
+            if (yb) {
+                g[0] = fmaf(yb[o], gqv, g[0]);
+                if (j1) g[1] = fmaf(yb[o + 1], gqv, g[1]);
+                if (i1) g[2] = fmaf(yb[o + Wo], gqv, g[2]);
+                if (i1 && j1) g[3] = fmaf(yb[o + Wo + 1], gqv, g[3]);
+            }
+        }
+    };
+    const int t0 = chunk * a.TT, t1 = min(t0 + a.TT, T);
+    float G[3][4];
+    ldg(t0 - 1, G[1]);
+    ldg(t0, G[2]);
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int t = t0; t < t1; ++t) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { G[0][k] = G[1][k]; G[1][k] = G[2][k]; }
+        ldg(t + 1, G[2]);
+        // gx[t] = sum_kt W[kt] * g'[t+1-kt]  -> frame slot 2-kt
+        float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+#pragma unroll
         for (int kt = 0; kt < 3; ++kt) {
-            const int to = t + 1 - kt;
-            if (to < 0 || to >= T) continue;
-            for (int kh = 0; kh < 3; ++kh) {
-                const int hh = h + 1 - kh;
-                if (hh < 0 || (hh & 1)) continue;
-                const int oh = hh >> 1;
-                if (oh >= Ho) continue;
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int ww = wq + 1 - kw;
-                    if (ww < 0 || (ww & 1)) continue;
-                    const int ow = ww >> 1;
-                    if (ow >= Wo) continue;
-                    const long o = (((long)nc * T + to) * Ho + oh) * Wo + ow;
-                    float g = gy[o] + gsv;
-                    if (y) g = fmaf(y[o], gqv, g);
-                    da = fmaf(w[c * 27 + kt * 9 + kh * 3 + kw], g, da);
+            const float* g = G[2 - kt];
+            const float* wk = w + kt * 9;
+            o00 = fmaf(wk[4], g[0], o00);                                          // kh=1,kw=1
+            o01 = fmaf(wk[3], g[1], fmaf(wk[5], g[0], o01));                       // kh=1; kw=0 -> j+1, kw=2 -> j
+            o10 = fmaf(wk[1], g[2], fmaf(wk[7], g[0], o10));                       // kw=1; kh=0 -> i+1, kh=2 -> i
+            o11 = fmaf(wk[0], g[3], fmaf(wk[2], g[2], fmaf(wk[6], g[1], fmaf(wk[8], g[0], o11))));
+        }
+        if (ok) {
+            const long o = ((long)nc * T + t) * pi + (long)(2 * i) * Wi + 2 * j;
+            float v[4] = {o00, o01, o10, o11};
+            const bool in[4] = {true, c1, r1, r1 && c1};
+            const long off[4] = {0, 1, Wi, (long)Wi + 1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!in[k]) continue;
+                if (a.A) {
+                    const float xv = a.x[o + off[k]];
+                    const float dz = v[k] * cfn_act_grad_rt(fmaf(xv, pa, pb2), a.act);
+                    s1 = fmaf(dz, xv, s1);
+                    s2 += dz;
+                    v[k] = dz * pa;
                 }
+                a.gx[o + off[k]] = v[k];
             }
         }
     }
-    float s1 = 0.0f, s2 = 0.0f;
-    if (ok) {
-        const long o = ((long)nc * T + t) * Hi * Wi + p;
-        if (A) {
-            const float xa = A[nc], xb = B[nc], xv = x[o];
-            const float dz = da * cfn_act_grad_rt(fmaf(xv, xa, xb), act);
-            s1 = dz * xv; s2 = dz;
-            gx[o] = dz * xa;
-        } else {
-            gx[o] = da;
-        }
-    }
-    if (A && gA) {
+    if (a.A && a.gA) {
         s1 = cfn_wave_sum(s1); s2 = cfn_wave_sum(s2);
-        __shared__ float r1[4], r2[4];
-        if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+        if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s1; sh[4 + (threadIdx.x >> 6)] = s2; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            atomicAdd(&gA[nc], (double)(r1[0] + r1[1] + r1[2] + r1[3]));
-            atomicAdd(&gB[nc], (double)(r2[0] + r2[1] + r2[2] + r2[3]));
+            atomicAdd(&a.gA[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
+            atomicAdd(&a.gB[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
         }
     }
 }
@@ -503,10 +540,16 @@ extern "C" int cfn_dwconv3d_bwd_data(const float* gy, const float* y, const doub
     const int Ho = (Hi + 2 - 3) / stride + 1, Wo = (Wi + 2 - 3) / stride + 1;
     CfnProfScope prof(CFN_K_DWCONV_BWD, st, 4.0 * N * C * T * ((double)Hi * Wi * (A ? 2 : 1) + (double)Ho * Wo * (y ? 2 : 1)));
     if (stride == 2) {
-        dim3 grid(cfn_cdiv((long)Hi * Wi, 256), T, N * C);
-        CFN_REQUIRE((long)N * C <= 65535 && T <= 65535, "cfn_dwconv3d_bwd_data: grid too large");
-        hipLaunchKernelGGL(dw3d_dgrad_s2_kernel, grid, dim3(256), 0, st, gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB,
-                           C, T, Hi, Wi, Ho, Wo);
+        DwS2Args a = {};
+        a.gy = gy; a.y = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.w = w; a.x = x; a.A = A; a.B = B; a.gx = gx;
+        a.gA = gA; a.gB = gB; a.C = C; a.T = T; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.act = act;
+        CFN_REQUIRE((long)N * C <= 65535, "cfn_dwconv3d_bwd_data: N*C exceeds grid.y");
+        a.pblocks = cfn_cdiv((long)Ho * Wo, 256);
+        int TT = 64;
+        while (TT > 8 && (long)N * C * a.pblocks * cfn_cdiv(T, TT) < 2048) TT >>= 1;
+        a.TT = TT > T ? T : TT;
+        a.nchunks = cfn_cdiv(T, a.TT);
+        hipLaunchKernelGGL(dw3d_dgrad_s2_kernel, dim3(a.pblocks * a.nchunks, N * C), dim3(256), 0, st, a);
         return cfn_check_launch("dwconv3d_bwd_data_s2");
     }
     DwArgs a = {};

@@ -38,7 +38,7 @@ struct PwArgs {
     double* s2;          // FWD: sum(y^2)                 DGRAD: sum(dz)
     int N, M, K, Q, Pin, Hi, Wi, Ho, Wo, stride, act;
     int Cin;             // row pitch of w
-    int mtiles, nstrips, tpb, resident, Kpad;
+    int mtiles, nstrips, tpb, kres, Kpad;   // kres: weight rows resident in LDS per pass (multiple of 8)
     int stem, Cimg;      // stem != 0: B operand is the im2col view of a (N,Cimg,T,Hi,Wi) clip for a 1x3x3 stride-2 pad-1 conv
 };
 
@@ -50,12 +50,24 @@ __device__ __forceinline__ int pw_pmap(int q, int Ho, int Wo, int Hi, int Wi, in
     return (t * Hi + oh * stride) * Wi + ow * stride;
 }
 
-template <int MT, int MODE, bool STATS>
+#define PW_UNIT 8        // input channels per pipelined unit (4 MFMA k-steps)
+#define PW_KRES_MAX 512  // weight rows kept in LDS at once (K > 512 streams the weights in chunks)
+
+__device__ __forceinline__ float pw_bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+// One workgroup = 4 waves = a strip of `tpb` tiles of 128 positions x BM = 32*MT output rows.  The inner
+// loop is branch-free: a unit of 8 input channels = 4 buffer loads per lane (SGPR row offset, one VGPR
+// position offset, out-of-range rows read as 0 through the buffer bounds check) whose successors are
+// already in flight while the 4*MT MFMAs of the current unit issue.
+template <int MT, int MODE, bool STATS, int ACT, bool STEM>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BM = 32 * MT;
+    constexpr int NU = PW_UNIT / 2;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
-    const int K = a.K, M = a.M, Q = a.Q, Kpad = a.Kpad;
+    const int K = a.K, M = a.M, Q = a.Q, Kpad = a.Kpad, kres = a.kres;
 
     unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
     const int mtile = L % a.mtiles; L /= a.mtiles;
@@ -63,30 +75,29 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
     const int n = L / a.nstrips;
     const int m0 = mtile * BM;
 
-    const int as_rows = a.resident ? Kpad : PW_KC;
-    float* As = smem;                         // [as_rows][BM]
-    float* sPA = As + as_rows * BM;           // [Kpad]
-    float* sPB = sPA + Kpad;                  // [Kpad]
-    float* sEA = sPB + Kpad;                  // [BM]
-    float* sEB = sEA + BM;                    // [BM]
-    float* sSt = sEB + BM;                    // [BM][2]
-    float* red = sSt + 2 * BM + wave * (32 * PW_RED_PITCH);   // per wave [32][33]
+    float* As = smem;                                     // [kres][BM]
+    float2* sP = reinterpret_cast<float2*>(As + kres * BM);   // [Kpad + PW_UNIT] prologue coefficients
+    float2* sE = sP + Kpad + PW_UNIT;                     // [BM] epilogue coefficients (DGRAD)
+    float* sSt = reinterpret_cast<float*>(sE + BM);       // [BM][2]
+    float* red = sSt + 2 * BM + wave * (32 * PW_RED_PITCH);
 
-    for (int k = tid; k < Kpad; k += 256) {
-        float va, vb;
+    for (int k = tid; k < Kpad + PW_UNIT; k += 256) {
+        float2 c;
         if (MODE == PW_FWD) {
-            va = (k < K && a.pa) ? a.pa[(long)n * K + k] : 1.0f;
-            vb = (k < K && a.pb) ? a.pb[(long)n * K + k] : 0.0f;
+            c.x = (k < K && a.pa) ? a.pa[(long)n * K + k] : 1.0f;
+            c.y = (k < K && a.pb) ? a.pb[(long)n * K + k] : 0.0f;
         } else {
-            va = (k < K && a.gs) ? (float)a.gs[(long)n * K + k] : 0.0f;
-            vb = (k < K && a.gq && a.src2) ? 2.0f * (float)a.gq[(long)n * K + k] : 0.0f;
+            c.x = (k < K && a.gs) ? (float)a.gs[(long)n * K + k] : 0.0f;
+            c.y = (k < K && a.gq && a.src2) ? 2.0f * (float)a.gq[(long)n * K + k] : 0.0f;
         }
-        sPA[k] = va; sPB[k] = vb;
+        sP[k] = c;
     }
     for (int m = tid; m < BM; m += 256) {
         const bool ok = (m0 + m) < M && MODE == PW_DGRAD && a.ea;
-        sEA[m] = ok ? a.ea[(long)n * M + m0 + m] : 1.0f;
-        sEB[m] = ok ? a.eb[(long)n * M + m0 + m] : 0.0f;
+        float2 c;
+        c.x = ok ? a.ea[(long)n * M + m0 + m] : 1.0f;
+        c.y = ok ? a.eb[(long)n * M + m0 + m] : 0.0f;
+        sE[m] = c;
         sSt[2 * m] = 0.0f; sSt[2 * m + 1] = 0.0f;
     }
     auto load_w = [&](int kbase, int rows) {   // As[kk][m] = Wm[m0+m][kbase+kk], zero padded
@@ -98,14 +109,23 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
             As[e] = v;
         }
     };
-    if (a.resident) load_w(0, Kpad);
+    const bool resident = kres >= Kpad;
+    if (resident) load_w(0, Kpad);
     __syncthreads();
 
     const bool two_src = MODE == PW_DGRAD && a.src2 != nullptr;
-    const long src_n = a.stem ? (long)n * a.Cimg * a.Pin : (long)n * K * (MODE == PW_FWD ? a.Pin : Q);
-    const long dst_n = (long)n * M * (MODE == PW_FWD ? Q : a.Pin);
     const int src_pitch = MODE == PW_FWD ? a.Pin : Q;
     const int dst_pitch = MODE == PW_FWD ? Q : a.Pin;
+    const long src_n = STEM ? (long)n * a.Cimg * a.Pin : (long)n * K * src_pitch;
+    const long dst_n = (long)n * M * dst_pitch;
+    const int row_bytes = src_pitch * 4;
+    __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src + src_n), 0,
+                                                                   STEM ? 0 : K * row_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((two_src ? a.src2 : a.src) + src_n), 0,
+                                                                   STEM ? 0 : K * row_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.dst + dst_n, 0, M * dst_pitch * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((a.ex ? a.ex : a.src) + (a.ex ? dst_n : 0)), 0,
+                                                                   a.ex ? M * dst_pitch * 4 : 0, 0x00020000);
     float sacc[MT], qacc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) { sacc[i] = 0.0f; qacc[i] = 0.0f; }
@@ -119,8 +139,33 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
         const int pm = pw_pmap(qc, a.Ho, a.Wo, a.Hi, a.Wi, a.stride);
         const int in_pos = MODE == PW_FWD ? pm : qc;
         const int out_pos = MODE == PW_FWD ? qc : pm;
-        const float* bp = a.src + src_n + in_pos;
-        const float* bp2 = two_src ? a.src2 + src_n + in_pos : nullptr;
+        const int voff = (half * src_pitch + in_pos) * 4;
+        // stem: im2col coordinates of this lane's output position
+        int s_oh = 0, s_ow = 0;
+        const float* s_base = nullptr;
+        if (STEM) {
+            const int hw = a.Ho * a.Wo;
+            const int tq = qc / hw, rq = qc - tq * hw;
+            s_oh = rq / a.Wo; s_ow = rq - s_oh * a.Wo;
+            s_base = a.src + src_n + (long)tq * a.Hi * a.Wi;
+        }
+        auto bload = [&](int k0, float (&d)[NU], float (&d2)[NU]) {   // rows k0 + 2j + half, j < NU
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                if (STEM) {
+                    const int k = k0 + 2 * j + half;
+                    const int ci = k / 9, kr = k - ci * 9, kh = kr / 3, kw = kr - kh * 3;
+                    const int ih = s_oh * 2 + kh - 1, iw = s_ow * 2 + kw - 1;
+                    const bool inb = k < K && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+                    const int ihc = min(max(ih, 0), a.Hi - 1), iwc = min(max(iw, 0), a.Wi - 1), cic = min(ci, a.Cimg - 1);
+                    const float v = s_base[(long)cic * a.Pin + (long)ihc * a.Wi + iwc];
+                    d[j] = inb ? v : 0.0f;
+                } else {
+                    d[j] = pw_bload(r1, voff, (k0 + 2 * j) * row_bytes);
+                    if (MODE == PW_DGRAD) d2[j] = two_src ? pw_bload(r2, voff, (k0 + 2 * j) * row_bytes) : 0.0f;
+                }
+            }
+        };
 
         f16v acc[MT];
 #pragma unroll
@@ -128,95 +173,73 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-        for (int kc = 0; kc < Kpad; kc += PW_KC) {
-            const int kcount = min(PW_KC, Kpad - kc);   // even
-            if (!a.resident) {
+        for (int kc0 = 0; kc0 < Kpad; kc0 += kres) {
+            const int rows = min(kres, Kpad - kc0);
+            if (!resident) {
                 __syncthreads();
-                load_w(kc, PW_KC);
+                load_w(kc0, rows);
                 __syncthreads();
             }
-            float bv[PW_KC / 2], bv2[PW_KC / 2];
-            if (MODE == PW_FWD && a.stem) {   // im2col gather: k -> (ci, kh, kw), zero outside the image
-                const int hw = a.Ho * a.Wo;
-                const int tq = qc / hw, rq = qc - tq * hw;
-                const int oh = rq / a.Wo, ow = rq - oh * a.Wo;
-                const float* sp = a.src + src_n + (long)tq * a.Hi * a.Wi;
+            float cur[NU], cur2[NU], nxt[NU], nxt2[NU];
+            bload(kc0, cur, cur2);
+            for (int u = 0; u < rows; u += PW_UNIT) {
+                bload(kc0 + u + PW_UNIT, nxt, nxt2);       // one unit ahead; past the end reads 0 (bounds check)
+                __builtin_amdgcn_sched_barrier(0);         // keep the prefetch in front of this unit's MFMAs
 #pragma unroll
-                for (int s = 0; s < PW_KC / 2; ++s) {
-                    const int k = kc + 2 * s + half;
-                    if (2 * s < kcount) {
-                        const int ci = k / 9, kr = k - ci * 9, kh = kr / 3, kw = kr - kh * 3;
-                        const int ih = oh * 2 + kh - 1, iw = ow * 2 + kw - 1;
-                        const bool inb = k < K && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
-                        bv[s] = inb ? sp[(long)ci * a.Pin + (long)ih * a.Wi + iw] : 0.0f;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < PW_KC / 2; ++s) {
-                    const int k = kc + 2 * s + half;
-                    const int kq = k < K ? k : K - 1;
-                    if (2 * s < kcount) {
-                        bv[s] = bp[(long)kq * src_pitch];
-                        if (MODE == PW_DGRAD && two_src) bv2[s] = bp2[(long)kq * src_pitch];
-                    }
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < PW_KC / 2; ++s) {
-                if (2 * s < kcount) {
-                    const int k = kc + 2 * s + half;
-                    float v = bv[s];
-                    const float ca = sPA[k], cb = sPB[k];   // k < Kpad always
-                    if (MODE == PW_FWD) v = cfn_act_rt(fmaf(v, ca, cb), a.act);
-                    else v = two_src ? fmaf(bv2[s], cb, v + ca) : v + ca;
-                    if (!valid || k >= K) v = 0.0f;
-                    const float* ar = As + ((a.resident ? kc : 0) + 2 * s + half) * BM + col;
+                for (int j = 0; j < NU; ++j) {
+                    const int kl = u + 2 * j + half;
+                    const float2 c = sP[kc0 + kl];
+                    float v;
+                    if (MODE == PW_FWD) v = cfn_act<ACT>(fmaf(cur[j], c.x, c.y));
+                    else v = fmaf(cur2[j], c.y, cur[j] + c.x);
+                    const float* ar = As + kl * BM + col;
 #pragma unroll
                     for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i * 32], v, acc[i], 0, 0, 0);
                 }
+#pragma unroll
+                for (int j = 0; j < NU; ++j) { cur[j] = nxt[j]; cur2[j] = nxt2[j]; }
             }
         }
 
         // ---- epilogue ---------------------------------------------------------------------------
+        // branch-free stores: rows >= M fall outside the per-sample buffer descriptor and are dropped by the
+        // bounds check; lanes of a partial tile get an out-of-range offset.
+        const float vm = valid ? 1.0f : 0.0f;
+        const int dvoff = valid ? (4 * half * dst_pitch + out_pos) * 4 : 0x7fffffff;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             float t1[16], t2[16];
             float xe[16];
-            if (MODE == PW_DGRAD && a.ea) {
+            if (MODE == PW_DGRAD && ACT != CFN_ACT_NONE) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int mm = min(m0 + ml, M - 1);
-                    xe[r] = a.ex[dst_n + (long)mm * dst_pitch + out_pos];
-                }
+                for (int r = 0; r < 16; ++r)
+                    xe[r] = pw_bload(rx, dvoff, (m0 + i * 32 + (r & 3) + 8 * (r >> 2)) * dst_pitch * 4);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int mm = m0 + ml;
                 float v = acc[i][r];
                 if (MODE == PW_FWD) {
-                    t1[r] = v;
-                } else if (a.ea) {
-                    const float ca = sEA[ml], cb = sEB[ml];
-                    const float dz = (valid && mm < M) ? v * cfn_act_grad_rt(fmaf(xe[r], ca, cb), a.act) : 0.0f;
+                    t1[r] = v * vm;
+                } else if (ACT != CFN_ACT_NONE) {
+                    const float2 c = sE[ml];
+                    const float dz = v * cfn_act_grad<ACT>(fmaf(xe[r], c.x, c.y)) * vm;
                     t1[r] = dz * xe[r];
                     t2[r] = dz;
-                    v = dz * ca;
+                    v = dz * c.x;
                 }
-                if (valid && mm < M) a.dst[dst_n + (long)mm * dst_pitch + out_pos] = v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, dvoff,
+                                                      (m0 + i * 32 + (r & 3) + 8 * (r >> 2)) * dst_pitch * 4, 0);
             }
             if (STATS) {
-                // wave-private transpose through LDS: lane -> (row = lane&31, 16 of the 32 columns)
+                // wave-private transpose through LDS (in-order per wave): lane -> (row lane&31, 16 of 32 columns)
 #pragma unroll
                 for (int pass = 0; pass < (MODE == PW_FWD ? 1 : 2); ++pass) {
-                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         red[((r & 3) + 8 * (r >> 2) + 4 * half) * PW_RED_PITCH + col] = pass == 0 ? t1[r] : t2[r];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
                     float s = 0.0f, qq = 0.0f;
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
@@ -227,7 +250,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
                     if (MODE == PW_FWD) { sacc[i] += s; qacc[i] += qq; }
                     else if (pass == 0) sacc[i] += s;
                     else qacc[i] += s;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    asm volatile("" ::: "memory");
                 }
             }
         }
@@ -410,12 +433,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-template <int MODE, bool STATS>
-static int pw_launch(const PwArgs& a, int MT, unsigned blocks, size_t lds, hipStream_t st) {
+template <int MODE, bool STATS, int ACT, bool STEM>
+static int pw_launch_mt(const PwArgs& a, int MT, unsigned blocks, size_t lds, hipStream_t st) {
 #define CFN_PW_GO(MTV)                                                                                         \
     do {                                                                                                       \
-        auto k = pw_gemm_kernel<MTV, MODE, STATS>;                                                             \
-        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        auto k = pw_gemm_kernel<MTV, MODE, STATS, ACT, STEM>;                                                  \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, a);                                            \
     } while (0)
     switch (MT) {
@@ -428,22 +451,40 @@ static int pw_launch(const PwArgs& a, int MT, unsigned blocks, size_t lds, hipSt
     return cfn_check_launch("pwconv");
 }
 
+template <int MODE, bool STATS>
+static int pw_launch(const PwArgs& a, int MT, unsigned blocks, size_t lds, hipStream_t st) {
+    switch (a.act) {
+        case CFN_ACT_RELU: return pw_launch_mt<MODE, STATS, CFN_ACT_RELU, false>(a, MT, blocks, lds, st);
+        case CFN_ACT_SWISH: return pw_launch_mt<MODE, STATS, CFN_ACT_SWISH, false>(a, MT, blocks, lds, st);
+        default: return pw_launch_mt<MODE, STATS, CFN_ACT_NONE, false>(a, MT, blocks, lds, st);
+    }
+}
+
 static int pw_plan(PwArgs& a, int& MT, unsigned& blocks, size_t& lds) {
+    a.Kpad = (a.K + PW_UNIT - 1) / PW_UNIT * PW_UNIT;
+    a.kres = a.Kpad <= PW_KRES_MAX ? a.Kpad : PW_KRES_MAX;
     const int M32 = cfn_cdiv(a.M, 32);
-    // fewest row tiles of <=128 rows, then the smallest tile that covers M with that count
-    const int ntile = cfn_cdiv(M32, 4);
+    // rows per workgroup: as many 32-row tiles as keep the resident weight image <= 64 KiB (max 4),
+    // then the smallest tile that covers M with that number of row tiles
+    int mt_fit = (64 * 1024 / 4 / a.kres) / 32;
+    if (mt_fit > 4) mt_fit = 4;
+    if (a.ea && mt_fit > 2) mt_fit = 2;   // DGRAD with the act' epilogue: keep the register footprint spill-free
+    if (mt_fit < 1) mt_fit = 1;
+    const int ntile = cfn_cdiv(M32, mt_fit);
     MT = cfn_cdiv(M32, ntile);
     a.mtiles = cfn_cdiv(a.M, 32 * MT);
-    a.Kpad = (a.K + 1) & ~1;
     const int BM = 32 * MT;
-    a.resident = ((size_t)a.Kpad * BM * 4 <= 40 * 1024) ? 1 : 0;
     const long tiles = cfn_cdiv(a.Q, 128);
     int tpb = 1;
     while (tpb < 16 && (long)a.N * cfn_cdiv(tiles, tpb * 2) * a.mtiles >= 2048) tpb *= 2;
     a.tpb = tpb;
     a.nstrips = cfn_cdiv(tiles, tpb);
     blocks = (unsigned)((long)a.N * a.nstrips * a.mtiles);
-    lds = ((size_t)(a.resident ? a.Kpad : PW_KC) * BM + 2 * a.Kpad + 4 * BM + 4 * 32 * PW_RED_PITCH) * sizeof(float);
+    lds = ((size_t)a.kres * BM + 2 * (a.Kpad + PW_UNIT) + 2 * BM + 2 * BM + 4 * 32 * PW_RED_PITCH) * sizeof(float);
+    const long span = (long)a.K * (a.stem ? 1 : (a.src2 || a.gs || a.gq || a.ex ? a.Q : a.Pin)) * 4;
+    if ((!a.stem && ((long)a.K * a.Pin * 4 >= (1L << 31) || (long)a.K * a.Q * 4 >= (1L << 31))) ||
+        (long)a.M * a.Pin * 4 >= (1L << 31) || (long)a.M * a.Q * 4 >= (1L << 31))
+        return cfn_fail(CFN_ERR_UNSUPPORTED, "pwconv: one sample's K x positions x 4 B = %ld exceeds the 2 GiB buffer-descriptor range", span);
     return CFN_OK;
 }
 
@@ -469,7 +510,7 @@ extern "C" int cfn_pwconv_fwd(const float* x, const float* A, const float* B, in
     pw_geom(a, T, Hi, Wi, stride);
     CFN_REQUIRE((long)T * Hi * Wi < (1L << 31), "cfn_pwconv_fwd: per-sample volume too large");
     int MT; unsigned blocks; size_t lds;
-    pw_plan(a, MT, blocks, lds);
+    { int rc = pw_plan(a, MT, blocks, lds); if (rc) return rc; }
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_FWD, st, 4.0 * N * ((double)Cin * a.Q + (double)Cout * a.Q) + 4.0 * Cin * Cout);
     return sum ? pw_launch<PW_FWD, true>(a, MT, blocks, lds, st) : pw_launch<PW_FWD, false>(a, MT, blocks, lds, st);
@@ -491,10 +532,11 @@ extern "C" int cfn_pwconv_bwd_data(const float* gy, const float* y, const double
     a.N = N; a.M = Cin; a.K = Cout; a.Cin = Cin;
     pw_geom(a, T, Hi, Wi, stride);
     int MT; unsigned blocks; size_t lds;
-    pw_plan(a, MT, blocks, lds);
+    { int rc = pw_plan(a, MT, blocks, lds); if (rc) return rc; }
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_BWD, st, 4.0 * N * ((double)Cout * a.Q * (a.src2 ? 2 : 1) + (double)Cin * a.Q * (A ? 2 : 1)));
-    return A ? pw_launch<PW_DGRAD, true>(a, MT, blocks, lds, st) : pw_launch<PW_DGRAD, false>(a, MT, blocks, lds, st);
+    if (!A) { a.act = CFN_ACT_NONE; return pw_launch<PW_DGRAD, false>(a, MT, blocks, lds, st); }
+    return pw_launch<PW_DGRAD, true>(a, MT, blocks, lds, st);
 }
 
 extern "C" int cfn_pwconv_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq,
@@ -557,10 +599,10 @@ extern "C" int cfn_stem_conv_fwd(const float* x, const float* w, float* y, int N
     a.Ho = (Hi + 2 - 3) / 2 + 1; a.Wo = (Wi + 2 - 3) / 2 + 1;
     a.Pin = T * Hi * Wi; a.Q = T * a.Ho * a.Wo;
     int MT; unsigned blocks; size_t lds;
-    pw_plan(a, MT, blocks, lds);
+    { int rc = pw_plan(a, MT, blocks, lds); if (rc) return rc; }
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_STEM, st, 4.0 * N * ((double)Cimg * a.Pin + (double)Cout * a.Q));
-    return pw_launch<PW_FWD, false>(a, MT, blocks, lds, st);
+    return pw_launch_mt<PW_FWD, false, CFN_ACT_NONE, true>(a, MT, blocks, lds, st);
 }
 
 extern "C" int cfn_stem_conv_bwd_weight(const float* gy, const float* x, double* gw, int N, int Cimg, int Cout, int T,

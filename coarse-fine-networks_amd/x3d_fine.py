@@ -78,38 +78,21 @@ class SubBatchNorm3d(nn.Module):
             self.bn.running_mean.data = mean.detach()
             self.bn.running_var.data = var.detach()
 
-    def fold(self, s, q, count, n):
-        """(A, B) fp32 (n, C) such that SubBN(y)[n,c,...] = A[n,c]*y + B[n,c].
+    def fold(self, s, q, count, n, se=None):
+        """(A, B) fp32 (n, C) such that SubBN(y)[n,c,...] = A[n,c]*y + B[n,c]  (one fused HIP kernel).
 
-        training: s, q = fp64 (n, C) per-sample sums of y and y*y over ``count`` positions each;
-        statistics are taken per split group exactly like ``x.view(n//S, c*S, ...)`` (x3d_fine.py:52-57).
-        eval: running statistics of ``self.bn``."""
-        C, S = self.num_features, self.num_splits
+        training: s, q = fp64 (n, C) per-sample sums of y and y*y over ``count`` positions each; statistics
+        are taken per split group exactly like ``x.view(n//S, c*S, ...)`` (x3d_fine.py:52-57) and the
+        split_bn running statistics are updated like nn.BatchNorm3d does.  eval: running statistics of
+        ``self.bn``.  ``se`` = (fc1.weight, fc1.bias, fc2.weight, fc2.bias) additionally folds the
+        squeeze-excite gate of x3d_fine.py:157-163 into (A, B) (needs ``s`` in eval mode too)."""
         if self.training:
-            cnt = float(count) * (n // S)
-            sg = s.view(n // S, S, C).sum(0)
-            qg = q.view(n // S, S, C).sum(0)
-            mean = sg / cnt
-            var = (qg / cnt - mean * mean).clamp_min(0.0)          # biased, as F.batch_norm normalises
-            with torch.no_grad():
-                sb, m = self.split_bn, self.momentum
-                sb.running_mean.mul_(1 - m).add_(mean.reshape(-1).to(sb.running_mean.dtype), alpha=m)
-                unb = var * (cnt / max(cnt - 1.0, 1.0))
-                sb.running_var.mul_(1 - m).add_(unb.reshape(-1).to(sb.running_var.dtype), alpha=m)
-                sb.num_batches_tracked += 1
-            rstd = torch.rsqrt(var + self.eps)
+            bufs = (self.split_bn.running_mean, self.split_bn.running_var, self.split_bn.num_batches_tracked)
         else:
-            mean = self.bn.running_mean.double().view(1, C)
-            rstd = torch.rsqrt(self.bn.running_var.double().view(1, C) + self.eps)
-            S = 1
-        if self.affine:
-            a = rstd * self.weight.double().view(1, C)
-            b = self.bias.double().view(1, C) - mean * a
-        else:
-            a, b = rstd, -mean * rstd
-        A = a.unsqueeze(0).expand(n // S, S, C).reshape(n, C).float().contiguous()
-        B = b.unsqueeze(0).expand(n // S, S, C).reshape(n, C).float().contiguous()
-        return A, B
+            bufs = (self.bn.running_mean, self.bn.running_var, self.bn.num_batches_tracked)
+        gamma, beta = (self.weight, self.bias) if self.affine else (None, None)
+        return ops.bn_fold(s, q, gamma, beta, bufs, self.training, n, self.num_features, self.num_splits, count, self.eps,
+                           self.momentum, se=se, pool_count=count)
 
     def forward(self, x):
         n = x.shape[0]
@@ -191,14 +174,9 @@ class Bottleneck(nn.Module):
         y1, s1, q1 = ops.pwconv(xr, self.conv1.weight, xa, xb, xact, 1, stats=tr)
         A1, B1 = self.bn1.fold(s1, q1, _count(y1), n)
         y2, s2, q2 = ops.dwconv3d(y1, self.conv2.weight, A1, B1, ACT_RELU, self.stride, stats=tr or has_se)
-        A2, B2 = self.bn2.fold(s2, q2, _count(y2), n)
-        if has_se:
-            # global average of bn2(y2) = bn2 affine of the per-sample mean of y2 (x3d_fine.py:157-163)
-            cm = self.conv2.weight.shape[0]
-            pooled = (s2 / float(_count(y2))).float() * A2 + B2
-            se = F.relu(F.linear(pooled, self.fc1.weight.view(-1, cm), self.fc1.bias))
-            se = torch.sigmoid(F.linear(se, self.fc2.weight.view(cm, -1), self.fc2.bias))
-            A2, B2 = A2 * se, B2 * se
+        # bn2 (+ SE: the global average of bn2(y2) is the bn2 affine of the per-sample mean of y2, x3d_fine.py:157-163)
+        se = (self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias) if has_se else None
+        A2, B2 = self.bn2.fold(s2, q2, _count(y2), n, se=se)
         y3, s3, q3 = ops.pwconv(y2, self.conv3.weight, A2, B2, ACT_SWISH, 1, stats=tr)
         A3, B3 = self.bn3.fold(s3, q3, _count(y3), n)
 

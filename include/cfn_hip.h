@@ -77,6 +77,22 @@ int cfn_stem_conv_fwd(const float* x, const float* w, float* y, int N, int Cimg,
 int cfn_stem_conv_bwd_weight(const float* gy, const float* x, double* gw, int N, int Cimg, int Cout, int T, int Hi, int Wi,
                              void* stream);
 
+/* ---- SubBatchNorm3d statistics -> (A,B) prologue, fused with the SE gate: SubBatchNorm3d.forward x3d_fine.py:51-62
+ * (split groups, shared affine), nn.BatchNorm3d running-stat update, SE branch x3d_fine.py:157-163.
+ * training: s,q (N,C) fp64 sums over `count` positions; run_mean/run_var = split_bn buffers (S*C) updated in place,
+ * nbt = num_batches_tracked.  eval: run_mean/run_var = bn buffers (C).  Wd>0 enables SE (fc1 (Wd,C), fc2 (C,Wd),
+ * pool_count = positions of the SE average).  Saved tensors (mean,rstd (S,C) fp64; A0,B0,gate,pooled (N,C); hbuf (N,Wd))
+ * feed cfn_bn_fold_bwd, which returns gs,gq (N,C) fp64 and the parameter gradients (SE ones zero-filled by caller). ---- */
+int cfn_bn_fold_fwd(const double* s, const double* q, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                    long* nbt, int training, int N, int C, int S, double count, double eps, double momentum, const float* w1,
+                    const float* b1, const float* w2, const float* b2, int Wd, double pool_count, float* A, float* B,
+                    double* mean, double* rstd, float* A0, float* B0, float* gate, float* hbuf, float* pooled, void* stream);
+int cfn_bn_fold_bwd(const float* gA, const float* gB, const double* s, const float* gamma, const double* mean,
+                    const double* rstd, const float* A0, const float* B0, const float* gate, const float* hbuf,
+                    const float* pooled, const float* w1, const float* w2, int training, int N, int C, int S, int Wd,
+                    double count, double pool_count, double* gs, double* gq, float* ggamma, float* gbeta, float* gw1,
+                    float* gb1, float* gw2, float* gb2, float* tA, float* tB, void* stream);
+
 /* ---- block tail  out = relu(A y + B + (Ar res + Br)) : bn3 + (downsample bn) + `out += residual` + relu,
  * x3d_fine.py:167-173.  Ar/Br NULL = identity shortcut.  vol = T*H*W, NC = N*C. ---- */
 int cfn_bn_add_relu_fwd(const float* y, const float* A, const float* B, const float* res, const float* Ar, const float* Br,

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmarks on the X3D-M layer shapes (GPU box only).
+
+    python tools/microbench.py [pw|dw|all] [--frames 256] [--bwd]
+
+Times each op with HIP events on torch's current stream (the stream the C ABI launches on) and prints
+algorithmic GB/s (N_in + N_out elements x 4 B per pass, as SURVEY 8d counts them) and TFLOP/s."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'coarse-fine-networks_amd'))
+import torch                      # noqa: E402
+from cfn_hip import ops           # noqa: E402
+
+DEV = 'cuda'
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+# (name, Cin, Cout, H(in), stride)
+PW_LAYERS = [('L1.0 conv1 24->54 @112', 24, 54, 112, 1), ('L1.0 ds 24->24 s2', 24, 24, 112, 2),
+             ('L1.x conv3 54->24 @56', 54, 24, 56, 1), ('L1.x conv1 24->54 @56', 24, 54, 56, 1),
+             ('L2.0 conv1 24->108 @56', 24, 108, 56, 1), ('L2.x conv3 108->48 @28', 108, 48, 28, 1),
+             ('L2.x conv1 48->108 @28', 48, 108, 28, 1), ('L3.x conv1 96->216 @14', 96, 216, 14, 1),
+             ('L3.x conv3 216->96 @14', 216, 96, 14, 1), ('L4.x conv1 192->432 @7', 192, 432, 7, 1),
+             ('L4.x conv3 432->192 @7', 432, 192, 7, 1)]
+DW_LAYERS = [('L1.0 dw 54 112->56 s2', 54, 112, 2), ('L1.x dw 54 @56', 54, 56, 1), ('L2.0 dw 108 56->28 s2', 108, 56, 2),
+             ('L2.x dw 108 @28', 108, 28, 1), ('L3.0 dw 216 28->14 s2', 216, 28, 2), ('L3.x dw 216 @14', 216, 14, 1),
+             ('L4.0 dw 432 14->7 s2', 432, 14, 2), ('L4.x dw 432 @7', 432, 7, 1)]
+
+
+def bench_pw(T, bwd):
+    print('%-28s %9s %9s %9s %s' % ('pointwise layer', 'ms', 'GB/s', 'TFLOP/s', '(fwd)'))
+    for name, ci, co, H, s in PW_LAYERS:
+        x = torch.randn(1, ci, T, H, H, device=DEV)
+        w = torch.randn(co, ci, 1, 1, 1, device=DEV) * 0.1
+        A = torch.rand(1, ci, device=DEV) + 0.5
+        B = torch.randn(1, ci, device=DEV) * 0.1
+        Ho = (H - 1) // s + 1
+        Q = T * Ho * Ho
+        ms = timeit(lambda: ops.pwconv(x, w, A, B, 1, s, True))
+        gb = 4.0 * (ci * Q + co * Q) / 1e9
+        print('%-28s %9.3f %9.1f %9.2f' % (name, ms, gb / ms * 1e3, 2.0 * ci * co * Q / ms / 1e9))
+        if bwd:
+            xr = x.clone().requires_grad_(True)
+            wr = w.clone().requires_grad_(True)
+            Ar, Br = A.clone().requires_grad_(True), B.clone().requires_grad_(True)
+            y, sm, sq = ops.pwconv(xr, wr, Ar, Br, 1, s, True)
+            gy, gs, gq = torch.randn_like(y), torch.randn_like(sm) * 0.01, torch.randn_like(sq) * 0.001
+
+            def f():
+                torch.autograd.grad((y, sm, sq), (xr, wr, Ar, Br), (gy, gs, gq), retain_graph=True)
+            ms = timeit(f, iters=3, warm=1)
+            gbb = 4.0 * (2 * ci * Q + 2 * co * Q + ci * Q + 2 * co * Q) / 1e9
+            print('%-28s %9.3f %9.1f %9.2f   (dgrad+wgrad; bytes = 2in+2out | in+2out)' %
+                  ('', ms, gbb / ms * 1e3, 4.0 * ci * co * Q / ms / 1e9))
+
+
+def bench_dw(T, bwd):
+    print('%-28s %9s %9s %9s %s' % ('depthwise layer', 'ms', 'GB/s', 'TFLOP/s', '(fwd)'))
+    for name, c, H, s in DW_LAYERS:
+        x = torch.randn(1, c, T, H, H, device=DEV)
+        w = torch.randn(c, 1, 3, 3, 3, device=DEV) * 0.2
+        A = torch.rand(1, c, device=DEV) + 0.5
+        B = torch.randn(1, c, device=DEV) * 0.1
+        Ho = (H + 2 - 3) // s + 1
+        ms = timeit(lambda: ops.dwconv3d(x, w, A, B, 1, s, True))
+        gb = 4.0 * c * T * (H * H + Ho * Ho) / 1e9
+        print('%-28s %9.3f %9.1f %9.2f' % (name, ms, gb / ms * 1e3, 54.0 * c * T * Ho * Ho / ms / 1e9))
+        if bwd:
+            xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            Ar, Br = A.clone().requires_grad_(True), B.clone().requires_grad_(True)
+            y, sm, sq = ops.dwconv3d(xr, wr, Ar, Br, 1, s, True)
+            gy, gs, gq = torch.randn_like(y), torch.randn_like(sm) * 0.01, torch.randn_like(sq) * 0.001
+
+            def f():
+                torch.autograd.grad((y, sm, sq), (xr, wr, Ar, Br), (gy, gs, gq), retain_graph=True)
+            ms = timeit(f, iters=3, warm=1)
+            print('%-28s %9.3f   (dgrad+wgrad)' % ('', ms))
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('what', nargs='?', default='all')
+    ap.add_argument('--frames', type=int, default=256)
+    ap.add_argument('--bwd', action='store_true')
+    a = ap.parse_args()
+    if a.what in ('pw', 'all'):
+        bench_pw(a.frames, a.bwd)
+    if a.what in ('dw', 'all'):
+        bench_dw(a.frames, a.bwd)
