@@ -17,7 +17,7 @@ HEADER = os.path.join(_ROOT, 'include', 'cfn_hip.h')
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 FAMILIES = {'dwconv_fwd': 0, 'dwconv_bwd': 1, 'pwconv_fwd': 2, 'pwconv_bwd': 3, 'gridpool': 4, 'elementwise': 5,
-            'stem': 6, 'fusion': 7}
+            'stem': 6, 'fusion': 7, 'pwconv_wgrad': 8, 'dwconv_wgrad': 9}
 
 _lib = None
 _protos = None
@@ -28,7 +28,7 @@ def header_prototypes(path=HEADER):
     txt = open(path).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     out = {}
-    for m in re.finditer(r'(const\s+char\s*\*|int)\s+(cfn_\w+)\s*\(([^)]*)\)\s*;', txt):
+    for m in re.finditer(r'(const\s+char\s*\*|int|long)\s+(cfn_\w+)\s*\(([^)]*)\)\s*;', txt):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         at = []
         if args and args != 'void':
@@ -44,7 +44,7 @@ def header_prototypes(path=HEADER):
                     at.append(ctypes.c_int)
                 else:
                     raise ValueError('unhandled C type in %s: %r' % (name, a))
-        out[name] = (ctypes.c_char_p if 'char' in ret else ctypes.c_int, at)
+        out[name] = (ctypes.c_char_p if 'char' in ret else (ctypes.c_long if ret == 'long' else ctypes.c_int), at)
     return out
 
 
@@ -94,6 +94,11 @@ def call(name, *args):
     rc = getattr(lib, name)(*conv, stream())
     if rc != 0:
         raise RuntimeError('%s failed (%d): %s' % (name, rc, last_error()))
+
+
+def query(name, *args):
+    """host-only helper entry points (no stream argument), e.g. workspace sizes"""
+    return getattr(load(), name)(*args)
 
 
 def check(t, dtype=torch.float32):

@@ -11,11 +11,40 @@ full-size tensor is touched only inside the HIP kernels.
 import torch
 from torch.autograd import Function
 
-from . import call, check, ACT_NONE, ACT_RELU, ACT_SWISH  # noqa: F401
+from . import call, check, query, ACT_NONE, ACT_RELU, ACT_SWISH  # noqa: F401
+
+
+class _ZeroArena(object):
+    """fp64 zero-filled scratch handed out in slices: the statistics / gradient accumulators of ~400 kernel
+    launches per step come out of a few large memsets instead of one tiny fill kernel each.  A chunk stays alive
+    as long as any slice of it does (autograd may save them)."""
+    CHUNK = 1 << 16
+
+    def __init__(self):
+        self.buf, self.off = {}, {}
+
+    def take(self, numel, dev):
+        numel_al = (numel + 1) & ~1
+        key = (dev.type, dev.index)
+        if key not in self.buf or self.off[key] + numel_al > self.buf[key].numel():
+            self.buf[key] = torch.zeros(max(self.CHUNK, numel_al), dtype=torch.float64, device=dev)
+            self.off[key] = 0
+        o = self.off[key]
+        self.off[key] = o + numel_al
+        return self.buf[key][o:o + numel]
+
+
+_arena = _ZeroArena()
 
 
 def _f64(n, c, dev):
-    return torch.zeros(n, c, dtype=torch.float64, device=dev)
+    return _arena.take(n * c, dev).view(n, c)
+
+
+def _f64pair(n, c, dev):
+    """two adjacent (n,c) accumulators, returned together so one cast converts both"""
+    t = _arena.take(2 * n * c, dev).view(2, n, c)
+    return t, t[0], t[1]
 
 
 def _opt(t):
@@ -55,14 +84,15 @@ class _PwConv(Function):
         gx = gA = gB = gw = None
         if ctx.needs_input_grad[0] or (A is not None and ctx.needs_input_grad[1]):
             gx = torch.zeros_like(x) if stride != 1 else torch.empty_like(x)
-            a64 = b64 = None
+            ab = a64 = b64 = None
             if A is not None:
-                a64, b64 = _f64(N, Cin, x.device), _f64(N, Cin, x.device)
+                ab, a64, b64 = _f64pair(N, Cin, x.device)
             call('cfn_pwconv_bwd_data', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, Cin, Cout, T, H, W, stride)
             if A is not None:
-                gA, gB = a64.float(), b64.float()
+                ab = ab.float()
+                gA, gB = ab[0], ab[1]
         if ctx.needs_input_grad[3]:
-            g64 = torch.zeros(Cout, Cin, dtype=torch.float64, device=x.device)
+            g64 = _f64(Cout, Cin, x.device)
             call('cfn_pwconv_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, Cin, Cout, T, H, W, stride)
             gw = g64.float().view(wshape)
         return gx, gA, gB, gw, None, None, None
@@ -104,14 +134,15 @@ class _DwConv3d(Function):
         gx = gA = gB = gw = None
         if ctx.needs_input_grad[0] or (A is not None and ctx.needs_input_grad[1]):
             gx = torch.empty_like(x)
-            a64 = b64 = None
+            ab = a64 = b64 = None
             if A is not None:
-                a64, b64 = _f64(N, C, x.device), _f64(N, C, x.device)
+                ab, a64, b64 = _f64pair(N, C, x.device)
             call('cfn_dwconv3d_bwd_data', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, C, T, H, W, stride)
             if A is not None:
-                gA, gB = a64.float(), b64.float()
+                ab = ab.float()
+                gA, gB = ab[0], ab[1]
         if ctx.needs_input_grad[3]:
-            g64 = torch.zeros(C, 27, dtype=torch.float64, device=x.device)
+            g64 = _f64(C, 27, x.device)
             call('cfn_dwconv3d_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, C, T, H, W, stride)
             gw = g64.float().view(wshape)
         return gx, gA, gB, gw, None, None, None
@@ -151,7 +182,7 @@ class _DwConvT5(Function):
             gx = torch.empty_like(x)
             call('cfn_dwconv_t5_bwd_data', gy, y, gs, gq, w2, gx, N, C, T, H * W)
         if ctx.needs_input_grad[1]:
-            g64 = torch.zeros(C, 5, dtype=torch.float64, device=x.device)
+            g64 = _f64(C, 5, x.device)
             call('cfn_dwconv_t5_bwd_weight', gy, y, gs, gq, x, g64, N, C, T, H * W)
             gw = g64.float().view(ctx.wshape)
         return gx, gw, None
@@ -184,7 +215,7 @@ class _StemConv(Function):
         Co = ctx.wshape[0]
         gw = None
         if ctx.needs_input_grad[1]:
-            g64 = torch.zeros(Co, Ci * 9, dtype=torch.float64, device=x.device)
+            g64 = _f64(Co, Ci * 9, x.device)
             call('cfn_stem_conv_bwd_weight', gy.contiguous(), x, g64, N, Ci, Co, T, H, W)
             gw = g64.float().view(ctx.wshape)
         return None, gw
@@ -276,11 +307,12 @@ class _BnAddRelu(Function):
         N, C = y.shape[:2]
         vol = y[0, 0].numel()
         gy, gres = torch.empty_like(y), torch.empty_like(res)
-        a64, b64 = _f64(N, C, y.device), _f64(N, C, y.device)
-        r64 = _f64(N, C, y.device) if Ar is not None else None
-        call('cfn_bn_add_relu_bwd', gout.contiguous(), out, y, A, res, Ar, gy, gres, a64, b64, r64, N * C, vol)
-        gA, gB = a64.float(), b64.float()
-        gAr = r64.float() if Ar is not None else None
+        t3 = _arena.take(3 * N * C, y.device).view(3, N, C)
+        call('cfn_bn_add_relu_bwd', gout.contiguous(), out, y, A, res, Ar, gy, gres, t3[0], t3[1],
+             t3[2] if Ar is not None else None, N * C, vol)
+        t3 = t3.float()
+        gA, gB = t3[0], t3[1]
+        gAr = t3[2] if Ar is not None else None
         gBr = gB if Ar is not None else None
         return gy, gA, gB, gres, gAr, gBr
 

@@ -577,6 +577,6 @@ extern "C" int cfn_dwconv3d_bwd_weight(const float* gy, const float* y, const do
     int rc = dw_plan(a, stride, DW_WGRAD, pl);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    CfnProfScope prof(CFN_K_DWCONV_BWD, st, 4.0 * N * C * T * ((double)Hi * Wi + (double)a.Ho * a.Wo * (a.yout ? 2 : 1)));
+    CfnProfScope prof(CFN_K_DWCONV_WGRAD, st, 4.0 * N * C * T * ((double)Hi * Wi + (double)a.Ho * a.Wo * (a.yout ? 2 : 1)));
     return stride == 1 ? dw_launch<DW_WGRAD, 1>(a, pl, st) : dw_launch<DW_WGRAD, 2>(a, pl, st);
 }

@@ -289,7 +289,7 @@ struct WgArgs {
     const double* gs; const double* gq;   // [n,m] (may be null)
     const float* x;      // (N,K,Pin) forward input raw
     const float* pa; const float* pb;     // forward prologue [n,k] (null = identity)
-    double* gw;          // (M,K) fp64 accumulators (row pitch Kc)
+    double* gw;          // (M,K) fp64 accumulators, zero-filled by the caller
     int N, M, K, Q, Pin, Hi, Wi, Ho, Wo, stride, act;
     int mtiles, ktiles, nstrips, stages;   // stages = LDS stages (of 64 positions) per block
     int stem, Cimg;      // stem != 0: x rows are the im2col view (k -> ci,kh,kw) of a (N,Cimg,T,Hi,Wi) clip
@@ -299,6 +299,7 @@ template <int MTW, int NTW>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BM = 32 * MTW, BN = 32 * NTW;
+    constexpr int NG = BM / 16, NX = BN / 16;      // float4 per thread per stage (G rows / X rows)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
     unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
     const int mt = L % a.mtiles; L /= a.mtiles;
@@ -331,44 +332,77 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     __syncthreads();
 
-    const bool vec_ok = (Q % 4 == 0) && a.stride == 1;
-    const bool xvec_ok = vec_ok && !a.stem;
-    for (int st = 0; st < a.stages; ++st) {
-        const int q0 = (strip * a.stages + st) * WG_PT;
-        if (q0 >= Q) break;
-        if (st) __syncthreads();
-        // ---- stage G rows (BM x 64) and X rows (BN x 64) with their prologues -----------------
+    // fast path: contiguous positions, float4 rows, next stage's global loads in flight during the MFMAs
+    const bool fast = (Q % 4 == 0) && a.stride == 1 && !a.stem;
+    const int lrow = tid >> 4, c4 = (tid & 15) * 4;          // 16 lanes cover one 64-position row segment
+    f4v pg[NG], py[NG], px[NX];
+    auto prefetch = [&](int q0) {
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            const int ch = m0 + it * 16 + lrow;
+            pg[it] = (f4v){0.f, 0.f, 0.f, 0.f};
+            py[it] = (f4v){0.f, 0.f, 0.f, 0.f};
+            if (ch < M && q0 + c4 < Q) {
+                const long base = ((long)n * M + ch) * Q + q0 + c4;
+                pg[it] = *reinterpret_cast<const f4v*>(a.gy + base);
+                if (a.y) py[it] = *reinterpret_cast<const f4v*>(a.y + base);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int ch = k0 + it * 16 + lrow;
+            px[it] = (f4v){0.f, 0.f, 0.f, 0.f};
+            if (ch < K && q0 + c4 < Q) px[it] = *reinterpret_cast<const f4v*>(a.x + ((long)n * K + ch) * a.Pin + q0 + c4);
+        }
+    };
+    auto stage_fast = [&](int q0) {
+        const bool inq = q0 + c4 < Q;
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            const int row = it * 16 + lrow;
+            const float cs = sCg[2 * row], cq = sCg[2 * row + 1];
+            const bool ok = inq && (m0 + row < M);
+            float* d = sG + row * WG_PITCH + c4;
+            d[0] = ok ? fmaf(py[it].x, cq, pg[it].x + cs) : 0.0f;
+            d[1] = ok ? fmaf(py[it].y, cq, pg[it].y + cs) : 0.0f;
+            d[2] = ok ? fmaf(py[it].z, cq, pg[it].z + cs) : 0.0f;
+            d[3] = ok ? fmaf(py[it].w, cq, pg[it].w + cs) : 0.0f;
+        }
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int row = it * 16 + lrow;
+            const float ca = sCx[2 * row], cb = sCx[2 * row + 1];
+            const bool ok = inq && (k0 + row < K);
+            float* d = sX + row * WG_PITCH + c4;
+            d[0] = ok ? cfn_act_rt(fmaf(px[it].x, ca, cb), a.act) : 0.0f;
+            d[1] = ok ? cfn_act_rt(fmaf(px[it].y, ca, cb), a.act) : 0.0f;
+            d[2] = ok ? cfn_act_rt(fmaf(px[it].z, ca, cb), a.act) : 0.0f;
+            d[3] = ok ? cfn_act_rt(fmaf(px[it].w, ca, cb), a.act) : 0.0f;
+        }
+    };
+    auto stage_slow = [&](int q0) {          // strided / im2col / ragged positions: element-wise gather
         for (int e = tid; e < (BM + BN) * (WG_PT / 4); e += 256) {
-            const int row = e / (WG_PT / 4), c4 = (e - row * (WG_PT / 4)) * 4;
+            const int row = e / (WG_PT / 4), cc = (e - row * (WG_PT / 4)) * 4;
             const bool isg = row < BM;
             const int ch = isg ? m0 + row : k0 + row - BM;
             const bool chok = isg ? ch < M : ch < K;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (chok) {
                 if (isg) {
-                    const long base = ((long)n * M + ch) * Q + q0 + c4;
+                    const long base = ((long)n * M + ch) * Q + q0 + cc;
                     const float cs = sCg[2 * row], cq = sCg[2 * row + 1];
-                    if (vec_ok && q0 + c4 + 3 < Q) {
-                        const f4v g = *reinterpret_cast<const f4v*>(a.gy + base);
-                        f4v yy = {0.f, 0.f, 0.f, 0.f};
-                        if (a.y) yy = *reinterpret_cast<const f4v*>(a.y + base);
-                        v[0] = fmaf(yy.x, cq, g.x + cs); v[1] = fmaf(yy.y, cq, g.y + cs);
-                        v[2] = fmaf(yy.z, cq, g.z + cs); v[3] = fmaf(yy.w, cq, g.w + cs);
-                    } else {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (q0 + c4 + u < Q) v[u] = fmaf(a.y ? a.y[base + u] : 0.0f, cq, a.gy[base + u] + cs);
-                    }
+                    for (int u = 0; u < 4; ++u)
+                        if (q0 + cc + u < Q) v[u] = fmaf(a.y ? a.y[base + u] : 0.0f, cq, a.gy[base + u] + cs);
                 } else {
                     const int kr = row - BM;
                     const float ca = sCx[2 * kr], cb = sCx[2 * kr + 1];
-                    const long base = ((long)n * K + ch) * a.Pin;
                     if (a.stem) {
                         const int ci = ch / 9, kr9 = ch - ci * 9, kh = kr9 / 3, kw = kr9 - kh * 3;
                         const int hw = a.Ho * a.Wo;
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const int qq = q0 + c4 + u;
+                            const int qq = q0 + cc + u;
                             if (qq < Q) {
                                 const int tq = qq / hw, rq = qq - tq * hw;
                                 const int oh = rq / a.Wo, ow = rq - oh * a.Wo;
@@ -377,22 +411,29 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
                                     v[u] = a.x[((long)n * a.Cimg + ci) * a.Pin + ((long)tq * a.Hi + ih) * a.Wi + iw];
                             }
                         }
-                    } else if (xvec_ok && q0 + c4 + 3 < Q) {
-                        const f4v xx = *reinterpret_cast<const f4v*>(a.x + base + q0 + c4);
-                        v[0] = cfn_act_rt(fmaf(xx.x, ca, cb), a.act); v[1] = cfn_act_rt(fmaf(xx.y, ca, cb), a.act);
-                        v[2] = cfn_act_rt(fmaf(xx.z, ca, cb), a.act); v[3] = cfn_act_rt(fmaf(xx.w, ca, cb), a.act);
                     } else {
+                        const long base = ((long)n * K + ch) * a.Pin;
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            if (q0 + c4 + u < Q)
-                                v[u] = cfn_act_rt(fmaf(a.x[base + pw_pmap(q0 + c4 + u, a.Ho, a.Wo, a.Hi, a.Wi, a.stride)], ca, cb), a.act);
+                            if (q0 + cc + u < Q)
+                                v[u] = cfn_act_rt(fmaf(a.x[base + pw_pmap(q0 + cc + u, a.Ho, a.Wo, a.Hi, a.Wi, a.stride)], ca, cb), a.act);
                     }
                 }
             }
-            float* d = (isg ? sG + row * WG_PITCH : sX + (row - BM) * WG_PITCH) + c4;
+            float* d = (isg ? sG + row * WG_PITCH : sX + (row - BM) * WG_PITCH) + cc;
             d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         }
+    };
+
+    const int qbeg = strip * a.stages * WG_PT;
+    if (fast && qbeg < Q) prefetch(qbeg);
+    for (int st = 0; st < a.stages; ++st) {
+        const int q0 = qbeg + st * WG_PT;
+        if (q0 >= Q) break;
+        if (st) __syncthreads();                 // previous stage fully consumed
+        if (fast) stage_fast(q0); else stage_slow(q0);
         __syncthreads();
+        if (fast && st + 1 < a.stages && q0 + WG_PT < Q) prefetch(q0 + WG_PT);
         // ---- each wave contracts its 16 positions of the stage ---------------------------------
         const int pbase = wave * (WG_PT / 4);
 #pragma unroll
@@ -409,9 +450,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
                 for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
     }
-    // ---- combine the 4 waves through LDS, then fp64 atomics ---------------------------------------
+    // ---- combine the 4 waves through LDS, then one fp64 atomic per element per workgroup -----------------
     __syncthreads();
-    float* cw = smem;   // [BM][BN+1] reuse (BM*(BN+1) <= (BM+BN)*65 holds for BM<=96, BN<=64)
+    float* cw = smem;   // [BM][BN+1] reuse (BM*(BN+1) <= (BM+BN)*65 holds for BM<=64, BN<=64)
     for (int e = tid; e < BM * (BN + 1); e += 256) cw[e] = 0.0f;
     __syncthreads();
 #pragma unroll
@@ -475,9 +516,11 @@ static int pw_plan(PwArgs& a, int& MT, unsigned& blocks, size_t& lds) {
     a.mtiles = cfn_cdiv(a.M, 32 * MT);
     const int BM = 32 * MT;
     const long tiles = cfn_cdiv(a.Q, 128);
-    int tpb = 1;
-    while (tpb < 16 && (long)a.N * cfn_cdiv(tiles, tpb * 2) * a.mtiles >= 2048) tpb *= 2;
-    a.tpb = tpb;
+    // ~3 workgroups per CU: long strips amortise the per-workgroup statistics atomics (all workgroups of one
+    // (n, row) hit the same fp64 address) and the weight staging
+    long tpb = (tiles * a.N * a.mtiles + 767) / 768;
+    if (tpb < 1) tpb = 1;
+    a.tpb = (int)tpb;
     a.nstrips = cfn_cdiv(tiles, tpb);
     blocks = (unsigned)((long)a.N * a.nstrips * a.mtiles);
     lds = ((size_t)a.kres * BM + 2 * (a.Kpad + PW_UNIT) + 2 * BM + 2 * BM + 4 * 32 * PW_RED_PITCH) * sizeof(float);
@@ -539,6 +582,46 @@ extern "C" int cfn_pwconv_bwd_data(const float* gy, const float* y, const double
     return pw_launch<PW_DGRAD, true>(a, MT, blocks, lds, st);
 }
 
+static void wg_plan(WgArgs& a, int& MTW, int& NTW) {
+    // tile shape: rows <= 64, cols <= 64 (register footprint of the prefetch + accumulators: 2 waves / SIMD)
+    const int M32 = cfn_cdiv(a.M, 32), K32 = cfn_cdiv(a.K, 32);
+    MTW = cfn_cdiv(M32, cfn_cdiv(M32, 2));
+    NTW = cfn_cdiv(K32, cfn_cdiv(K32, 2));
+    a.mtiles = cfn_cdiv(a.M, 32 * MTW);
+    a.ktiles = cfn_cdiv(a.K, 32 * NTW);
+    // ~2.5 workgroups per CU over (samples x tiles x position strips)
+    const long nst = cfn_cdiv(a.Q, WG_PT);
+    long want = 640 / ((long)a.N * a.mtiles * a.ktiles);
+    if (want < 1) want = 1;
+    int stages = cfn_cdiv(nst, want);
+    if (stages < 4) stages = 4;
+    a.stages = stages;
+    a.nstrips = cfn_cdiv(nst, stages);
+}
+
+static int wg_launch(const WgArgs& a, int MTW, int NTW, hipStream_t st) {
+    const unsigned blocks = (unsigned)((long)a.N * a.nstrips * a.mtiles * a.ktiles);
+    const size_t lds = ((size_t)(32 * MTW + 32 * NTW) * WG_PITCH + 2 * (32 * MTW + 32 * NTW)) * sizeof(float);
+#define CFN_WG_GO(MW, NW)                                                                                       \
+    do {                                                                                                        \
+        auto k = pw_wgrad_kernel<MW, NW>;                                                                       \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, a);                                             \
+    } while (0)
+    if (MTW == 1 && NTW == 1) CFN_WG_GO(1, 1);
+    else if (MTW == 1) CFN_WG_GO(1, 2);
+    else if (NTW == 1) CFN_WG_GO(2, 1);
+    else CFN_WG_GO(2, 2);
+#undef CFN_WG_GO
+    return cfn_check_launch("pwconv_bwd_weight");
+}
+
+static void wg_geom(WgArgs& a, int N, int Cin, int Cout, int T, int Hi, int Wi, int stride) {
+    a.N = N; a.M = Cout; a.K = Cin; a.Hi = Hi; a.Wi = Wi; a.stride = stride;
+    a.Ho = (Hi - 1) / stride + 1; a.Wo = (Wi - 1) / stride + 1;
+    a.Pin = T * Hi * Wi; a.Q = T * a.Ho * a.Wo;
+}
+
 extern "C" int cfn_pwconv_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq,
                                      const float* x, const float* A, const float* B, int act, double* gw, int N,
                                      int Cin, int Cout, int T, int Hi, int Wi, int stride, void* stream) {
@@ -548,40 +631,14 @@ extern "C" int cfn_pwconv_bwd_weight(const float* gy, const float* y, const doub
     CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_pwconv_bwd_weight: gsumsq needs y");
     WgArgs a = {};
     a.gy = gy; a.y = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.x = x; a.pa = A; a.pb = B; a.act = act;
-    a.gw = gw; a.N = N; a.M = Cout; a.K = Cin;
-    a.Hi = Hi; a.Wi = Wi; a.stride = stride;
-    a.Ho = (Hi - 1) / stride + 1; a.Wo = (Wi - 1) / stride + 1;
-    a.Pin = T * Hi * Wi; a.Q = T * a.Ho * a.Wo;
-    // tile shape: rows <= 96, cols <= 64
-    const int M32 = cfn_cdiv(Cout, 32), K32 = cfn_cdiv(Cin, 32);
-    const int MTW = cfn_cdiv(M32, cfn_cdiv(M32, 3)), NTW = cfn_cdiv(K32, cfn_cdiv(K32, 2));
-    a.mtiles = cfn_cdiv(Cout, 32 * MTW);
-    a.ktiles = cfn_cdiv(Cin, 32 * NTW);
-    const long nst = cfn_cdiv(a.Q, WG_PT);
-    int stages = 64;
-    while (stages > 4 && (long)N * cfn_cdiv(nst, stages) * a.mtiles * a.ktiles < 1024) stages >>= 1;
-    a.stages = stages;
-    a.nstrips = cfn_cdiv(nst, stages);
-    const unsigned blocks = (unsigned)((long)N * a.nstrips * a.mtiles * a.ktiles);
-    const size_t lds = ((size_t)(32 * MTW + 32 * NTW) * WG_PITCH + 2 * (32 * MTW + 32 * NTW)) * sizeof(float);
+    a.gw = gw;
+    wg_geom(a, N, Cin, Cout, T, Hi, Wi, stride);
+    int MTW, NTW;
+    wg_plan(a, MTW, NTW);
     hipStream_t st = (hipStream_t)stream;
-    CfnProfScope prof(CFN_K_PWCONV_BWD, st, 4.0 * N * ((double)Cout * a.Q * (a.y ? 2 : 1) + (double)Cin * a.Q));
-#define CFN_WG_GO(MW, NW)                                                                                       \
-    do {                                                                                                        \
-        auto k = pw_wgrad_kernel<MW, NW>;                                                                       \
-        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, a);                                             \
-    } while (0)
-    if (MTW == 1 && NTW == 1) CFN_WG_GO(1, 1);
-    else if (MTW == 1) CFN_WG_GO(1, 2);
-    else if (MTW == 2 && NTW == 1) CFN_WG_GO(2, 1);
-    else if (MTW == 2) CFN_WG_GO(2, 2);
-    else if (NTW == 1) CFN_WG_GO(3, 1);
-    else CFN_WG_GO(3, 2);
-#undef CFN_WG_GO
-    return cfn_check_launch("pwconv_bwd_weight");
+    CfnProfScope prof(CFN_K_PWCONV_WGRAD, st, 4.0 * N * ((double)Cout * a.Q * (a.y ? 2 : 1) + (double)Cin * a.Q));
+    return wg_launch(a, MTW, NTW, st);
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // X3D stem spatial conv (conv1_s: 1x3x3, stride (1,2,2), pad (0,1,1), x3d_fine.py:210-215) as the
@@ -614,25 +671,9 @@ extern "C" int cfn_stem_conv_bwd_weight(const float* gy, const float* x, double*
     a.Hi = Hi; a.Wi = Wi; a.stride = 1;
     a.Ho = (Hi + 2 - 3) / 2 + 1; a.Wo = (Wi + 2 - 3) / 2 + 1;
     a.Pin = T * Hi * Wi; a.Q = T * a.Ho * a.Wo;
-    const int M32 = cfn_cdiv(Cout, 32), K32 = cfn_cdiv(a.K, 32);
-    CFN_REQUIRE(M32 <= 3 && K32 <= 2, "cfn_stem_conv_bwd_weight: Cout <= 96 and Cimg*9 <= 64 supported (got %d, %d)", Cout, a.K);
-    a.mtiles = 1; a.ktiles = 1;
-    const long nst = cfn_cdiv(a.Q, WG_PT);
-    int stages = 64;
-    while (stages > 4 && (long)N * cfn_cdiv(nst, stages) < 1024) stages >>= 1;
-    a.stages = stages;
-    a.nstrips = cfn_cdiv(nst, stages);
-    const unsigned blocks = (unsigned)((long)N * a.nstrips);
-    const size_t lds = ((size_t)(32 * M32 + 32 * K32) * WG_PITCH + 2 * (32 * M32 + 32 * K32)) * sizeof(float);
+    int MTW, NTW;
+    wg_plan(a, MTW, NTW);
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_STEM, st, 4.0 * N * ((double)Cimg * a.Pin + (double)Cout * a.Q));
-#define CFN_WG_GO(MW, NW) hipLaunchKernelGGL((pw_wgrad_kernel<MW, NW>), dim3(blocks), dim3(256), lds, st, a)
-    if (M32 == 1 && K32 == 1) CFN_WG_GO(1, 1);
-    else if (M32 == 1) CFN_WG_GO(1, 2);
-    else if (M32 == 2 && K32 == 1) CFN_WG_GO(2, 1);
-    else if (M32 == 2) CFN_WG_GO(2, 2);
-    else if (K32 == 1) CFN_WG_GO(3, 1);
-    else CFN_WG_GO(3, 2);
-#undef CFN_WG_GO
-    return cfn_check_launch("stem_conv_bwd_weight");
+    return wg_launch(a, MTW, NTW, st);
 }

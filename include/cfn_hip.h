@@ -31,7 +31,8 @@ const char* cfn_version(void);
 int cfn_device_info(int* cus, int* lds_per_cu, char* name, int name_len);
 
 /* opt-in HIP-event timing per kernel family (bench.py roofline leg). family: 0 dwconv fwd, 1 dwconv
- * bwd, 2 pwconv fwd, 3 pwconv bwd, 4 gridpool, 5 elementwise, 6 stem, 7 fusion.  collect() sums and
+ * bwd-data, 2 pwconv fwd, 3 pwconv bwd-data, 4 gridpool, 5 elementwise, 6 stem, 7 fusion, 8 pwconv bwd-weight,
+ * 9 dwconv bwd-weight.  collect() sums and
  * clears: total device ms between the bracketing events, launches, algorithmic bytes. */
 int cfn_prof_enable(int family, int on);
 int cfn_prof_collect(int family, double* total_ms, long* launches, double* total_bytes);
@@ -60,7 +61,8 @@ int cfn_dwconv_t5_bwd_weight(const float* gy, const float* y, const double* gsum
 
 /* ---- pointwise 1x1x1, spatial stride s in {1,2}: conv1x1x1 x3d_fine.py:100-105 (conv1 :115, conv3 :119,
  * shortcut :284-287), conv5 :245-250, fc1 :256; fp32 MFMA (v_mfma_f32_32x32x2_f32).  w is (Cout,Cin).
- * bwd_data with stride 2 writes only the strided positions: caller zero-fills gx. ---- */
+ * bwd_data with stride 2 writes only the strided positions: caller zero-fills gx.
+ * bwd_weight accumulates into gw (Cout,Cin) fp64, zero-filled by the caller (one atomic per element per workgroup). ---- */
 int cfn_pwconv_fwd(const float* x, const float* A, const float* B, int act, const float* w, float* y, double* sum,
                    double* sumsq, int N, int Cin, int Cout, int T, int Hi, int Wi, int stride, void* stream);
 int cfn_pwconv_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,

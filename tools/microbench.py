@@ -12,9 +12,31 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'coarse-fine-networks_amd'))
 import torch                      # noqa: E402
+import cfn_hip                    # noqa: E402
 from cfn_hip import ops           # noqa: E402
 
 DEV = 'cuda'
+
+
+FAMS = ('dwconv_fwd', 'dwconv_bwd', 'dwconv_wgrad', 'pwconv_fwd', 'pwconv_bwd', 'pwconv_wgrad')
+
+
+def devtime(fn, iters=3):
+    """device ms per call of each kernel family (HIP events around every launch inside the C ABI)"""
+    fn()
+    torch.cuda.synchronize()
+    for f in FAMS:
+        cfn_hip.prof_enable(f, True)
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    out = {}
+    for f in FAMS:
+        cfn_hip.prof_enable(f, False)
+        ms, n, _ = cfn_hip.prof_collect(f)
+        if n:
+            out[f] = ms / iters
+    return out
 
 
 def timeit(fn, iters=5, warm=2):
@@ -51,7 +73,7 @@ def bench_pw(T, bwd):
         B = torch.randn(1, ci, device=DEV) * 0.1
         Ho = (H - 1) // s + 1
         Q = T * Ho * Ho
-        ms = timeit(lambda: ops.pwconv(x, w, A, B, 1, s, True))
+        ms = devtime(lambda: ops.pwconv(x, w, A, B, 1, s, True))['pwconv_fwd']
         gb = 4.0 * (ci * Q + co * Q) / 1e9
         print('%-28s %9.3f %9.1f %9.2f' % (name, ms, gb / ms * 1e3, 2.0 * ci * co * Q / ms / 1e9))
         if bwd:
@@ -63,10 +85,11 @@ def bench_pw(T, bwd):
 
             def f():
                 torch.autograd.grad((y, sm, sq), (xr, wr, Ar, Br), (gy, gs, gq), retain_graph=True)
-            ms = timeit(f, iters=3, warm=1)
-            gbb = 4.0 * (2 * ci * Q + 2 * co * Q + ci * Q + 2 * co * Q) / 1e9
-            print('%-28s %9.3f %9.1f %9.2f   (dgrad+wgrad; bytes = 2in+2out | in+2out)' %
-                  ('', ms, gbb / ms * 1e3, 4.0 * ci * co * Q / ms / 1e9))
+            d = devtime(f)
+            md, mw = d.get('pwconv_bwd', 0.0), d.get('pwconv_wgrad', 0.0)
+            print('%-28s dgrad %7.3f ms %7.1f GB/s %6.2f TF | wgrad %7.3f ms %7.1f GB/s %6.2f TF' %
+                  ('', md, 4.0 * (2 * ci + 2 * co) * Q / 1e6 / md, 2.0 * ci * co * Q / md / 1e9,
+                   mw, 4.0 * (ci + 2 * co) * Q / 1e6 / mw, 2.0 * ci * co * Q / mw / 1e9))
 
 
 def bench_dw(T, bwd):
@@ -77,7 +100,7 @@ def bench_dw(T, bwd):
         A = torch.rand(1, c, device=DEV) + 0.5
         B = torch.randn(1, c, device=DEV) * 0.1
         Ho = (H + 2 - 3) // s + 1
-        ms = timeit(lambda: ops.dwconv3d(x, w, A, B, 1, s, True))
+        ms = devtime(lambda: ops.dwconv3d(x, w, A, B, 1, s, True))['dwconv_fwd']
         gb = 4.0 * c * T * (H * H + Ho * Ho) / 1e9
         print('%-28s %9.3f %9.1f %9.2f' % (name, ms, gb / ms * 1e3, 54.0 * c * T * Ho * Ho / ms / 1e9))
         if bwd:
@@ -88,8 +111,10 @@ def bench_dw(T, bwd):
 
             def f():
                 torch.autograd.grad((y, sm, sq), (xr, wr, Ar, Br), (gy, gs, gq), retain_graph=True)
-            ms = timeit(f, iters=3, warm=1)
-            print('%-28s %9.3f   (dgrad+wgrad)' % ('', ms))
+            d = devtime(f)
+            md, mw = d.get('dwconv_bwd', 0.0), d.get('dwconv_wgrad', 0.0)
+            print('%-28s dgrad %7.3f ms %7.1f GB/s | wgrad %7.3f ms %7.1f GB/s' %
+                  ('', md, 4.0 * c * T * (2 * H * H + 2 * Ho * Ho) / 1e6 / md, mw, 4.0 * c * T * (H * H + 2 * Ho * Ho) / 1e6 / mw))
 
 
 if __name__ == '__main__':
