@@ -15,7 +15,7 @@ _ROOT = os.path.dirname(os.path.dirname(_HERE))
 LIB_PATH = os.path.join(_HERE, 'libcfn_hip.so')
 HEADER = os.path.join(_ROOT, 'include', 'cfn_hip.h')
 
-ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 FAMILIES = {'dwconv_fwd': 0, 'dwconv_bwd': 1, 'pwconv_fwd': 2, 'pwconv_bwd': 3, 'gridpool': 4, 'elementwise': 5,
             'stem': 6, 'fusion': 7, 'pwconv_wgrad': 8, 'dwconv_wgrad': 9}
 

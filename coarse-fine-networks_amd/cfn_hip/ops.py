@@ -11,7 +11,9 @@ full-size tensor is touched only inside the HIP kernels.
 import torch
 from torch.autograd import Function
 
-from . import call, check, query, ACT_NONE, ACT_RELU, ACT_SWISH  # noqa: F401
+import ctypes
+
+from . import call, check, query, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID  # noqa: F401
 
 
 class _ZeroArena(object):
@@ -533,3 +535,94 @@ class _TimeResize(Function):
 
 def time_resize(x, L):
     return _TimeResize.apply(x, L)
+
+
+def _geom(kernel, stride, padding):
+    return (ctypes.c_int * 9)(*(tuple(kernel) + tuple(stride) + tuple(padding)))
+
+
+class _ConvDense(Function):
+    """dense conv3d (no bias) as implicit GEMM; prologue / stats convention of the other convs.  cfn_conv3d_dense_*."""
+
+    @staticmethod
+    def forward(ctx, x, A, B, w, act, kernel, stride, padding, want_stats):
+        x = check(x).contiguous()
+        N, Ci, T, H, W = x.shape
+        Co = w.shape[0]
+        g = _geom(kernel, stride, padding)
+        To = (T + 2 * padding[0] - kernel[0]) // stride[0] + 1
+        Ho = (H + 2 * padding[1] - kernel[1]) // stride[1] + 1
+        Wo = (W + 2 * padding[2] - kernel[2]) // stride[2] + 1
+        y = torch.empty(N, Co, To, Ho, Wo, dtype=torch.float32, device=x.device)
+        s = q = None
+        if want_stats:
+            s, q = _f64(N, Co, x.device), _f64(N, Co, x.device)
+        w2 = w.reshape(Co, -1).contiguous()
+        A, B = _opt(A), _opt(B)
+        call('cfn_conv3d_dense_fwd', x, A, B, act, w2, y, s, q, N, Ci, Co, T, H, W, g)
+        ctx.save_for_backward(x, A, B, w2, y)
+        ctx.meta = (act, tuple(kernel), tuple(stride), tuple(padding), tuple(w.shape))
+        if not want_stats:
+            return y, None, None
+        return y, s, q
+
+    @staticmethod
+    def backward(ctx, gy, gs, gq):
+        x, A, B, w2, y = ctx.saved_tensors
+        act, kernel, stride, padding, wshape = ctx.meta
+        N, Ci, T, H, W = x.shape
+        Co = w2.shape[0]
+        g = _geom(kernel, stride, padding)
+        gy = torch.zeros_like(y) if gy is None else gy.contiguous()
+        gs, gq = _opt(gs), _opt(gq)
+        gx = gA = gB = gw = None
+        if ctx.needs_input_grad[0] or (A is not None and ctx.needs_input_grad[1]):
+            gx = torch.empty_like(x)
+            ab = a64 = b64 = None
+            if A is not None:
+                ab, a64, b64 = _f64pair(N, Ci, x.device)
+            call('cfn_conv3d_dense_bwd_data', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, Ci, Co, T, H, W, g)
+            if A is not None:
+                ab = ab.float()
+                gA, gB = ab[0], ab[1]
+        if ctx.needs_input_grad[3]:
+            g64 = _f64(Co, w2.shape[1], x.device)
+            call('cfn_conv3d_dense_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, Ci, Co, T, H, W, g)
+            gw = g64.float().view(wshape)
+        return gx, gA, gB, gw, None, None, None, None, None
+
+
+def conv3d_dense(x, w, kernel, stride, padding, A=None, B=None, act=ACT_NONE, stats=True):
+    return _ConvDense.apply(x, A, B, w, act, kernel, stride, padding, stats)
+
+
+class _FusionGather(Function):
+    """z[b,c,k,p] = sum_t x[b,c,t,p] at[b,t,p] gm[b,t,k] / (sum_t at gm + 1e-6)   (cfn_fusion_gather_*)"""
+
+    @staticmethod
+    def forward(ctx, x, at, gm):
+        x, at, gm = check(x).contiguous(), check(at).contiguous(), check(gm).contiguous()
+        B, C, Tf, P = x.shape
+        K = gm.shape[2]
+        z = torch.empty(B, C, K, P, dtype=torch.float32, device=x.device)
+        den = torch.empty(B, K, P, dtype=torch.float32, device=x.device)
+        call('cfn_fusion_gather_fwd', x, at, gm, z, den, B, C, Tf, K, P)
+        ctx.save_for_backward(x, at, gm, z, den)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, at, gm, z, den = ctx.saved_tensors
+        B, C, Tf, P = x.shape
+        K = gm.shape[2]
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(B, Tf, K, P, dtype=torch.float32, device=x.device)
+        call('cfn_fusion_gather_bwd', gz.contiguous(), z, den, x, at, gm, gx, dw, B, C, Tf, K, P)
+        gat = torch.einsum('btkp,btk->btp', dw, gm) if ctx.needs_input_grad[1] else None
+        ggm = torch.einsum('btkp,btp->btk', dw, at) if ctx.needs_input_grad[2] else None
+        return gx, gat, ggm
+
+
+def fusion_gather(x, at, gm):
+    """x (B,C,Tf,P), at (B,Tf,P), gm (B,Tf,K) -> (B,C,K,P)"""
+    return _FusionGather.apply(x, at, gm)

@@ -11,7 +11,7 @@
 #define CFN_ERR_UNSUPPORTED 3
 
 // activation codes of the load-time prologue  a = act(A[n,c] * x + B[n,c])
-enum { CFN_ACT_NONE = 0, CFN_ACT_RELU = 1, CFN_ACT_SWISH = 2 };
+enum { CFN_ACT_NONE = 0, CFN_ACT_RELU = 1, CFN_ACT_SWISH = 2, CFN_ACT_SIGMOID = 3 };
 
 extern "C" const char* cfn_last_error(void);
 int cfn_fail(int code, const char* fmt, ...);  // records the message, returns code
@@ -51,11 +51,15 @@ __device__ __forceinline__ float cfn_act_grad(float z) {
     return 1.0f;
 }
 __device__ __forceinline__ float cfn_act_rt(float z, int act) {
-    return act == CFN_ACT_RELU ? fmaxf(z, 0.0f) : (act == CFN_ACT_SWISH ? z * cfn_sigmoid(z) : z);
+    if (act == CFN_ACT_RELU) return fmaxf(z, 0.0f);
+    if (act == CFN_ACT_SWISH) return z * cfn_sigmoid(z);
+    if (act == CFN_ACT_SIGMOID) return cfn_sigmoid(z);
+    return z;
 }
 __device__ __forceinline__ float cfn_act_grad_rt(float z, int act) {
     if (act == CFN_ACT_RELU) return z > 0.0f ? 1.0f : 0.0f;
     if (act == CFN_ACT_SWISH) { float s = cfn_sigmoid(z); return s * (1.0f + z * (1.0f - s)); }
+    if (act == CFN_ACT_SIGMOID) { float s = cfn_sigmoid(z); return s * (1.0f - s); }
     return 1.0f;
 }
 

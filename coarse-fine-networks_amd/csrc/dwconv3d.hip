@@ -35,7 +35,7 @@ struct DwArgs {
     double* s1;          // FWD: sum(y)      DGRAD: sum(dz*x)     WGRAD: gw (C,27) accumulators
     double* s2;          // FWD: sum(y*y)    DGRAD: sum(dz)
     int N, C, T, Hi, Wi, Ho, Wo, act;
-    int TT, nchunks, CG, ngroups, GB, nbands, IPCb, RIN, WP, XO;
+    int TT, nchunks, CG, ngroups, GB, nbands, IPCb, IPCp, RIN, WP, XO;   // IPCp: thread slots per channel (>= IPCb)
 };
 
 // contiguous-segment sum inside a wave: lanes with equal key form runs; the first lane of each
@@ -50,8 +50,11 @@ __device__ __forceinline__ float seg_wave_sum(float v, int key, int lane) {
     return v;
 }
 
-template <int MODE, int S, int HS, int VEC, int MAXLD>
-__global__ __launch_bounds__(512) void dw3d_kernel(const DwArgs a) {
+// UNIW: every wave works on a single channel (thread slots per channel padded to a multiple of 64), so the 27
+// weights live in SGPRs; together with the 128-VGPR cap this lets two 7-wave workgroups share a CU.
+// DEPTH 2 (float4 loaders with <= 2 loads per thread): two input frames are in flight per workgroup.
+template <int MODE, int S, int HS, int VEC, int MAXLD, bool UNIW>
+__global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_FWD ? 4 : 3) : 2) : 2) void dw3d_kernel(const DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HSIN = (HS - 1) * S + 3;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
@@ -72,12 +75,13 @@ __global__ __launch_bounds__(512) void dw3d_kernel(const DwArgs a) {
     const int total_ld = ncg * per_ch;
     const long plane_i = (long)Hi * Wi, plane_o = (long)Ho * Wo;
 
-    float* buf = smem;
-    float* sA = buf + a.CG * RIN * WP;
+    const int bufsz = a.CG * RIN * WP;                         // one frame image (all CG channels) incl. zero halo
+    float* buf = smem;                                         // two images: frame parity selects one
+    float* sA = buf + 2 * bufsz;
     float* sB = sA + a.CG;
     float* sR = sB + a.CG;                                     // reduction scratch: 27*CG floats
 
-    for (int i = tid; i < a.CG * RIN * WP; i += nthr) buf[i] = 0.0f;
+    for (int i = tid; i < 2 * bufsz; i += nthr) buf[i] = 0.0f;
     for (int i = tid; i < a.CG * 27; i += nthr) sR[i] = 0.0f;
     if (tid < a.CG) {
         if (MODE == DW_DGRAD) {   // staged tensor is gy + gs + y * 2gq
@@ -109,10 +113,10 @@ __global__ __launch_bounds__(512) void dw3d_kernel(const DwArgs a) {
     }
 
     // ---- compute-thread identity ----------------------------------------------------------------
-    const int IPCb = a.IPCb;
-    const bool active = tid < ncg * IPCb;
-    const int c_local = active ? tid / IPCb : 0;
-    const int item = tid - c_local * IPCb;
+    const int IPCb = a.IPCb, IPCp = a.IPCp;
+    const int c_slot = tid / IPCp, item = tid - c_slot * IPCp;
+    const bool active = c_slot < ncg && item < IPCb;
+    const int c_local = c_slot < ncg ? c_slot : 0;
     const int gl = active ? item / Wo : 0;
     const int wo = active ? item - gl * Wo : 0;
     const int c = c0 + c_local;
@@ -123,7 +127,10 @@ __global__ __launch_bounds__(512) void dw3d_kernel(const DwArgs a) {
     float wr[27];
     if (MODE != DW_WGRAD) {
 #pragma unroll
-        for (int j = 0; j < 27; ++j) wr[j] = active ? a.w[(long)c * 27 + (MODE == DW_DGRAD ? 26 - j : j)] : 0.0f;
+        for (int j = 0; j < 27; ++j) {
+            const float wv = a.w[(long)c * 27 + (MODE == DW_DGRAD ? 26 - j : j)];
+            wr[j] = UNIW ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wv))) : wv;
+        }
     }
     // stats-gradient terms of the incoming gradient (DGRAD: on the LDS-staged tensor; WGRAD: on gy)
     float gs_c = 0.0f, gq2_c = 0.0f;
@@ -146,11 +153,12 @@ __global__ __launch_bounds__(512) void dw3d_kernel(const DwArgs a) {
     float st1 = 0.0f, st2 = 0.0f;
 
     typedef float __attribute__((ext_vector_type(4))) f4;
-    f4 pf[MAXLD], pf2[MAXLD];
+    constexpr int DEPTH = (MODE == DW_FWD && VEC == 4 && MAXLD == 2) ? 2 : 1;
+    f4 pfA[MAXLD], pfA2[MAXLD], pfB[DEPTH == 2 ? MAXLD : 1], pfB2[DEPTH == 2 ? MAXLD : 1];
     const bool two_src = (MODE == DW_DGRAD) && a.src2 != nullptr;
 
     auto frame_valid = [&](int f) { return f >= 0 && f < T; };
-    auto prefetch = [&](int f) {
+    auto prefetch = [&](int f, f4* pf, f4* pf2) {
         const long base = (((long)n * C + c0) * T + f) * plane_i;
 #pragma unroll
         for (int k = 0; k < MAXLD; ++k) {
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(512) void dw3d_kernel(const DwArgs a) {
             }
         }
     };
-    auto stage = [&]() {   // registers -> LDS with the load-time prologue
+    auto stage = [&](const f4* pf, const f4* pf2, float* img) {   // registers -> LDS with the load-time prologue
 #pragma unroll
         for (int k = 0; k < MAXLD; ++k) {
             if (rel[k] >= 0) {
@@ -192,8 +200,8 @@ __global__ __launch_bounds__(512) void dw3d_kernel(const DwArgs a) {
                         v.w = cfn_act_rt(fmaf(v.w, pa, pb), a.act);
                     }
                 }
-                if (VEC == 4) *reinterpret_cast<f4*>(buf + lo) = v;
-                else buf[lo] = v.x;
+                if (VEC == 4) *reinterpret_cast<f4*>(img + lo) = v;
+                else img[lo] = v.x;
             }
         }
     };
@@ -216,15 +224,23 @@ __global__ __launch_bounds__(512) void dw3d_kernel(const DwArgs a) {
     __syncthreads();   // zero fill + sA/sB visible
 
     const int f_first = t0 - 1, f_last = t1;   // input frames t0-1 .. t1 (inclusive)
-    if (frame_valid(f_first)) prefetch(f_first);
     if (MODE == DW_WGRAD) { load_g(t0, gro[0]); load_g(t0 + 1, gnn); }
+    // prime the pipeline: frame f_first staged in image 0, the next DEPTH frames in flight in registers
+    if (frame_valid(f_first)) prefetch(f_first, pfA, pfA2);
+    if (DEPTH == 2 && f_first + 1 <= f_last && frame_valid(f_first + 1)) prefetch(f_first + 1, pfB, pfB2);
+    if (frame_valid(f_first)) stage(pfA, pfA2, buf);
+    if (f_first + DEPTH <= f_last && frame_valid(f_first + DEPTH)) prefetch(f_first + DEPTH, pfA, pfA2);
+    __syncthreads();
 
-    for (int f = f_first; f <= f_last; ++f) {
+    // one frame step (ONE barrier): stage frame f+1 from `nx` into the other LDS image, refill `nx` with frame
+    // f+1+DEPTH, compute frame f from image `par`, emit output frame f-1
+    auto step = [&](int f, int par, f4* nx, f4* nx2) {
         const bool fv = frame_valid(f);
-        if (f != f_first) __syncthreads();         // everyone finished reading the previous frame
-        if (fv) stage();
-        __syncthreads();
-        if (f + 1 <= f_last && frame_valid(f + 1)) prefetch(f + 1);
+        if (f + 1 <= f_last) {
+            if (frame_valid(f + 1)) stage(nx, nx2, buf + (par ^ 1) * bufsz);
+            if (f + 1 + DEPTH <= f_last && frame_valid(f + 1 + DEPTH)) prefetch(f + 1 + DEPTH, nx, nx2);
+        }
+        const float* tbp = tb + par * bufsz;
 
         // DGRAD epilogue operand for the frame that completes in this step
         const int to = f - 1;
@@ -239,7 +255,7 @@ __global__ __launch_bounds__(512) void dw3d_kernel(const DwArgs a) {
         if (fv && active) {
 #pragma unroll
             for (int r = 0; r < HSIN; ++r) {
-                const float v0 = tb[r * WP], v1 = tb[r * WP + 1], v2 = tb[r * WP + 2];
+                const float v0 = tbp[r * WP], v1 = tbp[r * WP + 1], v2 = tbp[r * WP + 2];
 #pragma unroll
                 for (int i = 0; i < HS; ++i) {
                     const int kh = r - i * S;
@@ -289,6 +305,12 @@ __global__ __launch_bounds__(512) void dw3d_kernel(const DwArgs a) {
 #pragma unroll
             for (int i = 0; i < HS; ++i) { acc[2][i] = acc[1][i]; acc[1][i] = acc[0][i]; acc[0][i] = 0.0f; }
         }
+        __syncthreads();   // image par fully consumed, image par^1 fully written
+    };
+    // frame f_first+1 sits in set B (DEPTH 2) or A (DEPTH 1); sets alternate with the frame parity
+    for (int f = f_first; f <= f_last; f += 2) {
+        step(f, 0, DEPTH == 2 ? pfB : pfA, DEPTH == 2 ? pfB2 : pfA2);
+        if (f + 1 <= f_last) step(f + 1, 1, pfA, pfA2);
     }
 
     // ---- block reductions -> one fp64 atomic per (channel, value) per block -----------------
@@ -418,7 +440,7 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
 // ---------------------------------------------------------------------------------------------
 // host side: geometry heuristics + dispatch
 // ---------------------------------------------------------------------------------------------
-struct DwPlan { int HS, VEC, MAXLD, threads; size_t lds; unsigned blocks; };
+struct DwPlan { int HS, VEC, MAXLD, threads; bool UNIW; size_t lds; unsigned blocks; };
 
 static int pick_hs(int Ho) {
     if (Ho % 7 == 0) return 7;
@@ -442,7 +464,7 @@ static int dw_plan(DwArgs& a, int S, int mode, DwPlan& pl) {
         const int rin = (GB * HS - 1) * S + 3;
         const long ipcb = (long)GB * a.Wo;
         const long thr = (ipcb + 63) / 64 * 64;
-        const bool fits = ipcb <= 512 && (long)rin * a.WP * 4 <= 60 * 1024 && (long)rin * a.Wi <= (long)VEC * 8 * thr;
+        const bool fits = ipcb <= 256 && (long)rin * a.WP * 8 <= 60 * 1024 && (long)rin * a.Wi <= (long)VEC * 8 * thr;
         if (fits || GB == 1) break;
         --GB;
     }
@@ -450,15 +472,22 @@ static int dw_plan(DwArgs& a, int S, int mode, DwPlan& pl) {
     a.nbands = G / GB;
     a.RIN = (GB * HS - 1) * S + 3;
     a.IPCb = GB * a.Wo;
-    if (a.IPCb > 512 || (long)a.RIN * a.WP * 4 > 150 * 1024)
+    if (a.IPCb > 512 || (long)a.RIN * a.WP * 8 > 150 * 1024)
         return cfn_fail(CFN_ERR_UNSUPPORTED, "dwconv3d: plane %dx%d does not fit the LDS band scheme", a.Hi, a.Wi);
-    int CG = 512 / a.IPCb;
+    // thread slots per channel: pad to whole waves when that costs <= 15 % idle lanes (=> wave-uniform channel,
+    // weights in SGPRs)
+    const int ipc64 = (a.IPCb + 63) / 64 * 64;
+    pl.UNIW = a.IPCb >= 64 && ipc64 <= 256 && (ipc64 - a.IPCb) * 100 <= 15 * ipc64;
+    a.IPCp = pl.UNIW ? ipc64 : a.IPCb;
+    // UNIW: 4-wave workgroups (several fit on a CU, barriers stay cheap); small planes: up to 8 waves
+    int CG = (pl.UNIW ? 256 : 512) / a.IPCp;
+    if (CG < 1) CG = 1;
     if (CG > a.C) CG = a.C;
     if (CG > 128) CG = 128;
-    while (CG > 1 && ((long)CG * a.RIN * a.WP * 4 > 48 * 1024)) --CG;
+    while (CG > 1 && ((long)CG * a.RIN * a.WP * 8 > 48 * 1024)) --CG;
     int threads;
     for (;; --CG) {   // loader capacity: VEC*8 elements per thread per frame
-        threads = (CG * a.IPCb + 63) / 64 * 64;
+        threads = (CG * a.IPCp + 63) / 64 * 64;
         if ((long)CG * a.RIN * a.Wi <= (long)VEC * 8 * threads || CG == 1) break;
     }
     if ((long)CG * a.RIN * a.Wi > (long)VEC * 8 * threads)
@@ -469,28 +498,45 @@ static int dw_plan(DwArgs& a, int S, int mode, DwPlan& pl) {
     const int MAXLD = (VEC == 4 && per_thread <= 2) ? 2 : 8;
     // frames per chunk: as long as possible while keeping >= ~6 workgroups per CU in the grid
     const long planes = (long)a.N * a.ngroups * a.nbands;
-    int TT = 32;
-    while (TT > 8 && planes * cfn_cdiv(a.T, TT) < 1536) TT >>= 1;
+    // Whole rounds: resident workgroups per CU follow from the register budget of the variant (launch bounds),
+    // so size the t-chunks such that the grid fills R full rounds of the chip (a 1.1-round grid costs 2 rounds).
+    const int per_cu = !pl.UNIW ? (threads > 256 ? 1 : 2) : (MAXLD != 2 ? 2 : (mode == DW_FWD ? 4 : 3));
+    const long slots = 256L * per_cu;
+    int TT = a.T;
+    for (int R = 1; R <= 8; ++R) {
+        long nch = slots * R / planes;
+        if (nch < 1) continue;
+        if (nch > a.T) nch = a.T;
+        TT = cfn_cdiv(a.T, nch);
+        if (TT <= 40) break;
+    }
+    if (TT < 8) TT = 8;
     if (TT > a.T) TT = a.T;
     a.TT = TT;
     a.nchunks = cfn_cdiv(a.T, TT);
     pl.HS = HS; pl.VEC = VEC; pl.MAXLD = MAXLD; pl.threads = threads;
-    pl.lds = ((size_t)CG * a.RIN * a.WP + 2 * CG + 27 * CG) * sizeof(float);
+    pl.lds = ((size_t)2 * CG * a.RIN * a.WP + 2 * CG + 27 * CG) * sizeof(float);
     pl.blocks = (unsigned)(planes * a.nchunks);
     return CFN_OK;
 }
 
 template <int MODE, int S, int HS>
 static int dw_launch_hs(const DwArgs& a, const DwPlan& pl, hipStream_t st) {
-#define CFN_DW_GO(VEC, MAXLD)                                                                                          \
+#define CFN_DW_GO(VEC, MAXLD, UW)                                                                                      \
     do {                                                                                                               \
-        auto k = dw3d_kernel<MODE, S, HS, VEC, MAXLD>;                                                                 \
-        if (pl.lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
+        auto k = dw3d_kernel<MODE, S, HS, VEC, MAXLD, UW>;                                                             \
+        if (pl.lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
         hipLaunchKernelGGL(k, dim3(pl.blocks), dim3(pl.threads), pl.lds, st, a);                                       \
     } while (0)
-    if (pl.VEC == 4 && pl.MAXLD == 2) CFN_DW_GO(4, 2);
-    else if (pl.VEC == 4) CFN_DW_GO(4, 8);
-    else CFN_DW_GO(1, 8);
+    if (pl.UNIW) {
+        if (pl.VEC == 4 && pl.MAXLD == 2) CFN_DW_GO(4, 2, true);
+        else if (pl.VEC == 4) CFN_DW_GO(4, 8, true);
+        else CFN_DW_GO(1, 8, true);
+    } else {
+        if (pl.VEC == 4 && pl.MAXLD == 2) CFN_DW_GO(4, 2, false);
+        else if (pl.VEC == 4) CFN_DW_GO(4, 8, false);
+        else CFN_DW_GO(1, 8, false);
+    }
 #undef CFN_DW_GO
     return cfn_check_launch("dwconv3d");
 }

@@ -1,0 +1,188 @@
+// Coarse-stream specific kernels:
+//   * data gradient of the dense (Grid Pool saliency) convolutions, gather form;
+//   * the Multi-stage Fusion temporal-alignment gather of RewightLayer (x3d_coarse.py:199-226), evaluated at the
+//     fine features' native 7x7 resolution: the reference first up-samples them with adaptive_max_pool2d
+//     (7 -> 56/28/14: each output cell copies exactly one input cell) and materialises a
+//     (B,C,T',K,h,w) product; every quantity is constant over the (h/7 x w/7) blocks, so the 7x7
+//     result up-sampled is identical (measured 3e-8).
+#include "cfn_common.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// gx[n,ci,it,ih,iw] = act'(A x + B) * A * sum_{co, taps hitting (it,ih,iw)} W[co,ci,kt,kh,kw] * g'[n,co,to,oh,ow]
+// with g' = gy + gs[n,co] + 2 y gq[n,co];  gA += sum dz*x, gB += sum dz.
+// ---------------------------------------------------------------------------------------------------------
+struct DenseBwdArgs {
+    const float* gy; const float* y; const double* gs; const double* gq; const float* w;
+    const float* x; const float* A; const float* B; float* gx; double* gA; double* gB;
+    int Cin, Cout, Ti, Hi, Wi, To, Ho, Wo, kT, kH, kW, sT, sH, sW, pT, pH, pW, act;
+};
+
+__global__ __launch_bounds__(256) void conv3d_dense_bwd_data_kernel(const DenseBwdArgs a) {
+    __shared__ float sh[8];
+    extern __shared__ float sg[];            // gs[Cout] | 2gq[Cout]
+    const int nci = blockIdx.y, n = nci / a.Cin, ci = nci - n * a.Cin;
+    for (int co = threadIdx.x; co < a.Cout; co += 256) {
+        sg[co] = a.gs ? (float)a.gs[(long)n * a.Cout + co] : 0.0f;
+        sg[a.Cout + co] = (a.gq && a.y) ? 2.0f * (float)a.gq[(long)n * a.Cout + co] : 0.0f;
+    }
+    __syncthreads();
+    const long pin = (long)a.Ti * a.Hi * a.Wi, po = (long)a.To * a.Ho * a.Wo;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    if (p < pin) {
+        const int iw = (int)(p % a.Wi), ih = (int)((p / a.Wi) % a.Hi), it = (int)(p / ((long)a.Wi * a.Hi));
+        const int KV = a.kT * a.kH * a.kW;
+        float da = 0.f;
+        for (int kt = 0; kt < a.kT; ++kt) {
+            const int tt = it + a.pT - kt;
+            if (tt < 0 || tt % a.sT) continue;
+            const int to = tt / a.sT;
+            if (to >= a.To) continue;
+            for (int kh = 0; kh < a.kH; ++kh) {
+                const int hh = ih + a.pH - kh;
+                if (hh < 0 || hh % a.sH) continue;
+                const int oh = hh / a.sH;
+                if (oh >= a.Ho) continue;
+                for (int kw = 0; kw < a.kW; ++kw) {
+                    const int ww = iw + a.pW - kw;
+                    if (ww < 0 || ww % a.sW) continue;
+                    const int ow = ww / a.sW;
+                    if (ow >= a.Wo) continue;
+                    const long oq = ((long)to * a.Ho + oh) * a.Wo + ow;
+                    const int tap = (kt * a.kH + kh) * a.kW + kw;
+                    for (int co = 0; co < a.Cout; ++co) {
+                        const long o = ((long)n * a.Cout + co) * po + oq;
+                        float g = a.gy[o] + sg[co];
+                        if (a.y) g = fmaf(a.y[o], sg[a.Cout + co], g);
+                        da = fmaf(a.w[((long)co * a.Cin + ci) * KV + tap], g, da);
+                    }
+                }
+            }
+        }
+        const long o = (long)nci * pin + p;
+        if (a.A) {
+            const float xa = a.A[nci], xb = a.B[nci], xv = a.x[o];
+            const float dz = da * cfn_act_grad_rt(fmaf(xv, xa, xb), a.act);
+            s1 = dz * xv; s2 = dz;
+            a.gx[o] = dz * xa;
+        } else {
+            a.gx[o] = da;
+        }
+    }
+    if (a.A && a.gA) {
+        s1 = cfn_wave_sum(s1); s2 = cfn_wave_sum(s2);
+        if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s1; sh[4 + (threadIdx.x >> 6)] = s2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&a.gA[nci], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
+            atomicAdd(&a.gB[nci], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
+        }
+    }
+}
+
+extern "C" int cfn_conv3d_dense_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq,
+                                         const float* w, const float* x, const float* A, const float* B, int act, float* gx,
+                                         double* gA, double* gB, int N, int Cin, int Cout, int T, int Hi, int Wi,
+                                         const int* geom, void* stream) {
+    CFN_REQUIRE(gy && w && gx && geom, "cfn_conv3d_dense_bwd_data: null tensor");
+    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_conv3d_dense_bwd_data: A/B mismatch");
+    CFN_REQUIRE(A == nullptr || (x && gA && gB), "cfn_conv3d_dense_bwd_data: prologue needs x, gA, gB");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_conv3d_dense_bwd_data: gsumsq needs y");
+    CFN_REQUIRE((long)N * Cin <= 65535, "cfn_conv3d_dense_bwd_data: N*Cin exceeds grid.y");
+    DenseBwdArgs a = {};
+    a.gy = gy; a.y = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.w = w; a.x = x; a.A = A; a.B = B; a.gx = gx;
+    a.gA = gA; a.gB = gB; a.Cin = Cin; a.Cout = Cout; a.Ti = T; a.Hi = Hi; a.Wi = Wi; a.act = act;
+    a.kT = geom[0]; a.kH = geom[1]; a.kW = geom[2]; a.sT = geom[3]; a.sH = geom[4]; a.sW = geom[5];
+    a.pT = geom[6]; a.pH = geom[7]; a.pW = geom[8];
+    a.To = (T + 2 * a.pT - a.kT) / a.sT + 1;
+    a.Ho = (Hi + 2 * a.pH - a.kH) / a.sH + 1;
+    a.Wo = (Wi + 2 * a.pW - a.kW) / a.sW + 1;
+    const long pin = (long)T * Hi * Wi;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_STEM, st, 4.0 * N * ((double)Cin * pin * 2 + (double)Cout * a.To * a.Ho * a.Wo));
+    hipLaunchKernelGGL(conv3d_dense_bwd_data_kernel, dim3(cfn_cdiv(pin, 256), N * Cin), dim3(256), 2 * Cout * sizeof(float), st, a);
+    return cfn_check_launch("conv3d_dense_bwd_data");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fusion gather.  x (B,C,Tf,P) fine features, at (B,Tf,P) attention, gm (B,Tf,K) = Gaussian alignment * mask.
+//   w[b,t,k,p] = at[b,t,p] * gm[b,t,k];  den[b,k,p] = sum_t w + 1e-6;  z[b,c,k,p] = sum_t x*w / den
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fusion_gather_fwd_kernel(const float* __restrict__ x, const float* __restrict__ at,
+                                                                const float* __restrict__ gm, float* __restrict__ z,
+                                                                float* __restrict__ den, int C, int Tf, int K, int P, long total) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int p = (int)(e % P), k = (int)((e / P) % K), c = (int)((e / ((long)P * K)) % C);
+    const long b = e / ((long)P * K * C);
+    const float* xp = x + ((b * C + c) * Tf) * (long)P + p;
+    const float* ap = at + b * Tf * (long)P + p;
+    const float* gp = gm + b * Tf * (long)K + k;
+    float num = 0.f, d = 0.f;
+    for (int t = 0; t < Tf; ++t) {
+        const float w = ap[(long)t * P] * gp[(long)t * K];
+        num = fmaf(xp[(long)t * P], w, num);
+        d += w;
+    }
+    d += 1e-6f;
+    z[e] = num / d;
+    if (c == 0) den[(b * K + k) * (long)P + p] = d;
+}
+
+// gx[b,c,t,p] = sum_k (gz/den)[b,c,k,p] * w[b,t,k,p]
+__global__ __launch_bounds__(256) void fusion_gather_bwd_x_kernel(const float* __restrict__ gz, const float* __restrict__ den,
+                                                                  const float* __restrict__ at, const float* __restrict__ gm,
+                                                                  float* __restrict__ gx, int C, int Tf, int K, int P, long total) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int p = (int)(e % P), t = (int)((e / P) % Tf), c = (int)((e / ((long)P * Tf)) % C);
+    const long b = e / ((long)P * Tf * C);
+    const float a0 = at[(b * Tf + t) * (long)P + p];
+    const float* gp = gm + (b * Tf + t) * (long)K;
+    const float* zp = gz + ((b * C + c) * K) * (long)P + p;
+    const float* dp = den + b * K * (long)P + p;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(zp[(long)k * P] / dp[(long)k * P], gp[k], acc);
+    gx[e] = acc * a0;
+}
+
+// dw[b,t,k,p] = sum_c (gz/den)[b,c,k,p] * (x[b,c,t,p] - z[b,c,k,p])      (d num and d den together)
+__global__ __launch_bounds__(256) void fusion_gather_bwd_w_kernel(const float* __restrict__ gz, const float* __restrict__ z,
+                                                                  const float* __restrict__ den, const float* __restrict__ x,
+                                                                  float* __restrict__ dw, int C, int Tf, int K, int P, long total) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int p = (int)(e % P), k = (int)((e / P) % K), t = (int)((e / ((long)P * K)) % Tf);
+    const long b = e / ((long)P * K * Tf);
+    const float id = 1.0f / den[(b * K + k) * (long)P + p];
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const long o = ((b * C + c) * K + k) * (long)P + p;
+        acc = fmaf(gz[o], x[((b * C + c) * Tf + t) * (long)P + p] - z[o], acc);
+    }
+    dw[e] = acc * id;
+}
+
+extern "C" int cfn_fusion_gather_fwd(const float* x, const float* at, const float* gm, float* z, float* den, int B, int C,
+                                     int Tf, int K, int P, void* stream) {
+    CFN_REQUIRE(x && at && gm && z && den, "cfn_fusion_gather_fwd: null tensor");
+    const long total = (long)B * C * K * P;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_FUSION, st, 4.0 * B * ((double)C * Tf * P + (double)C * K * P));
+    hipLaunchKernelGGL(fusion_gather_fwd_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, st, x, at, gm, z, den, C, Tf, K, P, total);
+    return cfn_check_launch("fusion_gather_fwd");
+}
+
+extern "C" int cfn_fusion_gather_bwd(const float* gz, const float* z, const float* den, const float* x, const float* at,
+                                     const float* gm, float* gx, float* dw, int B, int C, int Tf, int K, int P, void* stream) {
+    CFN_REQUIRE(gz && z && den && x && at && gm && dw, "cfn_fusion_gather_bwd: null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_FUSION, st, 4.0 * B * ((double)C * Tf * P * 2 + (double)C * K * P * 2));
+    if (gx) {
+        const long total = (long)B * C * Tf * P;
+        hipLaunchKernelGGL(fusion_gather_bwd_x_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, st, gz, den, at, gm, gx, C, Tf, K, P, total);
+    }
+    const long total = (long)B * Tf * K * P;
+    hipLaunchKernelGGL(fusion_gather_bwd_w_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, st, gz, z, den, x, dw, C, Tf, K, P, total);
+    return cfn_check_launch("fusion_gather_bwd");
+}

@@ -159,26 +159,39 @@ __device__ __forceinline__ void resize_src(int j, int Kin, int Lout, int& i0, in
     l0 = 1.0f - l1;
 }
 
+// one thread per output element (bc, j, p), p fastest
 __global__ __launch_bounds__(256) void time_resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int Kin,
-                                                              int Lout, long P) {
-    const long bc = blockIdx.z;
-    const int j = blockIdx.y;
-    const long p = (long)blockIdx.x * 256 + threadIdx.x;
-    if (p >= P) return;
+                                                              int Lout, long P, long total) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long p = e % P, r = e / P;
+    const int j = (int)(r % Lout);
+    const long bc = r / Lout;
     int i0, i1; float l0, l1;
     resize_src(j, Kin, Lout, i0, i1, l0, l1);
     const float* xp = x + bc * Kin * P + p;
-    out[(bc * Lout + j) * P + p] = l0 * xp[(long)i0 * P] + l1 * xp[(long)i1 * P];
+    out[e] = l0 * xp[(long)i0 * P] + l1 * xp[(long)i1 * P];
 }
 
+// one thread per input element (bc, k, p): gathers the few outputs j whose source interval touches k
+// (src(j) = j*(Kin-1)/(Lout-1) in [k-1, k+1]  =>  j in [(k-1)/scale, (k+1)/scale], checked exactly)
 __global__ __launch_bounds__(256) void time_resize_bwd_kernel(const float* __restrict__ g, float* __restrict__ gx, int Kin,
-                                                              int Lout, long P) {
-    const long bc = blockIdx.z;
-    const int k = blockIdx.y;
-    const long p = (long)blockIdx.x * 256 + threadIdx.x;
-    if (p >= P) return;
+                                                              int Lout, long P, long total) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long p = e % P, r = e / P;
+    const int k = (int)(r % Kin);
+    const long bc = r / Kin;
+    int jlo = 0, jhi = Lout - 1;
+    if (Kin > 1 && Lout > 1) {
+        const double inv = (double)(Lout - 1) / (double)(Kin - 1);
+        jlo = (int)floor((k - 1) * inv) - 1;
+        jhi = (int)ceil((k + 1) * inv) + 1;
+        if (jlo < 0) jlo = 0;
+        if (jhi > Lout - 1) jhi = Lout - 1;
+    }
     float acc = 0.f;
-    for (int j = 0; j < Lout; ++j) {     // Lout <= a few hundred; uniform branch per block
+    for (int j = jlo; j <= jhi; ++j) {
         int i0, i1; float l0, l1;
         resize_src(j, Kin, Lout, i0, i1, l0, l1);
         if (i0 != k && i1 != k) continue;
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(256) void time_resize_bwd_kernel(const float* __res
         if (i0 == k) acc = fmaf(gv, l0, acc);
         if (i1 == k) acc = fmaf(gv, l1, acc);
     }
-    gx[(bc * Kin + k) * P + p] = acc;
+    gx[e] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -245,15 +258,15 @@ extern "C" int cfn_interp1d_bwd(const float* g, const float* x, const float* y, 
 }
 
 extern "C" int cfn_time_resize_fwd(const float* x, float* out, long BC, int Kin, int Lout, long P, void* stream) {
-    CFN_REQUIRE(x && out && Kin > 0 && Lout > 0, "cfn_time_resize_fwd: bad argument");
-    CFN_GRID_CHECK(BC, Lout);
-    hipLaunchKernelGGL(time_resize_fwd_kernel, dim3(cfn_cdiv(P, 256), Lout, (unsigned)BC), dim3(256), 0, (hipStream_t)stream, x, out, Kin, Lout, P);
+    CFN_REQUIRE(x && out && Kin > 0 && Lout > 0 && BC > 0 && P > 0, "cfn_time_resize_fwd: bad argument");
+    const long total = BC * Lout * P;
+    hipLaunchKernelGGL(time_resize_fwd_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out, Kin, Lout, P, total);
     return cfn_check_launch("time_resize_fwd");
 }
 
 extern "C" int cfn_time_resize_bwd(const float* g, float* gx, long BC, int Kin, int Lout, long P, void* stream) {
-    CFN_REQUIRE(g && gx && Kin > 0 && Lout > 0, "cfn_time_resize_bwd: bad argument");
-    CFN_GRID_CHECK(BC, Kin);
-    hipLaunchKernelGGL(time_resize_bwd_kernel, dim3(cfn_cdiv(P, 256), Kin, (unsigned)BC), dim3(256), 0, (hipStream_t)stream, g, gx, Kin, Lout, P);
+    CFN_REQUIRE(g && gx && Kin > 0 && Lout > 0 && BC > 0 && P > 0, "cfn_time_resize_bwd: bad argument");
+    const long total = BC * Kin * P;
+    hipLaunchKernelGGL(time_resize_bwd_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, g, gx, Kin, Lout, P, total);
     return cfn_check_launch("time_resize_bwd");
 }

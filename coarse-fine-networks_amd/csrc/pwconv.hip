@@ -39,7 +39,9 @@ struct PwArgs {
     int N, M, K, Q, Pin, Hi, Wi, Ho, Wo, stride, act;
     int Cin;             // row pitch of w
     int mtiles, nstrips, tpb, kres, Kpad;   // kres: weight rows resident in LDS per pass (multiple of 8)
-    int stem, Cimg;      // stem != 0: B operand is the im2col view of a (N,Cimg,T,Hi,Wi) clip for a 1x3x3 stride-2 pad-1 conv
+    // stem != 0: dense convolution as an implicit GEMM -- the B operand is the im2col view of a (N,Cimg,Ti,Hi,Wi)
+    // tensor for a (kT,kH,kW) kernel with strides (sT,sH,sW) and zero padding (pT,pH,pW); K = Cimg*kT*kH*kW
+    int stem, Cimg, kT, kH, kW, sT, sH, sW, pT, pH, pW, Ti, To;
 };
 
 __device__ __forceinline__ int pw_pmap(int q, int Ho, int Wo, int Hi, int Wi, int stride) {
@@ -80,10 +82,21 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
     float2* sE = sP + Kpad + PW_UNIT;                     // [BM] epilogue coefficients (DGRAD)
     float* sSt = reinterpret_cast<float*>(sE + BM);       // [BM][2]
     float* red = sSt + 2 * BM + wave * (32 * PW_RED_PITCH);
+    int2* sK = reinterpret_cast<int2*>(sSt + 2 * BM + 4 * (32 * PW_RED_PITCH));   // [Kpad + PW_UNIT] im2col row table (STEM)
+    const int KV = STEM ? a.kT * a.kH * a.kW : 1;
 
     for (int k = tid; k < Kpad + PW_UNIT; k += 256) {
         float2 c;
-        if (MODE == PW_FWD) {
+        if (STEM) {
+            const int ci = k / KV, r = k - ci * KV;
+            const int kt = r / (a.kH * a.kW), r2 = r - kt * a.kH * a.kW, kh = r2 / a.kW, kw = r2 - kh * a.kW;
+            c.x = (k < K && a.pa) ? a.pa[(long)n * a.Cimg + ci] : 1.0f;
+            c.y = (k < K && a.pb) ? a.pb[(long)n * a.Cimg + ci] : 0.0f;
+            int2 e;   // .x: element offset relative to the output position's base, .y: kt | kh<<8 | kw<<16 | valid<<24
+            e.x = (int)((long)min(ci, a.Cimg - 1) * a.Pin) + ((kt - a.pT) * a.Hi + (kh - a.pH)) * a.Wi + (kw - a.pW);
+            e.y = kt | (kh << 8) | (kw << 16) | ((k < K ? 1 : 0) << 24);
+            sK[k] = e;
+        } else if (MODE == PW_FWD) {
             c.x = (k < K && a.pa) ? a.pa[(long)n * K + k] : 1.0f;
             c.y = (k < K && a.pb) ? a.pb[(long)n * K + k] : 0.0f;
         } else {
@@ -140,31 +153,33 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
         const int in_pos = MODE == PW_FWD ? pm : qc;
         const int out_pos = MODE == PW_FWD ? qc : pm;
         const int voff = (half * src_pitch + in_pos) * 4;
-        // stem: im2col coordinates of this lane's output position
-        int s_oh = 0, s_ow = 0;
-        const float* s_base = nullptr;
+        // implicit GEMM: input coordinates of this lane's output position (before adding the tap)
+        int s_t = 0, s_h = 0, s_w = 0, s_pos = 0;
+        const float* s_base = a.src + src_n;
         if (STEM) {
             const int hw = a.Ho * a.Wo;
             const int tq = qc / hw, rq = qc - tq * hw;
-            s_oh = rq / a.Wo; s_ow = rq - s_oh * a.Wo;
-            s_base = a.src + src_n + (long)tq * a.Hi * a.Wi;
+            const int oh = rq / a.Wo, ow = rq - oh * a.Wo;
+            s_t = tq * a.sT; s_h = oh * a.sH; s_w = ow * a.sW;
+            s_pos = (s_t * a.Hi + s_h) * a.Wi + s_w;
         }
-        auto bload = [&](int k0, float (&d)[NU], float (&d2)[NU]) {   // rows k0 + 2j + half, j < NU
+        // rows k0 + 2j + half, j < NU; returns the in-bounds mask of the taps (STEM)
+        auto bload = [&](int k0, float (&d)[NU], float (&d2)[NU]) -> unsigned {
+            unsigned msk = 0;
 #pragma unroll
             for (int j = 0; j < NU; ++j) {
                 if (STEM) {
-                    const int k = k0 + 2 * j + half;
-                    const int ci = k / 9, kr = k - ci * 9, kh = kr / 3, kw = kr - kh * 3;
-                    const int ih = s_oh * 2 + kh - 1, iw = s_ow * 2 + kw - 1;
-                    const bool inb = k < K && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
-                    const int ihc = min(max(ih, 0), a.Hi - 1), iwc = min(max(iw, 0), a.Wi - 1), cic = min(ci, a.Cimg - 1);
-                    const float v = s_base[(long)cic * a.Pin + (long)ihc * a.Wi + iwc];
-                    d[j] = inb ? v : 0.0f;
+                    const int2 e = sK[min(k0 + 2 * j + half, Kpad + PW_UNIT - 1)];
+                    const int it = s_t + (e.y & 255) - a.pT, ih = s_h + ((e.y >> 8) & 255) - a.pH, iw = s_w + ((e.y >> 16) & 255) - a.pW;
+                    const bool inb = (e.y >> 24) && it >= 0 && it < a.Ti && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+                    d[j] = s_base[inb ? (long)(s_pos + e.x) : 0];
+                    msk |= (inb ? 1u : 0u) << j;
                 } else {
                     d[j] = pw_bload(r1, voff, (k0 + 2 * j) * row_bytes);
                     if (MODE == PW_DGRAD) d2[j] = two_src ? pw_bload(r2, voff, (k0 + 2 * j) * row_bytes) : 0.0f;
                 }
             }
+            return msk;
         };
 
         f16v acc[MT];
@@ -181,10 +196,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
                 __syncthreads();
             }
             float cur[NU], cur2[NU], nxt[NU], nxt2[NU];
-            bload(kc0, cur, cur2);
+            unsigned curm = bload(kc0, cur, cur2), nxtm;
             for (int u = 0; u < rows; u += PW_UNIT) {
-                bload(kc0 + u + PW_UNIT, nxt, nxt2);       // one unit ahead; past the end reads 0 (bounds check)
-                __builtin_amdgcn_sched_barrier(0);         // keep the prefetch in front of this unit's MFMAs
+                nxtm = bload(kc0 + u + PW_UNIT, nxt, nxt2);   // one unit ahead; past the end reads 0 (bounds check)
+                __builtin_amdgcn_sched_barrier(0);            // keep the prefetch in front of this unit's MFMAs
 #pragma unroll
                 for (int j = 0; j < NU; ++j) {
                     const int kl = u + 2 * j + half;
@@ -192,12 +207,14 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
                     float v;
                     if (MODE == PW_FWD) v = cfn_act<ACT>(fmaf(cur[j], c.x, c.y));
                     else v = fmaf(cur2[j], c.y, cur[j] + c.x);
+                    if (STEM) v = ((curm >> j) & 1u) ? v : 0.0f;   // zero padding is applied after the prologue
                     const float* ar = As + kl * BM + col;
 #pragma unroll
                     for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i * 32], v, acc[i], 0, 0, 0);
                 }
 #pragma unroll
                 for (int j = 0; j < NU; ++j) { cur[j] = nxt[j]; cur2[j] = nxt2[j]; }
+                curm = nxtm;
             }
         }
 
@@ -292,7 +309,7 @@ struct WgArgs {
     double* gw;          // (M,K) fp64 accumulators, zero-filled by the caller
     int N, M, K, Q, Pin, Hi, Wi, Ho, Wo, stride, act;
     int mtiles, ktiles, nstrips, stages;   // stages = LDS stages (of 64 positions) per block
-    int stem, Cimg;      // stem != 0: x rows are the im2col view (k -> ci,kh,kw) of a (N,Cimg,T,Hi,Wi) clip
+    int stem, Cimg, kT, kH, kW, sT, sH, sW, pT, pH, pW, Ti, To;   // stem != 0: x rows are im2col rows (see PwArgs)
 };
 
 template <int MTW, int NTW>
@@ -320,8 +337,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
     }
     for (int k = tid; k < BN; k += 256) {
         const bool ok = k0 + k < K && a.pa;
-        sCx[2 * k] = ok ? a.pa[(long)n * K + k0 + k] : 1.0f;
-        sCx[2 * k + 1] = ok ? a.pb[(long)n * K + k0 + k] : 0.0f;
+        const long ci = a.stem ? (long)n * a.Cimg + (k0 + k) / (a.kT * a.kH * a.kW) : (long)n * K + k0 + k;
+        sCx[2 * k] = ok ? a.pa[ci] : 1.0f;
+        sCx[2 * k + 1] = ok ? a.pb[ci] : 0.0f;
     }
     f16v acc[MTW][NTW];
 #pragma unroll
@@ -398,7 +416,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
                     const int kr = row - BM;
                     const float ca = sCx[2 * kr], cb = sCx[2 * kr + 1];
                     if (a.stem) {
-                        const int ci = ch / 9, kr9 = ch - ci * 9, kh = kr9 / 3, kw = kr9 - kh * 3;
+                        const int KV = a.kT * a.kH * a.kW;
+                        const int ci = ch / KV, r = ch - ci * KV;
+                        const int kt = r / (a.kH * a.kW), r2 = r - kt * a.kH * a.kW, kh = r2 / a.kW, kw = r2 - kh * a.kW;
                         const int hw = a.Ho * a.Wo;
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -406,9 +426,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
                             if (qq < Q) {
                                 const int tq = qq / hw, rq = qq - tq * hw;
                                 const int oh = rq / a.Wo, ow = rq - oh * a.Wo;
-                                const int ih = oh * 2 + kh - 1, iw = ow * 2 + kw - 1;
-                                if (ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
-                                    v[u] = a.x[((long)n * a.Cimg + ci) * a.Pin + ((long)tq * a.Hi + ih) * a.Wi + iw];
+                                const int it = tq * a.sT + kt - a.pT, ih = oh * a.sH + kh - a.pH, iw = ow * a.sW + kw - a.pW;
+                                if (it >= 0 && it < a.Ti && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                                    v[u] = cfn_act_rt(fmaf(a.x[((long)n * a.Cimg + ci) * a.Pin + ((long)it * a.Hi + ih) * a.Wi + iw], ca, cb), a.act);
                             }
                         }
                     } else {
@@ -523,7 +543,7 @@ static int pw_plan(PwArgs& a, int& MT, unsigned& blocks, size_t& lds) {
     a.tpb = (int)tpb;
     a.nstrips = cfn_cdiv(tiles, tpb);
     blocks = (unsigned)((long)a.N * a.nstrips * a.mtiles);
-    lds = ((size_t)a.kres * BM + 2 * (a.Kpad + PW_UNIT) + 2 * BM + 2 * BM + 4 * 32 * PW_RED_PITCH) * sizeof(float);
+    lds = ((size_t)a.kres * BM + 2 * (a.Kpad + PW_UNIT) + 2 * BM + 2 * BM + 4 * 32 * PW_RED_PITCH + (a.stem ? 2 * (a.Kpad + PW_UNIT) : 0)) * sizeof(float);
     const long span = (long)a.K * (a.stem ? 1 : (a.src2 || a.gs || a.gq || a.ex ? a.Q : a.Pin)) * 4;
     if ((!a.stem && ((long)a.K * a.Pin * 4 >= (1L << 31) || (long)a.K * a.Q * 4 >= (1L << 31))) ||
         (long)a.M * a.Pin * 4 >= (1L << 31) || (long)a.M * a.Q * 4 >= (1L << 31))
@@ -641,39 +661,79 @@ extern "C" int cfn_pwconv_bwd_weight(const float* gy, const float* y, const doub
 }
 
 // ---------------------------------------------------------------------------------------------
-// X3D stem spatial conv (conv1_s: 1x3x3, stride (1,2,2), pad (0,1,1), x3d_fine.py:210-215) as the
-// same MFMA contraction over the im2col view of the clip: K = Cimg*9, no im2col buffer in HBM.
+// Dense 3-D convolution as an implicit GEMM on the same MFMA kernels (no im2col buffer in HBM): the X3D stem
+// conv1_s (1x3x3, stride (1,2,2), pad (0,1,1), x3d_fine.py:210-215) and the Grid Pool saliency convolutions
+// (3x3x3 stride 2 and 1x3x3 stride (1,2,2), x3d_coarse.py:362-366).  geom = {kT,kH,kW,sT,sH,sW,pT,pH,pW}.
 // ---------------------------------------------------------------------------------------------
+template <typename ARGS>
+static int dense_geom(ARGS& a, int Cimg, int T, int Hi, int Wi, const int* g) {
+    a.stem = 1; a.Cimg = Cimg;
+    a.kT = g[0]; a.kH = g[1]; a.kW = g[2]; a.sT = g[3]; a.sH = g[4]; a.sW = g[5]; a.pT = g[6]; a.pH = g[7]; a.pW = g[8];
+    if (a.kT < 1 || a.kH < 1 || a.kW < 1 || a.kT > 7 || a.kH > 7 || a.kW > 7 || a.sT < 1 || a.sH < 1 || a.sW < 1)
+        return cfn_fail(CFN_ERR_ARG, "conv3d_dense: unsupported kernel / stride");
+    a.Ti = T; a.Hi = Hi; a.Wi = Wi; a.stride = 1;
+    a.To = (T + 2 * a.pT - a.kT) / a.sT + 1;
+    a.Ho = (Hi + 2 * a.pH - a.kH) / a.sH + 1;
+    a.Wo = (Wi + 2 * a.pW - a.kW) / a.sW + 1;
+    if (a.To < 1 || a.Ho < 1 || a.Wo < 1) return cfn_fail(CFN_ERR_ARG, "conv3d_dense: empty output");
+    a.Pin = T * Hi * Wi; a.Q = a.To * a.Ho * a.Wo;
+    if ((long)Cimg * a.Pin >= (1L << 31)) return cfn_fail(CFN_ERR_UNSUPPORTED, "conv3d_dense: sample too large for 32-bit offsets");
+    return CFN_OK;
+}
+
+extern "C" int cfn_conv3d_dense_fwd(const float* x, const float* A, const float* B, int act, const float* w, float* y,
+                                    double* sum, double* sumsq, int N, int Cin, int Cout, int T, int Hi, int Wi,
+                                    const int* geom, void* stream) {
+    CFN_REQUIRE(x && w && y && geom, "cfn_conv3d_dense_fwd: null tensor");
+    CFN_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && T > 0 && Hi > 0 && Wi > 0, "cfn_conv3d_dense_fwd: bad shape");
+    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_conv3d_dense_fwd: A/B mismatch");
+    CFN_REQUIRE((sum == nullptr) == (sumsq == nullptr), "cfn_conv3d_dense_fwd: sum/sumsq mismatch");
+    CFN_REQUIRE(act == CFN_ACT_NONE || act == CFN_ACT_RELU, "cfn_conv3d_dense_fwd: prologue act must be none or relu");
+    PwArgs a = {};
+    a.src = x; a.pa = A; a.pb = B; a.act = act; a.w = w; a.dst = y; a.s1 = sum; a.s2 = sumsq;
+    int rc = dense_geom(a, Cin, T, Hi, Wi, geom);
+    if (rc) return rc;
+    a.N = N; a.M = Cout; a.K = Cin * a.kT * a.kH * a.kW; a.Cin = a.K;
+    int MT; unsigned blocks; size_t lds;
+    rc = pw_plan(a, MT, blocks, lds);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_STEM, st, 4.0 * N * ((double)Cin * a.Pin + (double)Cout * a.Q));
+    if (sum) {
+        if (act == CFN_ACT_RELU) return pw_launch_mt<PW_FWD, true, CFN_ACT_RELU, true>(a, MT, blocks, lds, st);
+        return pw_launch_mt<PW_FWD, true, CFN_ACT_NONE, true>(a, MT, blocks, lds, st);
+    }
+    if (act == CFN_ACT_RELU) return pw_launch_mt<PW_FWD, false, CFN_ACT_RELU, true>(a, MT, blocks, lds, st);
+    return pw_launch_mt<PW_FWD, false, CFN_ACT_NONE, true>(a, MT, blocks, lds, st);
+}
+
+extern "C" int cfn_conv3d_dense_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq,
+                                           const float* x, const float* A, const float* B, int act, double* gw, int N,
+                                           int Cin, int Cout, int T, int Hi, int Wi, const int* geom, void* stream) {
+    CFN_REQUIRE(gy && x && gw && geom, "cfn_conv3d_dense_bwd_weight: null tensor");
+    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_conv3d_dense_bwd_weight: A/B mismatch");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_conv3d_dense_bwd_weight: gsumsq needs y");
+    WgArgs a = {};
+    a.gy = gy; a.y = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.x = x; a.pa = A; a.pb = B; a.act = act; a.gw = gw;
+    int rc = dense_geom(a, Cin, T, Hi, Wi, geom);
+    if (rc) return rc;
+    a.N = N; a.M = Cout; a.K = Cin * a.kT * a.kH * a.kW;
+    int MTW, NTW;
+    wg_plan(a, MTW, NTW);
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_STEM, st, 4.0 * N * ((double)Cin * a.Pin + (double)Cout * a.Q));
+    return wg_launch(a, MTW, NTW, st);
+}
+
+static const int kStemGeom[9] = {1, 3, 3, 1, 2, 2, 0, 1, 1};
+
 extern "C" int cfn_stem_conv_fwd(const float* x, const float* w, float* y, int N, int Cimg, int Cout, int T, int Hi, int Wi,
                                  void* stream) {
-    CFN_REQUIRE(x && w && y, "cfn_stem_conv_fwd: null tensor");
-    CFN_REQUIRE(N > 0 && Cimg > 0 && Cout > 0 && T > 0 && Hi > 1 && Wi > 1, "cfn_stem_conv_fwd: bad shape");
-    PwArgs a = {};
-    a.src = x; a.w = w; a.dst = y; a.act = CFN_ACT_NONE;
-    a.N = N; a.M = Cout; a.K = Cimg * 9; a.Cin = Cimg * 9;
-    a.stem = 1; a.Cimg = Cimg;
-    a.Hi = Hi; a.Wi = Wi; a.stride = 1;
-    a.Ho = (Hi + 2 - 3) / 2 + 1; a.Wo = (Wi + 2 - 3) / 2 + 1;
-    a.Pin = T * Hi * Wi; a.Q = T * a.Ho * a.Wo;
-    int MT; unsigned blocks; size_t lds;
-    { int rc = pw_plan(a, MT, blocks, lds); if (rc) return rc; }
-    hipStream_t st = (hipStream_t)stream;
-    CfnProfScope prof(CFN_K_STEM, st, 4.0 * N * ((double)Cimg * a.Pin + (double)Cout * a.Q));
-    return pw_launch_mt<PW_FWD, false, CFN_ACT_NONE, true>(a, MT, blocks, lds, st);
+    return cfn_conv3d_dense_fwd(x, nullptr, nullptr, CFN_ACT_NONE, w, y, nullptr, nullptr, N, Cimg, Cout, T, Hi, Wi, kStemGeom, stream);
 }
 
 extern "C" int cfn_stem_conv_bwd_weight(const float* gy, const float* x, double* gw, int N, int Cimg, int Cout, int T,
                                         int Hi, int Wi, void* stream) {
-    CFN_REQUIRE(gy && x && gw, "cfn_stem_conv_bwd_weight: null tensor");
-    WgArgs a = {};
-    a.gy = gy; a.x = x; a.act = CFN_ACT_NONE; a.gw = gw; a.N = N; a.M = Cout; a.K = Cimg * 9;
-    a.stem = 1; a.Cimg = Cimg;
-    a.Hi = Hi; a.Wi = Wi; a.stride = 1;
-    a.Ho = (Hi + 2 - 3) / 2 + 1; a.Wo = (Wi + 2 - 3) / 2 + 1;
-    a.Pin = T * Hi * Wi; a.Q = T * a.Ho * a.Wo;
-    int MTW, NTW;
-    wg_plan(a, MTW, NTW);
-    hipStream_t st = (hipStream_t)stream;
-    CfnProfScope prof(CFN_K_STEM, st, 4.0 * N * ((double)Cimg * a.Pin + (double)Cout * a.Q));
-    return wg_launch(a, MTW, NTW, st);
+    return cfn_conv3d_dense_bwd_weight(gy, nullptr, nullptr, nullptr, x, nullptr, nullptr, CFN_ACT_NONE, gw, N, Cimg, Cout, T, Hi, Wi,
+                                       kStemGeom, stream);
 }

@@ -1,0 +1,340 @@
+"""x3d_coarse -- the Coarse stream of Coarse-Fine Networks on MI355X (drop-in for the reference's
+``x3d_coarse.py``): X3D trunk + Grid Pool / Grid Unpool + Multi-stage Fusion, same ``generate_model`` /
+``ResNet.forward([x, feat, feat_masks, i, meta])`` surface and state_dict keys.
+
+Hot-path design (all full-size tensors go through the gfx950 kernels of ``cfn_hip``):
+  * trunk: shared with ``x3d_fine`` (deferred BN/activation prologues, MFMA pointwise, LDS-tiled depthwise);
+  * Grid Pool: the saliency convolutions are implicit-GEMM dense convs; the 5-D ``grid_sample`` is a 2-tap
+    temporal lerp whose frame indices are bit-identical to ATen's (x3d_coarse.py:394-403);
+  * fusion: the reference up-samples the 7x7 fine features to 56/28/14 and materialises a
+    (B,C,T',K,h,w) product (1.3 GB / sample for rw2).  All of it is constant over the up-sampling blocks,
+    so the branch is evaluated once at 7x7 (gather kernel + MFMA pointwise convs) and applied by a
+    block-broadcast FiLM kernel; biases ride in the next op's prologue;
+  * Grid Unpool: Interp1d (bit-exact indices) + the same temporal lerp + temporal linear resize.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from cfn_hip import ops, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID
+from interp1d import Interp1d
+from x3d_fine import (SubBatchNorm3d, Swish, Bottleneck, Deferred, conv3x3x3, conv1x1x1, _count,  # noqa: F401
+                      get_inplanes, get_blocks)
+import x3d_fine
+
+FUSION_HW = 7     # spatial size of the pre-extracted fine features (extract_fineFEAT / x3d_fine.py:345-363)
+
+
+def _w5(conv1d):
+    """Conv1d (O,I,1) weight as a 1x1x1 conv weight"""
+    w = conv1d.weight
+    return w.view(w.shape[0], w.shape[1], 1, 1, 1)
+
+
+def _rows(vec, n):
+    """(C,) parameter -> (n, C) per-sample prologue coefficient"""
+    return vec.view(1, -1).expand(n, -1).contiguous()
+
+
+class RewightLayer(nn.Module):
+    """Temporal-alignment gather + two small MLP heads (x3d_coarse.py:175-247)."""
+
+    def __init__(self, channels, g_channels, depth, height, pool=False):
+        super(RewightLayer, self).__init__()
+        self.at1 = nn.Conv1d(depth, depth, kernel_size=1)
+        self.at2 = nn.Conv1d(depth, 1, kernel_size=1)
+        self.fc1 = nn.Conv1d(depth, depth, kernel_size=1)
+        self.fc2 = nn.Conv1d(depth, channels, kernel_size=1)
+        if g_channels is not None:
+            self.fc3 = nn.Conv1d(depth, depth, kernel_size=1)
+            self.fc4 = nn.Conv1d(depth, g_channels, kernel_size=1)
+        self.dropout = nn.Dropout(0.5)
+        self.depth, self.height, self.channels, self.g_channels, self.pool = depth, height, channels, g_channels, pool
+
+    def _mlp(self, z5, first, second):
+        n = z5.shape[0]
+        h, _, _ = ops.pwconv(z5, _w5(first), stats=False)
+        one = torch.ones(n, h.shape[1], device=z5.device)
+        if self.pool and self.training and self.dropout.p > 0:     # x3d_coarse.py:232-233 (rw6 only)
+            h = self.dropout(ops.affine_act(h, one, _rows(first.bias, n), ACT_RELU))
+            out, _, _ = ops.pwconv(h, _w5(second), stats=False)
+        else:
+            out, _, _ = ops.pwconv(h, _w5(second), one, _rows(first.bias, n), ACT_RELU, stats=False)
+        return out                                                  # raw: the bias of `second` is still to be added
+
+    def gather(self, x, b2, mask, GX):
+        """fine features (B,C,T',7,7) -> aligned (b2,C,K,7,7)  (x3d_coarse.py:204-223 at native resolution)"""
+        b, c, t, h, w = x.shape
+        if mask.shape[1] != t:
+            mask = F.adaptive_max_pool1d(mask.unsqueeze(1), t).squeeze(1)
+            GX = F.adaptive_avg_pool2d(GX.unsqueeze(1), (t, None)).squeeze(1)
+        if b != b2:      # multi-crop testing
+            x = x.unsqueeze(1).repeat(1, b2 // b, 1, 1, 1, 1).view(b2, c, t, h, w)
+            mask = mask.unsqueeze(1).repeat(1, b2 // b, 1).view(b2, t)
+        y1, _, _ = ops.pwconv(x, _w5(self.at1), stats=False)
+        one = torch.ones(b2, c, device=x.device)
+        y2, _, _ = ops.pwconv(y1, _w5(self.at2), one, _rows(self.at1.bias, b2), ACT_RELU, stats=False)
+        at = torch.sigmoid(y2.view(b2, t, h * w) + self.at2.bias)
+        gm = GX * mask.unsqueeze(2)
+        z = ops.fusion_gather(x.reshape(b2, c, t, h * w), at, gm)
+        return z.view(b2, c, GX.shape[2], h, w)
+
+    def forward7(self, x, b2, mask, GX, is_mixing):
+        """-> ((bias_raw, bias_b), (scale_raw, scale_b)) at the fine features' own resolution; the Conv1d output
+        biases are returned separately so that the consumer folds them into its prologue."""
+        z5 = self.gather(x, b2, mask, GX)
+        if self.pool:
+            z5 = z5.mean(dim=(3, 4), keepdim=True)
+        x1 = self._mlp(z5, self.fc1, self.fc2)
+        if self.g_channels is None:
+            return (x1, self.fc2.bias), None
+        x2 = self._mlp(z5, self.fc3, self.fc4)
+        return (x1, self.fc2.bias), (x2, self.fc4.bias)
+
+    def forward(self, inp):
+        """reference signature: [x_fine, lx, mask, gx, i, GX, isMixing] -> tensors at (height, height)"""
+        x, lx, mask, _gx, _i, GX, is_mixing = inp
+        (x1, b1), sc = self.forward7(x, lx.shape[0], mask, GX, is_mixing)
+        up = (lambda v: v) if self.pool else (lambda v: _upsample(v, self.height))
+        x1 = up(x1 + b1.view(1, -1, 1, 1, 1))
+        if sc is None:
+            return x1
+        x2 = sc[0] + sc[1].view(1, -1, 1, 1, 1)
+        if not is_mixing:
+            x2 = torch.sigmoid(x2)
+        return x1, up(x2)
+
+
+def _upsample(v, height):
+    """7x7 -> height x height block replication (= adaptive_max_pool2d up-sampling of the reference)"""
+    f = height // v.shape[3]
+    if f <= 1:
+        return v
+    return v.repeat_interleave(f, dim=3).repeat_interleave(f, dim=4)
+
+
+class Gaussian(nn.Module):
+    """Temporal Gaussian alignment weights (x3d_coarse.py:251-286); (B,T',K) tensors, plain device-side torch."""
+
+    def __init__(self, ratio=1):
+        super(Gaussian, self).__init__()
+        self.ratio = ratio
+
+    def forward(self, inp):
+        meta, mask, gx, tx = inp
+        dev = gx.device
+        st, step = meta[:, 0].to(torch.float32), meta[:, 3]
+        b, b2, len_f = meta.shape[0], gx.shape[0], mask.shape[1]
+        if b2 != b:
+            offset = step.view(-1, 1) * torch.arange(0, b2 // b, device=dev).to(torch.float32).view(1, -1).repeat(b, 1)
+            st = (st.view(-1, 1).repeat(1, b2 // b) + offset).view(-1, 1)
+        if tx is not None:
+            len_x = gx.shape[1]
+            tl = (gx * tx).unsqueeze(1)
+        else:
+            len_x = gx.shape[2]
+            tl = torch.arange(0, len_x, device=dev).to(torch.float32).view(1, 1, -1).repeat(b2, 1, 1)
+        mu = (tl + st.view(b2, 1, 1)) / self.ratio
+        t = torch.arange(0, len_f, device=dev).to(torch.float32).view(1, -1, 1).repeat(b2, 1, 1)
+        std = (1 / 8 * torch.sum(mask, dim=1)).view(-1, 1).repeat(1, b2 // b).view(-1, 1)
+        t = t - mu
+        f = t ** 2 / (2 * (std ** 2).view(b2, 1, 1).repeat(1, len_f, len_x) + 1e-16)
+        f = torch.exp(-f)
+        f = f / (torch.max(f, dim=1)[0].view(b2, 1, len_x) + 1e-16)
+        return f.view(b2, len_f, len_x)
+
+
+class MixingLayer(nn.Module):
+    """Learned mixing of the four abstraction levels (x3d_coarse.py:289-351, learned path)."""
+
+    def __init__(self, depth, learned=False, index=0, isLogit=False):
+        super(MixingLayer, self).__init__()
+        self.learned, self.index, self.isLogit = learned, index, isLogit
+        self.in_depth = 432 if isLogit else (24 + 48 + 96 + 192)
+        self.range = 1 if isLogit else 4
+        self.dropout = nn.Dropout(0.5)
+        if learned:
+            self.conv_at = nn.Conv1d(self.in_depth, depth, kernel_size=1)
+            self.conv_at2 = nn.Conv1d(self.in_depth, depth, kernel_size=1)
+
+    def forward7(self, bias, scale):
+        """bias / scale: lists of (raw (B,c_i,K,7,7), bias (c_i,)) -> FiLM coefficients (c7, m7) (B,depth,K,7,7)"""
+        if not self.learned:
+            raise NotImplementedError('non-learned mixing (x3d_coarse.py:338-344) is unused by the reference scripts')
+        n = bias[0][0].shape[0]
+        one = torch.ones(n, self.in_depth, device=bias[0][0].device)
+
+        def mix(items, conv, act):
+            raw = torch.cat([r for r, _ in items], dim=1)
+            b = torch.cat([bb for _, bb in items]).view(1, -1).expand(n, -1).contiguous()
+            y, _, _ = ops.pwconv(raw, _w5(conv), one, b, ACT_NONE, stats=False)
+            return ops.affine_act(y, torch.ones(n, y.shape[1], device=y.device), _rows(conv.bias, n), act)
+
+        return mix(bias, self.conv_at, ACT_NONE), mix(scale, self.conv_at2, ACT_SIGMOID)
+
+    def forward(self, inp):
+        """reference signature [x, bias_list, scale_list] with full-resolution block-constant inputs -> (cs, ms) like x"""
+        x, bias, scale = inp
+        h = x.shape[3]
+        zero = lambda v: torch.zeros(v.shape[1], device=v.device)
+        down = lambda v: (v[:, :, :, ::v.shape[3] // FUSION_HW, ::v.shape[4] // FUSION_HW].contiguous(), zero(v))
+        c7, m7 = self.forward7([down(v) for v in bias], [down(v) for v in scale])
+        return _upsample(c7, h), _upsample(m7, h)
+
+
+class GridPoolLayer(nn.Module):
+    """Learned temporal resampler (x3d_coarse.py:355-416)."""
+
+    def __init__(self, ratio, depth):
+        super(GridPoolLayer, self).__init__()
+        self.ratio = 4
+        self.depth = depth
+        self.conv1 = nn.Conv3d(depth, depth, kernel_size=(3, 3, 3), stride=(self.ratio // 2, 2, 2), padding=1)
+        self.bn1 = SubBatchNorm3d(num_splits=1, num_features=depth, affine=True)
+        self.conv2 = nn.Conv3d(depth, depth, kernel_size=(3, 3, 3), stride=(self.ratio // 2, 2, 2), padding=1)
+        self.bn2 = SubBatchNorm3d(num_splits=1, num_features=depth, affine=True)
+        self.conv3 = nn.Conv3d(depth, 1, kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+        self.relu = nn.ReLU(inplace=True)
+        self.sigmoid = nn.Sigmoid()
+
+    def _conv_bn(self, x, conv, bn, A, B, act):
+        """conv (+bias) -> BN folded to the next prologue.  The kernel has no bias: BN(y+b) = A*(y+b)+B and the
+        statistics of y+b follow from those of y."""
+        n = x.shape[0]
+        st = tuple(conv.stride)
+        y, s, q = ops.conv3d_dense(x, conv.weight, (3, 3, 3), st, (1, 1, 1), A, B, act, stats=self.training)
+        cnt = _count(y)
+        bias = conv.bias.double().view(1, -1)
+        if self.training:
+            q = q + 2.0 * bias * s + cnt * bias * bias
+            s = s + cnt * bias
+        A2, B2 = bn.fold(s, q, cnt, n)
+        return y, A2, B2 + A2 * conv.bias.view(1, -1)
+
+    def saliency(self, x):
+        """(B,C,T,H,W) -> (B, T/4) saliency logits (x3d_coarse.py:379-383)"""
+        y1, A1, B1 = self._conv_bn(x, self.conv1, self.bn1, None, None, ACT_NONE)
+        y2, A2, B2 = self._conv_bn(y1, self.conv2, self.bn2, A1, B1, ACT_RELU)
+        y3, _, _ = ops.conv3d_dense(y2, self.conv3.weight, (1, 3, 3), (1, 2, 2), (0, 1, 1), A2, B2, ACT_RELU, stats=False)
+        g = ops.pool_hw(y3, 1, 1)
+        return g.view(g.shape[0], g.shape[2]) + self.conv3.bias
+
+    @staticmethod
+    def cdf(g):
+        """saliency logits -> CDF knots (B, K) (x3d_coarse.py:384-392); cumsum accumulates in fp64 like the CPU op"""
+        p = 1. - torch.sigmoid(g * 5e-1)
+        p = p / (torch.sum(p, dim=1, keepdim=True) + 1e-16)
+        c = torch.cumsum(p.double(), dim=1).float()
+        return torch.cat([torch.zeros(c.shape[0], 1, device=c.device), c], dim=1)
+
+    def forward(self, inp):
+        x = inp.materialize() if isinstance(inp, Deferred) else inp
+        gx_out = self.cdf(self.saliency(x))
+        return ops.time_sample(x, gx_out), gx_out
+
+
+def GridUnpool(inp, return_aux=False):
+    """inverse temporal grid (x3d_coarse.py:419-451)"""
+    x, gx, is_logit = inp
+    ratio = 4
+    b, k = gx.shape
+    mid = torch.arange(k, device=gx.device).to(torch.float32)
+    mid = (mid / (k - 1.)).view(1, -1).repeat(b, 1)
+    gx_inv, ind = Interp1d().forward(gx, mid, mid, None, return_index=True)
+    if is_logit:
+        y = ops.time_sample(x.unsqueeze(3), gx_inv).squeeze(3)
+    else:
+        y = ops.time_resize(ops.time_sample(x, gx_inv), x.shape[2] * ratio)
+    if return_aux:
+        return y, gx_inv, ind
+    return y
+
+
+class ResNet(x3d_fine.ResNet):
+    """Coarse stream (x3d_coarse.py:455-727); the X3D trunk, head and BN bookkeeping are x3d_fine's."""
+
+    def __init__(self, block, layers, block_inplanes, n_input_channels=3, feat_depth={}, conv1_t_size=7,
+                 conv1_t_stride=1, shortcut_type='B', widen_factor=1.0, dropout=0.5, n_classes=400, base_bn_splits=8,
+                 task='class', extract_feat=False, t_pool=None, learnedMixing=False, isMixing=False):
+        self.feat_depth, self.learnedMixing, self.isMixing, self.t_pool = feat_depth, learnedMixing, isMixing, t_pool
+        nn.Module.__init__(self)
+        planes = [(int(x * widen_factor), int(y * widen_factor)) for x, y in block_inplanes]
+        if t_pool in ('avg', 'max'):
+            raise NotImplementedError("t_pool='%s' is never used by the reference scripts and is not on the accelerated "
+                                      "path (use 'grid', 'stride' or None)" % t_pool)
+        if t_pool == 'grid':
+            self.pool_1 = GridPoolLayer(ratio=4, depth=planes[0][1])      # registered first, as in the reference
+        x3d_fine.ResNet.__init__(self, block, layers, block_inplanes, n_input_channels=n_input_channels,
+                                 shortcut_type=shortcut_type, widen_factor=widen_factor, dropout=dropout,
+                                 n_classes=n_classes, base_bn_splits=base_bn_splits, task=task,
+                                 extract_feat=extract_feat, _skip_module_init=True)
+        self.rw2 = RewightLayer(planes[0][1], planes[0][1], feat_depth['layer1'], 56)
+        self.rw3 = RewightLayer(planes[1][1], planes[1][1], feat_depth['layer2'], 28)
+        self.rw4 = RewightLayer(planes[2][1], planes[2][1], feat_depth['layer3'], 14)
+        self.rw5 = RewightLayer(planes[3][1], planes[3][1], feat_depth['layer4'], 7)
+        self.rw6 = RewightLayer(157, 157, feat_depth['conv5'], 7, pool=True)
+        if self.isMixing:
+            self.mix2 = MixingLayer(planes[0][1], learned=learnedMixing, index=0)
+            self.mix3 = MixingLayer(planes[1][1], learned=learnedMixing, index=1)
+            self.mix4 = MixingLayer(planes[2][1], learned=learnedMixing, index=2)
+            self.mix5 = MixingLayer(planes[3][1], learned=learnedMixing, index=3)
+        self.gauss = Gaussian(ratio=1)
+        for m in self.modules():      # x3d_coarse.py:557-561: every Conv3d incl. SE and Grid Pool convs
+            if isinstance(m, nn.Conv3d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+    def replace_logits(self, n_classes):
+        dev = self.fc1.weight.device
+        self.fc2 = nn.Linear(2048, n_classes).to(dev)
+        self.rw6 = RewightLayer(n_classes, n_classes, self.feat_depth['conv5'], 7, pool=True).to(dev)
+
+    def forward(self, inp):
+        x, feat, feat_masks, i, meta = inp
+        tl = x.shape[2]
+        x = self.layer1(self._stem(x))
+        if self.t_pool == 'grid':
+            x, gx = self.pool_1(x)
+            GX = self.gauss([meta, feat_masks, gx, tl])
+        else:
+            if self.t_pool == 'stride':
+                x = x[:, :, ::4].contiguous()
+            GX = self.gauss([meta, feat_masks, x, None])
+        b2 = x.shape[0]
+        levels = (('layer1', self.rw2), ('layer2', self.rw3), ('layer3', self.rw4), ('layer4', self.rw5))
+        stages = (None, self.layer2, self.layer3, self.layer4)
+        if self.isMixing:
+            rw = [m.forward7(feat[k], b2, feat_masks, GX, True) for k, m in levels]
+            rb, rs = [r[0] for r in rw], [r[1] for r in rw]
+            for li, mix in enumerate((self.mix2, self.mix3, self.mix4, self.mix5)):
+                if stages[li] is not None:
+                    x = stages[li](x)
+                c7, m7 = mix.forward7(rb, rs)
+                x = ops.film(x, m7, c7, x.shape[3] // FUSION_HW)
+        else:
+            for li, (k, m) in enumerate(levels):
+                if stages[li] is not None:
+                    x = stages[li](x)
+                (x1, b1), (x2, b2_) = m.forward7(feat[k], b2, feat_masks, GX, False)
+                one = torch.ones(b2, x1.shape[1], device=x.device)
+                c7 = ops.affine_act(x1, one, _rows(b1, b2), ACT_NONE)
+                m7 = ops.affine_act(x2, one, _rows(b2_, b2), ACT_SIGMOID)
+                x = ops.film(x, m7, c7, x.shape[3] // FUSION_HW)
+        x = self._head(x)
+        if self.extract_feat:
+            return x
+        (x1, b1), (x2, b2_) = self.rw6.forward7(feat['conv5'], b2, feat_masks, GX, False)
+        rw6 = x1.squeeze(4).squeeze(3) + b1.view(1, -1, 1)
+        rw6_g = torch.sigmoid(x2.squeeze(4).squeeze(3) + b2_.view(1, -1, 1))
+        x = x * rw6_g + rw6                                  # (B, n_classes, K): tiny
+        if self.t_pool == 'grid':
+            x = GridUnpool([x, gx, True])
+            x = ops.time_resize(x, (x.shape[2] - 1) * 4)
+        return x
+
+
+def replace_logits(self, n_classes):
+    self.fc2 = nn.Linear(2048, n_classes)
+
+
+def generate_model(x3d_version, **kwargs):
+    return ResNet(Bottleneck, get_blocks(x3d_version), get_inplanes(x3d_version), **kwargs)

@@ -195,8 +195,9 @@ class ResNet(nn.Module):
 
     def __init__(self, block, layers, block_inplanes, n_input_channels=3, conv1_t_size=7, conv1_t_stride=1,
                  shortcut_type='B', widen_factor=1.0, dropout=0.5, n_classes=400, base_bn_splits=8, task='class',
-                 extract_feat=False, global_tower=False, t_downsample=False, aux_losses=None):
-        super(ResNet, self).__init__()
+                 extract_feat=False, global_tower=False, t_downsample=False, aux_losses=None, _skip_module_init=False):
+        if not _skip_module_init:      # x3d_coarse registers pool_1 before the trunk, like the reference
+            super(ResNet, self).__init__()
         block_inplanes = [(int(x * widen_factor), int(y * widen_factor)) for x, y in block_inplanes]
         self.index = 0
         self.base_bn_splits = base_bn_splits

@@ -14,7 +14,7 @@
  *     shape); cfn_last_error() returns a thread-local message.  Nothing ever aborts.
  *   - "prologue": many ops read their input x through  a = act(A[n,c]*x + B[n,c])  where A/B (float,
  *     N*C, may be NULL = identity) carry the folded SubBatchNorm3d scale/shift (+ BN affine + SE gate)
- *     and act is 0 none / 1 ReLU / 2 Swish.  This is how SubBatchNorm3d.forward (x3d_fine.py:51-62),
+ *     and act is 0 none / 1 ReLU / 2 Swish / 3 sigmoid (sigmoid: cfn_affine_act_* only).  This is how SubBatchNorm3d.forward (x3d_fine.py:51-62),
  *     relu_ (:151), Swish (:74-86) and the SE multiply (:163) disappear into the next conv.
  *   - "stats": fp64 accumulators per (n,c) that the caller zero-fills; kernels atomically add
  *     per-workgroup partial sums.  sum/sumsq of a conv output are what batch_norm (train) and the SE
@@ -94,6 +94,28 @@ int cfn_bn_fold_bwd(const float* gA, const float* gB, const double* s, const flo
                     const float* pooled, const float* w1, const float* w2, int training, int N, int C, int S, int Wd,
                     double count, double pool_count, double* gs, double* gq, float* ggamma, float* gbeta, float* gw1,
                     float* gb1, float* gw2, float* gb2, float* tA, float* tB, void* stream);
+
+/* ---- dense 3-D convolution as implicit GEMM (no im2col buffer): Grid Pool saliency convs x3d_coarse.py:362-366,
+ * :379-381 (and the stem, which is the geom {1,3,3, 1,2,2, 0,1,1} case).  geom = int[9] {kT,kH,kW, sT,sH,sW, pT,pH,pW}
+ * in HOST memory.  w (Cout, Cin*kT*kH*kW); no bias (a bias is algebraically folded into the next prologue / the
+ * statistics by the caller).  Prologue act: none or relu; zero padding is applied after the prologue. ---- */
+int cfn_conv3d_dense_fwd(const float* x, const float* A, const float* B, int act, const float* w, float* y, double* sum,
+                         double* sumsq, int N, int Cin, int Cout, int T, int Hi, int Wi, const int* geom, void* stream);
+int cfn_conv3d_dense_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
+                              const float* x, const float* A, const float* B, int act, float* gx, double* gA, double* gB,
+                              int N, int Cin, int Cout, int T, int Hi, int Wi, const int* geom, void* stream);
+int cfn_conv3d_dense_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* x,
+                                const float* A, const float* B, int act, double* gw, int N, int Cin, int Cout, int T, int Hi,
+                                int Wi, const int* geom, void* stream);
+
+/* ---- Multi-stage Fusion temporal-alignment gather: RewightLayer.forward x3d_coarse.py:213-223 at the fine
+ * features' native resolution.  x (B,C,Tf,P) fine features, at (B,Tf,P) attention (after sigmoid), gm (B,Tf,K) =
+ * Gaussian alignment x mask;  z[b,c,k,p] = sum_t x at gm / (sum_t at gm + 1e-6), den (B,K,P) saved for the backward.
+ * bwd: gx (B,C,Tf,P) (may be NULL) and dw (B,Tf,K,P) = d loss / d (at*gm)[b,t,k,p]. ---- */
+int cfn_fusion_gather_fwd(const float* x, const float* at, const float* gm, float* z, float* den, int B, int C, int Tf, int K,
+                          int P, void* stream);
+int cfn_fusion_gather_bwd(const float* gz, const float* z, const float* den, const float* x, const float* at, const float* gm,
+                          float* gx, float* dw, int B, int C, int Tf, int K, int P, void* stream);
 
 /* ---- block tail  out = relu(A y + B + (Ar res + Br)) : bn3 + (downsample bn) + `out += residual` + relu,
  * x3d_fine.py:167-173.  Ar/Br NULL = identity shortcut.  vol = T*H*W, NC = N*C. ---- */

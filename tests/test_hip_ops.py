@@ -312,3 +312,40 @@ def test_ops_refuse_cpu_tensors():
     """the product path has no CPU fallback"""
     with pytest.raises(RuntimeError):
         ops().dwconv3d(torch.zeros(1, 2, 2, 7, 7), torch.zeros(2, 1, 3, 3, 3))
+
+
+# ---- dense implicit-GEMM conv (Grid Pool saliency convs) and the fusion gather ---------------------------
+DENSE_CASES = [
+    # N, Cin, Cout, T, H, W, kernel, stride, padding, act, pro
+    (2, 4, 4, 8, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1), 0, False),
+    (1, 24, 24, 6, 14, 14, (3, 3, 3), (2, 2, 2), (1, 1, 1), 1, True),
+    (1, 24, 1, 4, 14, 14, (1, 3, 3), (1, 2, 2), (0, 1, 1), 1, True),
+    (2, 3, 24, 3, 16, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1), 0, False),
+    (1, 5, 7, 5, 9, 7, (3, 3, 3), (2, 2, 2), (1, 1, 1), 1, True),
+]
+
+
+@pytest.mark.parametrize('N,Ci,Co,T,H,W,k,s,p,act,pro', DENSE_CASES)
+def test_conv3d_dense(N, Ci, Co, T, H, W, k, s, p, act, pro):
+    x, w = rnd(1, N, Ci, T, H, W), rnd(2, Co, Ci, *k, scale=(2.0 / (Ci * k[0] * k[1] * k[2])) ** 0.5)
+    A = (1 + 0.2 * rnd(3, N, Ci)) if pro else None
+    B = 0.3 * rnd(4, N, Ci) if pro else None
+    check_conv(lambda x_, w_, A_, B_: ops().conv3d_dense(x_, w_, k, s, p, A_, B_, act, True),
+               lambda a, w_: F.conv3d(a, w_, stride=s, padding=p), x, w, A, B, act, tol_f=3e-5, tol_g=3e-4)
+
+
+@pytest.mark.parametrize('B,C,Tf,K,P', [(2, 8, 12, 5, 49), (1, 24, 40, 17, 49), (1, 5, 7, 3, 1)])
+def test_fusion_gather(B, C, Tf, K, P):
+    x, at, gm = rnd(1, B, C, Tf, P).abs(), torch.sigmoid(rnd(2, B, Tf, P)), rnd(3, B, Tf, K).abs()
+    gm[:, -2:, :] = 0          # masked fine steps
+    c = [v.clone().requires_grad_(True) for v in (x, at, gm)]
+    g = [v.clone().to(DEV).requires_grad_(True) for v in (x, at, gm)]
+    wgt = c[1].unsqueeze(2) * c[2].unsqueeze(3)                       # B Tf K P
+    zc = torch.einsum('bctp,btkp->bckp', c[0], wgt) / (wgt.sum(1) + 1e-6).unsqueeze(1)
+    zg = ops().fusion_gather(*g)
+    assert relerr(zg, zc) <= 1e-5
+    r = rnd(5, *zc.shape)
+    (zc * r).sum().backward()
+    (zg * r.to(DEV)).sum().backward()
+    for a, b in zip(g, c):
+        assert relerr(a.grad, b.grad) <= 1e-4
