@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
         for (int i = 0; i < MT; ++i) {
             float t1[16], t2[16];
             float xe[16];
-            if (MODE == PW_DGRAD && ACT != CFN_ACT_NONE) {
+            if (MODE == PW_DGRAD && STATS) {   // STATS <=> the forward conv had a prologue (A,B given)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     xe[r] = pw_bload(rx, dvoff, (m0 + i * 32 + (r & 3) + 8 * (r >> 2)) * dst_pitch * 4);
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
                 float v = acc[i][r];
                 if (MODE == PW_FWD) {
                     t1[r] = v * vm;
-                } else if (ACT != CFN_ACT_NONE) {
+                } else if (STATS) {
                     const float2 c = sE[ml];
                     const float dz = v * cfn_act_grad<ACT>(fmaf(xe[r], c.x, c.y)) * vm;
                     t1[r] = dz * xe[r];

@@ -349,3 +349,12 @@ def test_fusion_gather(B, C, Tf, K, P):
     (zg * r.to(DEV)).sum().backward()
     for a, b in zip(g, c):
         assert relerr(a.grad, b.grad) <= 1e-4
+
+
+def test_pwconv_prologue_without_activation():
+    """bias-only prologue (A=1, B=b, act none) as used by the fusion MLPs: gradients w.r.t. A/B must flow"""
+    N, Cin, Cout = 2, 24, 16
+    x, w = rnd(1, N, Cin, 3, 7, 7), rnd(2, Cout, Cin, 1, 1, 1, scale=0.3)
+    A, B = 1 + 0.2 * rnd(3, N, Cin), 0.3 * rnd(4, N, Cin)
+    check_conv(lambda x_, w_, A_, B_: ops().pwconv(x_, w_, A_, B_, 0, 1, True),
+               lambda a, w_: F.conv3d(a, w_), x, w, A, B, 0, tol_f=3e-5, tol_g=3e-4)
