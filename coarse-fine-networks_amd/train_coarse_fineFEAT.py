@@ -67,6 +67,11 @@ class SyntheticCoarse(object):
             yield x, labels, masks, feat, fm, meta, ['synthetic_%d' % i] * self.bs, torch.full((self.bs,), tl / 24.0)
 
 
+def _mean_ap(apm):
+    v = apm.value()
+    return float(v.mean()) if torch.is_tensor(v) else float(v)
+
+
 def detection_loss(per_frame_logits, labels, masks, group=None):
     """train_coarse_fineFEAT.py:226-240; loc-loss normaliser over the GLOBAL batch (see train_fine.detection_loss)"""
     logits = F.interpolate(per_frame_logits, labels.size(2), mode='linear')
@@ -189,7 +194,7 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
                 tot_loc += float(loc_loss)
                 if train and steps % max(iters // 2, 1) == 0 and rank == 0:
                     log(' Epoch:{} {} steps: {} Loc Loss: {:.4f} Cls Loss: {:.4f} mAP: {:.4f}'.format(
-                        epochs, phase, steps, tot_loc / n_it, tot_cls / n_it, float(np.mean(tr_apm.value()))))
+                        epochs, phase, steps, tot_loc / n_it, tot_cls / n_it, _mean_ap(tr_apm)))
                     tr_apm.reset()
                 if train and steps % 1000 == 0 and rank == 0:
                     os.makedirs(os.path.dirname(save_model) or '.', exist_ok=True)
@@ -205,7 +210,7 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
                     write_file = writer = None
                 if rank == 0:
                     log(' Epoch:{} val Loc Loss: {:.4f} Cls Loss: {:.4f} mAP: {:.4f}'.format(
-                        epochs, tot_loc / max(n_it, 1), tot_cls / max(n_it, 1), float(np.mean(val_apm.value()))))
+                        epochs, tot_loc / max(n_it, 1), tot_cls / max(n_it, 1), _mean_ap(val_apm)))
                 val_apm.reset()
                 lr_sched.step()
     return net

@@ -77,6 +77,11 @@ def detection_loss(per_frame_logits, labels, masks, align_corners=True, group=No
     return cls_loss, loc_loss, probs
 
 
+def _mean_ap(apm):
+    v = apm.value()
+    return float(v.mean()) if torch.is_tensor(v) else float(v)
+
+
 def lr_warmup(init_lr, cur_steps, warmup_steps, opt):
     start_after = 1
     if cur_steps < warmup_steps and cur_steps > start_after:
@@ -167,7 +172,7 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
                     apm.add(probs[i][:, :v].transpose(0, 1).cpu().numpy(), labels[i][:, :v].transpose(0, 1).cpu().numpy())
                 if train and steps % max(iters // 2, 1) == 0 and rank == 0:
                     log(' Epoch:{} {} steps: {} Loc Loss: {:.4f} Cls Loss: {:.4f} mAP: {:.4f}'.format(
-                        epochs, phase, steps, tot_loc / n_it, tot_cls / n_it, float(np.mean(tr_apm.value()))))
+                        epochs, phase, steps, tot_loc / n_it, tot_cls / n_it, _mean_ap(tr_apm)))
                     tr_apm.reset()
                 if train and steps % 1000 == 0 and rank == 0:
                     os.makedirs(os.path.dirname(save_model) or '.', exist_ok=True)
@@ -178,7 +183,7 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
             if not train:
                 if rank == 0:
                     log(' Epoch:{} val Loc Loss: {:.4f} Cls Loss: {:.4f} mAP: {:.4f}'.format(
-                        epochs, tot_loc / max(n_it, 1), tot_cls / max(n_it, 1), float(np.mean(val_apm.value()))))
+                        epochs, tot_loc / max(n_it, 1), tot_cls / max(n_it, 1), _mean_ap(val_apm)))
                 val_apm.reset()
                 lr_sched.step()
     return net
