@@ -32,11 +32,13 @@ import torch.optim as optim                      # noqa: E402
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
 
 
-def cpu_baseline(frames_full, sample_frames=64):
+def cpu_baseline(frames_full, sample_frames=32):
     """CPU oracle (oracle/x3d_ref.py, stock torch CPU ops) fwd+bwd on one 3 x sample_frames x 224 x 224 clip;
     cost is linear in T, so clips/s at T=frames_full = (1/t) * sample_frames/frames_full."""
     from oracle import spec, x3d_ref
-    threads = os.cpu_count() or 1
+    # torch's CPU conv kernels stop scaling (and thrash) far below the 256 hardware threads of the GPU box:
+    # 16 threads is what the reference's own DataLoader-era hosts had and is near the measured optimum
+    threads = min(os.cpu_count() or 1, int(os.environ.get('CFN_CPU_THREADS', '16')))
     torch.set_num_threads(threads)
     sd = spec.procedural_fill(spec.fine_keys('M', 157, 1))
     for k, v in sd.items():
@@ -61,7 +63,7 @@ def main():
     ap.add_argument('--frames', type=int, default=256)
     ap.add_argument('--batch', type=int, default=1, help='clips per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-frames', type=int, default=64)
+    ap.add_argument('--cpu-sample-frames', type=int, default=32)
     args = ap.parse_args()
 
     from cfn_hip import dist as cdist
