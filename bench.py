@@ -112,6 +112,13 @@ def main():
 
     if rank == 0:
         achieved = (by / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+        # HBM traffic of the same kernels from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+        # passes, gfx950 correction applied) is measured offline -- bench.py cannot run under the counter tool -- and
+        # committed in profiles/; quoted only for the configuration it was measured on
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_dwfwd.json')
+        if os.path.exists(pmc) and T == 256:
+            traffic = round(json.load(open(pmc))['traffic_bytes_per_step'] * B)
         out = {
             'metric': 'clips/sec (fwd+bwd+SGD) x3d_fine X3D-M T=%dx224x224' % T,
             'value': round(world * B * args.steps / dt, 4),
@@ -124,7 +131,8 @@ def main():
                                    'random-init weights' % (B, T),
                        'clips_per_gpu': B, 'frames': T, 'parallelism': 'dp%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'traffic_note': 'bytes per step, 26 dw3d launches, profiles/r01_pmc_dwfwd.json',
                          'kernel': 'dw3d_kernel<FWD> + dwt5_kernel<FWD> (depthwise conv stack forward)',
                          'launches': launches, 'avg_launch_ms': round(ms / max(launches, 1), 4),
                          'algorithmic_bytes_per_step': round(by / max(args.steps, 1))},
