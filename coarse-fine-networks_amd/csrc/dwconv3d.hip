@@ -443,8 +443,12 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
 struct DwPlan { int HS, VEC, MAXLD, threads; bool UNIW; size_t lds; unsigned blocks; };
 
 static int pick_hs(int Ho) {
+    // small planes (<= 14 rows): short strips keep the register footprint low (more waves per CU), the data
+    // is L2 resident anyway; large planes: 7-row strips minimise LDS reads per output
+    if (Ho <= 14) return (Ho % 2 == 0) ? 2 : 1;
     if (Ho % 7 == 0) return 7;
     if (Ho % 4 == 0) return 4;
+    if (Ho % 2 == 0) return 2;
     return 1;
 }
 
@@ -546,6 +550,7 @@ static int dw_launch(const DwArgs& a, const DwPlan& pl, hipStream_t st) {
     switch (pl.HS) {
         case 7: return dw_launch_hs<MODE, S, 7>(a, pl, st);
         case 4: return dw_launch_hs<MODE, S, 4>(a, pl, st);
+        case 2: return dw_launch_hs<MODE, S, 2>(a, pl, st);
         default: return dw_launch_hs<MODE, S, 1>(a, pl, st);
     }
 }
