@@ -316,7 +316,6 @@ struct WgArgs {
     int N, M, K, Q, Pin, Hi, Wi, Ho, Wo, stride, act;
     int mtiles, ktiles, nstrips, stages;   // stages = LDS stages (of 64 positions) per block
     int stem, Cimg, kT, kH, kW, sT, sH, sW, pT, pH, pW, Ti, To;   // stem != 0: x rows are im2col rows (see PwArgs)
-    int dbg;             // ablation switches (CFN_WG_DBG): 1 no global atomics, 2 no MFMA, 4 no staging, 8 no prefetch
 };
 
 template <int MTW, int NTW>
@@ -333,11 +332,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
     const int m0 = mt * BM, k0 = kt * BN;
     const int M = a.M, K = a.K, Q = a.Q;
 
-    if (a.dbg & 16) return;
-    float* sG = smem;                       // [BM][65]
-    float* sX = sG + BM * WG_PITCH;         // [BN][65]
-    float* sCg = sX + BN * WG_PITCH;        // [BM][2]  (gs, 2gq)
-    float* sCx = sCg + 2 * BM;              // [BN][2]  (A, B)
+    constexpr int IMG = (BM + BN) * WG_PITCH;          // one staged image: G rows [BM][65] then X rows [BN][65]
+    float* img0 = smem;                                // two images (double buffer)
+    float* sCg = smem + 2 * IMG;                       // [BM][2]  (gs, 2gq)
+    float* sCx = sCg + 2 * BM;                         // [BN][2]  (A, B)
     for (int m = tid; m < BM; m += 256) {
         const bool ok = m0 + m < M;
         sCg[2 * m] = (ok && a.gs) ? (float)a.gs[(long)n * M + m0 + m] : 0.0f;
@@ -381,7 +379,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
             if (ch < K && q0 + c4 < Q) px[it] = *reinterpret_cast<const f4v*>(a.x + ((long)n * K + ch) * a.Pin + q0 + c4);
         }
     };
-    auto stage_fast = [&](int q0) {
+    auto stage_fast = [&](int q0, float* sG, float* sX) {
         const bool inq = q0 + c4 < Q;
 #pragma unroll
         for (int it = 0; it < NG; ++it) {
@@ -406,7 +404,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
             d[3] = ok ? cfn_act_rt(fmaf(px[it].w, ca, cb), a.act) : 0.0f;
         }
     };
-    auto stage_slow = [&](int q0) {          // strided / im2col / ragged positions: element-wise gather
+    auto stage_slow = [&](int q0, float* sG, float* sX) {          // strided / im2col / ragged positions: element-wise gather
         for (int e = tid; e < (BM + BN) * (WG_PT / 4); e += 256) {
             const int row = e / (WG_PT / 4), cc = (e - row * (WG_PT / 4)) * 4;
             const bool isg = row < BM;
@@ -453,17 +451,36 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
         }
     };
 
+    // Double-buffered images, ONE barrier per stage: inside a stage the LDS writes of stage s+1 (from registers
+    // loaded one stage earlier) and the global loads of stage s+2 sit in the same basic block as the MFMAs of
+    // stage s, so the compiler interleaves the staging VALU/LDS work under the matrix pipe.
     const int qbeg = strip * a.stages * WG_PT;
-    if (fast && qbeg < Q) prefetch(qbeg);
-    for (int st = 0; st < a.stages; ++st) {
+    const int nst = min(a.stages, (Q - qbeg + WG_PT - 1) / WG_PT);
+    if (nst > 0) {
+        if (fast) {
+            prefetch(qbeg);
+            stage_fast(qbeg, img0, img0 + BM * WG_PITCH);
+            if (nst > 1) prefetch(qbeg + WG_PT);
+        } else {
+            stage_slow(qbeg, img0, img0 + BM * WG_PITCH);
+        }
+    }
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
         const int q0 = qbeg + st * WG_PT;
-        if (q0 >= Q) break;
-        if (st) __syncthreads();                 // previous stage fully consumed
-        if (!(a.dbg & 4)) { if (fast) stage_fast(q0); else stage_slow(q0); }
-        __syncthreads();
-        if (fast && st + 1 < a.stages && q0 + WG_PT < Q && !(a.dbg & 8)) prefetch(q0 + WG_PT);
-        if (a.dbg & 2) continue;
+        float* cur = img0 + (st & 1) * IMG;
+        float* nxt = img0 + ((st + 1) & 1) * IMG;
+        if (st + 1 < nst) {
+            if (fast) {
+                stage_fast(q0 + WG_PT, nxt, nxt + BM * WG_PITCH);
+                if (st + 2 < nst) prefetch(q0 + 2 * WG_PT);
+            } else {
+                stage_slow(q0 + WG_PT, nxt, nxt + BM * WG_PITCH);
+            }
+        }
         // ---- each wave contracts its 16 positions of the stage ---------------------------------
+        const float* sG = cur;
+        const float* sX = cur + BM * WG_PITCH;
         const int pbase = wave * (WG_PT / 4);
 #pragma unroll
         for (int s = 0; s < WG_PT / 8; ++s) {
@@ -478,142 +495,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
+        __syncthreads();
     }
     // ---- combine the 4 waves through LDS (plain stores into per-wave images: LDS float atomics from 4 waves on
     // the same addresses cost ~1 us per instruction), then one fp64 atomic per element per workgroup --------------
-    if (a.dbg & 32) return;
-    __syncthreads();
     constexpr int CWP = BN + 1;
     float* cw = smem + wave * (BM * CWP);      // [4][BM][BN+1]
-#pragma unroll
-    for (int i = 0; i < MTW; ++i)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                cw[ml * CWP + j * 32 + col] = acc[i][j][r];
-            }
-    __syncthreads();
-    for (int e = tid; e < BM * BN; e += 256) {
-        const int ml = e / BN, kl = e - ml * BN;
-        const int o = ml * CWP + kl;
-        const float v = (smem[o] + smem[BM * CWP + o]) + (smem[2 * BM * CWP + o] + smem[3 * BM * CWP + o]);
-        if (m0 + ml < M && k0 + kl < K && !(a.dbg & 1)) atomicAdd(&a.gw[(long)(m0 + ml) * K + k0 + kl], (double)v);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// weight gradient, direct-register form (contiguous positions: stride 1, Q % 4 == 0, no im2col).
-// The contraction runs over positions, so any pairing of positions into MFMA k-steps is valid as long as both
-// operands use the same one.  Lane (i = l&31, kk = l>>5) therefore loads a float4 of ITS OWN channel row at
-// positions p0+4kk..+3 straight from global memory (32 B contiguous per row per instruction, the other 96 B of
-// the line are consumed by the wave's next three loads out of L1) and feeds .x/.y/.z/.w to four k-steps:
-// no LDS staging, no barriers, 16 MFMAs (64x64 tile) per 6 float4 loads, next iteration's loads in flight.
-// ---------------------------------------------------------------------------------------------
-template <int MTW, int NTW>
-__global__ __launch_bounds__(256) void pw_wgrad_direct_kernel(const WgArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int BM = 32 * MTW, BN = 32 * NTW;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
-    unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = L % a.mtiles; L /= a.mtiles;
-    const int kt = L % a.ktiles; L /= a.ktiles;
-    const int strip = L % a.nstrips;
-    const int n = L / a.nstrips;
-    const int m0 = mt * BM, k0 = kt * BN;
-    const int M = a.M, K = a.K, Q = a.Q;
-
-    // per-lane row constants
-    float cs[MTW], cq[MTW], ca[NTW], cb[NTW];
-    const float* gp[MTW]; const float* yp[MTW]; const float* xp[NTW];
-    bool okm[MTW], okk[NTW];
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-        const int ch = m0 + i * 32 + col;
-        okm[i] = ch < M;
-        const int chc = okm[i] ? ch : M - 1;
-        cs[i] = (okm[i] && a.gs) ? (float)a.gs[(long)n * M + chc] : 0.0f;
-        cq[i] = (okm[i] && a.gq && a.y) ? 2.0f * (float)a.gq[(long)n * M + chc] : 0.0f;
-        gp[i] = a.gy + ((long)n * M + chc) * Q + 4 * half;
-        yp[i] = a.y ? a.y + ((long)n * M + chc) * Q + 4 * half : nullptr;
-    }
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-        const int ch = k0 + j * 32 + col;
-        okk[j] = ch < K;
-        const int chc = okk[j] ? ch : K - 1;
-        ca[j] = (okk[j] && a.pa) ? a.pa[(long)n * K + chc] : 1.0f;
-        cb[j] = (okk[j] && a.pb) ? a.pb[(long)n * K + chc] : 0.0f;
-        xp[j] = a.x + ((long)n * K + chc) * a.Pin + 4 * half;
-    }
-    f16v acc[MTW][NTW];
-#pragma unroll
-    for (int i = 0; i < MTW; ++i)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // this wave's positions: [qb, qe) in steps of 8
-    const int per_block = a.stages * WG_PT;
-    const int qb = strip * per_block + wave * (per_block / 4);
-    const int qe = min(qb + per_block / 4, Q);
-
-    f4v g0[MTW], y0[MTW], x0[NTW], g1[MTW], y1[MTW], x1[NTW];
-    auto ld = [&](int q, f4v (&g)[MTW], f4v (&yy)[MTW], f4v (&xx)[NTW]) {
-        const bool in = q + 4 * half < Q;           // Q % 4 == 0: a float4 is entirely inside or outside
-        const int qc = in ? q : 0;
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-            g[i] = *reinterpret_cast<const f4v*>(gp[i] + qc);
-            if (a.y) yy[i] = *reinterpret_cast<const f4v*>(yp[i] + qc);
-        }
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) xx[j] = *reinterpret_cast<const f4v*>(xp[j] + qc);
-    };
-    auto mac = [&](int q, const f4v (&g)[MTW], const f4v (&yy)[MTW], const f4v (&xx)[NTW]) {
-        const bool in = q + 4 * half < Q;
-        f4v av[MTW], bv[NTW];
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-            const bool ok = in && okm[i];
-            f4v v = g[i] + cs[i];
-            if (a.y) v += yy[i] * cq[i];
-            av[i].x = ok ? v.x : 0.f; av[i].y = ok ? v.y : 0.f; av[i].z = ok ? v.z : 0.f; av[i].w = ok ? v.w : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            const bool ok = in && okk[j];
-            bv[j].x = ok ? cfn_act_rt(fmaf(xx[j].x, ca[j], cb[j]), a.act) : 0.f;
-            bv[j].y = ok ? cfn_act_rt(fmaf(xx[j].y, ca[j], cb[j]), a.act) : 0.f;
-            bv[j].z = ok ? cfn_act_rt(fmaf(xx[j].z, ca[j], cb[j]), a.act) : 0.f;
-            bv[j].w = ok ? cfn_act_rt(fmaf(xx[j].w, ca[j], cb[j]), a.act) : 0.f;
-        }
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-            for (int i = 0; i < MTW; ++i)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s4], bv[j][s4], acc[i][j], 0, 0, 0);
-    };
-    if (qb < qe) {
-        ld(qb, g0, y0, x0);
-        for (int q = qb; q < qe; q += 16) {
-            if (q + 8 < qe) ld(q + 8, g1, y1, x1);
-            __builtin_amdgcn_sched_barrier(0);
-            mac(q, g0, y0, x0);
-            if (q + 8 < qe) {
-                if (q + 16 < qe) ld(q + 16, g0, y0, x0);
-                __builtin_amdgcn_sched_barrier(0);
-                mac(q + 8, g1, y1, x1);
-            }
-        }
-    }
-    // ---- combine the 4 waves through per-wave LDS images, then one fp64 atomic per element per workgroup -------
-    constexpr int CWP = BN + 1;
-    float* cw = smem + wave * (BM * CWP);
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
 #pragma unroll
@@ -669,7 +556,10 @@ static int pw_plan(PwArgs& a, int& MT, unsigned& blocks, size_t& lds) {
     // rows per workgroup: as many 32-row tiles as keep the resident weight image <= 64 KiB (max 4),
     // then the smallest tile that covers M with that number of row tiles
     int mt_fit = (64 * 1024 / 4 / a.kres) / 32;
-    { const char* e = getenv("CFN_PW_MTCAP"); const int cap = e ? atoi(e) : 4; if (mt_fit > cap) mt_fit = cap; }
+    // measured: occupancy beats register tiling here -- 32-row tiles when the weight image is deep (K >= 96, the
+    // MFMA-bound layers 3-4), at most 64 rows otherwise
+    if (mt_fit > 2) mt_fit = 2;
+    if (a.K >= 96 && !a.stem) mt_fit = 1;
     if (a.ea && mt_fit > 2) mt_fit = 2;   // DGRAD with the act' epilogue: keep the register footprint spill-free
     if (mt_fit < 1) mt_fit = 1;
     const int ntile = cfn_cdiv(M32, mt_fit);
@@ -758,12 +648,11 @@ static void wg_plan(WgArgs& a, int& MTW, int& NTW) {
     if (stages < 4) stages = 4;
     a.stages = stages;
     a.nstrips = cfn_cdiv(nst, stages);
-    { const char* e = getenv("CFN_WG_DBG"); a.dbg = e ? atoi(e) : 0; }
 }
 
 static int wg_launch(const WgArgs& a, int MTW, int NTW, hipStream_t st) {
     const unsigned blocks = (unsigned)((long)a.N * a.nstrips * a.mtiles * a.ktiles);
-    size_t lds = ((size_t)(32 * MTW + 32 * NTW) * WG_PITCH + 2 * (32 * MTW + 32 * NTW)) * sizeof(float);
+    size_t lds = ((size_t)2 * (32 * MTW + 32 * NTW) * WG_PITCH + 2 * (32 * MTW + 32 * NTW)) * sizeof(float);
     const size_t lds_cw = (size_t)4 * 32 * MTW * (32 * NTW + 1) * sizeof(float);
     if (lds_cw > lds) lds = lds_cw;
 #define CFN_WG_GO(MW, NW)                                                                                       \
@@ -772,24 +661,6 @@ static int wg_launch(const WgArgs& a, int MTW, int NTW, hipStream_t st) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, a);                                             \
     } while (0)
-    // direct-register loads touch 32 rows x 32 B per instruction: fine out of L2, poor for HBM-streaming sizes
-    const bool direct = (a.Q % 4 == 0) && a.stride == 1 && !a.stem && !(a.dbg & 64) &&
-                        (double)(2 * a.M + a.K) * a.Q * 4.0 * a.N <= 160e6;
-    if (direct) {
-        const size_t ldsd = (size_t)4 * 32 * MTW * (32 * NTW + 1) * sizeof(float);
-#define CFN_WGD_GO(MW, NW)                                                                                      \
-    do {                                                                                                        \
-        auto k = pw_wgrad_direct_kernel<MW, NW>;                                                                \
-        if (ldsd > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd); \
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), ldsd, st, a);                                            \
-    } while (0)
-        if (MTW == 1 && NTW == 1) CFN_WGD_GO(1, 1);
-        else if (MTW == 1) CFN_WGD_GO(1, 2);
-        else if (NTW == 1) CFN_WGD_GO(2, 1);
-        else CFN_WGD_GO(2, 2);
-#undef CFN_WGD_GO
-        return cfn_check_launch("pwconv_bwd_weight_direct");
-    }
     if (MTW == 1 && NTW == 1) CFN_WG_GO(1, 1);
     else if (MTW == 1) CFN_WG_GO(1, 2);
     else if (NTW == 1) CFN_WG_GO(2, 1);
