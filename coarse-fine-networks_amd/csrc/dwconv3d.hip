@@ -145,15 +145,14 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     float acc[3][HS];      // FWD/DGRAD rolling accumulators: [0]=frame+1, [1]=frame, [2]=frame-1
     float dwa[27];         // WGRAD partial weight gradients
     float gro[3][HS];      // WGRAD rolling gradients: [0]=g(frame+1) [1]=g(frame) [2]=g(frame-1)
-    float gnn[HS];         // WGRAD prefetch g(frame+2)
 #pragma unroll
-    for (int i = 0; i < HS; ++i) { acc[0][i] = acc[1][i] = acc[2][i] = 0.0f; gro[0][i] = gro[1][i] = gro[2][i] = 0.0f; gnn[i] = 0.0f; }
+    for (int i = 0; i < HS; ++i) { acc[0][i] = acc[1][i] = acc[2][i] = 0.0f; gro[0][i] = gro[1][i] = gro[2][i] = 0.0f; }
 #pragma unroll
     for (int j = 0; j < 27; ++j) dwa[j] = 0.0f;
     float st1 = 0.0f, st2 = 0.0f;
 
     typedef float __attribute__((ext_vector_type(4))) f4;
-    constexpr int DEPTH = (MODE == DW_FWD && VEC == 4 && MAXLD == 2) ? 2 : 1;
+    constexpr int DEPTH = (MODE == DW_FWD && VEC == 4 && (MAXLD == 2 || UNIW)) ? 2 : 1;
     f4 pfA[MAXLD], pfA2[MAXLD], pfB[DEPTH == 2 ? MAXLD : 1], pfB2[DEPTH == 2 ? MAXLD : 1];
     const bool two_src = (MODE == DW_DGRAD) && a.src2 != nullptr;
 
@@ -205,26 +204,34 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
             }
         }
     };
-    // WGRAD: effective upstream gradient of output frame t for this thread's HS outputs
-    auto load_g = [&](int t, float (&g)[HS]) {
-        if (t >= t0 && t < t1 && active) {
+    // WGRAD: upstream gradient of output frame t for this thread's HS outputs.  The loads only land in registers
+    // (raw gy / y); the gy + gs + 2*y*gq arithmetic happens one frame later in take_g, so no wait sits behind the loads
+    float gnn[HS], gny[HS];   // raw gy / y of frame+2
+    bool gn_ok = false;
+    auto load_g = [&](int t) {
+        gn_ok = t >= t0 && t < t1 && active;
+        if (gn_ok) {
             const long o = (nc * T + t) * plane_o + (long)hrow0 * Wo + wo;
 #pragma unroll
             for (int i = 0; i < HS; ++i) {
-                float v = a.gy[o + (long)i * Wo] + gs_c;
-                if (a.yout) v = fmaf(a.yout[o + (long)i * Wo], gq2_c, v);
-                g[i] = v;
+                gnn[i] = a.gy[o + (long)i * Wo];
+                if (a.yout) gny[i] = a.yout[o + (long)i * Wo];
             }
-        } else {
+        }
+    };
+    auto take_g = [&](float (&g)[HS]) {
 #pragma unroll
-            for (int i = 0; i < HS; ++i) g[i] = 0.0f;
+        for (int i = 0; i < HS; ++i) {
+            float v = gnn[i] + gs_c;
+            if (a.yout) v = fmaf(gny[i], gq2_c, v);
+            g[i] = gn_ok ? v : 0.0f;
         }
     };
 
     __syncthreads();   // zero fill + sA/sB visible
 
     const int f_first = t0 - 1, f_last = t1;   // input frames t0-1 .. t1 (inclusive)
-    if (MODE == DW_WGRAD) { load_g(t0, gro[0]); load_g(t0 + 1, gnn); }
+    if (MODE == DW_WGRAD) { load_g(t0); take_g(gro[0]); load_g(t0 + 1); }
     // prime the pipeline: frame f_first staged in image 0, the next DEPTH frames in flight in registers
     if (frame_valid(f_first)) prefetch(f_first, pfA, pfA2);
     if (DEPTH == 2 && f_first + 1 <= f_last && frame_valid(f_first + 1)) prefetch(f_first + 1, pfB, pfB2);
@@ -281,8 +288,9 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
 
         if (MODE == DW_WGRAD) {
 #pragma unroll
-            for (int i = 0; i < HS; ++i) { gro[2][i] = gro[1][i]; gro[1][i] = gro[0][i]; gro[0][i] = gnn[i]; }
-            load_g(f + 3, gnn);
+            for (int i = 0; i < HS; ++i) { gro[2][i] = gro[1][i]; gro[1][i] = gro[0][i]; }
+            take_g(gro[0]);
+            load_g(f + 3);
         } else {
             if (emit) {
                 const long o = (nc * T + to) * plane_o + (long)hrow0 * Wo + wo;
@@ -371,31 +379,68 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
     const float* gyb = a.gy + (long)nc * T * po + (long)i * Wo + j;
     const float* yb = a.y ? a.y + (long)nc * T * po + (long)i * Wo + j : nullptr;
 
-    auto ldg = [&](int f, float (&g)[4]) {     // g'[f] at (i,j) (i,j+1) (i+1,j) (i+1,j+1), zero outside
-        g[0] = g[1] = g[2] = g[3] = 0.0f;
-        if (ok && f >= 0 && f < T) {
+    const int t0 = chunk * a.TT, t1 = min(t0 + a.TT, T);
+    // g'[f] at (i,j) (i,j+1) (i+1,j) (i+1,j+1), zero outside.  Software pipelined: ld_raw only issues the loads
+    // (frame t+2 while frame t is computed), fin applies gy + gs + 2*y*gq when the frame is consumed.
+    auto ld_raw = [&](int f, float (&g)[4], float (&y)[4]) -> bool {
+        const bool v = ok && f >= 0 && f < T;
+        if (v) {
             const long o = (long)f * po;
-            g[0] = gyb[o] + gsv;
-            if (j1) g[1] = gyb[o + 1] + gsv;
-            if (i1) g[2] = gyb[o + Wo] + gsv;
-            if (i1 && j1) g[3] = gyb[o + Wo + 1] + gsv;
+            g[0] = gyb[o];
+            if (j1) g[1] = gyb[o + 1];
+            if (i1) g[2] = gyb[o + Wo];
+            if (i1 && j1) g[3] = gyb[o + Wo + 1];
             if (yb) {
-                g[0] = fmaf(yb[o], gqv, g[0]);
-                if (j1) g[1] = fmaf(yb[o + 1], gqv, g[1]);
-                if (i1) g[2] = fmaf(yb[o + Wo], gqv, g[2]);
-                if (i1 && j1) g[3] = fmaf(yb[o + Wo + 1], gqv, g[3]);
+                y[0] = yb[o];
+                if (j1) y[1] = yb[o + 1];
+                if (i1) y[2] = yb[o + Wo];
+                if (i1 && j1) y[3] = yb[o + Wo + 1];
             }
         }
+        return v;
     };
-    const int t0 = chunk * a.TT, t1 = min(t0 + a.TT, T);
-    float G[3][4];
-    ldg(t0 - 1, G[1]);
-    ldg(t0, G[2]);
+    auto fin = [&](bool v, const float (&g)[4], const float (&y)[4], float (&out)[4]) {
+        const bool in[4] = {v, v && j1, v && i1, v && i1 && j1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float r = g[k] + gsv;
+            if (yb) r = fmaf(y[k], gqv, r);
+            out[k] = in[k] ? r : 0.0f;
+        }
+    };
+    typedef float __attribute__((ext_vector_type(2))) f2;
+    const bool pair = (Wi & 1) == 0;           // even rows => (2i, 2j) 8-byte aligned, column 2j+1 always inside
+    auto ld_x = [&](int t, float (&xv)[4]) {   // forward input of the 2x2 block (only needed with a prologue)
+        if (!(a.A && ok && t < t1)) return;
+        const long o = ((long)nc * T + t) * pi + (long)(2 * i) * Wi + 2 * j;
+        if (pair) {
+            const f2 u = *reinterpret_cast<const f2*>(a.x + o);
+            xv[0] = u.x; xv[1] = u.y;
+            if (r1) { const f2 d = *reinterpret_cast<const f2*>(a.x + o + Wi); xv[2] = d.x; xv[3] = d.y; }
+        } else {
+            xv[0] = a.x[o];
+            if (c1) xv[1] = a.x[o + 1];
+            if (r1) xv[2] = a.x[o + Wi];
+            if (r1 && c1) xv[3] = a.x[o + Wi + 1];
+        }
+    };
+    float G[3][4], rg[4], ry[4], xn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rg[k] = ry[k] = xn[k] = 0.0f;
+    { const bool v = ld_raw(t0 - 1, rg, ry); fin(v, rg, ry, G[1]); }
+    { const bool v = ld_raw(t0, rg, ry); fin(v, rg, ry, G[2]); }
+    bool rv = ld_raw(t0 + 1, rg, ry);
+    ld_x(t0, xn);
     float s1 = 0.0f, s2 = 0.0f;
     for (int t = t0; t < t1; ++t) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { G[0][k] = G[1][k]; G[1][k] = G[2][k]; }
-        ldg(t + 1, G[2]);
+        fin(rv, rg, ry, G[2]);                 // frame t+1 (loaded one iteration ago)
+        float xv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xv[k] = xn[k];
+        rv = ld_raw(t + 2, rg, ry);
+        ld_x(t + 1, xn);
         // gx[t] = sum_kt W[kt] * g'[t+1-kt]  -> frame slot 2-kt
         float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
 #pragma unroll
@@ -411,18 +456,24 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
             const long o = ((long)nc * T + t) * pi + (long)(2 * i) * Wi + 2 * j;
             float v[4] = {o00, o01, o10, o11};
             const bool in[4] = {true, c1, r1, r1 && c1};
-            const long off[4] = {0, 1, Wi, (long)Wi + 1};
+            if (a.A) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!in[k]) continue;
-                if (a.A) {
-                    const float xv = a.x[o + off[k]];
-                    const float dz = v[k] * cfn_act_grad_rt(fmaf(xv, pa, pb2), a.act);
-                    s1 = fmaf(dz, xv, s1);
+                for (int k = 0; k < 4; ++k) {
+                    if (!in[k]) continue;
+                    const float dz = v[k] * cfn_act_grad_rt(fmaf(xv[k], pa, pb2), a.act);
+                    s1 = fmaf(dz, xv[k], s1);
                     s2 += dz;
                     v[k] = dz * pa;
                 }
-                a.gx[o + off[k]] = v[k];
+            }
+            if (pair) {
+                *reinterpret_cast<f2*>(a.gx + o) = (f2){v[0], v[1]};
+                if (r1) *reinterpret_cast<f2*>(a.gx + o + Wi) = (f2){v[2], v[3]};
+            } else {
+                a.gx[o] = v[0];
+                if (c1) a.gx[o + 1] = v[1];
+                if (r1) a.gx[o + Wi] = v[2];
+                if (r1 && c1) a.gx[o + Wi + 1] = v[3];
             }
         }
     }
@@ -442,10 +493,10 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
 // ---------------------------------------------------------------------------------------------
 struct DwPlan { int HS, VEC, MAXLD, threads; bool UNIW; size_t lds; unsigned blocks; };
 
-static int pick_hs(int Ho) {
-    // small planes (<= 14 rows): short strips keep the register footprint low (more waves per CU), the data
-    // is L2 resident anyway; large planes: 7-row strips minimise LDS reads per output
-    if (Ho <= 14) return (Ho % 2 == 0) ? 2 : 1;
+static int pick_hs(int Ho, int mode) {
+    // small planes (<= 14 rows), backward kernels: short strips keep the register footprint low (more waves per
+    // CU; measured faster); everything else: 7-row strips minimise LDS reads per output
+    if (Ho <= 14 && mode != DW_FWD) return (Ho % 2 == 0) ? 2 : 1;
     if (Ho % 7 == 0) return 7;
     if (Ho % 4 == 0) return 4;
     if (Ho % 2 == 0) return 2;
@@ -455,7 +506,7 @@ static int pick_hs(int Ho) {
 static int dw_plan(DwArgs& a, int S, int mode, DwPlan& pl) {
     a.Ho = (a.Hi + 2 - 3) / S + 1;
     a.Wo = (a.Wi + 2 - 3) / S + 1;
-    const int HS = pick_hs(a.Ho);
+    const int HS = pick_hs(a.Ho, mode);
     const int G = a.Ho / HS;
     if (a.Wo > 512) return cfn_fail(CFN_ERR_UNSUPPORTED, "dwconv3d: output width %d > 512 not supported", a.Wo);
     const int VEC = (a.Wi % 4 == 0) ? 4 : 1;

@@ -57,34 +57,66 @@ __global__ __launch_bounds__(256) void dwt5_kernel(const T5Args a) {
         return v;
     };
 
-    f4v win[5];
+    // 5-frame register window + PF frames of look-ahead: PF independent loads stay in flight per thread, so the
+    // stream is not latency bound by one dependent load per output frame.  Look-ahead registers hold RAW loads; the
+    // gy + gs + 2*y*gq arithmetic is applied when a frame enters the window, so no wait sits right behind a load.
+    constexpr int PF = 4;
+    const f4v zero = {0.f, 0.f, 0.f, 0.f};
+    const bool two = MODE == T5_DGRAD && a.src2 != nullptr;
+    auto fin_src = [&](f4v v, f4v v2, int t) -> f4v {
+        if (MODE != T5_DGRAD) return v;
+        if (!(ok && t >= 0 && t < a.T)) return zero;
+        v += gsv;
+        if (two) v += v2 * gqv;
+        return v;
+    };
+    f4v win[5], nxt[PF], nxt2[PF];
 #pragma unroll
     for (int k = 0; k < 4; ++k) win[k + 1] = ld_src(t0 - 2 + k);   // frames t0-2 .. t0+1
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {                                 // t0+2 ..
+        const bool need = t0 + 2 + k <= t1 + 1;
+        nxt[k] = need ? ld(a.src, t0 + 2 + k) : zero;
+        nxt2[k] = (need && two) ? ld(a.src2, t0 + 2 + k) : zero;
+    }
+    f4v gr4[PF], yr4[PF];   // WGRAD: raw gy / y of frames t .. t+PF-1
+    const bool wy = MODE == T5_WGRAD && a.yout != nullptr;
+    if (MODE == T5_WGRAD) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) { gr4[k] = ld(a.gy, t0 + k); yr4[k] = wy ? ld(a.yout, t0 + k) : zero; }
+    }
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float st1 = 0.f, st2 = 0.f;
-    for (int t = t0; t < t1; ++t) {
+    for (int tb = t0; tb < t1; tb += PF) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) win[k] = win[k + 1];
-        win[4] = ld_src(t + 2);
-        if (MODE == T5_WGRAD) {
-            f4v g = ld(a.gy, t);
-            if (ok) {
-                g += gsv;
-                if (a.yout) g += ld(a.yout, t) * gqv;
-            }
+        for (int u = 0; u < PF; ++u) {
+            const int t = tb + u;
+            if (t >= t1) break;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const f4v pr = g * win[k];
-                acc[k] += VEC == 4 ? pr.x + pr.y + pr.z + pr.w : pr.x;
-            }
-        } else {
-            f4v y = win[0] * wk[0] + win[1] * wk[1] + win[2] * wk[2] + win[3] * wk[3] + win[4] * wk[4];
-            if (ok) {
-                if (VEC == 4) *reinterpret_cast<f4v*>(a.dst + base + (long)t * a.plane) = y;
-                else a.dst[base + (long)t * a.plane] = y.x;
-                if (MODE == T5_FWD) {
-                    if (VEC == 4) { st1 += y.x + y.y + y.z + y.w; st2 += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w; }
-                    else { st1 += y.x; st2 = fmaf(y.x, y.x, st2); }
+            for (int k = 0; k < 4; ++k) win[k] = win[k + 1];
+            win[4] = fin_src(nxt[u], nxt2[u], t + 2);
+            const bool need = t + 2 + PF <= t1 + 1;
+            nxt[u] = need ? ld(a.src, t + 2 + PF) : zero;
+            if (MODE == T5_DGRAD) nxt2[u] = (need && two) ? ld(a.src2, t + 2 + PF) : zero;
+            if (MODE == T5_WGRAD) {
+                f4v g = zero;
+                if (ok) { g = gr4[u] + gsv; if (wy) g += yr4[u] * gqv; }    // t < t1 <= T here
+                gr4[u] = (t + PF < t1) ? ld(a.gy, t + PF) : zero;
+                if (wy) yr4[u] = (t + PF < t1) ? ld(a.yout, t + PF) : zero;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const f4v pr = g * win[k];
+                    acc[k] += VEC == 4 ? pr.x + pr.y + pr.z + pr.w : pr.x;
+                }
+            } else {
+                f4v y = win[0] * wk[0] + win[1] * wk[1] + win[2] * wk[2] + win[3] * wk[3] + win[4] * wk[4];
+                if (ok) {
+                    if (VEC == 4) *reinterpret_cast<f4v*>(a.dst + base + (long)t * a.plane) = y;
+                    else a.dst[base + (long)t * a.plane] = y.x;
+                    if (MODE == T5_FWD) {
+                        if (VEC == 4) { st1 += y.x + y.y + y.z + y.w; st2 += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w; }
+                        else { st1 += y.x; st2 = fmaf(y.x, y.x, st2); }
+                    }
                 }
             }
         }

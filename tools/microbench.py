@@ -94,6 +94,18 @@ def bench_pw(T, bwd):
 
 def bench_dw(T, bwd):
     print('%-28s %9s %9s %9s %s' % ('depthwise layer', 'ms', 'GB/s', 'TFLOP/s', '(fwd)'))
+    x = torch.randn(1, 24, T, 112, 112, device=DEV)
+    w = torch.randn(24, 1, 5, 1, 1, device=DEV) * 0.3
+    ms = devtime(lambda: ops.dwconv_t5(x, w, True))['dwconv_fwd']
+    print('%-28s %9.3f %9.1f' % ('stem conv1_t 24 @112 (5x1x1)', ms, 8.0 * 24 * T * 112 * 112 / 1e6 / ms))
+    if bwd:
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y, sm, sq = ops.dwconv_t5(xr, wr, True)
+        gy, gs, gq = torch.randn_like(y), torch.randn_like(sm) * 0.01, torch.randn_like(sq) * 0.001
+        md = devtime(lambda: torch.autograd.grad((y, sm, sq), (xr, wr), (gy, gs, gq), retain_graph=True))['dwconv_bwd']
+        print('%-28s dgrad+wgrad %7.3f ms %7.1f GB/s' % ('', md, 28.0 * 24 * T * 112 * 112 / 1e6 / md))
+        del xr, y, gy
+    del x
     for name, c, H, s in DW_LAYERS:
         x = torch.randn(1, c, T, H, H, device=DEV)
         w = torch.randn(c, 1, 3, 3, 3, device=DEV) * 0.2
