@@ -272,8 +272,8 @@ class _BnFold(Function):
             gg, gbt = torch.empty(C, device=dev), torch.empty(C, device=dev)
         gw1 = gb1 = gw2 = gb2 = tA = tB = None
         if Wd:
-            gw1, gb1 = torch.zeros(Wd, C, device=dev), torch.zeros(Wd, device=dev)
-            gw2, gb2 = torch.zeros(C, Wd, device=dev), torch.zeros(C, device=dev)
+            gw1, gb1 = torch.empty(Wd, C, device=dev), torch.empty(Wd, device=dev)
+            gw2, gb2 = torch.empty(C, Wd, device=dev), torch.empty(C, device=dev)
             tA, tB = torch.empty(N, C, device=dev), torch.empty(N, C, device=dev)
         call('cfn_bn_fold_bwd', gA, gB, s, gamma, mean, rstd, A0, B0, gate, hbuf, pooled, w1c, w2c, int(training), N, C, S,
              Wd, float(count), float(pool_count), gs, gq, gg, gbt, gw1, gb1, gw2, gb2, tA, tB)

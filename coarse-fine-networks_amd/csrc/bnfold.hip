@@ -7,7 +7,8 @@
 // even-indexed bottlenecks, the SE branch (x3d_fine.py:157-163: global mean -> fc1 -> relu -> fc2 ->
 // sigmoid -> scale), whose global average pool of bn2(y) equals A*mean(y)+B.  The backward kernel is the
 // exact adjoint (statistics are differentiated: gsum/gsumsq flow back into the producing conv).
-// One workgroup; all arithmetic that feeds the normalisation is fp64.
+// One workgroup; all arithmetic that feeds the normalisation is fp64.  The SE matrices are staged in LDS and the
+// matrix-vector products are wave cooperative, so the kernel is a handful of dependent memory latencies long.
 #include "cfn_common.h"
 
 struct BnFoldArgs {
@@ -23,10 +24,28 @@ struct BnFoldArgs {
     float* A0; float* B0; float* gate; float* hbuf; float* pooled;   // SE saved: (N,C),(N,C),(N,C),(N,Wd),(N,C)
 };
 
-__global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const BnFoldArgs a) {
-    const int tid = threadIdx.x, N = a.N, C = a.C, S = a.training ? a.S : 1, G = N / S;
+#define BNF_NB 4   // samples per squeeze-excite pass (LDS tables are sized for this many)
+
+// stage the two SE matrices in LDS: w1s[j*C + c] (rows contiguous), w2s[c*(Wd+1) + j] (odd pitch => lanes along c
+// hit distinct banks)
+__device__ __forceinline__ void bnf_stage_se(const float* w1, const float* w2, float* w1s, float* w2s, int C, int Wd) {
+    for (int e = threadIdx.x; e < C * Wd; e += blockDim.x) {
+        w1s[e] = w1[e];
+        const int c = e / Wd, j = e - c * Wd;
+        w2s[c * (Wd + 1) + j] = w2[e];
+    }
+}
+
+__global__ __launch_bounds__(1024) void bn_fold_fwd_kernel(const BnFoldArgs a) {
+    const int tid = threadIdx.x, nthr = blockDim.x, N = a.N, C = a.C, S = a.training ? a.S : 1, G = N / S, Wd = a.Wd;
+    extern __shared__ float sh[];      // w1s[Wd*C] | w2s[C*(Wd+1)] | pooled[NB*C] | h[NB*Wd]
+    float* w1s = sh;
+    float* w2s = w1s + (Wd > 0 ? Wd * C : 0);
+    float* sp = w2s + (Wd > 0 ? C * (Wd + 1) : 0);
+    float* shh = sp + BNF_NB * C;
+    if (Wd > 0) bnf_stage_se(a.w1, a.w2, w1s, w2s, C, Wd);
     // (1) statistics per (split group, channel)
-    for (int e = tid; e < S * C; e += 256) {
+    for (int e = tid; e < S * C; e += nthr) {
         const int g = e / C, c = e - g * C;
         double mean, var;
         if (a.training) {
@@ -50,37 +69,41 @@ __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const BnFoldArgs a) {
         const float av = (float)(ga * rstd), bv = (float)(be - mean * ga * rstd);
         for (int i = 0; i < G; ++i) {
             const long o = (long)(i * S + g) * C + c;
-            if (a.Wd > 0) { a.A0[o] = av; a.B0[o] = bv; } else { a.A[o] = av; a.B[o] = bv; }
+            if (Wd > 0) { a.A0[o] = av; a.B0[o] = bv; } else { a.A[o] = av; a.B[o] = bv; }
         }
     }
     if (a.training && a.nbt && tid == 0) a.nbt[0] += 1;
-    if (a.Wd <= 0) return;
+    if (Wd <= 0) return;
     __syncthreads();
-    // (2) squeeze-excite gate per sample
-    extern __shared__ float sh[];      // pooled[C] | h[Wd]
-    float* sp = sh;
-    float* shh = sh + C;
-    for (int n = 0; n < N; ++n) {
-        for (int c = tid; c < C; c += 256) {
-            const long o = (long)n * C + c;
+    // (2) squeeze-excite gate, BNF_NB samples per pass; dot products are wave cooperative (lanes along the long axis)
+    const int wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
+    for (int n0 = 0; n0 < N; n0 += BNF_NB) {
+        const int nb = min(BNF_NB, N - n0);
+        for (int e = tid; e < nb * C; e += nthr) {
+            const long o = (long)n0 * C + e;
             const float pv = (float)(a.s[o] / a.pool_count) * a.A0[o] + a.B0[o];
-            sp[c] = pv;
+            sp[e] = pv;
             a.pooled[o] = pv;
         }
         __syncthreads();
-        for (int j = tid; j < a.Wd; j += 256) {
-            float acc = a.b1[j];
-            for (int c = 0; c < C; ++c) acc = fmaf(a.w1[(long)j * C + c], sp[c], acc);
-            acc = fmaxf(acc, 0.0f);
-            shh[j] = acc;
-            a.hbuf[(long)n * a.Wd + j] = acc;
+        for (int p = wave; p < nb * Wd; p += nwaves) {          // h[n][j] = relu(b1[j] + w1[j,:] . pooled[n,:])
+            const int nl = p / Wd, j = p - nl * Wd;
+            float acc = 0.0f;
+            for (int c = lane; c < C; c += 64) acc = fmaf(w1s[j * C + c], sp[nl * C + c], acc);
+            acc = cfn_wave_sum(acc);
+            if (lane == 0) {
+                acc = fmaxf(acc + a.b1[j], 0.0f);
+                shh[p] = acc;
+                a.hbuf[(long)(n0 + nl) * Wd + j] = acc;
+            }
         }
         __syncthreads();
-        for (int c = tid; c < C; c += 256) {
+        for (int e = tid; e < nb * C; e += nthr) {               // gate[n][c] = sigmoid(b2[c] + w2[c,:] . h[n,:])
+            const int nl = e / C, c = e - nl * C;
             float acc = a.b2[c];
-            for (int j = 0; j < a.Wd; ++j) acc = fmaf(a.w2[(long)c * a.Wd + j], shh[j], acc);
+            for (int j = 0; j < Wd; ++j) acc = fmaf(w2s[c * (Wd + 1) + j], shh[nl * Wd + j], acc);
             const float gt = 1.0f / (1.0f + expf(-acc));
-            const long o = (long)n * C + c;
+            const long o = (long)n0 * C + e;
             a.gate[o] = gt;
             a.A[o] = a.A0[o] * gt;
             a.B[o] = a.B0[o] * gt;
@@ -100,51 +123,72 @@ struct BnFoldBwdArgs {
     double count, pool_count;
     double* gs; double* gq;                 // (N,C) outputs (training) or null
     float* ggamma; float* gbeta;            // (C) outputs or null
-    float* gw1; float* gb1; float* gw2; float* gb2;   // SE parameter gradients (zero-filled by caller)
+    float* gw1; float* gb1; float* gw2; float* gb2;   // SE parameter gradients (overwritten)
     float* tA; float* tB;                   // (N,C) scratch: gradients w.r.t. the un-gated A0/B0
 };
 
-__global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const BnFoldBwdArgs a) {
-    const int tid = threadIdx.x, N = a.N, C = a.C, S = a.training ? a.S : 1, G = N / S;
-    extern __shared__ float sh[];      // gz2[C] | gz1[Wd] | h[Wd]
-    float* gz2 = sh;
-    float* gz1 = sh + C;
-    float* shh = gz1 + (a.Wd > 0 ? a.Wd : 0);
-    // (2') squeeze-excite adjoint -> gradients w.r.t. A0, B0, s (through pooled)
-    if (a.Wd > 0) {
-        for (int n = 0; n < N; ++n) {
-            for (int j = tid; j < a.Wd; j += 256) shh[j] = a.hbuf[(long)n * a.Wd + j];
-            for (int c = tid; c < C; c += 256) {
-                const long o = (long)n * C + c;
+__global__ __launch_bounds__(1024) void bn_fold_bwd_kernel(const BnFoldBwdArgs a) {
+    const int tid = threadIdx.x, nthr = blockDim.x, N = a.N, C = a.C, S = a.training ? a.S : 1, G = N / S, Wd = a.Wd;
+    extern __shared__ float sh[];      // w1s[Wd*C] | w2s[C*(Wd+1)] | z[NB*C] | pooled[NB*C] | gz1[NB*Wd] | h[NB*Wd]
+    // (2') squeeze-excite adjoint -> gradients w.r.t. A0, B0, s (through pooled) and the SE parameters
+    if (Wd > 0) {
+        float* w1s = sh;
+        float* w2s = w1s + Wd * C;
+        float* gz2 = w2s + C * (Wd + 1);
+        float* pl = gz2 + BNF_NB * C;
+        float* gz1 = pl + BNF_NB * C;
+        float* shh = gz1 + BNF_NB * Wd;
+        bnf_stage_se(a.w1, a.w2, w1s, w2s, C, Wd);
+        const int wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
+        for (int n0 = 0; n0 < N; n0 += BNF_NB) {
+            const int nb = min(BNF_NB, N - n0);
+            const bool first = n0 == 0;
+            for (int e = tid; e < nb * Wd; e += nthr) shh[e] = a.hbuf[(long)n0 * Wd + e];
+            for (int e = tid; e < nb * C; e += nthr) {
+                const long o = (long)n0 * C + e;
                 const float gt = a.gate[o];
                 const float ggate = a.gA[o] * a.A0[o] + a.gB[o] * a.B0[o];
-                const float z = ggate * gt * (1.0f - gt);
-                gz2[c] = z;
+                gz2[e] = ggate * gt * (1.0f - gt);
+                pl[e] = a.pooled[o];
                 a.tA[o] = a.gA[o] * gt;
                 a.tB[o] = a.gB[o] * gt;
-                atomicAdd(&a.gb2[c], z);
             }
             __syncthreads();
-            for (int e = tid; e < C * a.Wd; e += 256) {         // gw2[c][j] += gz2[c] * h[j]
-                const int c = e / a.Wd, j = e - c * a.Wd;
-                a.gw2[e] += gz2[c] * shh[j];
-            }
-            for (int j = tid; j < a.Wd; j += 256) {
+            for (int e = tid; e < C * Wd; e += nthr) {            // gw2[c][j] += sum_n gz2[n][c] * h[n][j]
+                const int c = e / Wd, j = e - c * Wd;
                 float acc = 0.0f;
-                for (int c = 0; c < C; ++c) acc = fmaf(gz2[c], a.w2[(long)c * a.Wd + j], acc);
-                acc = shh[j] > 0.0f ? acc : 0.0f;
-                gz1[j] = acc;
-                a.gb1[j] += acc;
+                for (int nl = 0; nl < nb; ++nl) acc = fmaf(gz2[nl * C + c], shh[nl * Wd + j], acc);
+                a.gw2[e] = first ? acc : a.gw2[e] + acc;
+            }
+            for (int c = tid; c < C; c += nthr) {
+                float acc = 0.0f;
+                for (int nl = 0; nl < nb; ++nl) acc += gz2[nl * C + c];
+                a.gb2[c] = first ? acc : a.gb2[c] + acc;
+            }
+            for (int p = wave; p < nb * Wd; p += nwaves) {       // gz1[n][j] = relu'(h) * gz2[n,:] . w2[:,j]
+                const int nl = p / Wd, j = p - nl * Wd;
+                float acc = 0.0f;
+                for (int c = lane; c < C; c += 64) acc = fmaf(gz2[nl * C + c], w2s[c * (Wd + 1) + j], acc);
+                acc = cfn_wave_sum(acc);
+                if (lane == 0) gz1[p] = shh[p] > 0.0f ? acc : 0.0f;
             }
             __syncthreads();
-            for (int e = tid; e < a.Wd * C; e += 256) {         // gw1[j][c] += gz1[j] * pooled[c]
+            for (int e = tid; e < Wd * C; e += nthr) {            // gw1[j][c] += sum_n gz1[n][j] * pooled[n][c]
                 const int j = e / C, c = e - j * C;
-                a.gw1[e] += gz1[j] * a.pooled[(long)n * C + c];
+                float acc = 0.0f;
+                for (int nl = 0; nl < nb; ++nl) acc = fmaf(gz1[nl * Wd + j], pl[nl * C + c], acc);
+                a.gw1[e] = first ? acc : a.gw1[e] + acc;
             }
-            for (int c = tid; c < C; c += 256) {
+            for (int j = tid; j < Wd; j += nthr) {
+                float acc = 0.0f;
+                for (int nl = 0; nl < nb; ++nl) acc += gz1[nl * Wd + j];
+                a.gb1[j] = first ? acc : a.gb1[j] + acc;
+            }
+            for (int e = tid; e < nb * C; e += nthr) {            // gradient of pooled[n][c]
+                const int nl = e / C, c = e - nl * C;
                 float gp = 0.0f;
-                for (int j = 0; j < a.Wd; ++j) gp = fmaf(gz1[j], a.w1[(long)j * C + c], gp);
-                const long o = (long)n * C + c;
+                for (int j = 0; j < Wd; ++j) gp = fmaf(gz1[nl * Wd + j], w1s[j * C + c], gp);
+                const long o = (long)n0 * C + e;
                 const float sm = (float)(a.s[o] / a.pool_count);
                 a.tA[o] += gp * sm;
                 a.tB[o] += gp;
@@ -153,10 +197,10 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const BnFoldBwdArgs a)
             __syncthreads();
         }
     }
-    const float* dA = a.Wd > 0 ? a.tA : a.gA;
-    const float* dB = a.Wd > 0 ? a.tB : a.gB;
+    const float* dA = Wd > 0 ? a.tA : a.gA;
+    const float* dB = Wd > 0 ? a.tB : a.gB;
     // (1') batch-norm adjoint per channel
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += nthr) {
         double ggam = 0.0, gbet = 0.0;
         for (int g = 0; g < S; ++g) {
             double ga = 0.0, gb = 0.0;
@@ -172,7 +216,7 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const BnFoldBwdArgs a)
                 const double g_mean = -gb * gam * rstd - 2.0 * mean * g_var;
                 for (int i = 0; i < G; ++i) {
                     const long o = (long)(i * S + g) * C + c;
-                    a.gs[o] = (a.Wd > 0 ? a.gs[o] : 0.0) + g_mean / cnt;
+                    a.gs[o] = (Wd > 0 ? a.gs[o] : 0.0) + g_mean / cnt;
                     a.gq[o] = g_var / cnt;
                 }
             }
@@ -192,8 +236,10 @@ extern "C" int cfn_bn_fold_fwd(const double* s, const double* q, const float* ga
     CFN_REQUIRE(Wd <= 0 || (w1 && b1 && w2 && b2 && s && A0 && B0 && gate && hbuf && pooled), "cfn_bn_fold_fwd: SE needs its tensors");
     BnFoldArgs a = {s, q, gamma, beta, run_mean, run_var, nbt, training, N, C, S, Wd, count, pool_count, eps, momentum,
                     w1, b1, w2, b2, A, B, mean, rstd, A0, B0, gate, hbuf, pooled};
-    const size_t lds = (size_t)(C + (Wd > 0 ? Wd : 0)) * sizeof(float);
-    hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, a);
+    const size_t lds = Wd > 0 ? ((size_t)Wd * C + (size_t)C * (Wd + 1) + BNF_NB * (size_t)(C + Wd)) * sizeof(float) : 0;
+    CFN_REQUIRE(lds <= 150 * 1024, "cfn_bn_fold_fwd: SE tables (C=%d, width=%d) exceed LDS", C, Wd);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)bn_fold_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3(1), dim3(Wd > 0 ? 1024 : 256), lds, (hipStream_t)stream, a);
     return cfn_check_launch("bn_fold_fwd");
 }
 
@@ -208,7 +254,9 @@ extern "C" int cfn_bn_fold_bwd(const float* gA, const float* gB, const double* s
     CFN_REQUIRE((gs == nullptr) == (gq == nullptr), "cfn_bn_fold_bwd: gs/gq mismatch");
     BnFoldBwdArgs a = {gA, gB, s, gamma, mean, rstd, A0, B0, gate, hbuf, pooled, w1, w2, training, N, C, S, Wd, count,
                        pool_count, gs, gq, ggamma, gbeta, gw1, gb1, gw2, gb2, tA, tB};
-    const size_t lds = (size_t)(C + 2 * (Wd > 0 ? Wd : 0)) * sizeof(float);
-    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, a);
+    const size_t lds = Wd > 0 ? ((size_t)Wd * C + (size_t)C * (Wd + 1) + 2 * BNF_NB * (size_t)(C + Wd)) * sizeof(float) : 0;
+    CFN_REQUIRE(lds <= 150 * 1024, "cfn_bn_fold_bwd: SE tables (C=%d, width=%d) exceed LDS", C, Wd);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)bn_fold_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3(1), dim3(Wd > 0 ? 1024 : 256), lds, (hipStream_t)stream, a);
     return cfn_check_launch("bn_fold_bwd");
 }
