@@ -35,7 +35,8 @@ static inline int cfn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float cfn_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): ~6 VALU slots instead of the ~16 of an IEEE division
+__device__ __forceinline__ float cfn_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 template <int ACT>
 __device__ __forceinline__ float cfn_act(float z) {

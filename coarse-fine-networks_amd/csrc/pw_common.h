@@ -1,0 +1,44 @@
+// Shared declarations of the pointwise-contraction kernels (pwconv.hip, pwdeep.hip).
+#pragma once
+#include "cfn_common.h"
+
+typedef float __attribute__((ext_vector_type(16))) f16v;
+typedef float __attribute__((ext_vector_type(4))) f4v;
+
+enum { PW_FWD = 0, PW_DGRAD = 1 };
+#define PW_KC 32
+#define PW_RED_PITCH 33
+
+struct PwArgs {
+    const float* src;    // FWD: x raw (N,K,Pin)          DGRAD: gy (N,K,Q)
+    const float* src2;   // DGRAD: y raw (N,K,Q) for the 2*y*gq term (may be null)
+    const float* pa;     // FWD: prologue A[n,k] (null = identity)
+    const float* pb;
+    const double* gs;    // DGRAD: d/d sum(y)   [n,k]  (may be null)
+    const double* gq;    // DGRAD: d/d sum(y^2) [n,k]  (may be null)
+    const float* w;      // (Cout, Cin) row major
+    float* dst;          // FWD: y (N,M,Q)                DGRAD: gx (N,M,Pin)
+    const float* ex;     // DGRAD: forward input x raw (N,M,Pin) (needed when ea != null)
+    const float* ea;     // DGRAD: forward prologue A[n,m] (null = identity => gx = da)
+    const float* eb;
+    double* s1;          // FWD: sum(y) [n,m]             DGRAD: sum(dz*x) [n,m]
+    double* s2;          // FWD: sum(y^2)                 DGRAD: sum(dz)
+    int N, M, K, Q, Pin, Hi, Wi, Ho, Wo, stride, act;
+    int Cin;             // row pitch of w
+    int mtiles, nstrips, tpb, kres, Kpad;   // kres: weight rows resident in LDS per pass (multiple of 8)
+    // stem != 0: dense convolution as an implicit GEMM -- the B operand is the im2col view of a (N,Cimg,Ti,Hi,Wi)
+    // tensor for a (kT,kH,kW) kernel with strides (sT,sH,sW) and zero padding (pT,pH,pW); K = Cimg*kT*kH*kW
+    int stem, Cimg, kT, kH, kW, sT, sH, sW, pT, pH, pW, Ti, To;
+};
+
+#define PW_UNIT 8        // input channels per pipelined unit (4 MFMA k-steps)
+#define PW_KRES_MAX 512  // weight rows kept in LDS at once (K > 512 streams the weights in chunks)
+
+__device__ __forceinline__ float pw_bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+
+// pwdeep.hip: returns -1 when the shape is not handled by the deep kernel (caller falls through to pw_gemm_kernel),
+// otherwise the launch status.  mode: PW_FWD / PW_DGRAD; stats: epilogue statistics / act' epilogue present.
+int pwd_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st);

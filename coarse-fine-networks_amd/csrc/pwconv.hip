@@ -16,34 +16,7 @@
 #include "cfn_common.h"
 #include <stdlib.h>
 
-typedef float __attribute__((ext_vector_type(16))) f16v;
-typedef float __attribute__((ext_vector_type(4))) f4v;
-
-enum { PW_FWD = 0, PW_DGRAD = 1 };
-#define PW_KC 32
-#define PW_RED_PITCH 33
-
-struct PwArgs {
-    const float* src;    // FWD: x raw (N,K,Pin)          DGRAD: gy (N,K,Q)
-    const float* src2;   // DGRAD: y raw (N,K,Q) for the 2*y*gq term (may be null)
-    const float* pa;     // FWD: prologue A[n,k] (null = identity)
-    const float* pb;
-    const double* gs;    // DGRAD: d/d sum(y)   [n,k]  (may be null)
-    const double* gq;    // DGRAD: d/d sum(y^2) [n,k]  (may be null)
-    const float* w;      // (Cout, Cin) row major
-    float* dst;          // FWD: y (N,M,Q)                DGRAD: gx (N,M,Pin)
-    const float* ex;     // DGRAD: forward input x raw (N,M,Pin) (needed when ea != null)
-    const float* ea;     // DGRAD: forward prologue A[n,m] (null = identity => gx = da)
-    const float* eb;
-    double* s1;          // FWD: sum(y) [n,m]             DGRAD: sum(dz*x) [n,m]
-    double* s2;          // FWD: sum(y^2)                 DGRAD: sum(dz)
-    int N, M, K, Q, Pin, Hi, Wi, Ho, Wo, stride, act;
-    int Cin;             // row pitch of w
-    int mtiles, nstrips, tpb, kres, Kpad;   // kres: weight rows resident in LDS per pass (multiple of 8)
-    // stem != 0: dense convolution as an implicit GEMM -- the B operand is the im2col view of a (N,Cimg,Ti,Hi,Wi)
-    // tensor for a (kT,kH,kW) kernel with strides (sT,sH,sW) and zero padding (pT,pH,pW); K = Cimg*kT*kH*kW
-    int stem, Cimg, kT, kH, kW, sT, sH, sW, pT, pH, pW, Ti, To;
-};
+#include "pw_common.h"
 
 __device__ __forceinline__ int pw_pmap(int q, int Ho, int Wo, int Hi, int Wi, int stride) {
     if (stride == 1) return q;
@@ -51,13 +24,6 @@ __device__ __forceinline__ int pw_pmap(int q, int Ho, int Wo, int Hi, int Wi, in
     const int t = q / hw, r = q - t * hw;
     const int oh = r / Wo, ow = r - oh * Wo;
     return (t * Hi + oh * stride) * Wi + ow * stride;
-}
-
-#define PW_UNIT 8        // input channels per pipelined unit (4 MFMA k-steps)
-#define PW_KRES_MAX 512  // weight rows kept in LDS at once (K > 512 streams the weights in chunks)
-
-__device__ __forceinline__ float pw_bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
 // One workgroup = 4 waves = a strip of `tpb` tiles of 128 positions x BM = 32*MT output rows.  The inner
@@ -603,10 +569,11 @@ extern "C" int cfn_pwconv_fwd(const float* x, const float* A, const float* B, in
     a.N = N; a.M = Cout; a.K = Cin; a.Cin = Cin;
     pw_geom(a, T, Hi, Wi, stride);
     CFN_REQUIRE((long)T * Hi * Wi < (1L << 31), "cfn_pwconv_fwd: per-sample volume too large");
-    int MT; unsigned blocks; size_t lds;
-    { int rc = pw_plan(a, MT, blocks, lds); if (rc) return rc; }
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_FWD, st, 4.0 * N * ((double)Cin * a.Q + (double)Cout * a.Q) + 4.0 * Cin * Cout);
+    { const int rc = pwd_try_launch(a, PW_FWD, sum != nullptr, st); if (rc >= 0) return rc; }
+    int MT; unsigned blocks; size_t lds;
+    { int rc = pw_plan(a, MT, blocks, lds); if (rc) return rc; }
     return sum ? pw_launch<PW_FWD, true>(a, MT, blocks, lds, st) : pw_launch<PW_FWD, false>(a, MT, blocks, lds, st);
 }
 
@@ -625,10 +592,11 @@ extern "C" int cfn_pwconv_bwd_data(const float* gy, const float* y, const double
     a.ex = x; a.ea = A; a.eb = B; a.act = act; a.s1 = gA; a.s2 = gB;
     a.N = N; a.M = Cin; a.K = Cout; a.Cin = Cin;
     pw_geom(a, T, Hi, Wi, stride);
-    int MT; unsigned blocks; size_t lds;
-    { int rc = pw_plan(a, MT, blocks, lds); if (rc) return rc; }
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_BWD, st, 4.0 * N * ((double)Cout * a.Q * (a.src2 ? 2 : 1) + (double)Cin * a.Q * (A ? 2 : 1)));
+    { const int rc = pwd_try_launch(a, PW_DGRAD, A != nullptr, st); if (rc >= 0) return rc; }
+    int MT; unsigned blocks; size_t lds;
+    { int rc = pw_plan(a, MT, blocks, lds); if (rc) return rc; }
     if (!A) { a.act = CFN_ACT_NONE; return pw_launch<PW_DGRAD, false>(a, MT, blocks, lds, st); }
     return pw_launch<PW_DGRAD, true>(a, MT, blocks, lds, st);
 }

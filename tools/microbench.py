@@ -64,23 +64,25 @@ DW_LAYERS = [('L1.0 dw 54 112->56 s2', 54, 112, 2), ('L1.x dw 54 @56', 54, 56, 1
              ('L4.0 dw 432 14->7 s2', 432, 14, 2), ('L4.x dw 432 @7', 432, 7, 1)]
 
 
-def bench_pw(T, bwd):
+def bench_pw(T, bwd, NB=1, only=None):
     print('%-28s %9s %9s %9s %s' % ('pointwise layer', 'ms', 'GB/s', 'TFLOP/s', '(fwd)'))
     for name, ci, co, H, s in PW_LAYERS:
-        x = torch.randn(1, ci, T, H, H, device=DEV)
+        if only and only not in name:
+            continue
+        x = torch.randn(NB, ci, T, H, H, device=DEV)
         w = torch.randn(co, ci, 1, 1, 1, device=DEV) * 0.1
-        A = torch.rand(1, ci, device=DEV) + 0.5
-        B = torch.randn(1, ci, device=DEV) * 0.1
+        A = torch.rand(NB, ci, device=DEV) + 0.5
+        B = torch.randn(NB, ci, device=DEV) * 0.1
         Ho = (H - 1) // s + 1
-        Q = T * Ho * Ho
-        ms = devtime(lambda: ops.pwconv(x, w, A, B, 1, s, True))['pwconv_fwd']
+        Q = NB * T * Ho * Ho
+        ms = devtime(lambda: ops.pwconv(x, w, A, B, 2, s, True))['pwconv_fwd']
         gb = 4.0 * (ci * Q + co * Q) / 1e9
         print('%-28s %9.3f %9.1f %9.2f' % (name, ms, gb / ms * 1e3, 2.0 * ci * co * Q / ms / 1e9))
         if bwd:
             xr = x.clone().requires_grad_(True)
             wr = w.clone().requires_grad_(True)
             Ar, Br = A.clone().requires_grad_(True), B.clone().requires_grad_(True)
-            y, sm, sq = ops.pwconv(xr, wr, Ar, Br, 1, s, True)
+            y, sm, sq = ops.pwconv(xr, wr, Ar, Br, 2, s, True)
             gy, gs, gq = torch.randn_like(y), torch.randn_like(sm) * 0.01, torch.randn_like(sq) * 0.001
 
             def f():
@@ -134,8 +136,10 @@ if __name__ == '__main__':
     ap.add_argument('what', nargs='?', default='all')
     ap.add_argument('--frames', type=int, default=256)
     ap.add_argument('--bwd', action='store_true')
+    ap.add_argument('--batch', type=int, default=1)
+    ap.add_argument('--only', default=None)
     a = ap.parse_args()
     if a.what in ('pw', 'all'):
-        bench_pw(a.frames, a.bwd)
+        bench_pw(a.frames, a.bwd, a.batch, a.only)
     if a.what in ('dw', 'all'):
         bench_dw(a.frames, a.bwd)
