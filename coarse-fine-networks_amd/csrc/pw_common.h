@@ -42,3 +42,7 @@ __device__ __forceinline__ float pw_bload(__amdgpu_buffer_rsrc_t r, int voff, in
 // pwdeep.hip: returns -1 when the shape is not handled by the deep kernel (caller falls through to pw_gemm_kernel),
 // otherwise the launch status.  mode: PW_FWD / PW_DGRAD; stats: epilogue statistics / act' epilogue present.
 int pwd_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st);
+
+// pwwgrad.hip: direct-operand weight gradient for M, K >= 48 (stride 1); -1 = shape not handled.
+int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const float* pa,
+                         const float* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st);

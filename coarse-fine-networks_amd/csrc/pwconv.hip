@@ -658,6 +658,10 @@ extern "C" int cfn_pwconv_bwd_weight(const float* gy, const float* y, const doub
     wg_plan(a, MTW, NTW);
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_WGRAD, st, 4.0 * N * ((double)Cout * a.Q * (a.y ? 2 : 1) + (double)Cin * a.Q));
+    if (stride == 1) {
+        const int rc = pwd_wgrad_try_launch(gy, a.y, gsum, gsumsq, x, A, B, act, gw, N, Cout, Cin, a.Q, st);
+        if (rc >= 0) return rc;
+    }
     return wg_launch(a, MTW, NTW, st);
 }
 

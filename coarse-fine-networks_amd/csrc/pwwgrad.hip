@@ -1,0 +1,171 @@
+// Weight gradient of the pointwise contractions for the MFMA-bound layers (M, K >= 48: X3D layers 2-4;
+// x3d_fine.py:100-105 conv1/conv3):   gW[m][k] += sum_q G'[m][q] * a[k][q],   G' = gy + gs + 2 y gq,  a = act(A x + B).
+//
+// Both MFMA operands are indexed (channel = lane & 31, position pair = lane >> 5), i.e. a lane streams along ONE
+// channel row.  Since the contraction runs over positions, their order inside a group of 8 is free: lane half h takes
+// positions 4h..4h+3 of the group, so every lane loads one aligned float4 per channel tile straight from HBM into
+// VGPRs (no LDS transpose, no workgroup barrier in the main loop), applies the load-time prologue with per-lane
+// coefficients held in registers, and feeds 4 MFMA k-steps.  A wave owns up to 3x3 tiles of 32x32 outputs (144
+// accumulator registers, 9 MFMAs per 9 loaded float4) over its own chunk of positions; the 8 waves of a workgroup share
+// the output tile group and are combined through LDS before one fp64 atomic per element leaves the workgroup.
+#include "pw_common.h"
+#include <stdlib.h>
+
+struct WdArgs {
+    const float* gy; const float* y; const double* gs; const double* gq;
+    const float* x; const float* pa; const float* pb;
+    double* gw;
+    int N, M, K, Q, act;
+    int mgroups, kgroups, nstrips;     // output tile groups (<= 3 tiles of 32 each way), workgroups per (group, sample)
+    int mt32, kt32;                    // tiles of 32 rows / cols in total
+};
+
+#define WD_WAVES 8
+#define WD_T 3
+
+// balanced split of `tiles` into `groups` runs: run g covers [first, first + count)
+__device__ __forceinline__ void wd_split(int tiles, int groups, int g, int& first, int& count) {
+    const int base = tiles / groups, rem = tiles - base * groups;
+    first = g * base + min(g, rem);
+    count = base + (g < rem ? 1 : 0);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const WdArgs a) {
+    __shared__ float cw[WD_WAVES][32 * 33];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, row = lane & 31;
+    unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    // tile groups vary fastest: workgroups that stream the same positions (and re-read the same operand rows) are
+    // neighbours on one XCD and find each other's lines in its L2
+    const int kg = L % a.kgroups; L /= a.kgroups;
+    const int mg = L % a.mgroups; L /= a.mgroups;
+    const int strip = L % a.nstrips;
+    const int n = L / a.nstrips;
+    const int M = a.M, K = a.K, Q = a.Q;
+    int mt0, mtn, kt0, ktn;
+    wd_split(a.mt32, a.mgroups, mg, mt0, mtn);
+    wd_split(a.kt32, a.kgroups, kg, kt0, ktn);
+    const int m0 = mt0 * 32, k0 = kt0 * 32;
+
+    // per-lane prologue coefficients (lane <-> channel row of each tile)
+    float cs[WD_T], cq[WD_T], ca[WD_T], cb[WD_T];
+#pragma unroll
+    for (int i = 0; i < WD_T; ++i) {
+        const int m = m0 + i * 32 + row;
+        const bool ok = i < mtn && m < M;
+        cs[i] = (ok && a.gs) ? (float)a.gs[(long)n * M + m] : 0.0f;
+        cq[i] = (ok && a.gq && a.y) ? 2.0f * (float)a.gq[(long)n * M + m] : 0.0f;
+        const int k = k0 + i * 32 + row;
+        const bool okk = i < ktn && k < K && a.pa;
+        ca[i] = okk ? a.pa[(long)n * K + k] : 1.0f;
+        cb[i] = okk ? a.pb[(long)n * K + k] : 0.0f;
+    }
+    // buffer descriptors over one sample: rows >= M / K fall outside and read 0
+    const int row_bytes = Q * 4;
+    __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy + (long)n * M * Q), 0, M * row_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((a.y ? a.y : a.gy) + (long)n * M * Q), 0, M * row_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)n * K * Q), 0, K * row_bytes, 0x00020000);
+    const bool has_y = a.y != nullptr;
+
+    // the workgroup owns a contiguous run of 8-position groups; its waves take them interleaved (wave w: g0+w, g0+w+8,
+    // ...) so that the four 32-byte pieces of every 128-byte line are consumed by neighbouring waves at about the same
+    // time and the line is fetched from L2 once
+    const int g8 = (Q + 7) / 8;
+    const int per = (g8 + a.nstrips - 1) / a.nstrips;
+    const int gbeg = strip * per + wave, gend = min(strip * per + per, g8);
+    f16v acc[WD_T][WD_T];
+#pragma unroll
+    for (int i = 0; i < WD_T; ++i)
+#pragma unroll
+        for (int j = 0; j < WD_T; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    typedef int __attribute__((ext_vector_type(4))) i4v;
+    auto ld4 = [&](__amdgpu_buffer_rsrc_t r, int voff) -> f4v {
+        return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+    };
+    f4v rG[WD_T], rY[WD_T], rX[WD_T];
+    auto load = [&](int g) {
+        const int q = g * 8 + 4 * half;
+        const bool inq = q < Q;                                  // Q % 4 == 0: a float4 is all inside or all outside
+#pragma unroll
+        for (int i = 0; i < WD_T; ++i) {
+            const int vm = inq && i < mtn ? ((m0 + i * 32 + row) * Q + q) * 4 : 0x7ffffff0;
+            rG[i] = ld4(rg, vm);
+            rY[i] = has_y ? ld4(ry, vm) : (f4v){0.f, 0.f, 0.f, 0.f};
+            const int vk = inq && i < ktn ? ((k0 + i * 32 + row) * Q + q) * 4 : 0x7ffffff0;
+            rX[i] = ld4(rx, vk);
+        }
+        return inq;
+    };
+    bool inq = false;
+    if (gbeg < gend) inq = load(gbeg);
+    for (int g = gbeg; g < gend; g += WD_WAVES) {
+        f4v G[WD_T], X[WD_T];
+        const float vm = inq ? 1.0f : 0.0f;                      // masks the constant terms of an out-of-range group
+#pragma unroll
+        for (int i = 0; i < WD_T; ++i) {
+            G[i] = rG[i] + rY[i] * cq[i] + cs[i] * vm;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) X[i][e] = cfn_act<ACT>(fmaf(rX[i][e], ca[i], cb[i])) * vm;
+        }
+        if (g + WD_WAVES < gend) inq = load(g + WD_WAVES);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < WD_T; ++i)
+#pragma unroll
+                for (int j = 0; j < WD_T; ++j)
+                    if (i < mtn && j < ktn) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(G[i][s], X[j][s], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- combine the 8 waves tile by tile through LDS, one fp64 atomic per element per workgroup ----------
+#pragma unroll
+    for (int i = 0; i < WD_T; ++i)
+#pragma unroll
+        for (int j = 0; j < WD_T; ++j) {
+            if (i < mtn && j < ktn) {                            // workgroup uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cw[wave][((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + row] = acc[i][j][r];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int el = tid + e * 64 * WD_WAVES;      // 1024 elements of the tile
+                    const int ml = el >> 5, kl = el & 31;
+                    float v = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < WD_WAVES; ++w) v += cw[w][ml * 33 + kl];
+                    const int m = m0 + i * 32 + ml, k = k0 + j * 32 + kl;
+                    if (m < M && k < K) atomicAdd(&a.gw[(long)m * K + k], (double)v);
+                }
+                __syncthreads();
+            }
+        }
+}
+
+int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const float* pa,
+                         const float* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st) {
+    if (M < 48 || K < 48 || Q % 4 != 0) return -1;
+    if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && act != CFN_ACT_SWISH) return -1;
+    if (((uintptr_t)gy | (uintptr_t)x | (uintptr_t)(y ? y : gy)) & 15) return -1;
+    if ((long)M * Q * 4 >= (1L << 31) - 64 || (long)K * Q * 4 >= (1L << 31) - 64) return -1;
+    { const char* e = getenv("CFN_PWD_OFF"); if (e && atoi(e)) return -1; }
+    WdArgs a = {gy, y, gs, gq, x, pa, pb, gw, N, M, K, Q, act};
+    a.mt32 = cfn_cdiv(M, 32); a.kt32 = cfn_cdiv(K, 32);
+    a.mgroups = cfn_cdiv(a.mt32, WD_T); a.kgroups = cfn_cdiv(a.kt32, WD_T);
+    const long groups = (long)N * a.mgroups * a.kgroups;
+    long strips = 256 / groups;                       // ~one workgroup per CU (measured: more, shorter strips lose)
+    if (strips < 1) strips = 1;
+    const long g8 = cfn_cdiv(Q, 8);
+    if (strips > cfn_cdiv(g8, WD_WAVES * 4)) strips = cfn_cdiv(g8, WD_WAVES * 4);   // >= 4 position groups per wave
+    a.nstrips = (int)strips;
+    const unsigned blocks = (unsigned)(groups * strips);
+    switch (act) {
+        case CFN_ACT_RELU: hipLaunchKernelGGL(pw_wgrad_direct_kernel<CFN_ACT_RELU>, dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
+        case CFN_ACT_SWISH: hipLaunchKernelGGL(pw_wgrad_direct_kernel<CFN_ACT_SWISH>, dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
+        default: hipLaunchKernelGGL(pw_wgrad_direct_kernel<CFN_ACT_NONE>, dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
+    }
+    return cfn_check_launch("pwconv_bwd_weight(direct)");
+}
