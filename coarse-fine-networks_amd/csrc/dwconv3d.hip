@@ -54,7 +54,7 @@ __device__ __forceinline__ float seg_wave_sum(float v, int key, int lane) {
 // weights live in SGPRs; together with the 128-VGPR cap this lets two 7-wave workgroups share a CU.
 // DEPTH 2 (float4 loaders with <= 2 loads per thread): two input frames are in flight per workgroup.
 template <int MODE, int S, int HS, int VEC, int MAXLD, bool UNIW>
-__global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_FWD ? 4 : 3) : 2) : 2) void dw3d_kernel(const DwArgs a) {
+__global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_FWD ? 4 : 3) : (MAXLD == 4 ? 3 : 2)) : 2) void dw3d_kernel(const DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HSIN = (HS - 1) * S + 3;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
@@ -156,6 +156,8 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     f4 pfA[MAXLD], pfA2[MAXLD], pfB[DEPTH == 2 ? MAXLD : 1], pfB2[DEPTH == 2 ? MAXLD : 1];
     const bool two_src = (MODE == DW_DGRAD) && a.src2 != nullptr;
 
+    const bool simple_act = a.act == CFN_ACT_NONE || a.act == CFN_ACT_RELU;
+    const float act_lo = a.act == CFN_ACT_RELU ? 0.0f : -__builtin_inff();
     auto frame_valid = [&](int f) { return f >= 0 && f < T; };
     auto prefetch = [&](int f, f4* pf, f4* pf2) {
         const long base = (((long)n * C + c0) * T + f) * plane_i;
@@ -190,6 +192,13 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
                     } else {
                         v.x += pa;
                         if (VEC == 4) { v.y += pa; v.z += pa; v.w += pa; }
+                    }
+                } else if (simple_act) {   // none / ReLU (every X3D conv2): branch-free max against -inf or 0
+                    v.x = fmaxf(fmaf(v.x, pa, pb), act_lo);
+                    if (VEC == 4) {
+                        v.y = fmaxf(fmaf(v.y, pa, pb), act_lo);
+                        v.z = fmaxf(fmaf(v.z, pa, pb), act_lo);
+                        v.w = fmaxf(fmaf(v.w, pa, pb), act_lo);
                     }
                 } else {
                     v.x = cfn_act_rt(fmaf(v.x, pa, pb), a.act);
@@ -550,12 +559,12 @@ static int dw_plan(DwArgs& a, int S, int mode, DwPlan& pl) {
     a.CG = CG;
     a.ngroups = cfn_cdiv(a.C, CG);
     const long per_thread = ((long)CG * a.RIN * a.Wi + (long)VEC * threads - 1) / ((long)VEC * threads);
-    const int MAXLD = (VEC == 4 && per_thread <= 2) ? 2 : 8;
+    const int MAXLD = (VEC == 4 && per_thread <= 2) ? 2 : ((VEC == 4 && per_thread <= 4) ? 4 : 8);
     // frames per chunk: as long as possible while keeping >= ~6 workgroups per CU in the grid
     const long planes = (long)a.N * a.ngroups * a.nbands;
     // Whole rounds: resident workgroups per CU follow from the register budget of the variant (launch bounds),
     // so size the t-chunks such that the grid fills R full rounds of the chip (a 1.1-round grid costs 2 rounds).
-    const int per_cu = !pl.UNIW ? (threads > 256 ? 1 : 2) : (MAXLD != 2 ? 2 : (mode == DW_FWD ? 4 : 3));
+    const int per_cu = !pl.UNIW ? (threads > 256 ? 1 : 2) : (MAXLD == 8 ? 2 : (MAXLD == 4 ? 3 : (mode == DW_FWD ? 4 : 3)));
     const long slots = 256L * per_cu;
     int TT = a.T;
     for (int R = 1; R <= 8; ++R) {
@@ -585,10 +594,12 @@ static int dw_launch_hs(const DwArgs& a, const DwPlan& pl, hipStream_t st) {
     } while (0)
     if (pl.UNIW) {
         if (pl.VEC == 4 && pl.MAXLD == 2) CFN_DW_GO(4, 2, true);
+        else if (pl.VEC == 4 && pl.MAXLD == 4) CFN_DW_GO(4, 4, true);
         else if (pl.VEC == 4) CFN_DW_GO(4, 8, true);
         else CFN_DW_GO(1, 8, true);
     } else {
         if (pl.VEC == 4 && pl.MAXLD == 2) CFN_DW_GO(4, 2, false);
+        else if (pl.VEC == 4 && pl.MAXLD == 4) CFN_DW_GO(4, 4, false);
         else if (pl.VEC == 4) CFN_DW_GO(4, 8, false);
         else CFN_DW_GO(1, 8, false);
     }

@@ -46,3 +46,9 @@ int pwd_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st);
 // pwwgrad.hip: direct-operand weight gradient for M, K >= 48 (stride 1); -1 = shape not handled.
 int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const float* pa,
                          const float* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st);
+int pwd_wgrad_try_strided(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const float* pa,
+                          const float* pb, int act, double* gw, int N, int M, int K, int T, int Hi, int Wi, int stride,
+                          hipStream_t st);
+int pwd_wgrad_try_dense(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const float* pa,
+                        const float* pb, int act, double* gw, int N, int M, int Cimg, int T, int Hi, int Wi, const int* g,
+                        hipStream_t st);

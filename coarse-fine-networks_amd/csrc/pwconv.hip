@@ -658,8 +658,9 @@ extern "C" int cfn_pwconv_bwd_weight(const float* gy, const float* y, const doub
     wg_plan(a, MTW, NTW);
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_WGRAD, st, 4.0 * N * ((double)Cout * a.Q * (a.y ? 2 : 1) + (double)Cin * a.Q));
-    if (stride == 1) {
-        const int rc = pwd_wgrad_try_launch(gy, a.y, gsum, gsumsq, x, A, B, act, gw, N, Cout, Cin, a.Q, st);
+    {
+        const int rc = stride == 1 ? pwd_wgrad_try_launch(gy, a.y, gsum, gsumsq, x, A, B, act, gw, N, Cout, Cin, a.Q, st)
+                                   : pwd_wgrad_try_strided(gy, a.y, gsum, gsumsq, x, A, B, act, gw, N, Cout, Cin, T, Hi, Wi, stride, st);
         if (rc >= 0) return rc;
     }
     return wg_launch(a, MTW, NTW, st);
@@ -727,6 +728,10 @@ extern "C" int cfn_conv3d_dense_bwd_weight(const float* gy, const float* y, cons
     wg_plan(a, MTW, NTW);
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_STEM, st, 4.0 * N * ((double)Cin * a.Pin + (double)Cout * a.Q));
+    {
+        const int rd = pwd_wgrad_try_dense(gy, a.y, gsum, gsumsq, x, A, B, act, gw, N, Cout, Cin, T, Hi, Wi, geom, st);
+        if (rd >= 0) return rd;
+    }
     return wg_launch(a, MTW, NTW, st);
 }
 

@@ -18,6 +18,10 @@ struct WdArgs {
     int N, M, K, Q, act;
     int mgroups, kgroups, nstrips;     // output tile groups (<= 3 tiles of 32 each way), workgroups per (group, sample)
     int mt32, kt32;                    // tiles of 32 rows / cols in total
+    // XMODE 1: pointwise conv with spatial stride (x row pitch Pin, position map); XMODE 2: dense conv, x rows are
+    // im2col rows of a (N,Cimg,Ti,Hi,Wi) tensor
+    int Pin, Hi, Wi, Ho, Wo, stride;
+    int Cimg, kT, kH, kW, sT, sH, sW, pT, pH, pW, Ti;
 };
 
 #define WD_WAVES 8
@@ -30,7 +34,7 @@ __device__ __forceinline__ void wd_split(int tiles, int groups, int g, int& firs
     count = base + (g < rem ? 1 : 0);
 }
 
-template <int ACT>
+template <int ACT, int XMODE>
 __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const WdArgs a) {
     __shared__ float cw[WD_WAVES][32 * 33];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, row = lane & 31;
@@ -57,14 +61,33 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
         cq[i] = (ok && a.gq && a.y) ? 2.0f * (float)a.gq[(long)n * M + m] : 0.0f;
         const int k = k0 + i * 32 + row;
         const bool okk = i < ktn && k < K && a.pa;
-        ca[i] = okk ? a.pa[(long)n * K + k] : 1.0f;
-        cb[i] = okk ? a.pb[(long)n * K + k] : 0.0f;
+        const long ci = XMODE == 2 ? (long)n * a.Cimg + k / (a.kT * a.kH * a.kW) : (long)n * K + k;
+        ca[i] = okk ? a.pa[ci] : 1.0f;
+        cb[i] = okk ? a.pb[ci] : 0.0f;
+    }
+    // XMODE 2: this lane's im2col row of every column tile -> (channel offset, tap)
+    int xbase[WD_T], xkt[WD_T], xkh[WD_T], xkw[WD_T];
+    bool xrow[WD_T];
+    if (XMODE == 2) {
+#pragma unroll
+        for (int j = 0; j < WD_T; ++j) {
+            const int k = k0 + j * 32 + row;
+            const int KV = a.kT * a.kH * a.kW;
+            const int ci = k / KV, r = k - ci * KV;
+            xkt[j] = r / (a.kH * a.kW);
+            const int r2 = r - xkt[j] * a.kH * a.kW;
+            xkh[j] = r2 / a.kW; xkw[j] = r2 - xkh[j] * a.kW;
+            xrow[j] = j < ktn && k < K;
+            xbase[j] = min(ci, a.Cimg - 1) * a.Pin;
+        }
     }
     // buffer descriptors over one sample: rows >= M / K fall outside and read 0
     const int row_bytes = Q * 4;
     __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy + (long)n * M * Q), 0, M * row_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((a.y ? a.y : a.gy) + (long)n * M * Q), 0, M * row_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)n * K * Q), 0, K * row_bytes, 0x00020000);
+    const long xn = XMODE == 2 ? (long)n * a.Cimg * a.Pin : (long)n * K * a.Pin;
+    const unsigned xspan = (unsigned)((XMODE == 2 ? (long)a.Cimg : (long)K) * a.Pin * 4);
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + xn), 0, xspan, 0x00020000);
     const bool has_y = a.y != nullptr;
 
     // the workgroup owns a contiguous run of 8-position groups; its waves take them interleaved (wave w: g0+w, g0+w+8,
@@ -86,6 +109,7 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
         return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
     };
     f4v rG[WD_T], rY[WD_T], rX[WD_T];
+    unsigned xmb[WD_T] = {0u, 0u, 0u};   // XMODE 2: in-bounds bits of the 4 taps of each tile's raw float4
     auto load = [&](int g) {
         const int q = g * 8 + 4 * half;
         const bool inq = q < Q;                                  // Q % 4 == 0: a float4 is all inside or all outside
@@ -94,8 +118,44 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
             const int vm = inq && i < mtn ? ((m0 + i * 32 + row) * Q + q) * 4 : 0x7ffffff0;
             rG[i] = ld4(rg, vm);
             rY[i] = has_y ? ld4(ry, vm) : (f4v){0.f, 0.f, 0.f, 0.f};
-            const int vk = inq && i < ktn ? ((k0 + i * 32 + row) * Q + q) * 4 : 0x7ffffff0;
-            rX[i] = ld4(rx, vk);
+        }
+        if (XMODE == 0) {
+#pragma unroll
+            for (int i = 0; i < WD_T; ++i) {
+                const int vk = inq && i < ktn ? ((k0 + i * 32 + row) * Q + q) * 4 : 0x7ffffff0;
+                rX[i] = ld4(rx, vk);
+            }
+        } else {
+            // the 4 output positions q..q+3 sit in one output row (Wo % 4 == 0): decode once
+            const int hw = a.Ho * a.Wo;
+            const int qc = inq ? q : 0;
+            const int to = qc / hw, rq = qc - to * hw;
+            const int oh = rq / a.Wo, ow = rq - oh * a.Wo;
+#pragma unroll
+            for (int i = 0; i < WD_T; ++i) {
+                f4v v = {0.f, 0.f, 0.f, 0.f};
+                if (XMODE == 1) {
+                    if (inq && i < ktn) {
+                        const int vo = ((k0 + i * 32 + row) * a.Pin + (to * a.Hi + oh * a.stride) * a.Wi + ow * a.stride) * 4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo + e * a.stride * 4, 0, 0));
+                    }
+                } else {
+                    const int it = to * a.sT + xkt[i] - a.pT, ih = oh * a.sH + xkh[i] - a.pH;
+                    const bool okr = inq && xrow[i] && it >= 0 && it < a.Ti && ih >= 0 && ih < a.Hi;
+                    const int iw0 = ow * a.sW + xkw[i] - a.pW;
+                    const int vo = (xbase[i] + (it * a.Hi + ih) * a.Wi + iw0) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int iw = iw0 + e * a.sW;
+                        const bool ok = okr && iw >= 0 && iw < a.Wi;
+                        v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? vo + e * a.sW * 4 : 0x7ffffff0, 0, 0));
+                        xmb[i] = e == 0 ? (ok ? 1u : 0u) : (xmb[i] | ((ok ? 1u : 0u) << e));
+                    }
+                }
+                rX[i] = v;
+            }
         }
         return inq;
     };
@@ -108,7 +168,10 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
         for (int i = 0; i < WD_T; ++i) {
             G[i] = rG[i] + rY[i] * cq[i] + cs[i] * vm;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) X[i][e] = cfn_act<ACT>(fmaf(rX[i][e], ca[i], cb[i])) * vm;
+            for (int e = 0; e < 4; ++e) {
+                const float xa = cfn_act<ACT>(fmaf(rX[i][e], ca[i], cb[i]));
+                X[i][e] = XMODE == 2 ? (((xmb[i] >> e) & 1u) ? xa : 0.0f) : xa * vm;   // zero padding applies after the prologue
+            }
         }
         if (g + WD_WAVES < gend) inq = load(g + WD_WAVES);
         __builtin_amdgcn_sched_barrier(0);
@@ -145,27 +208,70 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
         }
 }
 
-int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const float* pa,
-                         const float* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st) {
-    if (M < 48 || K < 48 || Q % 4 != 0) return -1;
-    if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && act != CFN_ACT_SWISH) return -1;
-    if (((uintptr_t)gy | (uintptr_t)x | (uintptr_t)(y ? y : gy)) & 15) return -1;
-    if ((long)M * Q * 4 >= (1L << 31) - 64 || (long)K * Q * 4 >= (1L << 31) - 64) return -1;
-    { const char* e = getenv("CFN_PWD_OFF"); if (e && atoi(e)) return -1; }
-    WdArgs a = {gy, y, gs, gq, x, pa, pb, gw, N, M, K, Q, act};
-    a.mt32 = cfn_cdiv(M, 32); a.kt32 = cfn_cdiv(K, 32);
+template <int XMODE>
+static int wd_launch(WdArgs& a, hipStream_t st) {
+    a.mt32 = cfn_cdiv(a.M, 32); a.kt32 = cfn_cdiv(a.K, 32);
     a.mgroups = cfn_cdiv(a.mt32, WD_T); a.kgroups = cfn_cdiv(a.kt32, WD_T);
-    const long groups = (long)N * a.mgroups * a.kgroups;
+    const long groups = (long)a.N * a.mgroups * a.kgroups;
     long strips = 256 / groups;                       // ~one workgroup per CU (measured: more, shorter strips lose)
     if (strips < 1) strips = 1;
-    const long g8 = cfn_cdiv(Q, 8);
+    const long g8 = cfn_cdiv(a.Q, 8);
     if (strips > cfn_cdiv(g8, WD_WAVES * 4)) strips = cfn_cdiv(g8, WD_WAVES * 4);   // >= 4 position groups per wave
     a.nstrips = (int)strips;
     const unsigned blocks = (unsigned)(groups * strips);
-    switch (act) {
-        case CFN_ACT_RELU: hipLaunchKernelGGL(pw_wgrad_direct_kernel<CFN_ACT_RELU>, dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
-        case CFN_ACT_SWISH: hipLaunchKernelGGL(pw_wgrad_direct_kernel<CFN_ACT_SWISH>, dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
-        default: hipLaunchKernelGGL(pw_wgrad_direct_kernel<CFN_ACT_NONE>, dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
+    switch (a.act) {
+        case CFN_ACT_RELU: hipLaunchKernelGGL((pw_wgrad_direct_kernel<CFN_ACT_RELU, XMODE>), dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
+        case CFN_ACT_SWISH: hipLaunchKernelGGL((pw_wgrad_direct_kernel<CFN_ACT_SWISH, XMODE>), dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
+        default: hipLaunchKernelGGL((pw_wgrad_direct_kernel<CFN_ACT_NONE, XMODE>), dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
     }
     return cfn_check_launch("pwconv_bwd_weight(direct)");
+}
+
+static bool wd_common_ok(const float* gy, const float* y, const float* x, int act, int M, int K, int Q) {
+    if (Q % 4 != 0) return false;
+    if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && act != CFN_ACT_SWISH) return false;
+    if (((uintptr_t)gy | (uintptr_t)(y ? y : gy)) & 15) return false;
+    if ((long)M * Q * 4 >= (1L << 31) - 64) return false;
+    const char* e = getenv("CFN_PWD_OFF");
+    return !(e && atoi(e));
+}
+
+// contiguous pointwise conv (stride 1): M, K >= 48 (smaller layers are HBM bound and stay on the LDS-staged kernel)
+int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const float* pa,
+                         const float* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st) {
+    if (M < 48 || K < 48 || !wd_common_ok(gy, y, x, act, M, K, Q)) return -1;
+    if (((uintptr_t)x & 15) || (long)K * Q * 4 >= (1L << 31) - 64) return -1;
+    WdArgs a = {gy, y, gs, gq, x, pa, pb, gw, N, M, K, Q, act};
+    a.Pin = Q;
+    return wd_launch<0>(a, st);
+}
+
+// pointwise conv with spatial stride 2 (shortcut convs): gathered x operand
+int pwd_wgrad_try_strided(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const float* pa,
+                          const float* pb, int act, double* gw, int N, int M, int K, int T, int Hi, int Wi, int stride,
+                          hipStream_t st) {
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    const int Q = T * Ho * Wo;
+    if (Wo % 4 != 0 || !wd_common_ok(gy, y, x, act, M, K, Q)) return -1;
+    if ((long)K * T * Hi * Wi * 4 >= (1L << 31) - 64) return -1;
+    WdArgs a = {gy, y, gs, gq, x, pa, pb, gw, N, M, K, Q, act};
+    a.Pin = T * Hi * Wi; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = stride;
+    return wd_launch<1>(a, st);
+}
+
+// dense conv (stem 1x3x3 / Grid Pool saliency convs): x rows are im2col rows; geom = {kT,kH,kW,sT,sH,sW,pT,pH,pW}
+int pwd_wgrad_try_dense(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const float* pa,
+                        const float* pb, int act, double* gw, int N, int M, int Cimg, int T, int Hi, int Wi, const int* g,
+                        hipStream_t st) {
+    const int To = (T + 2 * g[6] - g[0]) / g[3] + 1, Ho = (Hi + 2 * g[7] - g[1]) / g[4] + 1, Wo = (Wi + 2 * g[8] - g[2]) / g[5] + 1;
+    const int K = Cimg * g[0] * g[1] * g[2];
+    const long Ql = (long)To * Ho * Wo;
+    if (To < 1 || Ho < 1 || Wo < 1 || Wo % 4 != 0 || Ql >= (1L << 30)) return -1;
+    const int Q = (int)Ql;
+    if (!wd_common_ok(gy, y, x, act, M, K, Q)) return -1;
+    if ((long)Cimg * T * Hi * Wi * 4 >= (1L << 31) - 64) return -1;
+    WdArgs a = {gy, y, gs, gq, x, pa, pb, gw, N, M, K, Q, act};
+    a.Pin = T * Hi * Wi; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = 1; a.Ti = T; a.Cimg = Cimg;
+    a.kT = g[0]; a.kH = g[1]; a.kW = g[2]; a.sT = g[3]; a.sH = g[4]; a.sW = g[5]; a.pT = g[6]; a.pH = g[7]; a.pW = g[8];
+    return wd_launch<2>(a, st);
 }

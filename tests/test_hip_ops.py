@@ -105,6 +105,7 @@ PW_CASES = [
     (1, 432, 192, 2, 3, 3, 1, 2, True),
     (2, 24, 48, 3, 8, 8, 2, 1, True),     # shortcut conv, spatial stride 2
     (1, 24, 24, 2, 7, 7, 2, 0, False),
+    (2, 48, 96, 3, 16, 16, 2, 2, True),    # stride 2, gathered-operand weight gradient with Swish prologue
     (1, 432, 2048, 5, 1, 1, 1, 0, False),  # fc1
     (2, 2048, 157, 3, 1, 1, 1, 1, True),   # fc2 as pointwise
     (1, 3, 5, 40, 13, 11, 1, 1, True),     # odd everything, many position tiles
@@ -322,6 +323,8 @@ DENSE_CASES = [
     (1, 24, 1, 4, 14, 14, (1, 3, 3), (1, 2, 2), (0, 1, 1), 1, True),
     (2, 3, 24, 3, 16, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1), 0, False),
     (1, 5, 7, 5, 9, 7, (3, 3, 3), (2, 2, 2), (1, 1, 1), 1, True),
+    (1, 24, 24, 6, 16, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1), 1, True),   # Wo % 4 == 0: direct im2col weight gradient
+    (2, 6, 40, 5, 16, 24, (1, 3, 3), (1, 2, 2), (0, 1, 1), 1, True),
 ]
 
 
