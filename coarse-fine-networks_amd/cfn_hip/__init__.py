@@ -30,12 +30,15 @@ def header_prototypes(path=HEADER):
     out = {}
     for m in re.finditer(r'(const\s+char\s*\*|int|long)\s+(cfn_\w+)\s*\(([^)]*)\)\s*;', txt):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
-        at = []
+        at, dt = [], []
         if args and args != 'void':
             for a in args.split(','):
                 a = a.strip()
+                dt.append(None)
                 if '*' in a:
                     at.append(ctypes.c_void_p)
+                    base = a.replace('const', '').split('*')[0].strip()
+                    dt[-1] = {'float': torch.float32, 'double': torch.float64, 'long': torch.int64, 'int': torch.int32}.get(base)
                 elif a.startswith('long'):
                     at.append(ctypes.c_long)
                 elif a.startswith('double'):
@@ -44,7 +47,7 @@ def header_prototypes(path=HEADER):
                     at.append(ctypes.c_int)
                 else:
                     raise ValueError('unhandled C type in %s: %r' % (name, a))
-        out[name] = (ctypes.c_char_p if 'char' in ret else (ctypes.c_long if ret == 'long' else ctypes.c_int), at)
+        out[name] = (ctypes.c_char_p if 'char' in ret else (ctypes.c_long if ret == 'long' else ctypes.c_int), at, dt)
     return out
 
 
@@ -58,7 +61,7 @@ def load():
                            'there is no CPU fallback for the Coarse-Fine HIP ops' % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
     protos = header_prototypes()
-    for name, (ret, at) in protos.items():
+    for name, (ret, at, _dt) in protos.items():
         try:
             fn = getattr(lib, name)
         except AttributeError:
@@ -90,6 +93,10 @@ def stream():
 def call(name, *args):
     """Invoke one C entry point: tensors -> device pointers, appends the current HIP stream."""
     lib = load()
+    dts = _protos[name][2]
+    for i, a in enumerate(args):   # element types are part of the ABI (float* / double* / long*): refuse a mismatch
+        if isinstance(a, torch.Tensor) and dts[i] is not None and a.dtype != dts[i]:
+            raise RuntimeError('%s: argument %d must be a %s tensor, got %s' % (name, i, dts[i], a.dtype))
     conv = [(_ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a) for a in args]
     rc = getattr(lib, name)(*conv, stream())
     if rc != 0:

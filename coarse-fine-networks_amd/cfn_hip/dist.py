@@ -81,6 +81,8 @@ class GradReducer(object):
         ps = [p for p in self.buckets[bi] if p.grad is not None]
         if not ps:
             return
+        from . import ops
+        ops.flush_grad_casts()   # weight gradients are cast fp64 -> fp32 lazily; make this bucket's valid
         flat = torch.cat([p.grad.reshape(-1) for p in ps])
         flat.div_(self.world)
         st = self._comm_stream(flat.device)

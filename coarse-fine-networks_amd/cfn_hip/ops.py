@@ -20,7 +20,7 @@ class _ZeroArena(object):
     """fp64 zero-filled scratch handed out in slices: the statistics / gradient accumulators of ~400 kernel
     launches per step come out of a few large memsets instead of one tiny fill kernel each.  A chunk stays alive
     as long as any slice of it does (autograd may save them)."""
-    CHUNK = 1 << 16
+    CHUNK = 1 << 20
 
     def __init__(self):
         self.buf, self.off = {}, {}
@@ -49,8 +49,73 @@ def _f64pair(n, c, dev):
     return t, t[0], t[1]
 
 
+class _GradCast(object):
+    """fp64 weight-gradient accumulators -> fp32 gradients with ONE cast kernel per backward pass.
+
+    The wgrad kernels accumulate into fp64 (zero-filled) buffers.  Casting each of the ~110 buffers on its own costs a
+    ~6 us kernel apiece, so the accumulators of one backward pass are carved out of one fp64 chunk that is mirrored
+    by an fp32 chunk of the same layout; backward returns views of the fp32 chunk and a callback queued on the
+    autograd engine fills it with a single copy when the pass ends.  Only used when nobody can read the gradient
+    before that (leaf parameter without an existing .grad, no create_graph); GradReducer calls flush() before it
+    packs a bucket."""
+
+    def __init__(self):
+        self.cur, self.live, self.scheduled, self.last_total = {}, [], False, 0
+
+    def take(self, numel, shape, dev):
+        al = (numel + 3) & ~3
+        key = (dev.type, dev.index)
+        ch = self.cur.get(key)
+        if ch is None or ch['off'] + al > ch['f64'].numel():
+            size = max(int(self.last_total * 1.05) + 1024, al, 1 << 16)
+            ch = {'f64': torch.zeros(size, dtype=torch.float64, device=dev),
+                  'f32': torch.empty(size, dtype=torch.float32, device=dev), 'off': 0, 'done': 0}
+            self.cur[key] = ch
+            self.live.append(ch)
+        o = ch['off']
+        ch['off'] = o + al
+        if not self.scheduled:
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+            self.scheduled = True
+        return ch['f64'][o:o + numel], ch['f32'][o:o + numel].view(shape)
+
+    def flush(self):
+        for ch in self.live:
+            if ch['off'] > ch['done']:
+                ch['f32'][ch['done']:ch['off']].copy_(ch['f64'][ch['done']:ch['off']])
+                ch['done'] = ch['off']
+
+    def _end_of_backward(self):
+        self.flush()
+        self.last_total = max(sum(ch['off'] for ch in self.live), 1)
+        # the fp32 chunk now belongs to the gradients that view it; the next pass gets fresh chunks
+        self.cur, self.live, self.scheduled = {}, [], False
+
+
+_gradcast = _GradCast()
+
+
+def flush_grad_casts():
+    """make every weight gradient handed out so far in the running backward pass valid (see _GradCast)"""
+    _gradcast.flush()
+
+
+def _gw_buffers(w, rows, cols, dev):
+    """(fp64 accumulator (rows, cols), finish() -> fp32 gradient shaped like w)"""
+    if w is not None and w.is_leaf and w.grad is None and not torch.is_grad_enabled() and not w._backward_hooks:
+        g64, g32 = _gradcast.take(rows * cols, tuple(w.shape), dev)
+        return g64.view(rows, cols), (lambda: g32)
+    g64 = _f64(rows, cols, dev)
+    return g64, (lambda: g64.float().view(tuple(w.shape)))
+
+
 def _opt(t):
     return None if t is None else t.contiguous()
+
+
+def _coef(t):
+    """prologue coefficients (N,C): the ABI takes fp64 (bn_fold emits fp64; hand-made fp32 ones are widened here)"""
+    return None if t is None else t.to(torch.float64).contiguous()
 
 
 class _PwConv(Function):
@@ -67,10 +132,11 @@ class _PwConv(Function):
         if want_stats:
             s, q = _f64(N, Cout, x.device), _f64(N, Cout, x.device)
         w2 = w.reshape(Cout, Cin).contiguous()
-        A, B = _opt(A), _opt(B)
+        A, B = _coef(A), _coef(B)
         call('cfn_pwconv_fwd', x, A, B, act, w2, y, s, q, N, Cin, Cout, T, H, W, stride)
         ctx.save_for_backward(x, A, B, w2, y)
         ctx.meta = (act, stride, tuple(w.shape))
+        ctx.wparam = w
         if not want_stats:
             return y, None, None
         return y, s, q
@@ -91,12 +157,11 @@ class _PwConv(Function):
                 ab, a64, b64 = _f64pair(N, Cin, x.device)
             call('cfn_pwconv_bwd_data', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, Cin, Cout, T, H, W, stride)
             if A is not None:
-                ab = ab.float()
                 gA, gB = ab[0], ab[1]
         if ctx.needs_input_grad[3]:
-            g64 = _f64(Cout, Cin, x.device)
+            g64, fin = _gw_buffers(ctx.wparam, Cout, Cin, x.device)
             call('cfn_pwconv_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, Cin, Cout, T, H, W, stride)
-            gw = g64.float().view(wshape)
+            gw = fin()
         return gx, gA, gB, gw, None, None, None
 
 
@@ -118,10 +183,11 @@ class _DwConv3d(Function):
         if want_stats:
             s, q = _f64(N, C, x.device), _f64(N, C, x.device)
         w2 = w.reshape(C, 27).contiguous()
-        A, B = _opt(A), _opt(B)
+        A, B = _coef(A), _coef(B)
         call('cfn_dwconv3d_fwd', x, A, B, act, w2, y, s, q, N, C, T, H, W, stride)
         ctx.save_for_backward(x, A, B, w2, y)
         ctx.meta = (act, stride, tuple(w.shape))
+        ctx.wparam = w
         if not want_stats:
             return y, None, None
         return y, s, q
@@ -141,12 +207,11 @@ class _DwConv3d(Function):
                 ab, a64, b64 = _f64pair(N, C, x.device)
             call('cfn_dwconv3d_bwd_data', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, C, T, H, W, stride)
             if A is not None:
-                ab = ab.float()
                 gA, gB = ab[0], ab[1]
         if ctx.needs_input_grad[3]:
-            g64 = _f64(C, 27, x.device)
+            g64, fin = _gw_buffers(ctx.wparam, C, 27, x.device)
             call('cfn_dwconv3d_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, C, T, H, W, stride)
-            gw = g64.float().view(wshape)
+            gw = fin()
         return gx, gA, gB, gw, None, None, None
 
 
@@ -169,6 +234,7 @@ class _DwConvT5(Function):
         call('cfn_dwconv_t5_fwd', x, w2, y, s, q, N, C, T, H * W)
         ctx.save_for_backward(x, w2, y)
         ctx.wshape = tuple(w.shape)
+        ctx.wparam = w
         if not want_stats:
             return y, None, None
         return y, s, q
@@ -184,9 +250,9 @@ class _DwConvT5(Function):
             gx = torch.empty_like(x)
             call('cfn_dwconv_t5_bwd_data', gy, y, gs, gq, w2, gx, N, C, T, H * W)
         if ctx.needs_input_grad[1]:
-            g64 = _f64(C, 5, x.device)
+            g64, fin = _gw_buffers(ctx.wparam, C, 5, x.device)
             call('cfn_dwconv_t5_bwd_weight', gy, y, gs, gq, x, g64, N, C, T, H * W)
-            gw = g64.float().view(ctx.wshape)
+            gw = fin()
         return gx, gw, None
 
 
@@ -208,6 +274,7 @@ class _StemConv(Function):
         call('cfn_stem_conv_fwd', x, w2, y, N, Ci, Co, T, H, W)
         ctx.save_for_backward(x)
         ctx.wshape = tuple(w.shape)
+        ctx.wparam = w
         return y
 
     @staticmethod
@@ -217,9 +284,9 @@ class _StemConv(Function):
         Co = ctx.wshape[0]
         gw = None
         if ctx.needs_input_grad[1]:
-            g64 = _f64(Co, Ci * 9, x.device)
+            g64, fin = _gw_buffers(ctx.wparam, Co, Ci * 9, x.device)
             call('cfn_stem_conv_bwd_weight', gy.contiguous(), x, g64, N, Ci, Co, T, H, W)
-            gw = g64.float().view(ctx.wshape)
+            gw = fin()
         return None, gw
 
 
@@ -237,14 +304,14 @@ class _BnFold(Function):
         dev = run_mean.device
         Wd = w1.shape[0] if w1 is not None else 0
         Se = S if training else 1
-        A = torch.empty(N, C, dtype=torch.float32, device=dev)
-        B = torch.empty_like(A)
+        A = torch.empty(N, C, dtype=torch.float64, device=dev)   # prologue coefficients travel as fp64 (fp32 values):
+        B = torch.empty_like(A)                                    # their gradients are the kernels' fp64 accumulators, uncast
         mean = torch.empty(Se, C, dtype=torch.float64, device=dev)
         rstd = torch.empty_like(mean)
         A0 = B0 = gate = hbuf = pooled = None
         w1c = w2c = None
         if Wd:
-            A0, B0, gate, pooled = (torch.empty_like(A) for _ in range(4))
+            A0, B0, gate, pooled = (torch.empty(N, C, dtype=torch.float32, device=dev) for _ in range(4))
             hbuf = torch.empty(N, Wd, dtype=torch.float32, device=dev)
             w1c, w2c = w1.reshape(Wd, C).contiguous(), w2.reshape(C, Wd).contiguous()
         s, q = _opt(s), _opt(q)
@@ -261,8 +328,8 @@ class _BnFold(Function):
         s, gamma, mean, rstd, A0, B0, gate, hbuf, pooled, w1c, w2c = ctx.saved_tensors
         training, N, C, S, Wd, count, pool_count, w1s, w2s = ctx.cfg
         dev = mean.device
-        gA = torch.zeros(N, C, device=dev) if gA is None else gA.contiguous()
-        gB = torch.zeros(N, C, device=dev) if gB is None else gB.contiguous()
+        gA = torch.zeros(N, C, dtype=torch.float64, device=dev) if gA is None else gA.contiguous()
+        gB = torch.zeros(N, C, dtype=torch.float64, device=dev) if gB is None else gB.contiguous()
         gs = gq = None
         if training:
             gs = torch.empty(N, C, dtype=torch.float64, device=dev)
@@ -274,7 +341,7 @@ class _BnFold(Function):
         if Wd:
             gw1, gb1 = torch.empty(Wd, C, device=dev), torch.empty(Wd, device=dev)
             gw2, gb2 = torch.empty(C, Wd, device=dev), torch.empty(C, device=dev)
-            tA, tB = torch.empty(N, C, device=dev), torch.empty(N, C, device=dev)
+            tA, tB = (torch.empty(N, C, dtype=torch.float64, device=dev) for _ in range(2))
         call('cfn_bn_fold_bwd', gA, gB, s, gamma, mean, rstd, A0, B0, gate, hbuf, pooled, w1c, w2c, int(training), N, C, S,
              Wd, float(count), float(pool_count), gs, gq, gg, gbt, gw1, gb1, gw2, gb2, tA, tB)
         if Wd:
@@ -298,7 +365,7 @@ class _BnAddRelu(Function):
         N, C = y.shape[:2]
         vol = y[0, 0].numel()
         out = torch.empty_like(y)
-        A, B, Ar, Br = A.contiguous(), B.contiguous(), _opt(Ar), _opt(Br)
+        A, B, Ar, Br = _coef(A), _coef(B), _coef(Ar), _coef(Br)
         call('cfn_bn_add_relu_fwd', y, A, B, res, Ar, Br, out, N * C, vol)
         ctx.save_for_backward(y, A, res, Ar, out)
         return out
@@ -312,7 +379,6 @@ class _BnAddRelu(Function):
         t3 = _arena.take(3 * N * C, y.device).view(3, N, C)
         call('cfn_bn_add_relu_bwd', gout.contiguous(), out, y, A, res, Ar, gy, gres, t3[0], t3[1],
              t3[2] if Ar is not None else None, N * C, vol)
-        t3 = t3.float()
         gA, gB = t3[0], t3[1]
         gAr = t3[2] if Ar is not None else None
         gBr = gB if Ar is not None else None
@@ -329,7 +395,7 @@ class _AffineAct(Function):
         x = check(x).contiguous()
         N, C = x.shape[:2]
         out = torch.empty_like(x)
-        A, B = A.contiguous(), B.contiguous()
+        A, B = _coef(A), _coef(B)
         call('cfn_affine_act_fwd', x, A, B, act, out, N * C, x[0, 0].numel())
         ctx.save_for_backward(x, A, B)
         ctx.act = act
@@ -342,7 +408,7 @@ class _AffineAct(Function):
         gx = torch.empty_like(x)
         a64, b64 = _f64(N, C, x.device), _f64(N, C, x.device)
         call('cfn_affine_act_bwd', gout.contiguous(), x, A, B, ctx.act, gx, a64, b64, N * C, x[0, 0].numel())
-        return gx, a64.float(), b64.float(), None
+        return gx, a64, b64, None
 
 
 def affine_act(x, A, B, act=ACT_NONE):
@@ -386,7 +452,7 @@ class _PoolHW(Function):
         x = check(x).contiguous()
         N, C, T, H, W = x.shape
         out = torch.empty(N, C, T, OH, OW, dtype=torch.float32, device=x.device)
-        A, B = _opt(A), _opt(B)
+        A, B = _coef(A), _coef(B)
         call('cfn_pool_hw_fwd', x, A, B, act, out, N * C, T, H, W, OH, OW)
         ctx.save_for_backward(x, A, B)
         ctx.meta = (act, OH, OW)
@@ -404,7 +470,7 @@ class _PoolHW(Function):
         call('cfn_pool_hw_bwd', gout.contiguous(), x, A, B, act, gx, a64, b64, N * C, T, H, W, OH, OW)
         if A is None:
             return gx, None, None, None, None, None
-        return gx, a64.float(), b64.float(), None, None, None
+        return gx, a64, b64, None, None, None
 
 
 def pool_hw(x, OH, OW, A=None, B=None, act=ACT_NONE):
@@ -558,10 +624,11 @@ class _ConvDense(Function):
         if want_stats:
             s, q = _f64(N, Co, x.device), _f64(N, Co, x.device)
         w2 = w.reshape(Co, -1).contiguous()
-        A, B = _opt(A), _opt(B)
+        A, B = _coef(A), _coef(B)
         call('cfn_conv3d_dense_fwd', x, A, B, act, w2, y, s, q, N, Ci, Co, T, H, W, g)
         ctx.save_for_backward(x, A, B, w2, y)
         ctx.meta = (act, tuple(kernel), tuple(stride), tuple(padding), tuple(w.shape))
+        ctx.wparam = w
         if not want_stats:
             return y, None, None
         return y, s, q
@@ -583,12 +650,11 @@ class _ConvDense(Function):
                 ab, a64, b64 = _f64pair(N, Ci, x.device)
             call('cfn_conv3d_dense_bwd_data', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, Ci, Co, T, H, W, g)
             if A is not None:
-                ab = ab.float()
                 gA, gB = ab[0], ab[1]
         if ctx.needs_input_grad[3]:
-            g64 = _f64(Co, w2.shape[1], x.device)
+            g64, fin = _gw_buffers(ctx.wparam, Co, w2.shape[1], x.device)
             call('cfn_conv3d_dense_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, Ci, Co, T, H, W, g)
-            gw = g64.float().view(wshape)
+            gw = fin()
         return gx, gA, gB, gw, None, None, None, None, None
 
 

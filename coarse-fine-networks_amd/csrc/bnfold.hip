@@ -19,7 +19,7 @@ struct BnFoldArgs {
     int training, N, C, S, Wd;
     double count, pool_count, eps, momentum;
     const float* w1; const float* b1; const float* w2; const float* b2;   // SE (Wd > 0): fc1 (Wd,C), fc2 (C,Wd)
-    float* A; float* B;                     // (N,C) outputs (gated when SE)
+    double* A; double* B;                     // (N,C) outputs (gated when SE)
     double* mean; double* rstd;             // (S,C) saved
     float* A0; float* B0; float* gate; float* hbuf; float* pooled;   // SE saved: (N,C),(N,C),(N,C),(N,Wd),(N,C)
 };
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(1024) void bn_fold_fwd_kernel(const BnFoldArgs a) {
 }
 
 struct BnFoldBwdArgs {
-    const float* gA; const float* gB;       // (N,C) incoming gradients of the outputs
+    const double* gA; const double* gB;       // (N,C) incoming gradients of the outputs
     const double* s;                        // (N,C) (SE)
     const float* gamma;
     const double* mean; const double* rstd; // (S,C)
@@ -124,7 +124,7 @@ struct BnFoldBwdArgs {
     double* gs; double* gq;                 // (N,C) outputs (training) or null
     float* ggamma; float* gbeta;            // (C) outputs or null
     float* gw1; float* gb1; float* gw2; float* gb2;   // SE parameter gradients (overwritten)
-    float* tA; float* tB;                   // (N,C) scratch: gradients w.r.t. the un-gated A0/B0
+    double* tA; double* tB;                   // (N,C) scratch: gradients w.r.t. the un-gated A0/B0
 };
 
 __global__ __launch_bounds__(1024) void bn_fold_bwd_kernel(const BnFoldBwdArgs a) {
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(1024) void bn_fold_bwd_kernel(const BnFoldBwdArgs a
             __syncthreads();
         }
     }
-    const float* dA = Wd > 0 ? a.tA : a.gA;
-    const float* dB = Wd > 0 ? a.tB : a.gB;
+    const double* dA = Wd > 0 ? a.tA : a.gA;
+    const double* dB = Wd > 0 ? a.tB : a.gB;
     // (1') batch-norm adjoint per channel
     for (int c = tid; c < C; c += nthr) {
         double ggam = 0.0, gbet = 0.0;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(1024) void bn_fold_bwd_kernel(const BnFoldBwdArgs a
 extern "C" int cfn_bn_fold_fwd(const double* s, const double* q, const float* gamma, const float* beta, float* run_mean,
                                float* run_var, long* nbt, int training, int N, int C, int S, double count, double eps,
                                double momentum, const float* w1, const float* b1, const float* w2, const float* b2, int Wd,
-                               double pool_count, float* A, float* B, double* mean, double* rstd, float* A0, float* B0,
+                               double pool_count, double* A, double* B, double* mean, double* rstd, float* A0, float* B0,
                                float* gate, float* hbuf, float* pooled, void* stream) {
     CFN_REQUIRE(A && B && mean && rstd && run_mean && run_var, "cfn_bn_fold_fwd: null tensor");
     CFN_REQUIRE(!training || (s && q), "cfn_bn_fold_fwd: training needs sum / sumsq");
@@ -243,11 +243,11 @@ extern "C" int cfn_bn_fold_fwd(const double* s, const double* q, const float* ga
     return cfn_check_launch("bn_fold_fwd");
 }
 
-extern "C" int cfn_bn_fold_bwd(const float* gA, const float* gB, const double* s, const float* gamma, const double* mean,
+extern "C" int cfn_bn_fold_bwd(const double* gA, const double* gB, const double* s, const float* gamma, const double* mean,
                                const double* rstd, const float* A0, const float* B0, const float* gate, const float* hbuf,
                                const float* pooled, const float* w1, const float* w2, int training, int N, int C, int S,
                                int Wd, double count, double pool_count, double* gs, double* gq, float* ggamma, float* gbeta,
-                               float* gw1, float* gb1, float* gw2, float* gb2, float* tA, float* tB, void* stream) {
+                               float* gw1, float* gb1, float* gw2, float* gb2, double* tA, double* tB, void* stream) {
     CFN_REQUIRE(gA && gB && mean && rstd, "cfn_bn_fold_bwd: null tensor");
     CFN_REQUIRE(Wd <= 0 || (s && A0 && B0 && gate && hbuf && pooled && w1 && w2 && gw1 && gb1 && gw2 && gb2 && tA && tB),
                 "cfn_bn_fold_bwd: SE needs its tensors");

@@ -23,8 +23,8 @@ enum { DW_FWD = 0, DW_DGRAD = 1, DW_WGRAD = 2 };
 struct DwArgs {
     const float* src;    // FWD/WGRAD: x raw (N,C,T,Hi,Wi)      DGRAD: gy (N,C,T,H,W)
     const float* src2;   // DGRAD: y (raw conv output) for the 2*y*gq term, may be null
-    const float* A;      // per-(n,c) prologue scale of the forward input (null = identity)
-    const float* B;
+    const double* A;      // per-(n,c) prologue scale of the forward input (null = identity)
+    const double* B;
     const double* gs;    // DGRAD/WGRAD: d loss / d sum(y)   per (n,c), may be null
     const double* gq;    // DGRAD/WGRAD: d loss / d sum(y^2) per (n,c), may be null
     const float* w;      // (C,27)
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
 // ---------------------------------------------------------------------------------------------
 struct DwS2Args {
     const float* gy; const float* y; const double* gs; const double* gq; const float* w;
-    const float* x; const float* A; const float* B; float* gx; double* gA; double* gB;
+    const float* x; const double* A; const double* B; float* gx; double* gA; double* gB;
     int C, T, Hi, Wi, Ho, Wo, act, TT, nchunks, pblocks;
 };
 
@@ -621,7 +621,7 @@ static double dw_bytes(const DwArgs& a, int tensors_in, int tensors_out) {
     return 4.0 * a.N * a.C * a.T * ((double)tensors_in * a.Hi * a.Wi + (double)tensors_out * a.Ho * a.Wo);
 }
 
-extern "C" int cfn_dwconv3d_fwd(const float* x, const float* A, const float* B, int act, const float* w, float* y,
+extern "C" int cfn_dwconv3d_fwd(const float* x, const double* A, const double* B, int act, const float* w, float* y,
                                 double* sum, double* sumsq, int N, int C, int T, int Hi, int Wi, int stride,
                                 void* stream) {
     CFN_REQUIRE(x && w && y, "cfn_dwconv3d_fwd: null tensor");
@@ -641,7 +641,7 @@ extern "C" int cfn_dwconv3d_fwd(const float* x, const float* A, const float* B, 
 }
 
 extern "C" int cfn_dwconv3d_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq,
-                                     const float* w, const float* x, const float* A, const float* B, int act,
+                                     const float* w, const float* x, const double* A, const double* B, int act,
                                      float* gx, double* gA, double* gB, int N, int C, int T, int Hi, int Wi,
                                      int stride, void* stream) {
     CFN_REQUIRE(gy && w && gx, "cfn_dwconv3d_bwd_data: null tensor");
@@ -676,7 +676,7 @@ extern "C" int cfn_dwconv3d_bwd_data(const float* gy, const float* y, const doub
 }
 
 extern "C" int cfn_dwconv3d_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq,
-                                       const float* x, const float* A, const float* B, int act, double* gw, int N,
+                                       const float* x, const double* A, const double* B, int act, double* gw, int N,
                                        int C, int T, int Hi, int Wi, int stride, void* stream) {
     CFN_REQUIRE(gy && x && gw, "cfn_dwconv3d_bwd_weight: null tensor");
     CFN_REQUIRE(stride == 1 || stride == 2, "cfn_dwconv3d_bwd_weight: stride must be 1 or 2");

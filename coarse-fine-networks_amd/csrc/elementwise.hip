@@ -27,9 +27,9 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* sh /* [NV*4] */
 
 // ---- out = relu( A*y + B + (Ar*res + Br) ) --------------------------------------------------
 template <int VEC>
-__global__ __launch_bounds__(256) void bn_add_relu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ A,
-                                                              const float* __restrict__ B, const float* __restrict__ res,
-                                                              const float* __restrict__ Ar, const float* __restrict__ Br,
+__global__ __launch_bounds__(256) void bn_add_relu_fwd_kernel(const float* __restrict__ y, const double* __restrict__ A,
+                                                              const double* __restrict__ B, const float* __restrict__ res,
+                                                              const double* __restrict__ Ar, const double* __restrict__ Br,
                                                               float* __restrict__ out, long vol) {
     const long nc = blockIdx.y;
     const float a = A[nc], b = B[nc] + (Br ? Br[nc] : 0.0f), ar = Ar ? Ar[nc] : 1.0f;
@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256) void bn_add_relu_fwd_kernel(const float* __res
 // g = gout * (out > 0);  gy = g*A;  gres = g*Ar;  gA += sum g*y;  gB += sum g;  gAr += sum g*res
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_add_relu_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ out,
-                                                              const float* __restrict__ y, const float* __restrict__ A,
-                                                              const float* __restrict__ res, const float* __restrict__ Ar,
+                                                              const float* __restrict__ y, const double* __restrict__ A,
+                                                              const float* __restrict__ res, const double* __restrict__ Ar,
                                                               float* __restrict__ gy, float* __restrict__ gres,
                                                               double* __restrict__ gA, double* __restrict__ gB,
                                                               double* __restrict__ gAr, long vol) {
@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void bn_add_relu_bwd_kernel(const float* __res
 
 // ---- out = act(A*x + B)   (+ optional per-(n,c) sum / sumsq of x itself: channel statistics) ----
 template <int VEC>
-__global__ __launch_bounds__(256) void affine_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ A,
-                                                             const float* __restrict__ B, int act, float* __restrict__ out,
+__global__ __launch_bounds__(256) void affine_act_fwd_kernel(const float* __restrict__ x, const double* __restrict__ A,
+                                                             const double* __restrict__ B, int act, float* __restrict__ out,
                                                              long vol) {
     const long nc = blockIdx.y;
     const float a = A[nc], b = B[nc];
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void affine_act_fwd_kernel(const float* __rest
 // dz = gout * act'(A*x+B);  gx = dz*A;  gA += sum dz*x;  gB += sum dz
 template <int VEC>
 __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x,
-                                                             const float* __restrict__ A, const float* __restrict__ B, int act,
+                                                             const double* __restrict__ A, const double* __restrict__ B, int act,
                                                              float* __restrict__ gx, double* __restrict__ gA,
                                                              double* __restrict__ gB, long vol) {
     __shared__ float sh[8];
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
 __device__ __forceinline__ int ap_start(int o, int O, int S) { return (o * S) / O; }
 __device__ __forceinline__ int ap_end(int o, int O, int S) { return ((o + 1) * S + O - 1) / O; }
 
-__global__ __launch_bounds__(256) void pool_hw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ A,
-                                                          const float* __restrict__ B, int act, float* __restrict__ out,
+__global__ __launch_bounds__(256) void pool_hw_fwd_kernel(const float* __restrict__ x, const double* __restrict__ A,
+                                                          const double* __restrict__ B, int act, float* __restrict__ out,
                                                           int T, int H, int W, int OH, int OW) {
     const long nc = blockIdx.y;
     const long ovol = (long)T * OH * OW;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void pool_hw_fwd_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void pool_hw_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x,
-                                                          const float* __restrict__ A, const float* __restrict__ B, int act,
+                                                          const double* __restrict__ A, const double* __restrict__ B, int act,
                                                           float* __restrict__ gx, double* __restrict__ gA,
                                                           double* __restrict__ gB, int T, int H, int W, int OH, int OW) {
     __shared__ float sh[8];
@@ -284,8 +284,8 @@ static inline bool ew_vec4(long vol, const void* p0, const void* p1 = nullptr, c
 }
 #define CFN_NC_CHECK(NC) CFN_REQUIRE((NC) > 0 && (NC) <= 65535, "N*C = %ld exceeds grid.y limit", (long)(NC))
 
-extern "C" int cfn_bn_add_relu_fwd(const float* y, const float* A, const float* B, const float* res, const float* Ar,
-                                   const float* Br, float* out, long NC, long vol, void* stream) {
+extern "C" int cfn_bn_add_relu_fwd(const float* y, const double* A, const double* B, const float* res, const double* Ar,
+                                   const double* Br, float* out, long NC, long vol, void* stream) {
     CFN_REQUIRE(y && A && B && res && out, "cfn_bn_add_relu_fwd: null tensor");
     CFN_REQUIRE((Ar == nullptr) == (Br == nullptr), "cfn_bn_add_relu_fwd: Ar/Br mismatch");
     CFN_NC_CHECK(NC);
@@ -296,8 +296,8 @@ extern "C" int cfn_bn_add_relu_fwd(const float* y, const float* A, const float* 
     return cfn_check_launch("bn_add_relu_fwd");
 }
 
-extern "C" int cfn_bn_add_relu_bwd(const float* gout, const float* out, const float* y, const float* A, const float* res,
-                                   const float* Ar, float* gy, float* gres, double* gA, double* gB, double* gAr, long NC,
+extern "C" int cfn_bn_add_relu_bwd(const float* gout, const float* out, const float* y, const double* A, const float* res,
+                                   const double* Ar, float* gy, float* gres, double* gA, double* gB, double* gAr, long NC,
                                    long vol, void* stream) {
     CFN_REQUIRE(gout && out && y && A && gy && gres && gA && gB, "cfn_bn_add_relu_bwd: null tensor");
     CFN_REQUIRE(Ar == nullptr || (res != nullptr && gAr != nullptr), "cfn_bn_add_relu_bwd: Ar needs res and gAr");
@@ -311,7 +311,7 @@ extern "C" int cfn_bn_add_relu_bwd(const float* gout, const float* out, const fl
     return cfn_check_launch("bn_add_relu_bwd");
 }
 
-extern "C" int cfn_affine_act_fwd(const float* x, const float* A, const float* B, int act, float* out, long NC, long vol,
+extern "C" int cfn_affine_act_fwd(const float* x, const double* A, const double* B, int act, float* out, long NC, long vol,
                                   void* stream) {
     CFN_REQUIRE(x && A && B && out, "cfn_affine_act_fwd: null tensor");
     CFN_NC_CHECK(NC);
@@ -322,7 +322,7 @@ extern "C" int cfn_affine_act_fwd(const float* x, const float* A, const float* B
     return cfn_check_launch("affine_act_fwd");
 }
 
-extern "C" int cfn_affine_act_bwd(const float* gout, const float* x, const float* A, const float* B, int act, float* gx,
+extern "C" int cfn_affine_act_bwd(const float* gout, const float* x, const double* A, const double* B, int act, float* gx,
                                   double* gA, double* gB, long NC, long vol, void* stream) {
     CFN_REQUIRE(gout && x && A && B && gx && gA && gB, "cfn_affine_act_bwd: null tensor");
     CFN_NC_CHECK(NC);
@@ -343,7 +343,7 @@ extern "C" int cfn_channel_stats(const float* x, double* sum, double* sumsq, lon
     return cfn_check_launch("channel_stats");
 }
 
-extern "C" int cfn_pool_hw_fwd(const float* x, const float* A, const float* B, int act, float* out, long NC, int T, int H,
+extern "C" int cfn_pool_hw_fwd(const float* x, const double* A, const double* B, int act, float* out, long NC, int T, int H,
                                int W, int OH, int OW, void* stream) {
     CFN_REQUIRE(x && out, "cfn_pool_hw_fwd: null tensor");
     CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pool_hw_fwd: A/B mismatch");
@@ -355,7 +355,7 @@ extern "C" int cfn_pool_hw_fwd(const float* x, const float* A, const float* B, i
     return cfn_check_launch("pool_hw_fwd");
 }
 
-extern "C" int cfn_pool_hw_bwd(const float* gout, const float* x, const float* A, const float* B, int act, float* gx,
+extern "C" int cfn_pool_hw_bwd(const float* gout, const float* x, const double* A, const double* B, int act, float* gx,
                                double* gA, double* gB, long NC, int T, int H, int W, int OH, int OW, void* stream) {
     CFN_REQUIRE(gout && x && gx, "cfn_pool_hw_bwd: null tensor");
     CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pool_hw_bwd: A/B mismatch");

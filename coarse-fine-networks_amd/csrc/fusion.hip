@@ -13,7 +13,7 @@
 // ---------------------------------------------------------------------------------------------------------
 struct DenseBwdArgs {
     const float* gy; const float* y; const double* gs; const double* gq; const float* w;
-    const float* x; const float* A; const float* B; float* gx; double* gA; double* gB;
+    const float* x; const double* A; const double* B; float* gx; double* gA; double* gB;
     int Cin, Cout, Ti, Hi, Wi, To, Ho, Wo, kT, kH, kW, sT, sH, sW, pT, pH, pW, act;
 };
 
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void conv3d_dense_bwd_data_kernel(const DenseB
 }
 
 extern "C" int cfn_conv3d_dense_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq,
-                                         const float* w, const float* x, const float* A, const float* B, int act, float* gx,
+                                         const float* w, const float* x, const double* A, const double* B, int act, float* gx,
                                          double* gA, double* gB, int N, int Cin, int Cout, int T, int Hi, int Wi,
                                          const int* geom, void* stream) {
     CFN_REQUIRE(gy && w && gx && geom, "cfn_conv3d_dense_bwd_data: null tensor");

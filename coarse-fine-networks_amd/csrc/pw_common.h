@@ -12,15 +12,15 @@ enum { PW_FWD = 0, PW_DGRAD = 1 };
 struct PwArgs {
     const float* src;    // FWD: x raw (N,K,Pin)          DGRAD: gy (N,K,Q)
     const float* src2;   // DGRAD: y raw (N,K,Q) for the 2*y*gq term (may be null)
-    const float* pa;     // FWD: prologue A[n,k] (null = identity)
-    const float* pb;
+    const double* pa;     // FWD: prologue A[n,k] (null = identity)
+    const double* pb;
     const double* gs;    // DGRAD: d/d sum(y)   [n,k]  (may be null)
     const double* gq;    // DGRAD: d/d sum(y^2) [n,k]  (may be null)
     const float* w;      // (Cout, Cin) row major
     float* dst;          // FWD: y (N,M,Q)                DGRAD: gx (N,M,Pin)
     const float* ex;     // DGRAD: forward input x raw (N,M,Pin) (needed when ea != null)
-    const float* ea;     // DGRAD: forward prologue A[n,m] (null = identity => gx = da)
-    const float* eb;
+    const double* ea;     // DGRAD: forward prologue A[n,m] (null = identity => gx = da)
+    const double* eb;
     double* s1;          // FWD: sum(y) [n,m]             DGRAD: sum(dz*x) [n,m]
     double* s2;          // FWD: sum(y^2)                 DGRAD: sum(dz)
     int N, M, K, Q, Pin, Hi, Wi, Ho, Wo, stride, act;
@@ -44,11 +44,11 @@ __device__ __forceinline__ float pw_bload(__amdgpu_buffer_rsrc_t r, int voff, in
 int pwd_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st);
 
 // pwwgrad.hip: direct-operand weight gradient for M, K >= 48 (stride 1); -1 = shape not handled.
-int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const float* pa,
-                         const float* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st);
-int pwd_wgrad_try_strided(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const float* pa,
-                          const float* pb, int act, double* gw, int N, int M, int K, int T, int Hi, int Wi, int stride,
+int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const double* pa,
+                         const double* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st);
+int pwd_wgrad_try_strided(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const double* pa,
+                          const double* pb, int act, double* gw, int N, int M, int K, int T, int Hi, int Wi, int stride,
                           hipStream_t st);
-int pwd_wgrad_try_dense(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const float* pa,
-                        const float* pb, int act, double* gw, int N, int M, int Cimg, int T, int Hi, int Wi, const int* g,
+int pwd_wgrad_try_dense(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const double* pa,
+                        const double* pb, int act, double* gw, int N, int M, int Cimg, int T, int Hi, int Wi, const int* g,
                         hipStream_t st);

@@ -277,7 +277,7 @@ struct WgArgs {
     const float* y;      // (N,M,Q) raw conv output, for the gq term (may be null)
     const double* gs; const double* gq;   // [n,m] (may be null)
     const float* x;      // (N,K,Pin) forward input raw
-    const float* pa; const float* pb;     // forward prologue [n,k] (null = identity)
+    const double* pa; const double* pb;     // forward prologue [n,k] (null = identity)
     double* gw;          // (M,K) fp64 accumulators, zero-filled by the caller
     int N, M, K, Q, Pin, Hi, Wi, Ho, Wo, stride, act;
     int mtiles, ktiles, nstrips, stages;   // stages = LDS stages (of 64 positions) per block
@@ -556,7 +556,7 @@ static void pw_geom(PwArgs& a, int T, int Hi, int Wi, int stride) {
     a.Q = T * a.Ho * a.Wo;
 }
 
-extern "C" int cfn_pwconv_fwd(const float* x, const float* A, const float* B, int act, const float* w, float* y,
+extern "C" int cfn_pwconv_fwd(const float* x, const double* A, const double* B, int act, const float* w, float* y,
                               double* sum, double* sumsq, int N, int Cin, int Cout, int T, int Hi, int Wi, int stride,
                               void* stream) {
     CFN_REQUIRE(x && w && y, "cfn_pwconv_fwd: null tensor");
@@ -579,7 +579,7 @@ extern "C" int cfn_pwconv_fwd(const float* x, const float* A, const float* B, in
 
 // gx must be zero-filled by the caller when stride == 2 (only the strided positions are written)
 extern "C" int cfn_pwconv_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq,
-                                   const float* w, const float* x, const float* A, const float* B, int act, float* gx,
+                                   const float* w, const float* x, const double* A, const double* B, int act, float* gx,
                                    double* gA, double* gB, int N, int Cin, int Cout, int T, int Hi, int Wi, int stride,
                                    void* stream) {
     CFN_REQUIRE(gy && w && gx, "cfn_pwconv_bwd_data: null tensor");
@@ -644,7 +644,7 @@ static void wg_geom(WgArgs& a, int N, int Cin, int Cout, int T, int Hi, int Wi, 
 }
 
 extern "C" int cfn_pwconv_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq,
-                                     const float* x, const float* A, const float* B, int act, double* gw, int N,
+                                     const float* x, const double* A, const double* B, int act, double* gw, int N,
                                      int Cin, int Cout, int T, int Hi, int Wi, int stride, void* stream) {
     CFN_REQUIRE(gy && x && gw, "cfn_pwconv_bwd_weight: null tensor");
     CFN_REQUIRE(stride == 1 || stride == 2, "cfn_pwconv_bwd_weight: stride must be 1 or 2");
@@ -687,7 +687,7 @@ static int dense_geom(ARGS& a, int Cimg, int T, int Hi, int Wi, const int* g) {
     return CFN_OK;
 }
 
-extern "C" int cfn_conv3d_dense_fwd(const float* x, const float* A, const float* B, int act, const float* w, float* y,
+extern "C" int cfn_conv3d_dense_fwd(const float* x, const double* A, const double* B, int act, const float* w, float* y,
                                     double* sum, double* sumsq, int N, int Cin, int Cout, int T, int Hi, int Wi,
                                     const int* geom, void* stream) {
     CFN_REQUIRE(x && w && y && geom, "cfn_conv3d_dense_fwd: null tensor");
@@ -714,7 +714,7 @@ extern "C" int cfn_conv3d_dense_fwd(const float* x, const float* A, const float*
 }
 
 extern "C" int cfn_conv3d_dense_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq,
-                                           const float* x, const float* A, const float* B, int act, double* gw, int N,
+                                           const float* x, const double* A, const double* B, int act, double* gw, int N,
                                            int Cin, int Cout, int T, int Hi, int Wi, const int* geom, void* stream) {
     CFN_REQUIRE(gy && x && gw && geom, "cfn_conv3d_dense_bwd_weight: null tensor");
     CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_conv3d_dense_bwd_weight: A/B mismatch");

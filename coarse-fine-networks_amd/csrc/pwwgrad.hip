@@ -13,7 +13,7 @@
 
 struct WdArgs {
     const float* gy; const float* y; const double* gs; const double* gq;
-    const float* x; const float* pa; const float* pb;
+    const float* x; const double* pa; const double* pb;
     double* gw;
     int N, M, K, Q, act;
     int mgroups, kgroups, nstrips;     // output tile groups (<= 3 tiles of 32 each way), workgroups per (group, sample)
@@ -237,8 +237,8 @@ static bool wd_common_ok(const float* gy, const float* y, const float* x, int ac
 }
 
 // contiguous pointwise conv (stride 1): M, K >= 48 (smaller layers are HBM bound and stay on the LDS-staged kernel)
-int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const float* pa,
-                         const float* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st) {
+int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const double* pa,
+                         const double* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st) {
     if (M < 48 || K < 48 || !wd_common_ok(gy, y, x, act, M, K, Q)) return -1;
     if (((uintptr_t)x & 15) || (long)K * Q * 4 >= (1L << 31) - 64) return -1;
     WdArgs a = {gy, y, gs, gq, x, pa, pb, gw, N, M, K, Q, act};
@@ -247,8 +247,8 @@ int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, cons
 }
 
 // pointwise conv with spatial stride 2 (shortcut convs): gathered x operand
-int pwd_wgrad_try_strided(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const float* pa,
-                          const float* pb, int act, double* gw, int N, int M, int K, int T, int Hi, int Wi, int stride,
+int pwd_wgrad_try_strided(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const double* pa,
+                          const double* pb, int act, double* gw, int N, int M, int K, int T, int Hi, int Wi, int stride,
                           hipStream_t st) {
     const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
     const int Q = T * Ho * Wo;
@@ -260,8 +260,8 @@ int pwd_wgrad_try_strided(const float* gy, const float* y, const double* gs, con
 }
 
 // dense conv (stem 1x3x3 / Grid Pool saliency convs): x rows are im2col rows; geom = {kT,kH,kW,sT,sH,sW,pT,pH,pW}
-int pwd_wgrad_try_dense(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const float* pa,
-                        const float* pb, int act, double* gw, int N, int M, int Cimg, int T, int Hi, int Wi, const int* g,
+int pwd_wgrad_try_dense(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const double* pa,
+                        const double* pb, int act, double* gw, int N, int M, int Cimg, int T, int Hi, int Wi, const int* g,
                         hipStream_t st) {
     const int To = (T + 2 * g[6] - g[0]) / g[3] + 1, Ho = (Hi + 2 * g[7] - g[1]) / g[4] + 1, Wo = (Wi + 2 * g[8] - g[2]) / g[5] + 1;
     const int K = Cimg * g[0] * g[1] * g[2];

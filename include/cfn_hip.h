@@ -42,13 +42,13 @@ int cfn_prof_collect(int family, double* total_ms, long* launches, double* total
  * bwd_data   g' = gy + gsum[n,c] + 2 y gsumsq[n,c];  da = dwconv^T(g');  gx = da*act'(A x+B)*A;
  *            gA[N*C] += sum da*act'*x, gB += sum da*act'   (autograd of F.conv3d + batch_norm + relu_)
  * bwd_weight gw[C*27] (fp64, zero-filled by caller) += sum g' * act(A x + B)[tap] */
-int cfn_dwconv3d_fwd(const float* x, const float* A, const float* B, int act, const float* w, float* y, double* sum,
+int cfn_dwconv3d_fwd(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum,
                      double* sumsq, int N, int C, int T, int Hi, int Wi, int stride, void* stream);
 int cfn_dwconv3d_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
-                          const float* x, const float* A, const float* B, int act, float* gx, double* gA, double* gB,
+                          const float* x, const double* A, const double* B, int act, float* gx, double* gA, double* gB,
                           int N, int C, int T, int Hi, int Wi, int stride, void* stream);
 int cfn_dwconv3d_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* x,
-                            const float* A, const float* B, int act, double* gw, int N, int C, int T, int Hi, int Wi,
+                            const double* A, const double* B, int act, double* gw, int N, int C, int T, int Hi, int Wi,
                             int stride, void* stream);
 
 /* ---- depthwise 5x1x1, pad (2,0,0): conv1_t x3d_fine.py:216-222 / x3d_coarse.py:502-508 ; plane = H*W ---- */
@@ -63,13 +63,13 @@ int cfn_dwconv_t5_bwd_weight(const float* gy, const float* y, const double* gsum
  * shortcut :284-287), conv5 :245-250, fc1 :256; fp32 MFMA (v_mfma_f32_32x32x2_f32).  w is (Cout,Cin).
  * bwd_data with stride 2 writes only the strided positions: caller zero-fills gx.
  * bwd_weight accumulates into gw (Cout,Cin) fp64, zero-filled by the caller (one atomic per element per workgroup). ---- */
-int cfn_pwconv_fwd(const float* x, const float* A, const float* B, int act, const float* w, float* y, double* sum,
+int cfn_pwconv_fwd(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum,
                    double* sumsq, int N, int Cin, int Cout, int T, int Hi, int Wi, int stride, void* stream);
 int cfn_pwconv_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
-                        const float* x, const float* A, const float* B, int act, float* gx, double* gA, double* gB, int N,
+                        const float* x, const double* A, const double* B, int act, float* gx, double* gA, double* gB, int N,
                         int Cin, int Cout, int T, int Hi, int Wi, int stride, void* stream);
 int cfn_pwconv_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* x,
-                          const float* A, const float* B, int act, double* gw, int N, int Cin, int Cout, int T, int Hi,
+                          const double* A, const double* B, int act, double* gw, int N, int Cin, int Cout, int T, int Hi,
                           int Wi, int stride, void* stream);
 
 /* ---- stem 1x3x3 stride (1,2,2) pad (0,1,1) dense conv: conv1_s x3d_fine.py:210-215 (im2col view on MFMA);
@@ -87,25 +87,25 @@ int cfn_stem_conv_bwd_weight(const float* gy, const float* x, double* gw, int N,
  * feed cfn_bn_fold_bwd, which returns gs,gq (N,C) fp64 and the parameter gradients (all overwritten). ---- */
 int cfn_bn_fold_fwd(const double* s, const double* q, const float* gamma, const float* beta, float* run_mean, float* run_var,
                     long* nbt, int training, int N, int C, int S, double count, double eps, double momentum, const float* w1,
-                    const float* b1, const float* w2, const float* b2, int Wd, double pool_count, float* A, float* B,
+                    const float* b1, const float* w2, const float* b2, int Wd, double pool_count, double* A, double* B,
                     double* mean, double* rstd, float* A0, float* B0, float* gate, float* hbuf, float* pooled, void* stream);
-int cfn_bn_fold_bwd(const float* gA, const float* gB, const double* s, const float* gamma, const double* mean,
+int cfn_bn_fold_bwd(const double* gA, const double* gB, const double* s, const float* gamma, const double* mean,
                     const double* rstd, const float* A0, const float* B0, const float* gate, const float* hbuf,
                     const float* pooled, const float* w1, const float* w2, int training, int N, int C, int S, int Wd,
                     double count, double pool_count, double* gs, double* gq, float* ggamma, float* gbeta, float* gw1,
-                    float* gb1, float* gw2, float* gb2, float* tA, float* tB, void* stream);
+                    float* gb1, float* gw2, float* gb2, double* tA, double* tB, void* stream);
 
 /* ---- dense 3-D convolution as implicit GEMM (no im2col buffer): Grid Pool saliency convs x3d_coarse.py:362-366,
  * :379-381 (and the stem, which is the geom {1,3,3, 1,2,2, 0,1,1} case).  geom = int[9] {kT,kH,kW, sT,sH,sW, pT,pH,pW}
  * in HOST memory.  w (Cout, Cin*kT*kH*kW); no bias (a bias is algebraically folded into the next prologue / the
  * statistics by the caller).  Prologue act: none or relu; zero padding is applied after the prologue. ---- */
-int cfn_conv3d_dense_fwd(const float* x, const float* A, const float* B, int act, const float* w, float* y, double* sum,
+int cfn_conv3d_dense_fwd(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum,
                          double* sumsq, int N, int Cin, int Cout, int T, int Hi, int Wi, const int* geom, void* stream);
 int cfn_conv3d_dense_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
-                              const float* x, const float* A, const float* B, int act, float* gx, double* gA, double* gB,
+                              const float* x, const double* A, const double* B, int act, float* gx, double* gA, double* gB,
                               int N, int Cin, int Cout, int T, int Hi, int Wi, const int* geom, void* stream);
 int cfn_conv3d_dense_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* x,
-                                const float* A, const float* B, int act, double* gw, int N, int Cin, int Cout, int T, int Hi,
+                                const double* A, const double* B, int act, double* gw, int N, int Cin, int Cout, int T, int Hi,
                                 int Wi, const int* geom, void* stream);
 
 /* ---- Multi-stage Fusion temporal-alignment gather: RewightLayer.forward x3d_coarse.py:213-223 at the fine
@@ -119,24 +119,24 @@ int cfn_fusion_gather_bwd(const float* gz, const float* z, const float* den, con
 
 /* ---- block tail  out = relu(A y + B + (Ar res + Br)) : bn3 + (downsample bn) + `out += residual` + relu,
  * x3d_fine.py:167-173.  Ar/Br NULL = identity shortcut.  vol = T*H*W, NC = N*C. ---- */
-int cfn_bn_add_relu_fwd(const float* y, const float* A, const float* B, const float* res, const float* Ar, const float* Br,
+int cfn_bn_add_relu_fwd(const float* y, const double* A, const double* B, const float* res, const double* Ar, const double* Br,
                         float* out, long NC, long vol, void* stream);
-int cfn_bn_add_relu_bwd(const float* gout, const float* out, const float* y, const float* A, const float* res,
-                        const float* Ar, float* gy, float* gres, double* gA, double* gB, double* gAr, long NC, long vol,
+int cfn_bn_add_relu_bwd(const float* gout, const float* out, const float* y, const double* A, const float* res,
+                        const double* Ar, float* gy, float* gres, double* gA, double* gB, double* gAr, long NC, long vol,
                         void* stream);
 
 /* ---- materialised prologue out = act(A x + B) (SubBatchNorm3d.forward on its own, x3d_fine.py:51-62) and
  * per-(n,c) sum / sumsq of a tensor (batch statistics of an arbitrary input) ---- */
-int cfn_affine_act_fwd(const float* x, const float* A, const float* B, int act, float* out, long NC, long vol, void* stream);
-int cfn_affine_act_bwd(const float* gout, const float* x, const float* A, const float* B, int act, float* gx, double* gA,
+int cfn_affine_act_fwd(const float* x, const double* A, const double* B, int act, float* out, long NC, long vol, void* stream);
+int cfn_affine_act_bwd(const float* gout, const float* x, const double* A, const double* B, int act, float* gx, double* gA,
                        double* gB, long NC, long vol, void* stream);
 int cfn_channel_stats(const float* x, double* sum, double* sumsq, long NC, long vol, void* stream);
 
 /* ---- adaptive spatial mean of act(A x + B) to (OH,OW): adaptive_avg_pool3d((None,1,1)) x3d_fine.py:255/366 and
  * ((None,7,7)) :345-363 (ATen window rule: [floor(o*S/O), ceil((o+1)*S/O)) ) ---- */
-int cfn_pool_hw_fwd(const float* x, const float* A, const float* B, int act, float* out, long NC, int T, int H, int W, int OH,
+int cfn_pool_hw_fwd(const float* x, const double* A, const double* B, int act, float* out, long NC, int T, int H, int W, int OH,
                     int OW, void* stream);
-int cfn_pool_hw_bwd(const float* gout, const float* x, const float* A, const float* B, int act, float* gx, double* gA,
+int cfn_pool_hw_bwd(const float* gout, const float* x, const double* A, const double* B, int act, float* gx, double* gA,
                     double* gB, long NC, int T, int H, int W, int OH, int OW, void* stream);
 
 /* ---- FiLM x*m + c with (H/f x W/f)-block-constant m, c: `x = x * m2 + c2` x3d_coarse.py:663-679 after the
