@@ -25,7 +25,7 @@ struct WdArgs {
 };
 
 #define WD_WAVES 8
-#define WD_T 3
+#define WD_TMAX 3
 
 // balanced split of `tiles` into `groups` runs: run g covers [first, first + count)
 __device__ __forceinline__ void wd_split(int tiles, int groups, int g, int& first, int& count) {
@@ -34,7 +34,7 @@ __device__ __forceinline__ void wd_split(int tiles, int groups, int g, int& firs
     count = base + (g < rem ? 1 : 0);
 }
 
-template <int ACT, int XMODE>
+template <int ACT, int XMODE, int WD_T>
 __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const WdArgs a) {
     __shared__ float cw[WD_WAVES][32 * 33];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, row = lane & 31;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
         return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
     };
     f4v rG[WD_T], rY[WD_T], rX[WD_T];
-    unsigned xmb[WD_T] = {0u, 0u, 0u};   // XMODE 2: in-bounds bits of the 4 taps of each tile's raw float4
+    unsigned xmb[WD_T] = {};   // XMODE 2: in-bounds bits of the 4 taps of each tile's raw float4
     auto load = [&](int g) {
         const int q = g * 8 + 4 * half;
         const bool inq = q < Q;                                  // Q % 4 == 0: a float4 is all inside or all outside
@@ -208,21 +208,23 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
         }
 }
 
-template <int XMODE>
+template <int XMODE, int WD_T>
 static int wd_launch(WdArgs& a, hipStream_t st) {
     a.mt32 = cfn_cdiv(a.M, 32); a.kt32 = cfn_cdiv(a.K, 32);
     a.mgroups = cfn_cdiv(a.mt32, WD_T); a.kgroups = cfn_cdiv(a.kt32, WD_T);
     const long groups = (long)a.N * a.mgroups * a.kgroups;
-    long strips = 256 / groups;                       // ~one workgroup per CU (measured: more, shorter strips lose)
+    // ~one workgroup per CU (measured: more, shorter strips lose); the single-tile variant is load bound and small:
+    // four workgroups per CU
+    long strips = (WD_T == 1 ? 1024 : 256) / groups;
     if (strips < 1) strips = 1;
     const long g8 = cfn_cdiv(a.Q, 8);
     if (strips > cfn_cdiv(g8, WD_WAVES * 4)) strips = cfn_cdiv(g8, WD_WAVES * 4);   // >= 4 position groups per wave
     a.nstrips = (int)strips;
     const unsigned blocks = (unsigned)(groups * strips);
     switch (a.act) {
-        case CFN_ACT_RELU: hipLaunchKernelGGL((pw_wgrad_direct_kernel<CFN_ACT_RELU, XMODE>), dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
-        case CFN_ACT_SWISH: hipLaunchKernelGGL((pw_wgrad_direct_kernel<CFN_ACT_SWISH, XMODE>), dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
-        default: hipLaunchKernelGGL((pw_wgrad_direct_kernel<CFN_ACT_NONE, XMODE>), dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
+        case CFN_ACT_RELU: hipLaunchKernelGGL((pw_wgrad_direct_kernel<CFN_ACT_RELU, XMODE, WD_T>), dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
+        case CFN_ACT_SWISH: hipLaunchKernelGGL((pw_wgrad_direct_kernel<CFN_ACT_SWISH, XMODE, WD_T>), dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
+        default: hipLaunchKernelGGL((pw_wgrad_direct_kernel<CFN_ACT_NONE, XMODE, WD_T>), dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
     }
     return cfn_check_launch("pwconv_bwd_weight(direct)");
 }
@@ -243,7 +245,7 @@ int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, cons
     if (((uintptr_t)x & 15) || (long)K * Q * 4 >= (1L << 31) - 64) return -1;
     WdArgs a = {gy, y, gs, gq, x, pa, pb, gw, N, M, K, Q, act};
     a.Pin = Q;
-    return wd_launch<0>(a, st);
+    return wd_launch<0, 3>(a, st);
 }
 
 // pointwise conv with spatial stride 2 (shortcut convs): gathered x operand
@@ -256,7 +258,7 @@ int pwd_wgrad_try_strided(const float* gy, const float* y, const double* gs, con
     if ((long)K * T * Hi * Wi * 4 >= (1L << 31) - 64) return -1;
     WdArgs a = {gy, y, gs, gq, x, pa, pb, gw, N, M, K, Q, act};
     a.Pin = T * Hi * Wi; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = stride;
-    return wd_launch<1>(a, st);
+    return wd_launch<1, 3>(a, st);
 }
 
 // dense conv (stem 1x3x3 / Grid Pool saliency convs): x rows are im2col rows; geom = {kT,kH,kW,sT,sH,sW,pT,pH,pW}
@@ -273,5 +275,7 @@ int pwd_wgrad_try_dense(const float* gy, const float* y, const double* gs, const
     WdArgs a = {gy, y, gs, gq, x, pa, pb, gw, N, M, K, Q, act};
     a.Pin = T * Hi * Wi; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = 1; a.Ti = T; a.Cimg = Cimg;
     a.kT = g[0]; a.kH = g[1]; a.kW = g[2]; a.sT = g[3]; a.sH = g[4]; a.sW = g[5]; a.pT = g[6]; a.pH = g[7]; a.pW = g[8];
-    return wd_launch<2>(a, st);
+    // one 32x32 tile per wave when the whole problem is one or two tiles (stem: 24 x 27): no idle tile slots
+    if (cfn_cdiv(M, 32) * cfn_cdiv(K, 32) <= 2) return wd_launch<2, 1>(a, st);
+    return wd_launch<2, 3>(a, st);
 }
