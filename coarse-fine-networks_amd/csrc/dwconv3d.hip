@@ -503,9 +503,9 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
 struct DwPlan { int HS, VEC, MAXLD, threads; bool UNIW; size_t lds; unsigned blocks; };
 
 static int pick_hs(int Ho, int mode) {
-    // small planes (<= 14 rows), backward kernels: short strips keep the register footprint low (more waves per
-    // CU; measured faster); everything else: 7-row strips minimise LDS reads per output
-    if (Ho <= 14 && mode != DW_FWD) return (Ho % 2 == 0) ? 2 : 1;
+    // small planes (<= 14 rows), data gradient: short strips keep the register footprint low (more waves per CU;
+    // measured faster); everything else: 7-row strips minimise LDS reads per output
+    if (Ho <= 14 && mode == DW_DGRAD) return (Ho % 2 == 0) ? 2 : 1;
     if (Ho % 7 == 0) return 7;
     if (Ho % 4 == 0) return 4;
     if (Ho % 2 == 0) return 2;

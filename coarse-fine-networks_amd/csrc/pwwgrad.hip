@@ -245,6 +245,11 @@ int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, cons
     if (((uintptr_t)x & 15) || (long)K * Q * 4 >= (1L << 31) - 64) return -1;
     WdArgs a = {gy, y, gs, gq, x, pa, pb, gw, N, M, K, Q, act};
     a.Pin = Q;
+    {   // balanced groups never exceed 2 tiles either way (e.g. 108 x 48): the 2x2 variant needs half the registers
+        const int mt = cfn_cdiv(M, 32), kt = cfn_cdiv(K, 32);
+        const int gm = cfn_cdiv(mt, cfn_cdiv(mt, 3)), gk = cfn_cdiv(kt, cfn_cdiv(kt, 3));
+        if (gm <= 2 && gk <= 2) return wd_launch<0, 2>(a, st);
+    }
     return wd_launch<0, 3>(a, st);
 }
 

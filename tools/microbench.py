@@ -94,29 +94,29 @@ def bench_pw(T, bwd, NB=1, only=None):
                    mw, 4.0 * (ci + 2 * co) * Q / 1e6 / mw, 2.0 * ci * co * Q / mw / 1e9))
 
 
-def bench_dw(T, bwd):
+def bench_dw(T, bwd, NB=1):
     print('%-28s %9s %9s %9s %s' % ('depthwise layer', 'ms', 'GB/s', 'TFLOP/s', '(fwd)'))
-    x = torch.randn(1, 24, T, 112, 112, device=DEV)
+    x = torch.randn(NB, 24, T, 112, 112, device=DEV)
     w = torch.randn(24, 1, 5, 1, 1, device=DEV) * 0.3
     ms = devtime(lambda: ops.dwconv_t5(x, w, True))['dwconv_fwd']
-    print('%-28s %9.3f %9.1f' % ('stem conv1_t 24 @112 (5x1x1)', ms, 8.0 * 24 * T * 112 * 112 / 1e6 / ms))
+    print('%-28s %9.3f %9.1f' % ('stem conv1_t 24 @112 (5x1x1)', ms, 8.0 * NB * 24 * T * 112 * 112 / 1e6 / ms))
     if bwd:
         xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
         y, sm, sq = ops.dwconv_t5(xr, wr, True)
         gy, gs, gq = torch.randn_like(y), torch.randn_like(sm) * 0.01, torch.randn_like(sq) * 0.001
         md = devtime(lambda: torch.autograd.grad((y, sm, sq), (xr, wr), (gy, gs, gq), retain_graph=True))['dwconv_bwd']
-        print('%-28s dgrad+wgrad %7.3f ms %7.1f GB/s' % ('', md, 28.0 * 24 * T * 112 * 112 / 1e6 / md))
+        print('%-28s dgrad+wgrad %7.3f ms %7.1f GB/s' % ('', md, 28.0 * NB * 24 * T * 112 * 112 / 1e6 / md))
         del xr, y, gy
     del x
     for name, c, H, s in DW_LAYERS:
-        x = torch.randn(1, c, T, H, H, device=DEV)
+        x = torch.randn(NB, c, T, H, H, device=DEV)
         w = torch.randn(c, 1, 3, 3, 3, device=DEV) * 0.2
-        A = torch.rand(1, c, device=DEV) + 0.5
-        B = torch.randn(1, c, device=DEV) * 0.1
+        A = torch.rand(NB, c, device=DEV) + 0.5
+        B = torch.randn(NB, c, device=DEV) * 0.1
         Ho = (H + 2 - 3) // s + 1
         ms = devtime(lambda: ops.dwconv3d(x, w, A, B, 1, s, True))['dwconv_fwd']
-        gb = 4.0 * c * T * (H * H + Ho * Ho) / 1e9
-        print('%-28s %9.3f %9.1f %9.2f' % (name, ms, gb / ms * 1e3, 54.0 * c * T * Ho * Ho / ms / 1e9))
+        gb = 4.0 * NB * c * T * (H * H + Ho * Ho) / 1e9
+        print('%-28s %9.3f %9.1f %9.2f' % (name, ms, gb / ms * 1e3, 54.0 * NB * c * T * Ho * Ho / ms / 1e9))
         if bwd:
             xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
             Ar, Br = A.clone().requires_grad_(True), B.clone().requires_grad_(True)
@@ -128,7 +128,7 @@ def bench_dw(T, bwd):
             d = devtime(f)
             md, mw = d.get('dwconv_bwd', 0.0), d.get('dwconv_wgrad', 0.0)
             print('%-28s dgrad %7.3f ms %7.1f GB/s | wgrad %7.3f ms %7.1f GB/s' %
-                  ('', md, 4.0 * c * T * (2 * H * H + 2 * Ho * Ho) / 1e6 / md, mw, 4.0 * c * T * (H * H + 2 * Ho * Ho) / 1e6 / mw))
+                  ('', md, 4.0 * NB * c * T * (2 * H * H + 2 * Ho * Ho) / 1e6 / md, mw, 4.0 * NB * c * T * (H * H + 2 * Ho * Ho) / 1e6 / mw))
 
 
 if __name__ == '__main__':
@@ -142,4 +142,4 @@ if __name__ == '__main__':
     if a.what in ('pw', 'all'):
         bench_pw(a.frames, a.bwd, a.batch, a.only)
     if a.what in ('dw', 'all'):
-        bench_dw(a.frames, a.bwd)
+        bench_dw(a.frames, a.bwd, a.batch)
