@@ -152,7 +152,7 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     float st1 = 0.0f, st2 = 0.0f;
 
     typedef float __attribute__((ext_vector_type(4))) f4;
-    constexpr int DEPTH = (MODE == DW_FWD && VEC == 4 && (MAXLD == 2 || UNIW)) ? 2 : 1;
+    constexpr int DEPTH = (MODE == DW_FWD && VEC == 4) ? 2 : 1;
     f4 pfA[MAXLD], pfA2[MAXLD], pfB[DEPTH == 2 ? MAXLD : 1], pfB2[DEPTH == 2 ? MAXLD : 1];
     const bool two_src = (MODE == DW_DGRAD) && a.src2 != nullptr;
 
@@ -248,6 +248,9 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     if (f_first + DEPTH <= f_last && frame_valid(f_first + DEPTH)) prefetch(f_first + DEPTH, pfA, pfA2);
     __syncthreads();
 
+    float xen[HS];   // DGRAD: forward input of the next frame to be emitted
+#pragma unroll
+    for (int i = 0; i < HS; ++i) xen[i] = 0.0f;
     // one frame step (ONE barrier): stage frame f+1 from `nx` into the other LDS image, refill `nx` with frame
     // f+1+DEPTH, compute frame f from image `par`, emit output frame f-1
     auto step = [&](int f, int par, f4* nx, f4* nx2) {
@@ -258,14 +261,19 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
         }
         const float* tbp = tb + par * bufsz;
 
-        // DGRAD epilogue operand for the frame that completes in this step
+        // DGRAD epilogue operand: x of the frame that completes in this step was loaded one step ago (xen); the load
+        // for the next step's frame is issued here, a whole frame of work ahead of its use
         const int to = f - 1;
         const bool emit = (to >= t0 && to < t1) && active;
         float xe[HS];
-        if (MODE == DW_DGRAD && emit && a.A) {
-            const long o = (nc * T + to) * plane_o + (long)hrow0 * Wo + wo;
+        if (MODE == DW_DGRAD && a.A) {
 #pragma unroll
-            for (int i = 0; i < HS; ++i) xe[i] = a.xin[o + (long)i * Wo];
+            for (int i = 0; i < HS; ++i) xe[i] = xen[i];
+            if (to + 1 >= t0 && to + 1 < t1 && active) {
+                const long o = (nc * T + to + 1) * plane_o + (long)hrow0 * Wo + wo;
+#pragma unroll
+                for (int i = 0; i < HS; ++i) xen[i] = a.xin[o + (long)i * Wo];
+            }
         }
 
         if (fv && active) {
@@ -502,7 +510,10 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
 // ---------------------------------------------------------------------------------------------
 struct DwPlan { int HS, VEC, MAXLD, threads; bool UNIW; size_t lds; unsigned blocks; };
 
-static int pick_hs(int Ho, int mode) {
+static int pick_hs(int Ho, int mode, int S) {
+    // stride 2 (forward / weight gradient): one output row per thread.  A 7-row strip needs a 15-row input window per
+    // thread and leaves too few threads per plane (measured at 4 clips: 112->56 fwd 1.15 -> 0.67 ms, wgrad 1.17 -> 0.77)
+    if (S == 2) return 1;
     // small planes (<= 14 rows), data gradient: short strips keep the register footprint low (more waves per CU;
     // measured faster); everything else: 7-row strips minimise LDS reads per output
     if (Ho <= 14 && mode == DW_DGRAD) return (Ho % 2 == 0) ? 2 : 1;
@@ -515,7 +526,7 @@ static int pick_hs(int Ho, int mode) {
 static int dw_plan(DwArgs& a, int S, int mode, DwPlan& pl) {
     a.Ho = (a.Hi + 2 - 3) / S + 1;
     a.Wo = (a.Wi + 2 - 3) / S + 1;
-    const int HS = pick_hs(a.Ho, mode);
+    const int HS = pick_hs(a.Ho, mode, S);
     const int G = a.Ho / HS;
     if (a.Wo > 512) return cfn_fail(CFN_ERR_UNSUPPORTED, "dwconv3d: output width %d > 512 not supported", a.Wo);
     const int VEC = (a.Wi % 4 == 0) ? 4 : 1;
