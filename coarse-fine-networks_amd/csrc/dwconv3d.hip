@@ -374,15 +374,22 @@ struct DwS2Args {
     const float* gy; const float* y; const double* gs; const double* gq; const float* w;
     const float* x; const double* A; const double* B; float* gx; double* gA; double* gB;
     int C, T, Hi, Wi, Ho, Wo, act, TT, nchunks, pblocks;
+    int PB, CPB, NC;     // small planes: CPB channels of PB = Ho*Wo positions share a workgroup
 };
 
+// PACKED: several small-plane channels per workgroup (per-lane channel, weights in VGPRs); otherwise the channel is
+// workgroup uniform and its 27 weights and coefficients live in SGPRs
+template <bool PACKED>
 __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
-    __shared__ float sh[8];
-    const int nc = blockIdx.y, c = nc % a.C;
-    const int chunk = blockIdx.x % a.nchunks, pb = blockIdx.x / a.nchunks;
-    const int p = pb * 256 + threadIdx.x;
     const int Ho = a.Ho, Wo = a.Wo, Hi = a.Hi, Wi = a.Wi, T = a.T;
-    const bool ok = p < Ho * Wo;
+    const int chunk = blockIdx.x % a.nchunks, pb = blockIdx.x / a.nchunks;
+    // big planes: one (n,c) per blockIdx.y, 256 positions per workgroup; small planes (<= 128 positions): CPB channels
+    // per workgroup so that the lanes stay busy (a 7x7 plane would fill 49 of 256 threads)
+    const int cslot = PACKED ? threadIdx.x / a.PB : 0;
+    const int p = PACKED ? threadIdx.x - cslot * a.PB : pb * 256 + threadIdx.x;
+    const int ncr = PACKED ? blockIdx.y * a.CPB + cslot : blockIdx.y;
+    const bool ok = (!PACKED || (cslot < a.CPB && ncr < a.NC)) && p < Ho * Wo;
+    const int nc = (!PACKED || ncr < a.NC) ? ncr : a.NC - 1, c = nc % a.C;
     const int i = ok ? p / Wo : 0, j = ok ? p - i * Wo : 0;
     const bool i1 = i + 1 < Ho, j1 = j + 1 < Wo;              // neighbours inside the gradient plane
     const bool r1 = 2 * i + 1 < Hi, c1 = 2 * j + 1 < Wi;      // odd row / column inside the input plane
@@ -495,12 +502,26 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
         }
     }
     if (a.A && a.gA) {
-        s1 = cfn_wave_sum(s1); s2 = cfn_wave_sum(s2);
-        if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s1; sh[4 + (threadIdx.x >> 6)] = s2; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            atomicAdd(&a.gA[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
-            atomicAdd(&a.gB[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
+        __shared__ float sh[8];
+        const int lane = threadIdx.x & 63;
+        if (PACKED) {      // per-channel runs inside each wave -> one fp64 atomic pair per run
+            const int key = ok ? cslot : -1 - (int)(threadIdx.x >> 6);
+            const int prev_key = __shfl_up(key, 1, 64);
+            const bool head = ok && (lane == 0 || prev_key != key);
+            const float q1 = seg_wave_sum(s1, key, lane);
+            const float q2 = seg_wave_sum(s2, key, lane);
+            if (head) {
+                atomicAdd(&a.gA[nc], (double)q1);
+                atomicAdd(&a.gB[nc], (double)q2);
+            }
+        } else {           // one channel per workgroup: ONE atomic pair per workgroup (same-address fp64 atomics serialise)
+            s1 = cfn_wave_sum(s1); s2 = cfn_wave_sum(s2);
+            if (lane == 0) { sh[threadIdx.x >> 6] = s1; sh[4 + (threadIdx.x >> 6)] = s2; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                atomicAdd(&a.gA[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
+                atomicAdd(&a.gB[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
+            }
         }
     }
 }
@@ -667,13 +688,18 @@ extern "C" int cfn_dwconv3d_bwd_data(const float* gy, const float* y, const doub
         DwS2Args a = {};
         a.gy = gy; a.y = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.w = w; a.x = x; a.A = A; a.B = B; a.gx = gx;
         a.gA = gA; a.gB = gB; a.C = C; a.T = T; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.act = act;
-        CFN_REQUIRE((long)N * C <= 65535, "cfn_dwconv3d_bwd_data: N*C exceeds grid.y");
+        a.NC = N * C;
+        a.PB = Ho * Wo;
+        a.CPB = a.PB <= 128 ? 256 / a.PB : 1;
         a.pblocks = cfn_cdiv((long)Ho * Wo, 256);
+        const int ygrid = cfn_cdiv(a.NC, a.CPB);
+        CFN_REQUIRE(ygrid <= 65535, "cfn_dwconv3d_bwd_data: N*C exceeds grid.y");
         int TT = 64;
-        while (TT > 8 && (long)N * C * a.pblocks * cfn_cdiv(T, TT) < 2048) TT >>= 1;
+        while (TT > 8 && (long)ygrid * a.pblocks * cfn_cdiv(T, TT) < 2048) TT >>= 1;
         a.TT = TT > T ? T : TT;
         a.nchunks = cfn_cdiv(T, a.TT);
-        hipLaunchKernelGGL(dw3d_dgrad_s2_kernel, dim3(a.pblocks * a.nchunks, N * C), dim3(256), 0, st, a);
+        if (a.CPB > 1) hipLaunchKernelGGL(dw3d_dgrad_s2_kernel<true>, dim3(a.pblocks * a.nchunks, ygrid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(dw3d_dgrad_s2_kernel<false>, dim3(a.pblocks * a.nchunks, ygrid), dim3(256), 0, st, a);
         return cfn_check_launch("dwconv3d_bwd_data_s2");
     }
     DwArgs a = {};
