@@ -575,32 +575,32 @@ def interp1d(x, y, xnew):
 
 
 class _TimeResize(Function):
-    """linear resize along dim 2, align_corners=True."""
+    """linear resize along dim 2 (F.interpolate mode='linear', either align_corners convention)."""
 
     @staticmethod
-    def forward(ctx, x, L):
+    def forward(ctx, x, L, align_corners):
         x = check(x).contiguous()
         BC = x.shape[0] * x.shape[1]
         Kin = x.shape[2]
         P = x[0, 0, 0].numel()
         out = torch.empty(tuple(x.shape[:2]) + (L,) + tuple(x.shape[3:]), dtype=torch.float32, device=x.device)
-        call('cfn_time_resize_fwd', x, out, BC, Kin, L, P)
-        ctx.meta = (tuple(x.shape), L)
+        call('cfn_time_resize_fwd', x, out, BC, Kin, L, P, int(bool(align_corners)))
+        ctx.meta = (tuple(x.shape), L, int(bool(align_corners)))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        shape, L = ctx.meta
+        shape, L, ac = ctx.meta
         gx = torch.empty(shape, dtype=torch.float32, device=g.device)
         P = 1
         for d in shape[3:]:
             P *= d
-        call('cfn_time_resize_bwd', g.contiguous(), gx, shape[0] * shape[1], shape[2], L, P)
-        return gx, None
+        call('cfn_time_resize_bwd', g.contiguous(), gx, shape[0] * shape[1], shape[2], L, P, ac)
+        return gx, None, None
 
 
-def time_resize(x, L):
-    return _TimeResize.apply(x, L)
+def time_resize(x, L, align_corners=True):
+    return _TimeResize.apply(x, L, align_corners)
 
 
 def _geom(kernel, stride, padding):

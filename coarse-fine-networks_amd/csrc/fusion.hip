@@ -1,5 +1,5 @@
 // Coarse-stream specific kernels:
-//   * data gradient of the dense (Grid Pool saliency) convolutions, gather form;
+//   * data gradient of the dense (Grid Pool saliency) convolutions, gather form by stride-parity class;
 //   * the Multi-stage Fusion temporal-alignment gather of RewightLayer (x3d_coarse.py:199-226), evaluated at the
 //     fine features' native 7x7 resolution: the reference first up-samples them with adaptive_max_pool2d
 //     (7 -> 56/28/14: each output cell copies exactly one input cell) and materialises a
@@ -17,49 +17,63 @@ struct DenseBwdArgs {
     int Cin, Cout, Ti, Hi, Wi, To, Ho, Wo, kT, kH, kW, sT, sH, sW, pT, pH, pW, act;
 };
 
+// Threads are grouped by stride-parity class (blockIdx.z = (it%sT, ih%sH, iw%sW)): inside a class every lane sees the
+// same set of contributing taps (kt = k0, k0+sT, ...), so there is no divergence and no modulo test in the loops, and
+// consecutive lanes read consecutive output columns of g'.  Weights of this input channel sit in LDS.
 __global__ __launch_bounds__(256) void conv3d_dense_bwd_data_kernel(const DenseBwdArgs a) {
     __shared__ float sh[8];
-    extern __shared__ float sg[];            // gs[Cout] | 2gq[Cout]
+    extern __shared__ float sg[];            // gs[Cout] | 2gq[Cout] | w[Cout][KV] of this input channel
     const int nci = blockIdx.y, n = nci / a.Cin, ci = nci - n * a.Cin;
+    const int KV = a.kT * a.kH * a.kW;
+    float* sw = sg + 2 * a.Cout;
     for (int co = threadIdx.x; co < a.Cout; co += 256) {
         sg[co] = a.gs ? (float)a.gs[(long)n * a.Cout + co] : 0.0f;
         sg[a.Cout + co] = (a.gq && a.y) ? 2.0f * (float)a.gq[(long)n * a.Cout + co] : 0.0f;
     }
+    for (int e = threadIdx.x; e < a.Cout * KV; e += 256) {
+        const int co = e / KV, tap = e - co * KV;
+        sw[e] = a.w[((long)co * a.Cin + ci) * KV + tap];
+    }
     __syncthreads();
+    // parity class and the lattice of input positions it owns
+    int cls = blockIdx.z;
+    const int cw = cls % a.sW; cls /= a.sW;
+    const int ch = cls % a.sH;
+    const int ct = cls / a.sH;
+    const int nw = (a.Wi - cw + a.sW - 1) / a.sW, nh = (a.Hi - ch + a.sH - 1) / a.sH, nt = (a.Ti - ct + a.sT - 1) / a.sT;
     const long pin = (long)a.Ti * a.Hi * a.Wi, po = (long)a.To * a.Ho * a.Wo;
-    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    const long pc = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = nw > 0 && nh > 0 && nt > 0 && pc < (long)nt * nh * nw;
     float s1 = 0.f, s2 = 0.f;
-    if (p < pin) {
-        const int iw = (int)(p % a.Wi), ih = (int)((p / a.Wi) % a.Hi), it = (int)(p / ((long)a.Wi * a.Hi));
-        const int KV = a.kT * a.kH * a.kW;
+    if (ok) {
+        const int jw = (int)(pc % nw), jh = (int)((pc / nw) % nh), jt = (int)(pc / ((long)nw * nh));
+        const int iw = cw + jw * a.sW, ih = ch + jh * a.sH, it = ct + jt * a.sT;
+        // first tap of each axis that lands on an output sample: (i + p - k) % s == 0
+        const int kt0 = (ct + a.pT) % a.sT, kh0 = (ch + a.pH) % a.sH, kw0 = (cw + a.pW) % a.sW;
         float da = 0.f;
-        for (int kt = 0; kt < a.kT; ++kt) {
-            const int tt = it + a.pT - kt;
-            if (tt < 0 || tt % a.sT) continue;
-            const int to = tt / a.sT;
-            if (to >= a.To) continue;
-            for (int kh = 0; kh < a.kH; ++kh) {
-                const int hh = ih + a.pH - kh;
-                if (hh < 0 || hh % a.sH) continue;
-                const int oh = hh / a.sH;
-                if (oh >= a.Ho) continue;
-                for (int kw = 0; kw < a.kW; ++kw) {
-                    const int ww = iw + a.pW - kw;
-                    if (ww < 0 || ww % a.sW) continue;
-                    const int ow = ww / a.sW;
-                    if (ow >= a.Wo) continue;
+        for (int kt = kt0; kt < a.kT; kt += a.sT) {
+            const int to = (it + a.pT - kt) / a.sT;
+            if (it + a.pT - kt < 0 || to >= a.To) continue;
+            for (int kh = kh0; kh < a.kH; kh += a.sH) {
+                const int oh = (ih + a.pH - kh) / a.sH;
+                if (ih + a.pH - kh < 0 || oh >= a.Ho) continue;
+                for (int kw = kw0; kw < a.kW; kw += a.sW) {
+                    const int ow = (iw + a.pW - kw) / a.sW;
+                    if (iw + a.pW - kw < 0 || ow >= a.Wo) continue;
                     const long oq = ((long)to * a.Ho + oh) * a.Wo + ow;
                     const int tap = (kt * a.kH + kh) * a.kW + kw;
+                    const float* gyp = a.gy + (long)n * a.Cout * po + oq;
+                    const float* yp = a.y ? a.y + (long)n * a.Cout * po + oq : nullptr;
+#pragma unroll 4
                     for (int co = 0; co < a.Cout; ++co) {
-                        const long o = ((long)n * a.Cout + co) * po + oq;
-                        float g = a.gy[o] + sg[co];
-                        if (a.y) g = fmaf(a.y[o], sg[a.Cout + co], g);
-                        da = fmaf(a.w[((long)co * a.Cin + ci) * KV + tap], g, da);
+                        float g = gyp[(long)co * po] + sg[co];
+                        if (yp) g = fmaf(yp[(long)co * po], sg[a.Cout + co], g);
+                        da = fmaf(sw[co * KV + tap], g, da);
                     }
                 }
             }
         }
-        const long o = (long)nci * pin + p;
+        const long o = (long)nci * pin + ((long)it * a.Hi + ih) * a.Wi + iw;
         if (a.A) {
             const float xa = a.A[nci], xb = a.B[nci], xv = a.x[o];
             const float dz = da * cfn_act_grad_rt(fmaf(xv, xa, xb), a.act);
@@ -100,7 +114,12 @@ extern "C" int cfn_conv3d_dense_bwd_data(const float* gy, const float* y, const 
     const long pin = (long)T * Hi * Wi;
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_STEM, st, 4.0 * N * ((double)Cin * pin * 2 + (double)Cout * a.To * a.Ho * a.Wo));
-    hipLaunchKernelGGL(conv3d_dense_bwd_data_kernel, dim3(cfn_cdiv(pin, 256), N * Cin), dim3(256), 2 * Cout * sizeof(float), st, a);
+    const int ncls = a.sT * a.sH * a.sW;
+    const long pcls = (long)cfn_cdiv(T, a.sT) * cfn_cdiv(Hi, a.sH) * cfn_cdiv(Wi, a.sW);     // largest class
+    const size_t lds = ((size_t)2 * Cout + (size_t)Cout * a.kT * a.kH * a.kW) * sizeof(float);
+    CFN_REQUIRE(ncls <= 64 && lds <= 60 * 1024, "cfn_conv3d_dense_bwd_data: stride / weight slice too large");
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv3d_dense_bwd_data_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(conv3d_dense_bwd_data_kernel, dim3(cfn_cdiv(pcls, 256), N * Cin, ncls), dim3(256), lds, st, a);
     return cfn_check_launch("conv3d_dense_bwd_data");
 }
 

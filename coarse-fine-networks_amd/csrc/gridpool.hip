@@ -147,12 +147,20 @@ __global__ void interp1d_bwd_kernel(const float* __restrict__ g, const float* __
     if (gq) atomicAdd(&gq[(long)(qrow ? b : 0) * Pq + j], gv * slope);
 }
 
-// ---- temporal linear resize, align_corners=True (F.interpolate 'linear' x3d_coarse.py:725 and the
-// t-axis of 'trilinear' :449 when h,w keep their size) -------------------------------------------
-__device__ __forceinline__ void resize_src(int j, int Kin, int Lout, int& i0, int& i1, float& l0, float& l1) {
+// ---- temporal linear resize: align_corners=True (F.interpolate 'linear' x3d_coarse.py:725 and the t-axis of
+// 'trilinear' :449 when h,w keep their size) or half-pixel centres (align_corners=False: the loss upsampling of
+// train_coarse_fineFEAT.py:226) -- ATen's area_pixel_compute_scale / _source_index in the same operation order
+__device__ __forceinline__ void resize_src(int j, int Kin, int Lout, int ac, int& i0, int& i1, float& l0, float& l1) {
 #pragma clang fp contract(off)
-    const float scale = Lout > 1 ? (float)(Kin - 1) / (float)(Lout - 1) : 0.0f;   // ATen area_pixel_compute_scale
-    const float src = scale * (float)j;
+    float src;
+    if (ac) {
+        const float scale = Lout > 1 ? (float)(Kin - 1) / (float)(Lout - 1) : 0.0f;
+        src = scale * (float)j;
+    } else {
+        const float scale = (float)Kin / (float)Lout;
+        src = fmaf(scale, (float)j + 0.5f, -0.5f);   // ATen's CPU build contracts this expression into one FMA (checked
+        if (src < 0.0f) src = 0.0f;                  // against F.interpolate: 2e-7 with, 1e-5 without)
+    }
     i0 = (int)src;
     i1 = i0 + (i0 < Kin - 1 ? 1 : 0);
     l1 = src - (float)i0;
@@ -161,14 +169,14 @@ __device__ __forceinline__ void resize_src(int j, int Kin, int Lout, int& i0, in
 
 // one thread per output element (bc, j, p), p fastest
 __global__ __launch_bounds__(256) void time_resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int Kin,
-                                                              int Lout, long P, long total) {
+                                                              int Lout, long P, long total, int ac) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const long p = e % P, r = e / P;
     const int j = (int)(r % Lout);
     const long bc = r / Lout;
     int i0, i1; float l0, l1;
-    resize_src(j, Kin, Lout, i0, i1, l0, l1);
+    resize_src(j, Kin, Lout, ac, i0, i1, l0, l1);
     const float* xp = x + bc * Kin * P + p;
     out[e] = l0 * xp[(long)i0 * P] + l1 * xp[(long)i1 * P];
 }
@@ -176,14 +184,20 @@ __global__ __launch_bounds__(256) void time_resize_fwd_kernel(const float* __res
 // one thread per input element (bc, k, p): gathers the few outputs j whose source interval touches k
 // (src(j) = j*(Kin-1)/(Lout-1) in [k-1, k+1]  =>  j in [(k-1)/scale, (k+1)/scale], checked exactly)
 __global__ __launch_bounds__(256) void time_resize_bwd_kernel(const float* __restrict__ g, float* __restrict__ gx, int Kin,
-                                                              int Lout, long P, long total) {
+                                                              int Lout, long P, long total, int ac) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const long p = e % P, r = e / P;
     const int k = (int)(r % Kin);
     const long bc = r / Kin;
     int jlo = 0, jhi = Lout - 1;
-    if (Kin > 1 && Lout > 1) {
+    if (!ac) {              // src(j) = (j + 0.5) * Kin / Lout - 0.5 (clamped at 0) within [k-1, k+1]
+        const double inv = (double)Lout / (double)Kin;
+        jlo = k == 0 ? 0 : (int)floor((k - 0.5) * inv - 0.5) - 1;
+        jhi = (int)ceil((k + 1.5) * inv - 0.5) + 1;
+        if (jlo < 0) jlo = 0;
+        if (jhi > Lout - 1) jhi = Lout - 1;
+    } else if (Kin > 1 && Lout > 1) {
         const double inv = (double)(Lout - 1) / (double)(Kin - 1);
         jlo = (int)floor((k - 1) * inv) - 1;
         jhi = (int)ceil((k + 1) * inv) + 1;
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(256) void time_resize_bwd_kernel(const float* __res
     float acc = 0.f;
     for (int j = jlo; j <= jhi; ++j) {
         int i0, i1; float l0, l1;
-        resize_src(j, Kin, Lout, i0, i1, l0, l1);
+        resize_src(j, Kin, Lout, ac, i0, i1, l0, l1);
         if (i0 != k && i1 != k) continue;
         const float gv = g[(bc * Lout + j) * P + p];
         if (i0 == k) acc = fmaf(gv, l0, acc);
@@ -257,16 +271,18 @@ extern "C" int cfn_interp1d_bwd(const float* g, const float* x, const float* y, 
     return cfn_check_launch("interp1d_bwd");
 }
 
-extern "C" int cfn_time_resize_fwd(const float* x, float* out, long BC, int Kin, int Lout, long P, void* stream) {
+extern "C" int cfn_time_resize_fwd(const float* x, float* out, long BC, int Kin, int Lout, long P, int align_corners,
+                                   void* stream) {
     CFN_REQUIRE(x && out && Kin > 0 && Lout > 0 && BC > 0 && P > 0, "cfn_time_resize_fwd: bad argument");
     const long total = BC * Lout * P;
-    hipLaunchKernelGGL(time_resize_fwd_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out, Kin, Lout, P, total);
+    hipLaunchKernelGGL(time_resize_fwd_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out, Kin, Lout, P, total, align_corners);
     return cfn_check_launch("time_resize_fwd");
 }
 
-extern "C" int cfn_time_resize_bwd(const float* g, float* gx, long BC, int Kin, int Lout, long P, void* stream) {
+extern "C" int cfn_time_resize_bwd(const float* g, float* gx, long BC, int Kin, int Lout, long P, int align_corners,
+                                   void* stream) {
     CFN_REQUIRE(g && gx && Kin > 0 && Lout > 0 && BC > 0 && P > 0, "cfn_time_resize_bwd: bad argument");
     const long total = BC * Kin * P;
-    hipLaunchKernelGGL(time_resize_bwd_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, g, gx, Kin, Lout, P, total);
+    hipLaunchKernelGGL(time_resize_bwd_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, g, gx, Kin, Lout, P, total, align_corners);
     return cfn_check_launch("time_resize_bwd");
 }

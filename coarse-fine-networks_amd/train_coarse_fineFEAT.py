@@ -74,7 +74,11 @@ def _mean_ap(apm):
 
 def detection_loss(per_frame_logits, labels, masks, group=None):
     """train_coarse_fineFEAT.py:226-240; loc-loss normaliser over the GLOBAL batch (see train_fine.detection_loss)"""
-    logits = F.interpolate(per_frame_logits, labels.size(2), mode='linear')
+    if per_frame_logits.is_cuda:   # ATen's upsample_linear1d backward is a 17 ms atomic scatter at batch 16: own kernels
+        from cfn_hip import ops
+        logits = ops.time_resize(per_frame_logits, labels.size(2), False)
+    else:
+        logits = F.interpolate(per_frame_logits, labels.size(2), mode='linear')
     probs = torch.sigmoid(logits) * masks.unsqueeze(1)
     cls_loss = F.binary_cross_entropy(torch.max(probs, dim=2)[0], torch.max(labels, dim=2)[0])
     world = torch.distributed.get_world_size(group) if torch.distributed.is_initialized() else 1

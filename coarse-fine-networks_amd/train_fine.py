@@ -64,9 +64,9 @@ def detection_loss(per_frame_logits, labels, masks, align_corners=True, group=No
     ``loc_loss`` is normalised by the GLOBAL sum(masks) and multiplied by the world size, so that the
     average of the ranks' gradients equals the gradient of the reference's gathered-batch loss."""
     tl = labels.size(2)
-    if align_corners and per_frame_logits.is_cuda:
+    if per_frame_logits.is_cuda:
         from cfn_hip import ops
-        logits = ops.time_resize(per_frame_logits, tl)          # = F.interpolate(mode='linear', align_corners=True)
+        logits = ops.time_resize(per_frame_logits, tl, align_corners)   # = F.interpolate(mode='linear', align_corners=...)
     else:
         logits = F.interpolate(per_frame_logits, tl, mode='linear', align_corners=align_corners)
     probs = torch.sigmoid(logits) * masks.unsqueeze(1)

@@ -163,10 +163,11 @@ int cfn_interp1d_fwd(const float* x, const float* y, const float* xnew, float* y
 int cfn_interp1d_bwd(const float* g, const float* x, const float* y, const float* xnew, const long* ind, float* gx, float* gy,
                      float* gq, int B, int N, int Pq, int xrow, int yrow, int qrow, void* stream);
 
-/* ---- linear resize along t, align_corners=True: F.interpolate x3d_coarse.py:725 (and the t axis of :449).
+/* ---- linear resize along t: F.interpolate(mode='linear') x3d_coarse.py:725, the t axis of :449 (align_corners=1) and
+ * the loss upsampling train_coarse_fineFEAT.py:226 / train_fine.py:204 (align_corners=0, half-pixel centres).
  * x (BC,Kin,P) -> out (BC,Lout,P) ---- */
-int cfn_time_resize_fwd(const float* x, float* out, long BC, int Kin, int Lout, long P, void* stream);
-int cfn_time_resize_bwd(const float* g, float* gx, long BC, int Kin, int Lout, long P, void* stream);
+int cfn_time_resize_fwd(const float* x, float* out, long BC, int Kin, int Lout, long P, int align_corners, void* stream);
+int cfn_time_resize_bwd(const float* g, float* gx, long BC, int Kin, int Lout, long P, int align_corners, void* stream);
 
 #ifdef __cplusplus
 }

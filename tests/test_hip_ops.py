@@ -309,6 +309,21 @@ def test_time_resize(shape, L):
     assert relerr(xg.grad, xc.grad) <= 1e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,L', [((2, 7, 16), 160), ((3, 157, 64), 640), ((1, 2, 5), 3), ((1, 3, 9), 9)])
+def test_time_resize_half_pixel(shape, L):
+    """align_corners=False: the loss upsampling of train_coarse_fineFEAT.py:226 (ATen upsample_linear1d)"""
+    x = rnd(1, *shape)
+    xc, xg = x.clone().requires_grad_(True), x.clone().to(DEV).requires_grad_(True)
+    yc = F.interpolate(xc, L, mode='linear')
+    yg = ops().time_resize(xg, L, False)
+    assert maxdiff(yg, yc) <= 1e-6
+    r = rnd(2, *yc.shape)
+    (yc * r).sum().backward()
+    (yg * r.to(DEV)).sum().backward()
+    assert relerr(xg.grad, xc.grad) <= 1e-5
+
+
 def test_ops_refuse_cpu_tensors():
     """the product path has no CPU fallback"""
     with pytest.raises(RuntimeError):
