@@ -38,9 +38,12 @@ def init_from_env(backend=None):
 class GradReducer(object):
     """Bucketed, backward-overlapped gradient averaging for a replica's parameters."""
 
-    def __init__(self, params, bucket_bytes=4 << 20, group=None):
+    def __init__(self, params, bucket_bytes=4 << 20, group=None, force=False):
+        """force=True registers the bucket hooks even for a single rank (the collective is then an identity): used by the
+        GPU test of the backward-overlapped path, which cannot have two ranks on a one-GPU box"""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = bool(force) and dist.is_initialized()
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []            # list of lists of params, in reverse registration order
         cur, size = [], 0
@@ -60,7 +63,7 @@ class GradReducer(object):
         self._inflight = []
         self._stream = None
         self._hooks = []
-        if self.world > 1:
+        if self.world > 1 or self.force:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -97,7 +100,7 @@ class GradReducer(object):
 
     def finish(self):
         """Call after backward(): waits for the collectives and writes the averaged gradients back."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         for bi, left in enumerate(self._pending):   # buckets whose params got no gradient this step
             if left != 0 and left != len(self.buckets[bi]):
