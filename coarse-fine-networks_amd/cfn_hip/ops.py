@@ -357,10 +357,14 @@ def bn_fold(s, q, gamma, beta, bufs, training, N, C, S, count, eps, momentum, se
 
 
 class _BnAddRelu(Function):
-    """out = relu(A*y + B + (Ar*res + Br)); Ar/Br None = plain residual."""
+    """out = relu(A*y + B + (Ar*res + Br)); Ar/Br None = plain residual.
+
+    split=True returns the output twice (two tensor objects over one storage): the caller hands one to the next
+    block's conv1 and the other to its residual input, so autograd delivers their gradients separately and the backward
+    kernel sums them on the fly instead of a 3-pass add kernel in between.  Nothing may write to either in place."""
 
     @staticmethod
-    def forward(ctx, y, A, B, res, Ar, Br):
+    def forward(ctx, y, A, B, res, Ar, Br, split):
         y, res = check(y).contiguous(), check(res).contiguous()
         N, C = y.shape[:2]
         vol = y[0, 0].numel()
@@ -368,25 +372,33 @@ class _BnAddRelu(Function):
         A, B, Ar, Br = _coef(A), _coef(B), _coef(Ar), _coef(Br)
         call('cfn_bn_add_relu_fwd', y, A, B, res, Ar, Br, out, N * C, vol)
         ctx.save_for_backward(y, A, res, Ar, out)
-        return out
+        if not split:
+            return out
+        alias = torch.empty(0, dtype=out.dtype, device=out.device).set_(out.untyped_storage(), out.storage_offset(),
+                                                                         out.shape, out.stride())
+        return out, alias
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, gout2=None):
         y, A, res, Ar, out = ctx.saved_tensors
         N, C = y.shape[:2]
         vol = y[0, 0].numel()
+        if gout is None:
+            gout, gout2 = gout2, None
+        if gout is None:
+            gout = torch.zeros_like(out)
         gy, gres = torch.empty_like(y), torch.empty_like(res)
         t3 = _arena.take(3 * N * C, y.device).view(3, N, C)
-        call('cfn_bn_add_relu_bwd', gout.contiguous(), out, y, A, res, Ar, gy, gres, t3[0], t3[1],
-             t3[2] if Ar is not None else None, N * C, vol)
+        call('cfn_bn_add_relu_bwd', gout.contiguous(), None if gout2 is None else gout2.contiguous(), out, y, A, res, Ar, gy,
+             gres, t3[0], t3[1], t3[2] if Ar is not None else None, N * C, vol)
         gA, gB = t3[0], t3[1]
         gAr = t3[2] if Ar is not None else None
         gBr = gB if Ar is not None else None
-        return gy, gA, gB, gres, gAr, gBr
+        return gy, gA, gB, gres, gAr, gBr, None
 
 
-def bn_add_relu(y, A, B, res, Ar=None, Br=None):
-    return _BnAddRelu.apply(y, A, B, res, Ar, Br)
+def bn_add_relu(y, A, B, res, Ar=None, Br=None, split=False):
+    return _BnAddRelu.apply(y, A, B, res, Ar, Br, split)
 
 
 class _AffineAct(Function):

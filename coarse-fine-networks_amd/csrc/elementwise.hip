@@ -51,9 +51,12 @@ __global__ __launch_bounds__(256) void bn_add_relu_fwd_kernel(const float* __res
     }
 }
 
-// g = gout * (out > 0);  gy = g*A;  gres = g*Ar;  gA += sum g*y;  gB += sum g;  gAr += sum g*res
+// g = (gout [+ gout2]) * (out > 0);  gy = g*A;  gres = g*Ar;  gA += sum g*y;  gB += sum g;  gAr += sum g*res
+// gout2 (optional): the block output feeds two consumers (next conv1 and next residual); their two gradients are
+// summed here on the fly instead of by a separate 3-pass add kernel
 template <int VEC>
-__global__ __launch_bounds__(256) void bn_add_relu_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ out,
+__global__ __launch_bounds__(256) void bn_add_relu_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ gout2,
+                                                              const float* __restrict__ out,
                                                               const float* __restrict__ y, const double* __restrict__ A,
                                                               const float* __restrict__ res, const double* __restrict__ Ar,
                                                               float* __restrict__ gy, float* __restrict__ gres,
@@ -69,7 +72,8 @@ __global__ __launch_bounds__(256) void bn_add_relu_bwd_kernel(const float* __res
     for (int k = 0; k < EW_ITEMS; ++k, i += 256 * VEC) {
         if (i >= vol) break;
         if (VEC == 4) {
-            const f4v go = *reinterpret_cast<const f4v*>(gout + base + i);
+            f4v go = *reinterpret_cast<const f4v*>(gout + base + i);
+            if (gout2) go += *reinterpret_cast<const f4v*>(gout2 + base + i);
             const f4v ov = *reinterpret_cast<const f4v*>(out + base + i);
             const f4v yv = *reinterpret_cast<const f4v*>(y + base + i);
             f4v g;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void bn_add_relu_bwd_kernel(const float* __res
             *reinterpret_cast<f4v*>(gy + base + i) = g * a;
             *reinterpret_cast<f4v*>(gres + base + i) = g * ar;
         } else {
-            const float g = out[base + i] > 0.f ? gout[base + i] : 0.f;
+            const float g = out[base + i] > 0.f ? gout[base + i] + (gout2 ? gout2[base + i] : 0.f) : 0.f;
             acc[0] = fmaf(g, y[base + i], acc[0]);
             acc[1] += g;
             if (Ar) acc[2] = fmaf(g, res[base + i], acc[2]);
@@ -296,18 +300,18 @@ extern "C" int cfn_bn_add_relu_fwd(const float* y, const double* A, const double
     return cfn_check_launch("bn_add_relu_fwd");
 }
 
-extern "C" int cfn_bn_add_relu_bwd(const float* gout, const float* out, const float* y, const double* A, const float* res,
+extern "C" int cfn_bn_add_relu_bwd(const float* gout, const float* gout2, const float* out, const float* y, const double* A, const float* res,
                                    const double* Ar, float* gy, float* gres, double* gA, double* gB, double* gAr, long NC,
                                    long vol, void* stream) {
     CFN_REQUIRE(gout && out && y && A && gy && gres && gA && gB, "cfn_bn_add_relu_bwd: null tensor");
     CFN_REQUIRE(Ar == nullptr || (res != nullptr && gAr != nullptr), "cfn_bn_add_relu_bwd: Ar needs res and gAr");
     CFN_NC_CHECK(NC);
     hipStream_t st = (hipStream_t)stream;
-    CfnProfScope prof(CFN_K_ELEMWISE, st, (Ar ? 24.0 : 20.0) * NC * vol);
-    if (ew_vec4(vol, gout, out, y, res, gy, gres))
-        hipLaunchKernelGGL(bn_add_relu_bwd_kernel<4>, ew_grid(vol, NC, 4), dim3(256), 0, st, gout, out, y, A, res, Ar, gy, gres, gA, gB, gAr, vol);
+    CfnProfScope prof(CFN_K_ELEMWISE, st, ((Ar ? 24.0 : 20.0) + (gout2 ? 4.0 : 0.0)) * NC * vol);
+    if (ew_vec4(vol, gout, out, y, res, gy, gres) && (((uintptr_t)gout2) & 15) == 0)
+        hipLaunchKernelGGL(bn_add_relu_bwd_kernel<4>, ew_grid(vol, NC, 4), dim3(256), 0, st, gout, gout2, out, y, A, res, Ar, gy, gres, gA, gB, gAr, vol);
     else
-        hipLaunchKernelGGL(bn_add_relu_bwd_kernel<1>, ew_grid(vol, NC, 1), dim3(256), 0, st, gout, out, y, A, res, Ar, gy, gres, gA, gB, gAr, vol);
+        hipLaunchKernelGGL(bn_add_relu_bwd_kernel<1>, ew_grid(vol, NC, 1), dim3(256), 0, st, gout, gout2, out, y, A, res, Ar, gy, gres, gA, gB, gAr, vol);
     return cfn_check_launch("bn_add_relu_bwd");
 }
 

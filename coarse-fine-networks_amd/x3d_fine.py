@@ -154,6 +154,9 @@ class Bottleneck(nn.Module):
             self.sigmoid = nn.Sigmoid()
         self.downsample = downsample
         self.stride = stride
+        # set by ResNet._make_layer when the next module is an identity-shortcut Bottleneck: the output is then
+        # returned as a pair so that its two gradients (conv1 data gradient, residual) meet inside the tail kernel
+        self.split_out = False
 
     def round_width(self, width, multiplier=0.0625, min_width=8, divisor=8):
         if not multiplier:
@@ -166,6 +169,8 @@ class Bottleneck(nn.Module):
         return int(width_out)
 
     def forward(self, x):
+        # a (x_for_conv1, x_for_residual) pair: the previous block handed out its output twice (see split_out below)
+        x, x_res = x if isinstance(x, tuple) else (x, x)
         xr, xa, xb, xact = _unpack(x)
         n = xr.shape[0]
         tr = self.training
@@ -185,9 +190,9 @@ class Bottleneck(nn.Module):
                 raise NotImplementedError("shortcut_type 'A' is not on the accelerated path")
             yd, sd, qd = ops.pwconv(xr, self.downsample[0].weight, xa, xb, xact, self.stride, stats=tr)
             Ad, Bd = self.downsample[1].fold(sd, qd, _count(yd), n)
-            return ops.bn_add_relu(y3, A3, B3, yd, Ad, Bd)
-        res = x.materialize() if isinstance(x, Deferred) else x
-        return ops.bn_add_relu(y3, A3, B3, res)
+            return ops.bn_add_relu(y3, A3, B3, yd, Ad, Bd, split=self.split_out)
+        res = x_res.materialize() if isinstance(x_res, Deferred) else x_res
+        return ops.bn_add_relu(y3, A3, B3, res, split=self.split_out)
 
 
 class ResNet(nn.Module):
@@ -250,6 +255,8 @@ class ResNet(nn.Module):
                                 t_downsample=self.t_downsample))
             self.index += 1
         self.index = 0
+        for blk in layers[:-1]:
+            blk.split_out = True
         return nn.Sequential(*layers)
 
     def replace_logits(self, n_classes):

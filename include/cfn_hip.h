@@ -118,10 +118,12 @@ int cfn_fusion_gather_bwd(const float* gz, const float* z, const float* den, con
                           float* gx, float* dw, int B, int C, int Tf, int K, int P, void* stream);
 
 /* ---- block tail  out = relu(A y + B + (Ar res + Br)) : bn3 + (downsample bn) + `out += residual` + relu,
- * x3d_fine.py:167-173.  Ar/Br NULL = identity shortcut.  vol = T*H*W, NC = N*C. ---- */
+ * x3d_fine.py:167-173.  Ar/Br NULL = identity shortcut.  vol = T*H*W, NC = N*C.  bwd: gout2 (may be NULL) is a second
+ * upstream gradient of the same output (the block output feeds the next conv1 AND the next residual); it is added to
+ * gout on the fly. ---- */
 int cfn_bn_add_relu_fwd(const float* y, const double* A, const double* B, const float* res, const double* Ar, const double* Br,
                         float* out, long NC, long vol, void* stream);
-int cfn_bn_add_relu_bwd(const float* gout, const float* out, const float* y, const double* A, const float* res,
+int cfn_bn_add_relu_bwd(const float* gout, const float* gout2, const float* out, const float* y, const double* A, const float* res,
                         const double* Ar, float* gy, float* gres, double* gA, double* gB, double* gAr, long NC, long vol,
                         void* stream);
 

@@ -61,7 +61,7 @@ def test_grad_reducer_hooks_with_deferred_weight_casts():
     try:
         torch.manual_seed(0)
         net = train_fine.build_model(DEV, pretrained=None)
-        net.train(True)
+        net.train(False)   # running-statistics BN: well conditioned gradients, so the two passes can be compared tightly
         x = torch.randn(1, 3, 8, 64, 64, device=DEV)
         labels = (torch.rand(1, 157, 80, device=DEV) < 0.1).float()
         masks = torch.ones(1, 80, device=DEV)
@@ -80,13 +80,12 @@ def test_grad_reducer_hooks_with_deferred_weight_casts():
         net.load_state_dict(state)                       # same running statistics for the second pass
         hooked = grads(cdist.GradReducer(net.parameters(), bucket_bytes=1 << 18, force=True))
         assert len(plain) == len(hooked) > 200
-        # whole-net train-mode gradients are ill-conditioned in fp32: two plain runs already differ by
-        # ~1e-3 through the order of the fp64 atomics; a gradient read before its cast would be garbage / non finite
+        # a gradient read before its lazy cast would be garbage / non finite
         fa, fb = torch.cat([a.flatten() for a in plain]), torch.cat([b.flatten() for b in hooked])
         assert torch.isfinite(fb).all()
-        assert float((fa - fb).norm() / fa.norm()) <= 2e-2
+        assert float((fa - fb).norm() / fa.norm()) <= 1e-4
         for a, b in zip(plain, hooked):
-            assert float((a - b).norm()) <= 0.1 * float(a.norm()) + 1e-4
+            assert float((a - b).norm()) <= 1e-3 * float(a.norm()) + 1e-6
     finally:
         if created:
             dist.destroy_process_group()

@@ -34,7 +34,7 @@ from collections import Counter
 cnt = Counter()
 for ev in prof.events():
     if ev.name in names:
-        st = [s for s in ev.stack if 'coarse-fine' in s or 'train_fine' in s or 'optim' in s][:2]
-        cnt[(ev.name, ' <- '.join(s.split('coarse-fine-networks_amd/')[-1] for s in st))] += 1
+        st = [s for s in ev.stack if '.py' in s and 'profiler' not in s][:3]
+        cnt[(ev.name, ' <- '.join(s.split('/')[-1][:48] for s in st))] += 1
 for (k, st), v in cnt.most_common(60):
     print('%5d %-18s %s' % (v, k, st))
