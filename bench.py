@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Headline benchmark: clips/sec (fwd + loss + bwd + SGD step) of x3d_fine X3D-M on synthetic
-Bx3x256x224x224 clips (B = 4 clips per GPU by default), one process per GPU, gradients all-reduced over RCCL.
+Bx3x256x224x224 clips (B = 8 clips per GPU by default), one process per GPU, gradients all-reduced over RCCL.
 
     python bench.py --gpus 1 --steps 8 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -64,7 +64,7 @@ def main():
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--frames', type=int, default=256)
-    ap.add_argument('--batch', type=int, default=4, help='clips per GPU per step')
+    ap.add_argument('--batch', type=int, default=8, help='clips per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-frames', type=int, default=128)
     args = ap.parse_args()
