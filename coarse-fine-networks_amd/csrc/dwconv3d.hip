@@ -240,7 +240,7 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     __syncthreads();   // zero fill + sA/sB visible
 
     const int f_first = t0 - 1, f_last = t1;   // input frames t0-1 .. t1 (inclusive)
-    if (MODE == DW_WGRAD) { load_g(t0); take_g(gro[0]); load_g(t0 + 1); }
+    if (MODE == DW_WGRAD) load_g(t0);   // consumed (rotated in) at the start of the first step
     // prime the pipeline: frame f_first staged in image 0, the next DEPTH frames in flight in registers
     if (frame_valid(f_first)) prefetch(f_first, pfA, pfA2);
     if (DEPTH == 2 && f_first + 1 <= f_last && frame_valid(f_first + 1)) prefetch(f_first + 1, pfB, pfB2);
@@ -253,28 +253,34 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     for (int i = 0; i < HS; ++i) xen[i] = 0.0f;
     // one frame step (ONE barrier): stage frame f+1 from `nx` into the other LDS image, refill `nx` with frame
     // f+1+DEPTH, compute frame f from image `par`, emit output frame f-1
+    // Inside a step every consumer of loads issued one step earlier comes BEFORE any new load is issued: the loads sit
+    // under (uniform) conditions, so the compiler can only wait with vmcnt(0) -- a wait placed after a fresh prefetch
+    // would expose a full HBM round trip in every frame (measured: 60-75 % of the step).
     auto step = [&](int f, int par, f4* nx, f4* nx2) {
         const bool fv = frame_valid(f);
-        if (f + 1 <= f_last) {
-            if (frame_valid(f + 1)) stage(nx, nx2, buf + (par ^ 1) * bufsz);
-            if (f + 1 + DEPTH <= f_last && frame_valid(f + 1 + DEPTH)) prefetch(f + 1 + DEPTH, nx, nx2);
-        }
-        const float* tbp = tb + par * bufsz;
-
-        // DGRAD epilogue operand: x of the frame that completes in this step was loaded one step ago (xen); the load
-        // for the next step's frame is issued here, a whole frame of work ahead of its use
-        const int to = f - 1;
+        const int to = f - 1;                                  // output frame completed by this step
         const bool emit = (to >= t0 && to < t1) && active;
+        // ---- consume ------------------------------------------------------------------------------------------
         float xe[HS];
         if (MODE == DW_DGRAD && a.A) {
 #pragma unroll
             for (int i = 0; i < HS; ++i) xe[i] = xen[i];
-            if (to + 1 >= t0 && to + 1 < t1 && active) {
-                const long o = (nc * T + to + 1) * plane_o + (long)hrow0 * Wo + wo;
-#pragma unroll
-                for (int i = 0; i < HS; ++i) xen[i] = a.xin[o + (long)i * Wo];
-            }
         }
+        if (MODE == DW_WGRAD) {
+#pragma unroll
+            for (int i = 0; i < HS; ++i) { gro[2][i] = gro[1][i]; gro[1][i] = gro[0][i]; }
+            take_g(gro[0]);                                    // g(f+1), loaded during the previous step
+        }
+        if (f + 1 <= f_last && frame_valid(f + 1)) stage(nx, nx2, buf + (par ^ 1) * bufsz);
+        // ---- issue --------------------------------------------------------------------------------------------
+        if (f + 1 + DEPTH <= f_last && frame_valid(f + 1 + DEPTH)) prefetch(f + 1 + DEPTH, nx, nx2);
+        if (MODE == DW_DGRAD && a.A && to + 1 >= t0 && to + 1 < t1 && active) {
+            const long o = (nc * T + to + 1) * plane_o + (long)hrow0 * Wo + wo;
+#pragma unroll
+            for (int i = 0; i < HS; ++i) xen[i] = a.xin[o + (long)i * Wo];
+        }
+        if (MODE == DW_WGRAD) load_g(f + 2);
+        const float* tbp = tb + par * bufsz;
 
         if (fv && active) {
 #pragma unroll
@@ -303,12 +309,7 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
             }
         }
 
-        if (MODE == DW_WGRAD) {
-#pragma unroll
-            for (int i = 0; i < HS; ++i) { gro[2][i] = gro[1][i]; gro[1][i] = gro[0][i]; }
-            take_g(gro[0]);
-            load_g(f + 3);
-        } else {
+        if (MODE != DW_WGRAD) {
             if (emit) {
                 const long o = (nc * T + to) * plane_o + (long)hrow0 * Wo + wo;
 #pragma unroll
@@ -575,8 +576,10 @@ static int dw_plan(DwArgs& a, int S, int mode, DwPlan& pl) {
     const int ipc64 = (a.IPCb + 63) / 64 * 64;
     pl.UNIW = a.IPCb >= 64 && ipc64 <= 256 && (ipc64 - a.IPCb) * 100 <= 15 * ipc64;
     a.IPCp = pl.UNIW ? ipc64 : a.IPCb;
-    // UNIW: 4-wave workgroups (several fit on a CU, barriers stay cheap); small planes: up to 8 waves
-    int CG = (pl.UNIW ? 256 : 512) / a.IPCp;
+    // UNIW: 4-wave workgroups (several fit on a CU, barriers stay cheap)
+    // small planes: up to 8 waves; the data gradient (most registers, two staged tensors) runs better as 4-wave
+    // workgroups, several of which fit on a CU (measured at 4 clips: 14x14 0.31 -> 0.25 ms, 7x7 0.25 -> 0.16 ms)
+    int CG = (pl.UNIW || mode == DW_DGRAD ? 256 : 512) / a.IPCp;
     if (CG < 1) CG = 1;
     if (CG > a.C) CG = a.C;
     if (CG > 128) CG = 128;
@@ -591,12 +594,12 @@ static int dw_plan(DwArgs& a, int S, int mode, DwPlan& pl) {
     a.CG = CG;
     a.ngroups = cfn_cdiv(a.C, CG);
     const long per_thread = ((long)CG * a.RIN * a.Wi + (long)VEC * threads - 1) / ((long)VEC * threads);
-    const int MAXLD = (VEC == 4 && per_thread <= 2) ? 2 : ((VEC == 4 && per_thread <= 4) ? 4 : 8);
+    const int MAXLD = (VEC == 4 && per_thread <= 2) ? 2 : (per_thread <= 4 ? 4 : 8);
     // frames per chunk: as long as possible while keeping >= ~6 workgroups per CU in the grid
     const long planes = (long)a.N * a.ngroups * a.nbands;
     // Whole rounds: resident workgroups per CU follow from the register budget of the variant (launch bounds),
     // so size the t-chunks such that the grid fills R full rounds of the chip (a 1.1-round grid costs 2 rounds).
-    const int per_cu = !pl.UNIW ? (threads > 256 ? 1 : 2) : (MAXLD == 8 ? 2 : (MAXLD == 4 ? 3 : (mode == DW_FWD ? 4 : 3)));
+    const int per_cu = !pl.UNIW ? (threads > 256 ? 1 : (mode == DW_DGRAD ? 4 : 2)) : (MAXLD == 8 ? 2 : (MAXLD == 4 ? 3 : (mode == DW_FWD ? 4 : 3)));
     const long slots = 256L * per_cu;
     int TT = a.T;
     for (int R = 1; R <= 8; ++R) {
@@ -628,11 +631,13 @@ static int dw_launch_hs(const DwArgs& a, const DwPlan& pl, hipStream_t st) {
         if (pl.VEC == 4 && pl.MAXLD == 2) CFN_DW_GO(4, 2, true);
         else if (pl.VEC == 4 && pl.MAXLD == 4) CFN_DW_GO(4, 4, true);
         else if (pl.VEC == 4) CFN_DW_GO(4, 8, true);
+        else if (pl.MAXLD == 4) CFN_DW_GO(1, 4, true);
         else CFN_DW_GO(1, 8, true);
     } else {
         if (pl.VEC == 4 && pl.MAXLD == 2) CFN_DW_GO(4, 2, false);
         else if (pl.VEC == 4 && pl.MAXLD == 4) CFN_DW_GO(4, 4, false);
         else if (pl.VEC == 4) CFN_DW_GO(4, 8, false);
+        else if (pl.MAXLD == 4) CFN_DW_GO(1, 4, false);
         else CFN_DW_GO(1, 8, false);
     }
 #undef CFN_DW_GO
