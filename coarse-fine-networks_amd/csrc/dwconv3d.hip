@@ -124,6 +124,30 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     const float* tb = buf + (c_local * RIN + gl * HS * S) * WP + (XO - 1) + wo * S;
     const long nc = (long)n * C + c;
 
+    // ---- buffer descriptors over this (sample, channel group): every global access of the frame loop is an
+    // UNCONDITIONAL buffer load / store whose per-lane offset is out of range when the access is not wanted (loads return
+    // 0, stores are dropped).  With no vector-memory instruction under a branch the compiler can count them and waits
+    // with vmcnt(N) for exactly the frame it needs instead of vmcnt(0), so the frames prefetched behind it stay in flight.
+    // (measured: wins for the float4 forward and the data gradient; the scalar-loader forward and the weight gradient,
+    // whose consumer needs the youngest loads anyway, are faster with plain predicated accesses)
+    constexpr bool UNC = MODE == DW_DGRAD || (MODE == DW_FWD && VEC == 4);
+    constexpr int OOB = 0x7ffffff0;
+    const long gi0 = ((long)n * C + c0) * T * plane_i, go0 = ((long)n * C + c0) * T * plane_o;
+    const unsigned span_i = (unsigned)((long)ncg * T * plane_i * 4), span_o = (unsigned)((long)ncg * T * plane_o * 4);
+    __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src + gi0), 0, span_i, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((MODE == DW_DGRAD && a.src2 ? a.src2 : a.src) + gi0), 0, span_i, 0x00020000);
+    // per-thread operands / results at output resolution: FWD/DGRAD dst, DGRAD xin, WGRAD gy / yout
+    const float* po1 = MODE == DW_WGRAD ? a.gy : (MODE == DW_DGRAD && a.xin ? a.xin : a.src);
+    const float* po2 = MODE == DW_WGRAD && a.yout ? a.yout : po1;
+    __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(po1 + go0), 0, span_o, 0x00020000);
+    __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(po2 + go0), 0, span_o, 0x00020000);
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((MODE == DW_WGRAD ? const_cast<float*>(a.src) : a.dst) + (MODE == DW_WGRAD ? gi0 : go0), 0,
+                                                                   MODE == DW_WGRAD ? 0u : span_o, 0x00020000);
+    const int ovo = active ? (int)(((long)c_local * T * plane_o + (long)hrow0 * Wo + wo) * 4) : OOB;   // this thread's first output
+    int relb[MAXLD];
+#pragma unroll
+    for (int k = 0; k < MAXLD; ++k) relb[k] = rel[k] >= 0 ? rel[k] * 4 : OOB;
+
     float wr[27];
     if (MODE != DW_WGRAD) {
 #pragma unroll
@@ -156,21 +180,35 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     f4 pfA[MAXLD], pfA2[MAXLD], pfB[DEPTH == 2 ? MAXLD : 1], pfB2[DEPTH == 2 ? MAXLD : 1];
     const bool two_src = (MODE == DW_DGRAD) && a.src2 != nullptr;
 
+    const int f_last_ = t1;                                   // last input frame of this chunk
     const bool simple_act = a.act == CFN_ACT_NONE || a.act == CFN_ACT_RELU;
     const float act_lo = a.act == CFN_ACT_RELU ? 0.0f : -__builtin_inff();
     auto frame_valid = [&](int f) { return f >= 0 && f < T; };
-    auto prefetch = [&](int f, f4* pf, f4* pf2) {
-        const long base = (((long)n * C + c0) * T + f) * plane_i;
+    typedef int __attribute__((ext_vector_type(4))) i4;
+    auto prefetch = [&](int f, f4* pf, f4* pf2) {             // UNC: always issues MAXLD loads per tensor
+        const bool fvd = frame_valid(f);
+        if (!UNC) {
+            if (!fvd || f > f_last_) return;
+            const long base = gi0 + (long)f * plane_i;
+#pragma unroll
+            for (int k = 0; k < MAXLD; ++k) {
+                if (rel[k] >= 0) {
+                    if (VEC == 4) pf[k] = *reinterpret_cast<const f4*>(a.src + base + rel[k]);
+                    else pf[k].x = a.src[base + rel[k]];
+                }
+            }
+            return;
+        }
+        const int so = fvd ? f * (int)plane_i * 4 : 0;
 #pragma unroll
         for (int k = 0; k < MAXLD; ++k) {
-            if (rel[k] >= 0) {
-                if (VEC == 4) {
-                    pf[k] = *reinterpret_cast<const f4*>(a.src + base + rel[k]);
-                    if (MODE == DW_DGRAD && two_src) pf2[k] = *reinterpret_cast<const f4*>(a.src2 + base + rel[k]);
-                } else {
-                    pf[k].x = a.src[base + rel[k]];
-                    if (MODE == DW_DGRAD && two_src) pf2[k].x = a.src2[base + rel[k]];
-                }
+            const int vo = fvd ? relb[k] : OOB;
+            if (VEC == 4) {
+                pf[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, so, 0));
+                if (MODE == DW_DGRAD && two_src) pf2[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs2, vo, so, 0));
+            } else {
+                pf[k].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, vo, so, 0));
+                if (MODE == DW_DGRAD && two_src) pf2[k].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, vo, so, 0));
             }
         }
     };
@@ -242,10 +280,10 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     const int f_first = t0 - 1, f_last = t1;   // input frames t0-1 .. t1 (inclusive)
     if (MODE == DW_WGRAD) load_g(t0);   // consumed (rotated in) at the start of the first step
     // prime the pipeline: frame f_first staged in image 0, the next DEPTH frames in flight in registers
-    if (frame_valid(f_first)) prefetch(f_first, pfA, pfA2);
-    if (DEPTH == 2 && f_first + 1 <= f_last && frame_valid(f_first + 1)) prefetch(f_first + 1, pfB, pfB2);
-    if (frame_valid(f_first)) stage(pfA, pfA2, buf);
-    if (f_first + DEPTH <= f_last && frame_valid(f_first + DEPTH)) prefetch(f_first + DEPTH, pfA, pfA2);
+    prefetch(f_first, pfA, pfA2);
+    if (DEPTH == 2) prefetch(f_first + 1, pfB, pfB2);
+    if (UNC || frame_valid(f_first)) stage(pfA, pfA2, buf);
+    prefetch(f_first + DEPTH, pfA, pfA2);
     __syncthreads();
 
     float xen[HS];   // DGRAD: forward input of the next frame to be emitted
@@ -271,13 +309,14 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
             for (int i = 0; i < HS; ++i) { gro[2][i] = gro[1][i]; gro[1][i] = gro[0][i]; }
             take_g(gro[0]);                                    // g(f+1), loaded during the previous step
         }
-        if (f + 1 <= f_last && frame_valid(f + 1)) stage(nx, nx2, buf + (par ^ 1) * bufsz);
-        // ---- issue --------------------------------------------------------------------------------------------
-        if (f + 1 + DEPTH <= f_last && frame_valid(f + 1 + DEPTH)) prefetch(f + 1 + DEPTH, nx, nx2);
-        if (MODE == DW_DGRAD && a.A && to + 1 >= t0 && to + 1 < t1 && active) {
-            const long o = (nc * T + to + 1) * plane_o + (long)hrow0 * Wo + wo;
+        if (UNC || (f + 1 <= f_last && frame_valid(f + 1))) stage(nx, nx2, buf + (par ^ 1) * bufsz);   // UNC: junk frames are never read
+        // ---- issue (unconditional) ----------------------------------------------------------------------------
+        prefetch(f + 1 + DEPTH, nx, nx2);
+        if (MODE == DW_DGRAD && a.A) {
+            const bool want = to + 1 >= t0 && to + 1 < t1;
+            const int vo = want ? ovo : OOB, so = want ? (to + 1) * (int)plane_o * 4 : 0;
 #pragma unroll
-            for (int i = 0; i < HS; ++i) xen[i] = a.xin[o + (long)i * Wo];
+            for (int i = 0; i < HS; ++i) xen[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ro1, vo + i * Wo * 4, so, 0));
         }
         if (MODE == DW_WGRAD) load_g(f + 2);
         const float* tbp = tb + par * bufsz;
@@ -310,23 +349,23 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
         }
 
         if (MODE != DW_WGRAD) {
-            if (emit) {
-                const long o = (nc * T + to) * plane_o + (long)hrow0 * Wo + wo;
+            const int vo = emit ? ovo : OOB, so = emit ? to * (int)plane_o * 4 : 0;
+            const float em = emit ? 1.0f : 0.0f;
 #pragma unroll
-                for (int i = 0; i < HS; ++i) {
-                    float v = acc[2][i];
-                    if (MODE == DW_FWD) {
-                        st1 += v;
-                        st2 = fmaf(v, v, st2);
-                    } else if (a.A) {
-                        const float z = fmaf(xe[i], eA, eB);
-                        const float dz = v * cfn_act_grad_rt(z, a.act);
-                        st1 = fmaf(dz, xe[i], st1);
-                        st2 += dz;
-                        v = dz * eA;
-                    }
-                    a.dst[o + (long)i * Wo] = v;
+            for (int i = 0; i < HS; ++i) {
+                float v = acc[2][i];
+                if (MODE == DW_FWD) {
+                    st1 = fmaf(v, em, st1);
+                    st2 = fmaf(v * em, v, st2);
+                } else if (a.A) {
+                    const float z = fmaf(xe[i], eA, eB);
+                    const float dz = v * cfn_act_grad_rt(z, a.act) * em;
+                    st1 = fmaf(dz, xe[i], st1);
+                    st2 += dz;
+                    v = dz * eA;
                 }
+                if (UNC) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, vo + i * Wo * 4, so, 0);
+                else if (emit) a.dst[go0 + (long)c_local * T * plane_o + (long)to * plane_o + (long)hrow0 * Wo + wo + (long)i * Wo] = v;
             }
 #pragma unroll
             for (int i = 0; i < HS; ++i) { acc[2][i] = acc[1][i]; acc[1][i] = acc[0][i]; acc[0][i] = 0.0f; }
@@ -591,6 +630,8 @@ static int dw_plan(DwArgs& a, int S, int mode, DwPlan& pl) {
     }
     if ((long)CG * a.RIN * a.Wi > (long)VEC * 8 * threads)
         return cfn_fail(CFN_ERR_UNSUPPORTED, "dwconv3d: loader capacity exceeded for plane %dx%d", a.Hi, a.Wi);
+    if ((long)CG * a.T * a.Hi * a.Wi * 4 >= 0x7ffffff0L)
+        return cfn_fail(CFN_ERR_UNSUPPORTED, "dwconv3d: %d channels x %d frames of a %dx%d plane exceed the 2 GiB buffer range", CG, a.T, a.Hi, a.Wi);
     a.CG = CG;
     a.ngroups = cfn_cdiv(a.C, CG);
     const long per_thread = ((long)CG * a.RIN * a.Wi + (long)VEC * threads - 1) / ((long)VEC * threads);
