@@ -176,7 +176,7 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     float st1 = 0.0f, st2 = 0.0f;
 
     typedef float __attribute__((ext_vector_type(4))) f4;
-    constexpr int DEPTH = (MODE == DW_FWD && VEC == 4) ? 2 : 1;
+    constexpr int DEPTH = (MODE != DW_WGRAD && VEC == 4) ? 2 : 1;   // frames in flight in registers
     f4 pfA[MAXLD], pfA2[MAXLD], pfB[DEPTH == 2 ? MAXLD : 1], pfB2[DEPTH == 2 ? MAXLD : 1];
     const bool two_src = (MODE == DW_DGRAD) && a.src2 != nullptr;
 
