@@ -566,6 +566,130 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
     }
 }
 
+// Fast variant of the stride-2 data gradient for the training configuration (even input width, forward prologue and
+// the sum-of-squares term present): same arithmetic, but every global access of the frame loop is an unconditional
+// buffer load / store (out-of-range offset = not wanted), so the compiler waits with exact vmcnt values and the loads
+// of frame t+2 stay in flight while frame t is finished.
+template <bool PACKED>
+__global__ __launch_bounds__(256) void dw3d_dgrad_s2_fast_kernel(const DwS2Args a) {
+    const int Ho = a.Ho, Wo = a.Wo, Hi = a.Hi, Wi = a.Wi, T = a.T;
+    const int chunk = blockIdx.x % a.nchunks, pb = blockIdx.x / a.nchunks;
+    const int cslot = PACKED ? threadIdx.x / a.PB : 0;
+    const int p = PACKED ? threadIdx.x - cslot * a.PB : pb * 256 + threadIdx.x;
+    const int nc0 = PACKED ? blockIdx.y * a.CPB : blockIdx.y;            // first (n,c) of this workgroup
+    const int ncr = nc0 + cslot;
+    const bool ok = (!PACKED || (cslot < a.CPB && ncr < a.NC)) && p < Ho * Wo;
+    const int nc = (!PACKED || ncr < a.NC) ? ncr : a.NC - 1, c = nc % a.C;
+    const int i = ok ? p / Wo : 0, j = ok ? p - i * Wo : 0;
+    const bool i1 = i + 1 < Ho, j1 = j + 1 < Wo;
+    const bool r1 = 2 * i + 1 < Hi;
+    const float gsv = a.gs ? (float)a.gs[nc] : 0.0f;
+    const float gqv = 2.0f * (float)a.gq[nc];
+    float w[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) w[k] = a.w[c * 27 + k];
+    const float pa = a.A[nc], pb2 = a.B[nc];
+    const int po = Ho * Wo, pi = Hi * Wi;
+    constexpr int OOB = 0x7ffffff0;
+    const int nch = PACKED ? min(a.CPB, a.NC - nc0) : 1;
+    __amdgpu_buffer_rsrc_t rgy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy + (long)nc0 * T * po), 0, (unsigned)((long)nch * T * po * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.y + (long)nc0 * T * po), 0, (unsigned)((long)nch * T * po * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)nc0 * T * pi), 0, (unsigned)((long)nch * T * pi * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rgx = __builtin_amdgcn_make_buffer_rsrc(a.gx + (long)nc0 * T * pi, 0, (unsigned)((long)nch * T * pi * 4), 0x00020000);
+    const int gb = (cslot * T * po + i * Wo + j) * 4;
+    const int go[4] = {ok ? gb : OOB, ok && j1 ? gb + 4 : OOB, ok && i1 ? gb + Wo * 4 : OOB, ok && i1 && j1 ? gb + (Wo + 1) * 4 : OOB};
+    const int xb = (cslot * T * pi + 2 * i * Wi + 2 * j) * 4;
+    const int xo[2] = {ok ? xb : OOB, ok && r1 ? xb + Wi * 4 : OOB};
+    const int t0 = chunk * a.TT, t1 = min(t0 + a.TT, T);
+
+    typedef float __attribute__((ext_vector_type(2))) f2;
+    typedef int __attribute__((ext_vector_type(2))) i2;
+    auto ld_raw = [&](int f, float (&g)[4], float (&y)[4]) -> bool {
+        const bool fv = f >= 0 && f < T;
+        const int so = fv ? f * po * 4 : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int vo = fv ? go[k] : OOB;
+            g[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rgy, vo, so, 0));
+            y[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, vo, so, 0));
+        }
+        return ok && fv;
+    };
+    auto fin = [&](bool v, const float (&g)[4], const float (&y)[4], float (&out)[4]) {
+        const bool in[4] = {v, v && j1, v && i1, v && i1 && j1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = in[k] ? fmaf(y[k], gqv, g[k] + gsv) : 0.0f;
+    };
+    auto ld_x = [&](int t, float (&xv)[4]) {
+        const bool want = t < t1;
+        const int so = want ? t * pi * 4 : 0;
+        const f2 u = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rx, want ? xo[0] : OOB, so, 0));
+        const f2 d = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rx, want ? xo[1] : OOB, so, 0));
+        xv[0] = u.x; xv[1] = u.y; xv[2] = d.x; xv[3] = d.y;
+    };
+    float G[3][4], rg[4], ryv[4], xn[4];
+    { const bool v = ld_raw(t0 - 1, rg, ryv); fin(v, rg, ryv, G[1]); }
+    { const bool v = ld_raw(t0, rg, ryv); fin(v, rg, ryv, G[2]); }
+    bool rv = ld_raw(t0 + 1, rg, ryv);
+    ld_x(t0, xn);
+    float s1 = 0.0f, s2 = 0.0f;
+    const float m0 = ok ? 1.0f : 0.0f, m1 = ok && r1 ? 1.0f : 0.0f;      // statistics masks of the two rows
+    for (int t = t0; t < t1; ++t) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { G[0][k] = G[1][k]; G[1][k] = G[2][k]; }
+        fin(rv, rg, ryv, G[2]);
+        float xv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xv[k] = xn[k];
+        rv = ld_raw(t + 2, rg, ryv);
+        ld_x(t + 1, xn);
+        float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+            const float* g = G[2 - kt];
+            const float* wk = w + kt * 9;
+            o00 = fmaf(wk[4], g[0], o00);
+            o01 = fmaf(wk[3], g[1], fmaf(wk[5], g[0], o01));
+            o10 = fmaf(wk[1], g[2], fmaf(wk[7], g[0], o10));
+            o11 = fmaf(wk[0], g[3], fmaf(wk[2], g[2], fmaf(wk[6], g[1], fmaf(wk[8], g[0], o11))));
+        }
+        float v[4] = {o00, o01, o10, o11};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float dz = v[k] * cfn_act_grad_rt(fmaf(xv[k], pa, pb2), a.act) * (k < 2 ? m0 : m1);
+            s1 = fmaf(dz, xv[k], s1);
+            s2 += dz;
+            v[k] = dz * pa;
+        }
+        const int so = t * pi * 4;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i2, (f2){v[0], v[1]}), rgx, xo[0], so, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i2, (f2){v[2], v[3]}), rgx, xo[1], so, 0);
+    }
+    if (a.gA) {
+        __shared__ float sh[8];
+        const int lane = threadIdx.x & 63;
+        if (PACKED) {
+            const int key = ok ? cslot : -1 - (int)(threadIdx.x >> 6);
+            const int prev_key = __shfl_up(key, 1, 64);
+            const bool head = ok && (lane == 0 || prev_key != key);
+            const float q1 = seg_wave_sum(s1, key, lane);
+            const float q2 = seg_wave_sum(s2, key, lane);
+            if (head) {
+                atomicAdd(&a.gA[nc], (double)q1);
+                atomicAdd(&a.gB[nc], (double)q2);
+            }
+        } else {
+            s1 = cfn_wave_sum(s1); s2 = cfn_wave_sum(s2);
+            if (lane == 0) { sh[threadIdx.x >> 6] = s1; sh[4 + (threadIdx.x >> 6)] = s2; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                atomicAdd(&a.gA[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
+                atomicAdd(&a.gB[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side: geometry heuristics + dispatch
 // ---------------------------------------------------------------------------------------------
@@ -744,8 +868,12 @@ extern "C" int cfn_dwconv3d_bwd_data(const float* gy, const float* y, const doub
         while (TT > 8 && (long)ygrid * a.pblocks * cfn_cdiv(T, TT) < 2048) TT >>= 1;
         a.TT = TT > T ? T : TT;
         a.nchunks = cfn_cdiv(T, a.TT);
-        if (a.CPB > 1) hipLaunchKernelGGL(dw3d_dgrad_s2_kernel<true>, dim3(a.pblocks * a.nchunks, ygrid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(dw3d_dgrad_s2_kernel<false>, dim3(a.pblocks * a.nchunks, ygrid), dim3(256), 0, st, a);
+        const bool fast = (Wi % 2 == 0) && A && a.y && a.gq && gA && (long)a.CPB * T * Hi * Wi * 4 < 0x7ffffff0L;
+        const dim3 grid(a.pblocks * a.nchunks, ygrid);
+        if (fast && a.CPB > 1) hipLaunchKernelGGL(dw3d_dgrad_s2_fast_kernel<true>, grid, dim3(256), 0, st, a);
+        else if (fast) hipLaunchKernelGGL(dw3d_dgrad_s2_fast_kernel<false>, grid, dim3(256), 0, st, a);
+        else if (a.CPB > 1) hipLaunchKernelGGL(dw3d_dgrad_s2_kernel<true>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(dw3d_dgrad_s2_kernel<false>, grid, dim3(256), 0, st, a);
         return cfn_check_launch("dwconv3d_bwd_data_s2");
     }
     DwArgs a = {};
