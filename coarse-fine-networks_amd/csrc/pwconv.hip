@@ -162,11 +162,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
                 load_w(kc0, rows);
                 __syncthreads();
             }
-            float cur[NU], cur2[NU], nxt[NU], nxt2[NU];
-            unsigned curm = bload(kc0, cur, cur2), nxtm;
-            for (int u = 0; u < rows; u += PW_UNIT) {
-                nxtm = bload(kc0 + u + PW_UNIT, nxt, nxt2);   // one unit ahead; past the end reads 0 (bounds check)
-                __builtin_amdgcn_sched_barrier(0);            // keep the prefetch in front of this unit's MFMAs
+            // two register sets ping-pong over the units: a set is reloaded right after it is consumed and is not touched
+            // again for a whole unit, so no register copy (and no wait) sits at the end of a unit
+            float ra[NU], ra2[NU], rb[NU], rb2[NU];
+            auto unit = [&](const float (&cur)[NU], const float (&cur2)[NU], unsigned curm, int u) {
 #pragma unroll
                 for (int j = 0; j < NU; ++j) {
                     const int kl = u + 2 * j + half;
@@ -179,10 +178,18 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
 #pragma unroll
                     for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i * 32], v, acc[i], 0, 0, 0);
                 }
-#pragma unroll
-                for (int j = 0; j < NU; ++j) { cur[j] = nxt[j]; cur2[j] = nxt2[j]; }
-                curm = nxtm;
+            };
+            unsigned ma = bload(kc0, ra, ra2), mb = bload(kc0 + PW_UNIT, rb, rb2);   // past the end reads 0 (bounds check)
+            int u = 0;
+            for (; u + 2 * PW_UNIT <= rows; u += 2 * PW_UNIT) {
+                unit(ra, ra2, ma, u);
+                ma = bload(kc0 + u + 2 * PW_UNIT, ra, ra2);
+                __builtin_amdgcn_sched_barrier(0);
+                unit(rb, rb2, mb, u + PW_UNIT);
+                mb = bload(kc0 + u + 3 * PW_UNIT, rb, rb2);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (u < rows) unit(ra, ra2, ma, u);                   // odd number of units
         }
 
         // ---- epilogue ---------------------------------------------------------------------------
