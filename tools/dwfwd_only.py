@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, 'coarse-fine-networks_amd'))
 import torch
 from cfn_hip import ops
 T = int(os.environ.get('T', '256'))
-NB = int(os.environ.get('B', '4'))
+NB = int(os.environ.get('B', '8'))
 x = torch.randn(NB, 24, T, 112, 112, device='cuda')
 w = torch.randn(24, 1, 5, 1, 1, device='cuda') * 0.3
 for _ in range(2):
