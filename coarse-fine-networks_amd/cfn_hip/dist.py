@@ -107,11 +107,12 @@ class GradReducer(object):
                 self._launch(bi)
         for work, flat, ps in self._inflight:
             work.wait()
-            off = 0
+            views, off = [], 0
             for p in ps:
                 n = p.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                views.append(flat[off:off + n].view_as(p.grad))
                 off += n
+            torch._foreach_copy_([p.grad for p in ps], views)     # one multi-tensor launch per bucket, not one per parameter
         self._inflight = []
         self._pending = [len(b) for b in self.buckets]
 
