@@ -376,3 +376,36 @@ def test_pwconv_prologue_without_activation():
     A, B = 1 + 0.2 * rnd(3, N, Cin), 0.3 * rnd(4, N, Cin)
     check_conv(lambda x_, w_, A_, B_: ops().pwconv(x_, w_, A_, B_, 0, 1, True),
                lambda a, w_: F.conv3d(a, w_), x, w, A, B, 0, tol_f=3e-5, tol_g=3e-4)
+
+
+@pytest.mark.parametrize('case', ['1d_all', 'many_x_row_y', 'stacked_queries', 'row_query', 'edge_queries'])
+def test_interp1d_module_shape_rules(case):
+    """Interp1d()(x, y, xnew, out) call convention and broadcasting of interp1d.py:20-71 (1-D inputs, a single row
+    against several, stacked query rows, the `out` buffer), values and indices bit-exact against the oracle; queries
+    left / right of the knot range extrapolate from the first / last segment like the reference.  (One x row against
+    several y rows with several query rows raises inside torch.searchsorted in the reference itself: not a case.)"""
+    from interp1d import Interp1d
+    from oracle import x3d_ref as R
+    g = torch.Generator().manual_seed(11)
+    N, P, Bn = 17, 23, 4
+    xs = torch.sort(torch.rand(Bn, N, generator=g), 1)[0]
+    ys = torch.randn(Bn, N, generator=g)
+    qs = torch.rand(Bn, P, generator=g)
+    if case == '1d_all':
+        x, y, q = xs[0], ys[0], qs[0]
+    elif case == 'many_x_row_y':
+        x, y, q = xs, ys[:1], qs
+    elif case == 'stacked_queries':
+        x, y, q = xs[0], ys[0], qs
+    elif case == 'row_query':
+        x, y, q = xs, ys, qs[:1]
+    else:
+        x, y = xs, ys
+        q = torch.cat([torch.full((Bn, 2), -0.5), xs[:, :3], xs[:, -2:], torch.full((Bn, 2), 1.5)], 1)   # outside + on the knots
+    yc, indc = R.interp1d(x, y, q)
+    out = torch.zeros_like(yc).to(DEV)
+    yg, indg = Interp1d().forward(x.to(DEV), y.to(DEV), q.to(DEV), out=out, return_index=True)
+    assert yg.shape == yc.shape
+    assert torch.equal(indg.cpu().view(indc.shape), indc), case
+    assert torch.equal(yg.cpu(), yc), case
+    assert torch.equal(out.cpu().view(yc.shape), yc), case
