@@ -34,7 +34,7 @@ __device__ __forceinline__ void wd_split(int tiles, int groups, int g, int& firs
     count = base + (g < rem ? 1 : 0);
 }
 
-template <int ACT, int XMODE, int WD_T>
+template <int ACT, int XMODE, int WD_TM, int WD_TN>
 __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const WdArgs a) {
     __shared__ float cw[WD_WAVES][32 * 33];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, row = lane & 31;
@@ -47,18 +47,21 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
     const int n = L / a.nstrips;
     const int M = a.M, K = a.K, Q = a.Q;
     int mt0, mtn, kt0, ktn;
-    wd_split(a.mt32, a.mgroups, mg, mt0, mtn);
-    wd_split(a.kt32, a.kgroups, kg, kt0, ktn);
+    wd_split(a.mt32, a.mgroups, mg, mt0, mtn);   // <= WD_TM row tiles
+    wd_split(a.kt32, a.kgroups, kg, kt0, ktn);   // <= WD_TN column tiles
     const int m0 = mt0 * 32, k0 = kt0 * 32;
 
     // per-lane prologue coefficients (lane <-> channel row of each tile)
-    float cs[WD_T], cq[WD_T], ca[WD_T], cb[WD_T];
+    float cs[WD_TM], cq[WD_TM], ca[WD_TN], cb[WD_TN];
 #pragma unroll
-    for (int i = 0; i < WD_T; ++i) {
+    for (int i = 0; i < WD_TM; ++i) {
         const int m = m0 + i * 32 + row;
         const bool ok = i < mtn && m < M;
         cs[i] = (ok && a.gs) ? (float)a.gs[(long)n * M + m] : 0.0f;
         cq[i] = (ok && a.gq && a.y) ? 2.0f * (float)a.gq[(long)n * M + m] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < WD_TN; ++i) {
         const int k = k0 + i * 32 + row;
         const bool okk = i < ktn && k < K && a.pa;
         const long ci = XMODE == 2 ? (long)n * a.Cimg + k / (a.kT * a.kH * a.kW) : (long)n * K + k;
@@ -66,11 +69,11 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
         cb[i] = okk ? a.pb[ci] : 0.0f;
     }
     // XMODE 2: this lane's im2col row of every column tile -> (channel offset, tap)
-    int xbase[WD_T], xkt[WD_T], xkh[WD_T], xkw[WD_T];
-    bool xrow[WD_T];
+    int xbase[WD_TN], xkt[WD_TN], xkh[WD_TN], xkw[WD_TN];
+    bool xrow[WD_TN];
     if (XMODE == 2) {
 #pragma unroll
-        for (int j = 0; j < WD_T; ++j) {
+        for (int j = 0; j < WD_TN; ++j) {
             const int k = k0 + j * 32 + row;
             const int KV = a.kT * a.kH * a.kW;
             const int ci = k / KV, r = k - ci * KV;
@@ -96,11 +99,11 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
     const int g8 = (Q + 7) / 8;
     const int per = (g8 + a.nstrips - 1) / a.nstrips;
     const int gbeg = strip * per + wave, gend = min(strip * per + per, g8);
-    f16v acc[WD_T][WD_T];
+    f16v acc[WD_TM][WD_TN];
 #pragma unroll
-    for (int i = 0; i < WD_T; ++i)
+    for (int i = 0; i < WD_TM; ++i)
 #pragma unroll
-        for (int j = 0; j < WD_T; ++j)
+        for (int j = 0; j < WD_TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -108,20 +111,20 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
     auto ld4 = [&](__amdgpu_buffer_rsrc_t r, int voff) -> f4v {
         return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
     };
-    f4v rG[WD_T], rY[WD_T], rX[WD_T];
-    unsigned xmb[WD_T] = {};   // XMODE 2: in-bounds bits of the 4 taps of each tile's raw float4
+    f4v rG[WD_TM], rY[WD_TM], rX[WD_TN];
+    unsigned xmb[WD_TN] = {};   // XMODE 2: in-bounds bits of the 4 taps of each tile's raw float4
     auto load = [&](int g) {
         const int q = g * 8 + 4 * half;
         const bool inq = q < Q;                                  // Q % 4 == 0: a float4 is all inside or all outside
 #pragma unroll
-        for (int i = 0; i < WD_T; ++i) {
+        for (int i = 0; i < WD_TM; ++i) {
             const int vm = inq && i < mtn ? ((m0 + i * 32 + row) * Q + q) * 4 : 0x7ffffff0;
             rG[i] = ld4(rg, vm);
             rY[i] = has_y ? ld4(ry, vm) : (f4v){0.f, 0.f, 0.f, 0.f};
         }
         if (XMODE == 0) {
 #pragma unroll
-            for (int i = 0; i < WD_T; ++i) {
+            for (int i = 0; i < WD_TN; ++i) {
                 const int vk = inq && i < ktn ? ((k0 + i * 32 + row) * Q + q) * 4 : 0x7ffffff0;
                 rX[i] = ld4(rx, vk);
             }
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
             const int to = qc / hw, rq = qc - to * hw;
             const int oh = rq / a.Wo, ow = rq - oh * a.Wo;
 #pragma unroll
-            for (int i = 0; i < WD_T; ++i) {
+            for (int i = 0; i < WD_TN; ++i) {
                 f4v v = {0.f, 0.f, 0.f, 0.f};
                 if (XMODE == 1) {
                     if (inq && i < ktn) {
@@ -162,11 +165,12 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
     bool inq = false;
     if (gbeg < gend) inq = load(gbeg);
     for (int g = gbeg; g < gend; g += WD_WAVES) {
-        f4v G[WD_T], X[WD_T];
+        f4v G[WD_TM], X[WD_TN];
         const float vm = inq ? 1.0f : 0.0f;                      // masks the constant terms of an out-of-range group
 #pragma unroll
-        for (int i = 0; i < WD_T; ++i) {
-            G[i] = rG[i] + rY[i] * cq[i] + cs[i] * vm;
+        for (int i = 0; i < WD_TM; ++i) G[i] = rG[i] + rY[i] * cq[i] + cs[i] * vm;
+#pragma unroll
+        for (int i = 0; i < WD_TN; ++i) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float xa = cfn_act<ACT>(fmaf(rX[i][e], ca[i], cb[i]));
@@ -178,17 +182,17 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = 0; i < WD_T; ++i)
+            for (int i = 0; i < WD_TM; ++i)
 #pragma unroll
-                for (int j = 0; j < WD_T; ++j)
+                for (int j = 0; j < WD_TN; ++j)
                     if (i < mtn && j < ktn) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(G[i][s], X[j][s], acc[i][j], 0, 0, 0);
     }
 
     // ---- combine the 8 waves tile by tile through LDS, one fp64 atomic per element per workgroup ----------
 #pragma unroll
-    for (int i = 0; i < WD_T; ++i)
+    for (int i = 0; i < WD_TM; ++i)
 #pragma unroll
-        for (int j = 0; j < WD_T; ++j) {
+        for (int j = 0; j < WD_TN; ++j) {
             if (i < mtn && j < ktn) {                            // workgroup uniform
 #pragma unroll
                 for (int r = 0; r < 16; ++r) cw[wave][((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + row] = acc[i][j][r];
@@ -208,10 +212,11 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
         }
 }
 
-template <int XMODE, int WD_T>
+template <int XMODE, int WD_TM, int WD_TN>
 static int wd_launch(WdArgs& a, hipStream_t st) {
+    constexpr int WD_T = WD_TM * WD_TN;                 // 1 = the single-tile variant
     a.mt32 = cfn_cdiv(a.M, 32); a.kt32 = cfn_cdiv(a.K, 32);
-    a.mgroups = cfn_cdiv(a.mt32, WD_T); a.kgroups = cfn_cdiv(a.kt32, WD_T);
+    a.mgroups = cfn_cdiv(a.mt32, WD_TM); a.kgroups = cfn_cdiv(a.kt32, WD_TN);
     const long groups = (long)a.N * a.mgroups * a.kgroups;
     // ~one workgroup per CU (measured: more, shorter strips lose); the single-tile variant is load bound and small:
     // four workgroups per CU
@@ -222,9 +227,9 @@ static int wd_launch(WdArgs& a, hipStream_t st) {
     a.nstrips = (int)strips;
     const unsigned blocks = (unsigned)(groups * strips);
     switch (a.act) {
-        case CFN_ACT_RELU: hipLaunchKernelGGL((pw_wgrad_direct_kernel<CFN_ACT_RELU, XMODE, WD_T>), dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
-        case CFN_ACT_SWISH: hipLaunchKernelGGL((pw_wgrad_direct_kernel<CFN_ACT_SWISH, XMODE, WD_T>), dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
-        default: hipLaunchKernelGGL((pw_wgrad_direct_kernel<CFN_ACT_NONE, XMODE, WD_T>), dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
+        case CFN_ACT_RELU: hipLaunchKernelGGL((pw_wgrad_direct_kernel<CFN_ACT_RELU, XMODE, WD_TM, WD_TN>), dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
+        case CFN_ACT_SWISH: hipLaunchKernelGGL((pw_wgrad_direct_kernel<CFN_ACT_SWISH, XMODE, WD_TM, WD_TN>), dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
+        default: hipLaunchKernelGGL((pw_wgrad_direct_kernel<CFN_ACT_NONE, XMODE, WD_TM, WD_TN>), dim3(blocks), dim3(64 * WD_WAVES), 0, st, a); break;
     }
     return cfn_check_launch("pwconv_bwd_weight(direct)");
 }
@@ -248,9 +253,13 @@ int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, cons
     {   // balanced groups never exceed 2 tiles either way (e.g. 108 x 48): the 2x2 variant needs half the registers
         const int mt = cfn_cdiv(M, 32), kt = cfn_cdiv(K, 32);
         const int gm = cfn_cdiv(mt, cfn_cdiv(mt, 3)), gk = cfn_cdiv(kt, cfn_cdiv(kt, 3));
-        if (gm <= 2 && gk <= 2) return wd_launch<0, 2>(a, st);
+        // narrow x wide (e.g. 48 x 108): one 2x4 / 4x2 group instead of two 2x2 groups halves the re-reads of the operand
+        // both groups share
+        if (mt <= 2 && kt == 4) return wd_launch<0, 2, 4>(a, st);
+        if (mt == 4 && kt <= 2) return wd_launch<0, 4, 2>(a, st);
+        if (gm <= 2 && gk <= 2) return wd_launch<0, 2, 2>(a, st);
     }
-    return wd_launch<0, 3>(a, st);
+    return wd_launch<0, 3, 3>(a, st);
 }
 
 // pointwise conv with spatial stride 2 (shortcut convs): gathered x operand
@@ -263,7 +272,7 @@ int pwd_wgrad_try_strided(const float* gy, const float* y, const double* gs, con
     if ((long)K * T * Hi * Wi * 4 >= (1L << 31) - 64) return -1;
     WdArgs a = {gy, y, gs, gq, x, pa, pb, gw, N, M, K, Q, act};
     a.Pin = T * Hi * Wi; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = stride;
-    return wd_launch<1, 3>(a, st);
+    return wd_launch<1, 3, 3>(a, st);
 }
 
 // dense conv (stem 1x3x3 / Grid Pool saliency convs): x rows are im2col rows; geom = {kT,kH,kW,sT,sH,sW,pT,pH,pW}
@@ -281,6 +290,6 @@ int pwd_wgrad_try_dense(const float* gy, const float* y, const double* gs, const
     a.Pin = T * Hi * Wi; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = 1; a.Ti = T; a.Cimg = Cimg;
     a.kT = g[0]; a.kH = g[1]; a.kW = g[2]; a.sT = g[3]; a.sH = g[4]; a.sW = g[5]; a.pT = g[6]; a.pH = g[7]; a.pW = g[8];
     // one 32x32 tile per wave when the whole problem is one or two tiles (stem: 24 x 27): no idle tile slots
-    if (cfn_cdiv(M, 32) * cfn_cdiv(K, 32) <= 2) return wd_launch<2, 1>(a, st);
-    return wd_launch<2, 3>(a, st);
+    if (cfn_cdiv(M, 32) * cfn_cdiv(K, 32) <= 2) return wd_launch<2, 1, 1>(a, st);
+    return wd_launch<2, 3, 3>(a, st);
 }
