@@ -94,6 +94,101 @@ __global__ __launch_bounds__(256) void conv3d_dense_bwd_data_kernel(const DenseB
     }
 }
 
+// All-input-channels variant (Cin <= 32, weights of the whole layer <= 64 KiB): a thread owns ONE input position of
+// its parity class and accumulates the gradient of every input channel in registers, so g' = gy + gs + 2 y gq is
+// loaded once per (output channel, tap) instead of once per input channel as well (24x fewer loads for the 24-channel
+// saliency convs).  Weights live in LDS as [co][tap][ci] (ci fastest: one ds_read_b128 feeds 4 channels).
+template <int CI>
+__global__ __launch_bounds__(256) void conv3d_dense_bwd_data_allci_kernel(const DenseBwdArgs a) {
+    extern __shared__ float sg[];            // gs[Cout] | 2gq[Cout] | w[Cout][KV][CI] | red[2*CI]
+    const int n = blockIdx.y;
+    const int KV = a.kT * a.kH * a.kW;
+    float* sw = sg + 2 * a.Cout;
+    float* red = sw + a.Cout * KV * CI;
+    for (int co = threadIdx.x; co < a.Cout; co += 256) {
+        sg[co] = a.gs ? (float)a.gs[(long)n * a.Cout + co] : 0.0f;
+        sg[a.Cout + co] = (a.gq && a.y) ? 2.0f * (float)a.gq[(long)n * a.Cout + co] : 0.0f;
+    }
+    for (int e = threadIdx.x; e < a.Cout * KV * CI; e += 256) {
+        const int ci = e % CI, r = e / CI, tap = r % KV, co = r / KV;
+        sw[e] = ci < a.Cin ? a.w[((long)co * a.Cin + ci) * KV + tap] : 0.0f;
+    }
+    for (int e = threadIdx.x; e < 2 * CI; e += 256) red[e] = 0.0f;
+    __syncthreads();
+    int cls = blockIdx.z;
+    const int cw = cls % a.sW; cls /= a.sW;
+    const int ch = cls % a.sH;
+    const int ct = cls / a.sH;
+    const int nw = (a.Wi - cw + a.sW - 1) / a.sW, nh = (a.Hi - ch + a.sH - 1) / a.sH, nt = (a.Ti - ct + a.sT - 1) / a.sT;
+    const long pin = (long)a.Ti * a.Hi * a.Wi, po = (long)a.To * a.Ho * a.Wo;
+    const long pc = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = nw > 0 && nh > 0 && nt > 0 && pc < (long)nt * nh * nw;
+    float da[CI];
+#pragma unroll
+    for (int i = 0; i < CI; ++i) da[i] = 0.0f;
+    long opos = 0;
+    if (ok) {
+        const int jw = (int)(pc % nw), jh = (int)((pc / nw) % nh), jt = (int)(pc / ((long)nw * nh));
+        const int iw = cw + jw * a.sW, ih = ch + jh * a.sH, it = ct + jt * a.sT;
+        opos = ((long)it * a.Hi + ih) * a.Wi + iw;
+        const int kt0 = (ct + a.pT) % a.sT, kh0 = (ch + a.pH) % a.sH, kw0 = (cw + a.pW) % a.sW;
+        for (int kt = kt0; kt < a.kT; kt += a.sT) {
+            const int to = (it + a.pT - kt) / a.sT;
+            if (it + a.pT - kt < 0 || to >= a.To) continue;
+            for (int kh = kh0; kh < a.kH; kh += a.sH) {
+                const int oh = (ih + a.pH - kh) / a.sH;
+                if (ih + a.pH - kh < 0 || oh >= a.Ho) continue;
+                for (int kw = kw0; kw < a.kW; kw += a.sW) {
+                    const int ow = (iw + a.pW - kw) / a.sW;
+                    if (iw + a.pW - kw < 0 || ow >= a.Wo) continue;
+                    const long oq = ((long)to * a.Ho + oh) * a.Wo + ow;
+                    const int tap = (kt * a.kH + kh) * a.kW + kw;
+                    const float* gyp = a.gy + (long)n * a.Cout * po + oq;
+                    const float* yp = a.y ? a.y + (long)n * a.Cout * po + oq : nullptr;
+                    for (int co = 0; co < a.Cout; ++co) {
+                        float g = gyp[(long)co * po] + sg[co];
+                        if (yp) g = fmaf(yp[(long)co * po], sg[a.Cout + co], g);
+                        const float* wp = sw + (co * KV + tap) * CI;
+#pragma unroll
+                        for (int i = 0; i < CI; ++i) da[i] = fmaf(wp[i], g, da[i]);
+                    }
+                }
+            }
+        }
+    }
+    // epilogue per input channel; the per-(n,ci) sums go through wave reductions and one LDS atomic per wave
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < CI; ++i) {
+        float s1 = 0.f, s2 = 0.f;
+        if (i < a.Cin) {
+            const long nci = (long)n * a.Cin + i;
+            if (ok) {
+                const long o = nci * pin + opos;
+                if (a.A) {
+                    const float xa = a.A[nci], xb = a.B[nci], xv = a.x[o];
+                    const float dz = da[i] * cfn_act_grad_rt(fmaf(xv, xa, xb), a.act);
+                    s1 = dz * xv; s2 = dz;
+                    a.gx[o] = dz * xa;
+                } else {
+                    a.gx[o] = da[i];
+                }
+            }
+            if (a.A && a.gA) {
+                s1 = cfn_wave_sum(s1); s2 = cfn_wave_sum(s2);
+                if (lane == 0) { atomicAdd(&red[2 * i], s1); atomicAdd(&red[2 * i + 1], s2); }
+            }
+        }
+    }
+    if (a.A && a.gA) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.Cin; i += 256) {
+            atomicAdd(&a.gA[(long)n * a.Cin + i], (double)red[2 * i]);
+            atomicAdd(&a.gB[(long)n * a.Cin + i], (double)red[2 * i + 1]);
+        }
+    }
+}
+
 extern "C" int cfn_conv3d_dense_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq,
                                          const float* w, const float* x, const double* A, const double* B, int act, float* gx,
                                          double* gA, double* gB, int N, int Cin, int Cout, int T, int Hi, int Wi,
@@ -116,6 +211,22 @@ extern "C" int cfn_conv3d_dense_bwd_data(const float* gy, const float* y, const 
     CfnProfScope prof(CFN_K_STEM, st, 4.0 * N * ((double)Cin * pin * 2 + (double)Cout * a.To * a.Ho * a.Wo));
     const int ncls = a.sT * a.sH * a.sW;
     const long pcls = (long)cfn_cdiv(T, a.sT) * cfn_cdiv(Hi, a.sH) * cfn_cdiv(Wi, a.sW);     // largest class
+    {   // all-input-channels variant when the whole layer's weights fit in LDS
+        const int CI = Cin <= 8 ? 8 : (Cin <= 24 ? 24 : 32);
+        const size_t lds_all = ((size_t)2 * Cout + (size_t)Cout * a.kT * a.kH * a.kW * CI + 2 * CI) * sizeof(float);
+        if (Cin <= 32 && lds_all <= 64 * 1024 && ncls <= 64 && N <= 65535) {
+            const dim3 grid(cfn_cdiv(pcls, 256), N, ncls);
+#define CFN_DENSE_GO(CIV)                                                                                                 \
+            do {                                                                                                           \
+                auto k = conv3d_dense_bwd_data_allci_kernel<CIV>;                                                          \
+                if (lds_all > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all); \
+                hipLaunchKernelGGL(k, grid, dim3(256), lds_all, st, a);                                                    \
+            } while (0)
+            if (CI == 8) CFN_DENSE_GO(8); else if (CI == 24) CFN_DENSE_GO(24); else CFN_DENSE_GO(32);
+#undef CFN_DENSE_GO
+            return cfn_check_launch("conv3d_dense_bwd_data(all channels)");
+        }
+    }
     const size_t lds = ((size_t)2 * Cout + (size_t)Cout * a.kT * a.kH * a.kW) * sizeof(float);
     CFN_REQUIRE(ncls <= 64 && lds <= 60 * 1024, "cfn_conv3d_dense_bwd_data: stride / weight slice too large");
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv3d_dense_bwd_data_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
