@@ -118,11 +118,22 @@ def _coef(t):
     return None if t is None else t.to(torch.float64).contiguous()
 
 
+class ShortcutToken(object):
+    """Couples the two pointwise convs that read a stage-first block's input (conv1, stride 1, and the spatially
+    strided shortcut conv, x3d_fine.py:284-287) in the backward pass: the shortcut conv, whose backward runs first, leaves
+    its data gradient as a COMPACT tensor at output resolution here instead of a zero-filled sparse one, and conv1's
+    data-gradient kernel adds it on the stride lattice before its act' epilogue (the dense add between the two
+    gradients and the memset disappear).  If conv1's backward happens to run first the plain path is used."""
+
+    def __init__(self):
+        self.acc, self.acc_stride, self.main_done = None, 1, False
+
+
 class _PwConv(Function):
     """1x1x1 conv (optionally spatial stride 2) on fp32 MFMA; see include/cfn_hip.h cfn_pwconv_*."""
 
     @staticmethod
-    def forward(ctx, x, A, B, w, act, stride, want_stats):
+    def forward(ctx, x, A, B, w, act, stride, want_stats, token, role):
         x = check(x).contiguous()
         N, Cin, T, H, W = x.shape
         Cout = w.shape[0]
@@ -137,6 +148,7 @@ class _PwConv(Function):
         ctx.save_for_backward(x, A, B, w2, y)
         ctx.meta = (act, stride, tuple(w.shape))
         ctx.wparam = w
+        ctx.token, ctx.role = token, role
         if not want_stats:
             return y, None, None
         return y, s, q
@@ -145,29 +157,46 @@ class _PwConv(Function):
     def backward(ctx, gy, gs, gq):
         x, A, B, w2, y = ctx.saved_tensors
         act, stride, wshape = ctx.meta
+        token, role = ctx.token, ctx.role
         N, Cin, T, H, W = x.shape
         Cout = w2.shape[0]
         gy = torch.zeros_like(y) if gy is None else gy.contiguous()
         gs, gq = _opt(gs), _opt(gq)
         gx = gA = gB = gw = None
         if ctx.needs_input_grad[0] or (A is not None and ctx.needs_input_grad[1]):
-            gx = torch.zeros_like(x) if stride != 1 else torch.empty_like(x)
-            ab = a64 = b64 = None
-            if A is not None:
-                ab, a64, b64 = _f64pair(N, Cin, x.device)
-            call('cfn_pwconv_bwd_data', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, Cin, Cout, T, H, W, stride)
-            if A is not None:
-                gA, gB = ab[0], ab[1]
+            if token is not None and role == 'short' and stride > 1 and not token.main_done:
+                # compact W^T g' at output resolution (a stride-1 data gradient over the strided grid, no epilogue);
+                # conv1's data gradient consumes it
+                Ho, Wo = y.shape[3], y.shape[4]
+                da = torch.empty(N, Cin, T, Ho, Wo, dtype=torch.float32, device=x.device)
+                call('cfn_pwconv_bwd_data', gy, y, gs, gq, w2, None, None, None, ACT_NONE, da, None, None, N, Cin, Cout, T,
+                     Ho, Wo, 1)
+                token.acc, token.acc_stride = da, stride
+            else:
+                gx = torch.zeros_like(x) if stride != 1 else torch.empty_like(x)
+                ab = a64 = b64 = None
+                if A is not None:
+                    ab, a64, b64 = _f64pair(N, Cin, x.device)
+                if token is not None and role == 'main' and token.acc is not None:
+                    call('cfn_pwconv_bwd_data_acc', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, Cin, Cout, T, H, W, stride,
+                         token.acc, token.acc_stride)
+                    token.acc = None
+                else:
+                    if token is not None and role == 'main':
+                        token.main_done = True
+                    call('cfn_pwconv_bwd_data', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, Cin, Cout, T, H, W, stride)
+                if A is not None:
+                    gA, gB = ab[0], ab[1]
         if ctx.needs_input_grad[3]:
             g64, fin = _gw_buffers(ctx.wparam, Cout, Cin, x.device)
             call('cfn_pwconv_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, Cin, Cout, T, H, W, stride)
             gw = fin()
-        return gx, gA, gB, gw, None, None, None
+        return gx, gA, gB, gw, None, None, None, None, None
 
 
-def pwconv(x, w, A=None, B=None, act=ACT_NONE, stride=1, stats=True):
-    """returns (y, sum, sumsq); sum/sumsq are None when stats=False"""
-    return _PwConv.apply(x, A, B, w, act, stride, stats)
+def pwconv(x, w, A=None, B=None, act=ACT_NONE, stride=1, stats=True, token=None, role=None):
+    """returns (y, sum, sumsq); sum/sumsq are None when stats=False.  token / role ('main' | 'short'): see ShortcutToken"""
+    return _PwConv.apply(x, A, B, w, act, stride, stats, token, role)
 
 
 class _DwConv3d(Function):

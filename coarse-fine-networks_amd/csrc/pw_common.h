@@ -21,6 +21,10 @@ struct PwArgs {
     const float* ex;     // DGRAD: forward input x raw (N,M,Pin) (needed when ea != null)
     const double* ea;     // DGRAD: forward prologue A[n,m] (null = identity => gx = da)
     const double* eb;
+    // DGRAD: optional compact gradient (N, M, T, acc_Ho, acc_Wo) of a second, spatially strided consumer of the same
+    // input (the stride-s shortcut conv of a stage's first block): added to W^T g' on the lattice h % s == w % s == 0
+    // BEFORE the act' epilogue, so the zero-filled sparse tensor and the dense add kernel never exist
+    const float* acc; int acc_s, acc_Ho, acc_Wo;
     double* s1;          // FWD: sum(y) [n,m]             DGRAD: sum(dz*x) [n,m]
     double* s2;          // FWD: sum(y^2)                 DGRAD: sum(dz)
     int N, M, K, Q, Pin, Hi, Wi, Ho, Wo, stride, act;

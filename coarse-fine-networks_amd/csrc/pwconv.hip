@@ -106,6 +106,9 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
     __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.dst + dst_n, 0, M * dst_pitch * 4, 0x00020000);
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((a.ex ? a.ex : a.src) + (a.ex ? dst_n : 0)), 0,
                                                                    a.ex ? M * dst_pitch * 4 : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t racc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(MODE == PW_DGRAD && a.acc ? a.acc + (long)n * M * ((long)(a.Pin / (a.Hi * a.Wi)) * a.acc_Ho * a.acc_Wo) : a.src), 0,
+        MODE == PW_DGRAD && a.acc ? (unsigned)((long)M * (a.Pin / (a.Hi * a.Wi)) * a.acc_Ho * a.acc_Wo * 4) : 0u, 0x00020000);
     float sacc[MT], qacc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) { sacc[i] = 0.0f; qacc[i] = 0.0f; }
@@ -197,6 +200,17 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
         // bounds check; lanes of a partial tile get an out-of-range offset.
         const float vm = valid ? 1.0f : 0.0f;
         const int dvoff = valid ? (4 * half * dst_pitch + out_pos) * 4 : 0x7fffffff;
+        int avoff = 0x7fffffff;                                // compact offset of this lane's position on the acc lattice
+        long acc_pitch = 0;
+        if (MODE == PW_DGRAD && a.acc) {
+            const int hw = a.Hi * a.Wi;
+            const int tq = out_pos / hw, rq = out_pos - tq * hw;
+            const int hq = rq / a.Wi, wq = rq - hq * a.Wi;
+            acc_pitch = (long)(a.Pin / hw) * a.acc_Ho * a.acc_Wo;
+            if (valid && hq % a.acc_s == 0 && wq % a.acc_s == 0)
+                avoff = (int)((4 * half * acc_pitch + ((long)tq * a.acc_Ho + hq / a.acc_s) * a.acc_Wo + wq / a.acc_s) * 4);
+        }
+        const bool any_acc = MODE == PW_DGRAD && a.acc && __any(avoff != 0x7fffffff);   // tiles inside odd rows skip the loads
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             float t1[16], t2[16];
@@ -210,6 +224,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 float v = acc[i][r];
+                if (any_acc)
+                    v += pw_bload(racc, avoff, (int)((m0 + i * 32 + (r & 3) + 8 * (r >> 2)) * acc_pitch * 4));
                 if (MODE == PW_FWD) {
                     t1[r] = v * vm;
                 } else if (STATS) {
@@ -585,20 +601,24 @@ extern "C" int cfn_pwconv_fwd(const float* x, const double* A, const double* B, 
 }
 
 // gx must be zero-filled by the caller when stride == 2 (only the strided positions are written)
-extern "C" int cfn_pwconv_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq,
+// acc (optional): compact gradient (N,Cin,T,acc_Ho,acc_Wo) of a stride-acc_stride shortcut conv over the same input,
+// added on its lattice before the act' epilogue (stride must be 1 then)
+extern "C" int cfn_pwconv_bwd_data_acc(const float* gy, const float* y, const double* gsum, const double* gsumsq,
                                    const float* w, const float* x, const double* A, const double* B, int act, float* gx,
                                    double* gA, double* gB, int N, int Cin, int Cout, int T, int Hi, int Wi, int stride,
-                                   void* stream) {
+                                   const float* acc, int acc_stride, void* stream) {
     CFN_REQUIRE(gy && w && gx, "cfn_pwconv_bwd_data: null tensor");
     CFN_REQUIRE(stride == 1 || stride == 2, "cfn_pwconv_bwd_data: stride must be 1 or 2");
     CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pwconv_bwd_data: A/B mismatch");
     CFN_REQUIRE(A == nullptr || (x && gA && gB), "cfn_pwconv_bwd_data: prologue needs x, gA, gB");
     CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_pwconv_bwd_data: gsumsq needs y");
+    CFN_REQUIRE(acc == nullptr || (stride == 1 && acc_stride >= 1), "cfn_pwconv_bwd_data_acc: acc needs stride 1");
     PwArgs a = {};
     a.src = gy; a.src2 = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.w = w; a.dst = gx;
     a.ex = x; a.ea = A; a.eb = B; a.act = act; a.s1 = gA; a.s2 = gB;
     a.N = N; a.M = Cin; a.K = Cout; a.Cin = Cin;
     pw_geom(a, T, Hi, Wi, stride);
+    if (acc) { a.acc = acc; a.acc_s = acc_stride; a.acc_Ho = (Hi - 1) / acc_stride + 1; a.acc_Wo = (Wi - 1) / acc_stride + 1; }
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_BWD, st, 4.0 * N * ((double)Cout * a.Q * (a.src2 ? 2 : 1) + (double)Cin * a.Q * (A ? 2 : 1)));
     { const int rc = pwd_try_launch(a, PW_DGRAD, A != nullptr, st); if (rc >= 0) return rc; }
@@ -606,6 +626,13 @@ extern "C" int cfn_pwconv_bwd_data(const float* gy, const float* y, const double
     { int rc = pw_plan(a, MT, blocks, lds); if (rc) return rc; }
     if (!A) { a.act = CFN_ACT_NONE; return pw_launch<PW_DGRAD, false>(a, MT, blocks, lds, st); }
     return pw_launch<PW_DGRAD, true>(a, MT, blocks, lds, st);
+}
+
+extern "C" int cfn_pwconv_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq,
+                                   const float* w, const float* x, const double* A, const double* B, int act, float* gx,
+                                   double* gA, double* gB, int N, int Cin, int Cout, int T, int Hi, int Wi, int stride,
+                                   void* stream) {
+    return cfn_pwconv_bwd_data_acc(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, N, Cin, Cout, T, Hi, Wi, stride, nullptr, 1, stream);
 }
 
 static void wg_plan(WgArgs& a, int& MTW, int& NTW) {

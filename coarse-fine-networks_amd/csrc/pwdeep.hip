@@ -122,6 +122,9 @@ __global__ __launch_bounds__(64 * PWD_WAVES) void pw_deep_kernel(const PwArgs a)
     __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.dst + dst_n, 0, M * dst_pitch * 4, 0x00020000);
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((a.ex ? a.ex : a.src) + (a.ex ? dst_n : 0)), 0,
                                                                    a.ex ? M * dst_pitch * 4 : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t racc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(MODE == PW_DGRAD && a.acc ? a.acc + (long)n * M * ((long)(a.Pin / (a.Hi * a.Wi)) * a.acc_Ho * a.acc_Wo) : a.src), 0,
+        MODE == PW_DGRAD && a.acc ? (unsigned)((long)M * (a.Pin / (a.Hi * a.Wi)) * a.acc_Ho * a.acc_Wo * 4) : 0u, 0x00020000);
     float sacc[MT], qacc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) { sacc[i] = 0.0f; qacc[i] = 0.0f; }
@@ -208,6 +211,17 @@ __global__ __launch_bounds__(64 * PWD_WAVES) void pw_deep_kernel(const PwArgs a)
         // ---- epilogue (same scheme as pw_gemm_kernel) -------------------------------------------
         const float vm = valid ? 1.0f : 0.0f;
         const int dvoff = valid ? (4 * half * dst_pitch + qc) * 4 : 0x7fffffff;
+        int avoff = 0x7fffffff;                                // compact offset of this lane's position on the acc lattice
+        long acc_pitch = 0;
+        if (MODE == PW_DGRAD && a.acc) {
+            const int hw = a.Hi * a.Wi;
+            const int tq = qc / hw, rq = qc - tq * hw;
+            const int hq = rq / a.Wi, wq = rq - hq * a.Wi;
+            acc_pitch = (long)(a.Pin / hw) * a.acc_Ho * a.acc_Wo;
+            if (valid && hq % a.acc_s == 0 && wq % a.acc_s == 0)
+                avoff = (int)((4 * half * acc_pitch + ((long)tq * a.acc_Ho + hq / a.acc_s) * a.acc_Wo + wq / a.acc_s) * 4);
+        }
+        const bool any_acc = MODE == PW_DGRAD && a.acc && __any(avoff != 0x7fffffff);   // tiles inside odd rows skip the loads
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             float t1[16], t2[16];
@@ -221,6 +235,8 @@ __global__ __launch_bounds__(64 * PWD_WAVES) void pw_deep_kernel(const PwArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 float v = acc[i][r];
+                if (any_acc)
+                    v += pw_bload(racc, avoff, (int)((m0 + i * 32 + (r & 3) + 8 * (r >> 2)) * acc_pitch * 4));
                 if (MODE == PW_FWD) {
                     t1[r] = v * vm;
                 } else if (STATS) {

@@ -176,7 +176,9 @@ class Bottleneck(nn.Module):
         tr = self.training
         has_se = self.index % 2 == 0
 
-        y1, s1, q1 = ops.pwconv(xr, self.conv1.weight, xa, xb, xact, 1, stats=tr)
+        # stage-first block: conv1 and the strided shortcut conv read the same input; their data gradients are fused
+        tok = ops.ShortcutToken() if (isinstance(self.downsample, nn.Sequential) and self.stride > 1) else None
+        y1, s1, q1 = ops.pwconv(xr, self.conv1.weight, xa, xb, xact, 1, stats=tr, token=tok, role='main')
         A1, B1 = self.bn1.fold(s1, q1, _count(y1), n)
         y2, s2, q2 = ops.dwconv3d(y1, self.conv2.weight, A1, B1, ACT_RELU, self.stride, stats=tr or has_se)
         # bn2 (+ SE: the global average of bn2(y2) is the bn2 affine of the per-sample mean of y2, x3d_fine.py:157-163)
@@ -188,7 +190,7 @@ class Bottleneck(nn.Module):
         if self.downsample is not None:
             if not isinstance(self.downsample, nn.Sequential):
                 raise NotImplementedError("shortcut_type 'A' is not on the accelerated path")
-            yd, sd, qd = ops.pwconv(xr, self.downsample[0].weight, xa, xb, xact, self.stride, stats=tr)
+            yd, sd, qd = ops.pwconv(xr, self.downsample[0].weight, xa, xb, xact, self.stride, stats=tr, token=tok, role='short')
             Ad, Bd = self.downsample[1].fold(sd, qd, _count(yd), n)
             return ops.bn_add_relu(y3, A3, B3, yd, Ad, Bd, split=self.split_out)
         res = x_res.materialize() if isinstance(x_res, Deferred) else x_res

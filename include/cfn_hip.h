@@ -68,6 +68,11 @@ int cfn_pwconv_fwd(const float* x, const double* A, const double* B, int act, co
 int cfn_pwconv_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
                         const float* x, const double* A, const double* B, int act, float* gx, double* gA, double* gB, int N,
                         int Cin, int Cout, int T, int Hi, int Wi, int stride, void* stream);
+/* same, plus `acc`: compact gradient (N,Cin,T,ceil(Hi/acc_stride),ceil(Wi/acc_stride)) of a spatially strided shortcut conv
+ * over the same input (x3d_fine.py:284-287), added on its lattice before the act' epilogue (requires stride == 1) */
+int cfn_pwconv_bwd_data_acc(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
+                        const float* x, const double* A, const double* B, int act, float* gx, double* gA, double* gB, int N,
+                        int Cin, int Cout, int T, int Hi, int Wi, int stride, const float* acc, int acc_stride, void* stream);
 int cfn_pwconv_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* x,
                           const double* A, const double* B, int act, double* gw, int N, int Cin, int Cout, int T, int Hi,
                           int Wi, int stride, void* stream);
