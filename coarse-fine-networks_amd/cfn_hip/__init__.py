@@ -103,6 +103,20 @@ def call(name, *args):
         raise RuntimeError('%s failed (%d): %s' % (name, rc, last_error()))
 
 
+def call_try(name, *args):
+    """like call(), for entry points that may decline a geometry: returns False (nothing was launched) on -1"""
+    lib = load()
+    dts = _protos[name][2]
+    for i, a in enumerate(args):
+        if isinstance(a, torch.Tensor) and dts[i] is not None and a.dtype != dts[i]:
+            raise RuntimeError('%s: argument %d must be a %s tensor, got %s' % (name, i, dts[i], a.dtype))
+    conv = [(_ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a) for a in args]
+    rc = getattr(lib, name)(*conv, stream())
+    if rc > 0:
+        raise RuntimeError('%s failed (%d): %s' % (name, rc, last_error()))
+    return rc == 0
+
+
 def query(name, *args):
     """host-only helper entry points (no stream argument), e.g. workspace sizes"""
     return getattr(load(), name)(*args)

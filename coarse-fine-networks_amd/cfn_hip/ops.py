@@ -13,7 +13,7 @@ from torch.autograd import Function
 
 import ctypes
 
-from . import call, check, query, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID  # noqa: F401
+from . import call, call_try, check, query, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID  # noqa: F401
 
 
 class _ZeroArena(object):
@@ -229,17 +229,26 @@ class _DwConv3d(Function):
         gy = torch.zeros_like(y) if gy is None else gy.contiguous()
         gs, gq = _opt(gs), _opt(gq)
         gx = gA = gB = gw = None
-        if ctx.needs_input_grad[0] or (A is not None and ctx.needs_input_grad[1]):
+        want_x = ctx.needs_input_grad[0] or (A is not None and ctx.needs_input_grad[1])
+        want_w = ctx.needs_input_grad[3]
+        ab = a64 = b64 = g64 = fin = None
+        if want_x:
             gx = torch.empty_like(x)
-            ab = a64 = b64 = None
             if A is not None:
                 ab, a64, b64 = _f64pair(N, C, x.device)
-            call('cfn_dwconv3d_bwd_data', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, C, T, H, W, stride)
-            if A is not None:
-                gA, gB = ab[0], ab[1]
-        if ctx.needs_input_grad[3]:
+        if want_w:
             g64, fin = _gw_buffers(ctx.wparam, C, 27, x.device)
-            call('cfn_dwconv3d_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, C, T, H, W, stride)
+        # stride 1, big planes: data and weight gradient in ONE pass over gy, y, x (declines small planes)
+        fused = want_x and want_w and stride == 1 and call_try('cfn_dwconv3d_bwd_fused', gy, y, gs, gq, w2, x, A, B, act, gx,
+                                                             a64, b64, g64, N, C, T, H, W)
+        if not fused:
+            if want_x:
+                call('cfn_dwconv3d_bwd_data', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, C, T, H, W, stride)
+            if want_w:
+                call('cfn_dwconv3d_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, C, T, H, W, stride)
+        if want_x and A is not None:
+            gA, gB = ab[0], ab[1]
+        if want_w:
             gw = fin()
         return gx, gA, gB, gw, None, None, None
 

@@ -403,6 +403,291 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused backward of the stride-1 depthwise conv: data gradient AND weight gradient in one pass.  Both read gy, y and
+// x; run separately they move 7 tensor passes (dgrad: gy, y, x -> gx; wgrad: gy, y, x), fused 4.  Same band / t-chunk
+// skeleton as dw3d_kernel with TWO staged streams that are one frame apart:
+//   G image = g'(f) = gy + gs + 2 y gq   (window -> data gradient, centre -> weight gradient)
+//   A image = a(f-1) = act(A x + B)      (window -> weight gradient)
+// At step f:  gx accumulators += flipped taps * G-window(f);  gw[kt] += g'(f-kt)[centre] * A-window(f-1), the three g'
+// centres rolling in registers; output frame f-1 is finished with the act' epilogue (raw x of that frame prefetched
+// one step ahead).  DW_WGRAD's t_out = fa - kt + 1 pairing with fa = f-1.
+// ---------------------------------------------------------------------------------------------
+struct DwFusedArgs {
+    const float* gy; const float* y; const double* gs; const double* gq; const float* w; const float* x;
+    const double* A; const double* B; float* gx; double* gA; double* gB; double* gw;
+    int N, C, T, H, W, act;
+    int TT, nchunks, CG, ngroups, GB, nbands, IPCb, IPCp, RIN, WP, XO;
+};
+
+template <int HS, int VEC, int MAXLD, bool UNIW>
+__global__ __launch_bounds__(UNIW ? 256 : 512, 2) void dw3d_bwd_fused_kernel(const DwFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HSIN = HS + 2;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+    unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    const int chunk = L % a.nchunks; L /= a.nchunks;
+    const int band = L % a.nbands;   L /= a.nbands;
+    const int grp = L % a.ngroups;
+    const int n = L / a.ngroups;
+    const int c0 = grp * a.CG;
+    const int ncg = min(a.CG, a.C - c0);
+    const int t0 = chunk * a.TT, t1 = min(t0 + a.TT, a.T);
+    const int RIN = a.RIN, WP = a.WP, XO = a.XO;
+    const int H = a.H, W = a.W, T = a.T, C = a.C;
+    const int hin0 = band * a.GB * HS - 1;
+    const int row_lo = max(hin0, 0), row_hi = min(hin0 + RIN, H);
+    const int per_ch = (row_hi - row_lo) * W;
+    const int total_ld = ncg * per_ch;
+    const long plane = (long)H * W;
+
+    const int bufsz = a.CG * RIN * WP;
+    float* bufG = smem;                    // 2 images
+    float* bufA = smem + 2 * bufsz;        // 2 images
+    float* sGs = bufA + 2 * bufsz;         // [CG] gs, [CG] 2gq, [CG] A, [CG] B
+    float* sGq = sGs + a.CG;
+    float* sPa = sGq + a.CG;
+    float* sPb = sPa + a.CG;
+    float* sR = sPb + a.CG;                // 27*CG (+ reuse for the 2*CG statistics)
+    for (int i = tid; i < 4 * bufsz; i += nthr) smem[i] = 0.0f;
+    for (int i = tid; i < a.CG * 27; i += nthr) sR[i] = 0.0f;
+    if (tid < a.CG) {
+        const bool ok = tid < ncg;
+        const long nci = (long)n * C + c0 + tid;
+        sGs[tid] = (ok && a.gs) ? (float)a.gs[nci] : 0.0f;
+        sGq[tid] = (ok && a.gq && a.y) ? 2.0f * (float)a.gq[nci] : 0.0f;
+        sPa[tid] = (ok && a.A) ? (float)a.A[nci] : 1.0f;
+        sPb[tid] = (ok && a.A) ? (float)a.B[nci] : 0.0f;
+    }
+    int rel[MAXLD], lofs[MAXLD];
+#pragma unroll
+    for (int k = 0; k < MAXLD; ++k) {
+        const int e = (k * nthr + tid) * VEC;
+        if (e < total_ld) {
+            const int cl = e / per_ch, off = e - cl * per_ch;
+            const int r = off / W, col = off - r * W;
+            rel[k] = (int)((long)cl * T * plane) + row_lo * W + off;
+            lofs[k] = (cl << 16) | ((cl * RIN + (row_lo - hin0) + r) * WP + XO + col);
+        } else {
+            rel[k] = -1;
+            lofs[k] = 0;
+        }
+    }
+    const int IPCb = a.IPCb, IPCp = a.IPCp;
+    const int c_slot = tid / IPCp, item = tid - c_slot * IPCp;
+    const bool active = c_slot < ncg && item < IPCb;
+    const int c_local = c_slot < ncg ? c_slot : 0;
+    const int gl = active ? item / W : 0;
+    const int wo = active ? item - gl * W : 0;
+    const int c = c0 + c_local;
+    const int hrow0 = (band * a.GB + gl) * HS;
+    const int tofs = (c_local * RIN + gl * HS) * WP + (XO - 1) + wo;
+    const long nc = (long)n * C + c;
+
+    float wr[27];
+#pragma unroll
+    for (int j = 0; j < 27; ++j) {
+        const float wv = a.w[(long)c * 27 + 26 - j];             // flipped taps for the data gradient
+        wr[j] = UNIW ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wv))) : wv;
+    }
+    float eA = 1.0f, eB = 0.0f;
+    if (active && a.A) { eA = (float)a.A[nc]; eB = (float)a.B[nc]; }
+
+    float acc[3][HS], dwa[27], gro[3][HS], xen[HS];
+#pragma unroll
+    for (int i = 0; i < HS; ++i) { acc[0][i] = acc[1][i] = acc[2][i] = 0.0f; gro[0][i] = gro[1][i] = gro[2][i] = 0.0f; xen[i] = 0.0f; }
+#pragma unroll
+    for (int j = 0; j < 27; ++j) dwa[j] = 0.0f;
+    float st1 = 0.0f, st2 = 0.0f;
+
+    typedef float __attribute__((ext_vector_type(4))) f4;
+    f4 pfG[MAXLD], pfY[MAXLD], pfX[MAXLD];
+    const bool has_y = a.y != nullptr;
+    const long gbase = ((long)n * C + c0) * T * plane;
+    auto fvalid = [&](int f) { return f >= 0 && f < T; };
+    auto prefetchG = [&](int f) {
+        if (!fvalid(f) || f > t1) return;
+        const long base = gbase + (long)f * plane;
+#pragma unroll
+        for (int k = 0; k < MAXLD; ++k) {
+            if (rel[k] >= 0) {
+                if (VEC == 4) {
+                    pfG[k] = *reinterpret_cast<const f4*>(a.gy + base + rel[k]);
+                    if (has_y) pfY[k] = *reinterpret_cast<const f4*>(a.y + base + rel[k]);
+                } else {
+                    pfG[k].x = a.gy[base + rel[k]];
+                    if (has_y) pfY[k].x = a.y[base + rel[k]];
+                }
+            }
+        }
+    };
+    auto prefetchX = [&](int f) {
+        if (!fvalid(f) || f > t1) return;
+        const long base = gbase + (long)f * plane;
+#pragma unroll
+        for (int k = 0; k < MAXLD; ++k) {
+            if (rel[k] >= 0) {
+                if (VEC == 4) pfX[k] = *reinterpret_cast<const f4*>(a.x + base + rel[k]);
+                else pfX[k].x = a.x[base + rel[k]];
+            }
+        }
+    };
+    auto stageG = [&](float* img) {
+#pragma unroll
+        for (int k = 0; k < MAXLD; ++k) {
+            if (rel[k] >= 0) {
+                const int cl = lofs[k] >> 16, lo = lofs[k] & 0xffff;
+                const float ps = sGs[cl], pq = sGq[cl];
+                f4 v = pfG[k];
+                v.x = has_y ? fmaf(pfY[k].x, pq, v.x + ps) : v.x + ps;
+                if (VEC == 4) {
+                    v.y = has_y ? fmaf(pfY[k].y, pq, v.y + ps) : v.y + ps;
+                    v.z = has_y ? fmaf(pfY[k].z, pq, v.z + ps) : v.z + ps;
+                    v.w = has_y ? fmaf(pfY[k].w, pq, v.w + ps) : v.w + ps;
+                    *reinterpret_cast<f4*>(img + lo) = v;
+                } else {
+                    img[lo] = v.x;
+                }
+            }
+        }
+    };
+    auto stageA = [&](float* img) {
+#pragma unroll
+        for (int k = 0; k < MAXLD; ++k) {
+            if (rel[k] >= 0) {
+                const int cl = lofs[k] >> 16, lo = lofs[k] & 0xffff;
+                const float pa = sPa[cl], pb = sPb[cl];
+                f4 v = pfX[k];
+                v.x = cfn_act_rt(fmaf(v.x, pa, pb), a.act);
+                if (VEC == 4) {
+                    v.y = cfn_act_rt(fmaf(v.y, pa, pb), a.act);
+                    v.z = cfn_act_rt(fmaf(v.z, pa, pb), a.act);
+                    v.w = cfn_act_rt(fmaf(v.w, pa, pb), a.act);
+                    *reinterpret_cast<f4*>(img + lo) = v;
+                } else {
+                    img[lo] = v.x;
+                }
+            }
+        }
+    };
+
+    __syncthreads();
+    const int f_first = t0 - 1, f_last = t1 + 1;
+    // prime: G(f_first) and A(f_first - 1) in images 0 (the latter is never paired: all its t_out lie outside)
+    prefetchG(f_first);
+    if (fvalid(f_first)) stageG(bufG);
+    prefetchG(f_first + 1);
+    prefetchX(f_first);                                       // A(f_first) is staged during the first step
+    __syncthreads();
+
+    for (int f = f_first, par = 0; f <= f_last; ++f, par ^= 1) {
+        const bool fv = fvalid(f) && f <= t1;                  // G(f) staged and meaningful
+        const bool av = fvalid(f - 1) && f - 1 >= t0 - 1 && f - 1 <= t1 && f > f_first;   // A(f-1) staged
+        const int to = f - 1;
+        const bool emit = (to >= t0 && to < t1) && active;
+        // ---- consume ------------------------------------------------------------------------------------------
+        float xe[HS];
+#pragma unroll
+        for (int i = 0; i < HS; ++i) xe[i] = xen[i];
+        if (f + 1 <= t1 && fvalid(f + 1)) stageG(bufG + (par ^ 1) * bufsz);
+        if (f <= t1 && fvalid(f)) stageA(bufA + (par ^ 1) * bufsz);
+        // ---- issue --------------------------------------------------------------------------------------------
+        prefetchG(f + 2);
+        prefetchX(f + 1);
+        if (a.A && to + 1 >= t0 && to + 1 < t1 && active) {
+            const long o = (nc * T + to + 1) * plane + (long)hrow0 * W + wo;
+#pragma unroll
+            for (int i = 0; i < HS; ++i) xen[i] = a.x[o + (long)i * W];
+        }
+        // ---- data gradient from the G window, g' centres for the weight gradient ----------------------------
+#pragma unroll
+        for (int i = 0; i < HS; ++i) { gro[2][i] = gro[1][i]; gro[1][i] = gro[0][i]; gro[0][i] = 0.0f; }
+        if (fv && active) {
+            const float* tg = bufG + par * bufsz + tofs;
+            const bool inchunk = f >= t0 && f < t1;            // g'(f) is a weight-gradient term only inside the chunk
+#pragma unroll
+            for (int r = 0; r < HSIN; ++r) {
+                const float v0 = tg[r * WP], v1 = tg[r * WP + 1], v2 = tg[r * WP + 2];
+                if (r >= 1 && r <= HS) gro[0][r - 1] = inchunk ? v1 : 0.0f;
+#pragma unroll
+                for (int i = 0; i < HS; ++i) {
+                    const int kh = r - i;
+                    if (kh >= 0 && kh < 3) {
+#pragma unroll
+                        for (int kt = 0; kt < 3; ++kt)
+                            acc[kt][i] = fmaf(wr[kt * 9 + kh * 3 + 0], v0,
+                                         fmaf(wr[kt * 9 + kh * 3 + 1], v1,
+                                         fmaf(wr[kt * 9 + kh * 3 + 2], v2, acc[kt][i])));
+                    }
+                }
+            }
+        }
+        // ---- weight gradient: A window of frame f-1 against g'(f), g'(f-1), g'(f-2) -------------------------
+        if (av && active) {
+            const float* ta = bufA + par * bufsz + tofs;
+#pragma unroll
+            for (int r = 0; r < HSIN; ++r) {
+                const float v0 = ta[r * WP], v1 = ta[r * WP + 1], v2 = ta[r * WP + 2];
+#pragma unroll
+                for (int i = 0; i < HS; ++i) {
+                    const int kh = r - i;
+                    if (kh >= 0 && kh < 3) {
+#pragma unroll
+                        for (int kt = 0; kt < 3; ++kt) {
+                            dwa[kt * 9 + kh * 3 + 0] = fmaf(gro[kt][i], v0, dwa[kt * 9 + kh * 3 + 0]);
+                            dwa[kt * 9 + kh * 3 + 1] = fmaf(gro[kt][i], v1, dwa[kt * 9 + kh * 3 + 1]);
+                            dwa[kt * 9 + kh * 3 + 2] = fmaf(gro[kt][i], v2, dwa[kt * 9 + kh * 3 + 2]);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- emit gx(to) ----------------------------------------------------------------------------------------
+        if (emit) {
+            const long o = (nc * T + to) * plane + (long)hrow0 * W + wo;
+#pragma unroll
+            for (int i = 0; i < HS; ++i) {
+                float v = acc[2][i];
+                if (a.A) {
+                    const float dz = v * cfn_act_grad_rt(fmaf(xe[i], eA, eB), a.act);
+                    st1 = fmaf(dz, xe[i], st1);
+                    st2 += dz;
+                    v = dz * eA;
+                }
+                a.gx[o + (long)i * W] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < HS; ++i) { acc[2][i] = acc[1][i]; acc[1][i] = acc[0][i]; acc[0][i] = 0.0f; }
+        __syncthreads();
+    }
+
+    // ---- reductions: gw (27 per channel), then gA / gB ---------------------------------------------------------
+    const int key = active ? c_local : -1 - (tid >> 6);
+    const int prev_key = __shfl_up(key, 1, 64);
+    const bool head = active && (lane == 0 || prev_key != key);
+#pragma unroll
+    for (int j = 0; j < 27; ++j) {
+        const float r = seg_wave_sum(dwa[j], key, lane);
+        if (head) atomicAdd(&sR[c_local * 27 + j], r);
+    }
+    __syncthreads();
+    for (int i = tid; i < ncg * 27; i += nthr) atomicAdd(&a.gw[(long)c0 * 27 + i], (double)sR[i]);
+    if (a.A && a.gA) {
+        __syncthreads();
+        for (int i = tid; i < a.CG * 2; i += nthr) sR[i] = 0.0f;
+        __syncthreads();
+        const float r1 = seg_wave_sum(st1, key, lane);
+        const float r2 = seg_wave_sum(st2, key, lane);
+        if (head) { atomicAdd(&sR[c_local * 2], r1); atomicAdd(&sR[c_local * 2 + 1], r2); }
+        __syncthreads();
+        if (tid < ncg) {
+            atomicAdd(&a.gA[(long)n * C + c0 + tid], (double)sR[tid * 2]);
+            atomicAdd(&a.gB[(long)n * C + c0 + tid], (double)sR[tid * 2 + 1]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // stride-2 data gradient (first block of every stage).  A thread owns one position (i,j) of the
 // (Ho x Wo) gradient plane = the 2x2 input block (2i..2i+1, 2j..2j+1) and marches along t holding
 // the 2x2 neighbourhood g'[f][i..i+1][j..j+1] of three consecutive gradient frames in registers,
@@ -695,7 +980,9 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_fast_kernel(const DwS2Args 
 // ---------------------------------------------------------------------------------------------
 struct DwPlan { int HS, VEC, MAXLD, threads; bool UNIW; size_t lds; unsigned blocks; };
 
+static thread_local int g_force_hs = 0;   // fused backward: explicit strip height
 static int pick_hs(int Ho, int mode, int S) {
+    if (g_force_hs > 0 && Ho % g_force_hs == 0) return g_force_hs;
     // stride 2 (forward / weight gradient): one output row per thread.  A 7-row strip needs a 15-row input window per
     // thread and leaves too few threads per plane (measured at 4 clips: 112->56 fwd 1.15 -> 0.67 ms, wgrad 1.17 -> 0.77)
     if (S == 2) return 1;
@@ -903,4 +1190,54 @@ extern "C" int cfn_dwconv3d_bwd_weight(const float* gy, const float* y, const do
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_DWCONV_WGRAD, st, 4.0 * N * C * T * ((double)Hi * Wi + (double)a.Ho * a.Wo * (a.yout ? 2 : 1)));
     return stride == 1 ? dw_launch<DW_WGRAD, 1>(a, pl, st) : dw_launch<DW_WGRAD, 2>(a, pl, st);
+}
+
+// fused data + weight gradient (stride 1, big planes: wave-uniform channels, float4 rows); -1 = use the two kernels
+template <int HS>
+static int dwf_launch_hs(const DwFusedArgs& f, int MAXLD, unsigned blocks, int threads, size_t lds, hipStream_t st) {
+#define CFN_DWF_GO(ML)                                                                                                \
+    do {                                                                                                               \
+        auto k = dw3d_bwd_fused_kernel<HS, 4, ML, true>;                                                               \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), lds, st, f);                                                \
+    } while (0)
+    if (MAXLD == 2) CFN_DWF_GO(2); else if (MAXLD == 4) CFN_DWF_GO(4); else CFN_DWF_GO(8);
+#undef CFN_DWF_GO
+    return cfn_check_launch("dwconv3d_bwd_fused");
+}
+
+extern "C" int cfn_dwconv3d_bwd_fused(const float* gy, const float* y, const double* gsum, const double* gsumsq,
+                                      const float* w, const float* x, const double* A, const double* B, int act, float* gx,
+                                      double* gA, double* gB, double* gw, int N, int C, int T, int H, int W, void* stream) {
+    CFN_REQUIRE(gy && w && x && gx && gw, "cfn_dwconv3d_bwd_fused: null tensor");
+    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_dwconv3d_bwd_fused: A/B mismatch");
+    CFN_REQUIRE(A == nullptr || (gA != nullptr && gB != nullptr), "cfn_dwconv3d_bwd_fused: prologue needs gA, gB");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv3d_bwd_fused: gsumsq needs y");
+    DwArgs a = {};
+    a.N = N; a.C = C; a.T = T; a.Hi = H; a.Wi = W;
+    DwPlan pl;
+    // 4-row strips first (164 VGPRs -> 3 waves per SIMD; measured 56x56: 1.92 ms against 2.18 ms with 7 rows and 2.35 ms
+    // for the two separate kernels), 7-row strips when 4 rows do not give wave-uniform channels (28x28)
+    int rc = CFN_ERR_UNSUPPORTED;
+    bool ok = false;
+    for (int hs : {4, 0}) {
+        g_force_hs = hs;
+        rc = dw_plan(a, 1, DW_WGRAD, pl);
+        g_force_hs = 0;
+        if (rc == CFN_OK && pl.UNIW && pl.VEC == 4 && pl.MAXLD != 8 && (pl.HS == 4 || pl.HS == 7)) { ok = true; break; }
+    }
+    if (!ok) return -1;                            // small planes keep the two separate kernels
+    DwFusedArgs f = {gy, gsumsq ? y : nullptr, gsum, gsumsq, w, x, A, B, gx, A ? gA : nullptr, A ? gB : nullptr, gw,
+                     N, C, T, H, W, act};
+    f.TT = a.TT; f.nchunks = a.nchunks; f.CG = a.CG; f.ngroups = a.ngroups; f.GB = a.GB; f.nbands = a.nbands;
+    f.IPCb = a.IPCb; f.IPCp = a.IPCp; f.RIN = a.RIN; f.WP = a.WP; f.XO = a.XO;
+    const size_t lds = ((size_t)4 * a.CG * a.RIN * a.WP + 4 * a.CG + 27 * a.CG) * sizeof(float);
+    if (lds > 150 * 1024) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DWCONV_BWD, st, 4.0 * N * C * T * (double)H * W * (y ? 4 : 3));
+    switch (pl.HS) {
+        case 7: return dwf_launch_hs<7>(f, pl.MAXLD, pl.blocks, pl.threads, lds, st);
+        case 4: return dwf_launch_hs<4>(f, pl.MAXLD, pl.blocks, pl.threads, lds, st);
+        default: return -1;
+    }
 }
