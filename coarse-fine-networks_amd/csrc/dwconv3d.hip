@@ -1194,14 +1194,14 @@ extern "C" int cfn_dwconv3d_bwd_weight(const float* gy, const float* y, const do
 
 // fused data + weight gradient (stride 1, big planes: wave-uniform channels, float4 rows); -1 = use the two kernels
 template <int HS>
-static int dwf_launch_hs(const DwFusedArgs& f, int MAXLD, unsigned blocks, int threads, size_t lds, hipStream_t st) {
-#define CFN_DWF_GO(ML)                                                                                                \
+static int dwf_launch_hs(const DwFusedArgs& f, const DwPlan& pl, size_t lds, hipStream_t st) {
+#define CFN_DWF_GO(VECV, ML, UW)                                                                                       \
     do {                                                                                                               \
-        auto k = dw3d_bwd_fused_kernel<HS, 4, ML, true>;                                                               \
+        auto k = dw3d_bwd_fused_kernel<HS, VECV, ML, UW>;                                                              \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), lds, st, f);                                                \
+        hipLaunchKernelGGL(k, dim3(pl.blocks), dim3(pl.threads), lds, st, f);                                          \
     } while (0)
-    if (MAXLD == 2) CFN_DWF_GO(2); else if (MAXLD == 4) CFN_DWF_GO(4); else CFN_DWF_GO(8);
+    if (pl.MAXLD == 2) CFN_DWF_GO(4, 2, true); else CFN_DWF_GO(4, 4, true);   // measured: no gain on 14x14 / 7x7 planes
 #undef CFN_DWF_GO
     return cfn_check_launch("dwconv3d_bwd_fused");
 }
@@ -1236,8 +1236,8 @@ extern "C" int cfn_dwconv3d_bwd_fused(const float* gy, const float* y, const dou
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_DWCONV_BWD, st, 4.0 * N * C * T * (double)H * W * (y ? 4 : 3));
     switch (pl.HS) {
-        case 7: return dwf_launch_hs<7>(f, pl.MAXLD, pl.blocks, pl.threads, lds, st);
-        case 4: return dwf_launch_hs<4>(f, pl.MAXLD, pl.blocks, pl.threads, lds, st);
+        case 7: return dwf_launch_hs<7>(f, pl, lds, st);
+        case 4: return dwf_launch_hs<4>(f, pl, lds, st);
         default: return -1;
     }
 }
