@@ -1029,7 +1029,10 @@ static int dw_plan(DwArgs& a, int S, int mode, DwPlan& pl) {
     // UNIW: 4-wave workgroups (several fit on a CU, barriers stay cheap)
     // small planes: up to 8 waves; the data gradient (most registers, two staged tensors) runs better as 4-wave
     // workgroups, several of which fit on a CU (measured at 4 clips: 14x14 0.31 -> 0.25 ms, 7x7 0.25 -> 0.16 ms)
-    int CG = (pl.UNIW || mode == DW_DGRAD ? 256 : 512) / a.IPCp;
+    // 4-wave workgroups (two per CU at this variant's register budget) beat one 8-wave workgroup everywhere except the
+    // 7x7 forward (measured, 8 clips: 56->28 s2 fwd 0.80 -> 0.70 ms, 28->14 s2 0.42 -> 0.35, 14x14 wgrad 0.47 -> 0.45)
+    const int wg = (pl.UNIW || mode != DW_FWD || a.Ho * a.Wo > 64) ? 256 : 512;
+    int CG = wg / a.IPCp;
     if (CG < 1) CG = 1;
     if (CG > a.C) CG = a.C;
     if (CG > 128) CG = 128;
