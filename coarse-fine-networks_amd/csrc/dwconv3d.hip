@@ -57,6 +57,11 @@ template <int MODE, int S, int HS, int VEC, int MAXLD, bool UNIW>
 __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_FWD ? 4 : 3) : (MAXLD == 4 ? 3 : 2)) : 2) void dw3d_kernel(const DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HSIN = (HS - 1) * S + 3;
+    // VEC: 4 = rows are whole float4s; 1 = scalar loader; 2 = FLAT: the row width is only even, but a plane is a whole
+    // number of float4s and the band covers it: the loader walks the contiguous plane in float4s and writes each as two
+    // float2 halves (neither crosses a row: even width, even start)
+    constexpr bool FLAT = VEC == 2;
+    constexpr int LV = VEC == 1 ? 1 : 4;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
 
     unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
@@ -98,17 +103,23 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     // ---- loader bookkeeping (frame invariant) -------------------------------------------------
     int rel[MAXLD];      // element offset from the (n, c0, frame) base, -1 = nothing to load
     int lofs[MAXLD];     // (channel_local << 16) | LDS float offset
+    int lofs2[FLAT ? MAXLD : 1];   // FLAT: LDS float offset of elements 2, 3
 #pragma unroll
     for (int k = 0; k < MAXLD; ++k) {
-        const int e = (k * nthr + tid) * VEC;
+        const int e = (k * nthr + tid) * LV;
         if (e < total_ld) {
             const int cl = e / per_ch, off = e - cl * per_ch;
             const int r = off / Wi, col = off - r * Wi;
             rel[k] = (int)((long)cl * T * plane_i) + row_lo * Wi + off;
             lofs[k] = (cl << 16) | ((cl * RIN + (row_lo - hin0) + r) * WP + XO + col);
+            if (FLAT) {
+                const int r2 = (off + 2) / Wi, col2 = off + 2 - r2 * Wi;
+                lofs2[k] = (cl * RIN + (row_lo - hin0) + r2) * WP + XO + col2;
+            }
         } else {
             rel[k] = -1;
             lofs[k] = 0;
+            if (FLAT) lofs2[k] = 0;
         }
     }
 
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     // with vmcnt(N) for exactly the frame it needs instead of vmcnt(0), so the frames prefetched behind it stay in flight.
     // (measured: wins for the float4 forward and the data gradient; the scalar-loader forward and the weight gradient,
     // whose consumer needs the youngest loads anyway, are faster with plain predicated accesses)
-    constexpr bool UNC = MODE == DW_DGRAD || (MODE == DW_FWD && VEC == 4);
+    constexpr bool UNC = MODE == DW_DGRAD || (MODE == DW_FWD && LV == 4);
     constexpr int OOB = 0x7ffffff0;
     const long gi0 = ((long)n * C + c0) * T * plane_i, go0 = ((long)n * C + c0) * T * plane_o;
     const unsigned span_i = (unsigned)((long)ncg * T * plane_i * 4), span_o = (unsigned)((long)ncg * T * plane_o * 4);
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     float st1 = 0.0f, st2 = 0.0f;
 
     typedef float __attribute__((ext_vector_type(4))) f4;
-    constexpr int DEPTH = (MODE != DW_WGRAD && VEC == 4) ? 2 : 1;   // frames in flight in registers
+    constexpr int DEPTH = (MODE != DW_WGRAD && LV == 4) ? 2 : 1;   // frames in flight in registers
     f4 pfA[MAXLD], pfA2[MAXLD], pfB[DEPTH == 2 ? MAXLD : 1], pfB2[DEPTH == 2 ? MAXLD : 1];
     const bool two_src = (MODE == DW_DGRAD) && a.src2 != nullptr;
 
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
 #pragma unroll
             for (int k = 0; k < MAXLD; ++k) {
                 if (rel[k] >= 0) {
-                    if (VEC == 4) pf[k] = *reinterpret_cast<const f4*>(a.src + base + rel[k]);
+                    if (LV == 4) pf[k] = *reinterpret_cast<const f4*>(a.src + base + rel[k]);
                     else pf[k].x = a.src[base + rel[k]];
                 }
             }
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
 #pragma unroll
         for (int k = 0; k < MAXLD; ++k) {
             const int vo = fvd ? relb[k] : OOB;
-            if (VEC == 4) {
+            if (LV == 4) {
                 pf[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, so, 0));
                 if (MODE == DW_DGRAD && two_src) pf2[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs2, vo, so, 0));
             } else {
@@ -222,31 +233,35 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
                 if (MODE == DW_DGRAD) {
                     if (two_src) {
                         v.x = fmaf(pf2[k].x, pb, v.x + pa);
-                        if (VEC == 4) {
+                        if (LV == 4) {
                             v.y = fmaf(pf2[k].y, pb, v.y + pa);
                             v.z = fmaf(pf2[k].z, pb, v.z + pa);
                             v.w = fmaf(pf2[k].w, pb, v.w + pa);
                         }
                     } else {
                         v.x += pa;
-                        if (VEC == 4) { v.y += pa; v.z += pa; v.w += pa; }
+                        if (LV == 4) { v.y += pa; v.z += pa; v.w += pa; }
                     }
                 } else if (simple_act) {   // none / ReLU (every X3D conv2): branch-free max against -inf or 0
                     v.x = fmaxf(fmaf(v.x, pa, pb), act_lo);
-                    if (VEC == 4) {
+                    if (LV == 4) {
                         v.y = fmaxf(fmaf(v.y, pa, pb), act_lo);
                         v.z = fmaxf(fmaf(v.z, pa, pb), act_lo);
                         v.w = fmaxf(fmaf(v.w, pa, pb), act_lo);
                     }
                 } else {
                     v.x = cfn_act_rt(fmaf(v.x, pa, pb), a.act);
-                    if (VEC == 4) {
+                    if (LV == 4) {
                         v.y = cfn_act_rt(fmaf(v.y, pa, pb), a.act);
                         v.z = cfn_act_rt(fmaf(v.z, pa, pb), a.act);
                         v.w = cfn_act_rt(fmaf(v.w, pa, pb), a.act);
                     }
                 }
-                if (VEC == 4) *reinterpret_cast<f4*>(img + lo) = v;
+                typedef float __attribute__((ext_vector_type(2))) f2;
+                if (FLAT) {
+                    *reinterpret_cast<f2*>(img + lo) = f2{v.x, v.y};
+                    *reinterpret_cast<f2*>(img + lofs2[k]) = f2{v.z, v.w};
+                } else if (LV == 4) *reinterpret_cast<f4*>(img + lo) = v;
                 else img[lo] = v.x;
             }
         }
@@ -995,26 +1010,36 @@ static int pick_hs(int Ho, int mode, int S) {
     return 1;
 }
 
-static int dw_plan(DwArgs& a, int S, int mode, DwPlan& pl) {
+static int dw_plan_impl(DwArgs& a, int S, int mode, DwPlan& pl, bool allow_flat) {
     a.Ho = (a.Hi + 2 - 3) / S + 1;
     a.Wo = (a.Wi + 2 - 3) / S + 1;
     const int HS = pick_hs(a.Ho, mode, S);
     const int G = a.Ho / HS;
     if (a.Wo > 512) return cfn_fail(CFN_ERR_UNSUPPORTED, "dwconv3d: output width %d > 512 not supported", a.Wo);
-    const int VEC = (a.Wi % 4 == 0) ? 4 : 1;
-    a.XO = VEC == 4 ? 4 : 1;
-    a.WP = VEC == 4 ? a.Wi + 8 : a.Wi + 2;
-    // rows per band: largest divisor GB of G with GB*Wo <= 512 threads, LDS <= 64 KiB, loader capacity
-    int GB = G;
+    // loader: whole-float4 rows (4); else, when the width is even and the plane a whole number of float4s, float4s over
+    // the contiguous plane (2, needs the band to cover the plane); else scalar (1)
+    const bool aligned16 = ((uintptr_t)a.src % 16 == 0) && (mode != DW_DGRAD || a.src2 == nullptr || (uintptr_t)a.src2 % 16 == 0);
+    int VEC = (a.Wi % 4 == 0) ? 4 : ((allow_flat && a.Wi % 2 == 0 && (a.Hi * a.Wi) % 4 == 0 && aligned16) ? 2 : 1);
+    int GB;
     for (;; ) {
-        while (G % GB) --GB;
-        const int rin = (GB * HS - 1) * S + 3;
-        const long ipcb = (long)GB * a.Wo;
-        const long thr = (ipcb + 63) / 64 * 64;
-        const bool fits = ipcb <= 256 && (long)rin * a.WP * 8 <= 60 * 1024 && (long)rin * a.Wi <= (long)VEC * 8 * thr;
-        if (fits || GB == 1) break;
-        --GB;
+        const int LVh = VEC == 1 ? 1 : 4;
+        a.XO = VEC == 4 ? 4 : (VEC == 2 ? 2 : 1);
+        a.WP = VEC == 4 ? a.Wi + 8 : (VEC == 2 ? a.Wi + 4 : a.Wi + 2);
+        // rows per band: largest divisor GB of G with GB*Wo <= 512 threads, LDS <= 64 KiB, loader capacity
+        GB = G;
+        for (;; ) {
+            while (G % GB) --GB;
+            const int rin = (GB * HS - 1) * S + 3;
+            const long ipcb = (long)GB * a.Wo;
+            const long thr = (ipcb + 63) / 64 * 64;
+            const bool fits = ipcb <= 256 && (long)rin * a.WP * 8 <= 60 * 1024 && (long)rin * a.Wi <= (long)LVh * 8 * thr;
+            if (fits || GB == 1) break;
+            --GB;
+        }
+        if (VEC == 2 && GB != G) { VEC = 1; continue; }   // the flat loader needs the whole plane in one band
+        break;
     }
+    const int LVh = VEC == 1 ? 1 : 4;
     a.GB = GB;
     a.nbands = G / GB;
     a.RIN = (GB * HS - 1) * S + 3;
@@ -1038,18 +1063,18 @@ static int dw_plan(DwArgs& a, int S, int mode, DwPlan& pl) {
     if (CG > 128) CG = 128;
     while (CG > 1 && ((long)CG * a.RIN * a.WP * 8 > 48 * 1024)) --CG;
     int threads;
-    for (;; --CG) {   // loader capacity: VEC*8 elements per thread per frame
+    for (;; --CG) {   // loader capacity: LV*8 elements per thread per frame
         threads = (CG * a.IPCp + 63) / 64 * 64;
-        if ((long)CG * a.RIN * a.Wi <= (long)VEC * 8 * threads || CG == 1) break;
+        if ((long)CG * a.RIN * a.Wi <= (long)LVh * 8 * threads || CG == 1) break;
     }
-    if ((long)CG * a.RIN * a.Wi > (long)VEC * 8 * threads)
+    if ((long)CG * a.RIN * a.Wi > (long)LVh * 8 * threads)
         return cfn_fail(CFN_ERR_UNSUPPORTED, "dwconv3d: loader capacity exceeded for plane %dx%d", a.Hi, a.Wi);
     if ((long)CG * a.T * a.Hi * a.Wi * 4 >= 0x7ffffff0L)
         return cfn_fail(CFN_ERR_UNSUPPORTED, "dwconv3d: %d channels x %d frames of a %dx%d plane exceed the 2 GiB buffer range", CG, a.T, a.Hi, a.Wi);
     a.CG = CG;
     a.ngroups = cfn_cdiv(a.C, CG);
-    const long per_thread = ((long)CG * a.RIN * a.Wi + (long)VEC * threads - 1) / ((long)VEC * threads);
-    const int MAXLD = (VEC == 4 && per_thread <= 2) ? 2 : (per_thread <= 4 ? 4 : 8);
+    const long per_thread = ((long)CG * a.RIN * a.Wi + (long)LVh * threads - 1) / ((long)LVh * threads);
+    const int MAXLD = (LVh == 4 && per_thread <= 2) ? 2 : (per_thread <= 4 ? 4 : 8);
     // frames per chunk: as long as possible while keeping >= ~6 workgroups per CU in the grid
     const long planes = (long)a.N * a.ngroups * a.nbands;
     // Whole rounds: resident workgroups per CU follow from the register budget of the variant (launch bounds),
@@ -1074,6 +1099,13 @@ static int dw_plan(DwArgs& a, int S, int mode, DwPlan& pl) {
     return CFN_OK;
 }
 
+static int dw_plan(DwArgs& a, int S, int mode, DwPlan& pl) {
+    int rc = dw_plan_impl(a, S, mode, pl, true);
+    // the flat loader exists for per-lane channels and <= 4 loads per thread only
+    if (rc == CFN_OK && pl.VEC == 2 && (pl.UNIW || pl.MAXLD == 8)) rc = dw_plan_impl(a, S, mode, pl, false);
+    return rc;
+}
+
 template <int MODE, int S, int HS>
 static int dw_launch_hs(const DwArgs& a, const DwPlan& pl, hipStream_t st) {
 #define CFN_DW_GO(VEC, MAXLD, UW)                                                                                      \
@@ -1089,7 +1121,9 @@ static int dw_launch_hs(const DwArgs& a, const DwPlan& pl, hipStream_t st) {
         else if (pl.MAXLD == 4) CFN_DW_GO(1, 4, true);
         else CFN_DW_GO(1, 8, true);
     } else {
-        if (pl.VEC == 4 && pl.MAXLD == 2) CFN_DW_GO(4, 2, false);
+        if (pl.VEC == 2 && pl.MAXLD == 2) CFN_DW_GO(2, 2, false);
+        else if (pl.VEC == 2) CFN_DW_GO(2, 4, false);
+        else if (pl.VEC == 4 && pl.MAXLD == 2) CFN_DW_GO(4, 2, false);
         else if (pl.VEC == 4 && pl.MAXLD == 4) CFN_DW_GO(4, 4, false);
         else if (pl.VEC == 4) CFN_DW_GO(4, 8, false);
         else if (pl.MAXLD == 4) CFN_DW_GO(1, 4, false);
