@@ -15,14 +15,20 @@ import sys
 
 
 def per_kernel(path, counter):
-    out = collections.OrderedDict()
-    for r in csv.DictReader(open(path)):
-        if r['Counter_Name'] != counter:
-            continue
+    """[(kernel, grid, [bytes per launch, ...]), ...] in dispatch order; one entry per layer shape: a run of launches of
+    one (kernel, grid) is split where the counter jumps by > 25 % (two shapes can share kernel variant and grid)"""
+    rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter]
+    rows.sort(key=lambda r: int(r['Dispatch_Id']))
+    out = []
+    for r in rows:
         name = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')
         if not (name.startswith('dw3d_kernel<0') or name.startswith('dwt5_kernel<0')):
             continue
-        out.setdefault((name, r['Grid_Size']), []).append(float(r['Counter_Value']) * 1024.0)
+        v = float(r['Counter_Value']) * 1024.0
+        if out and out[-1][0] == name and out[-1][1] == r['Grid_Size'] and abs(v - out[-1][2][0]) <= 0.25 * out[-1][2][0]:
+            out[-1][2].append(v)
+        else:
+            out.append((name, r['Grid_Size'], [v]))
     return out
 
 
@@ -32,8 +38,10 @@ def main():
     T = int(sys.argv[5]) if len(sys.argv) > 5 else 256
     f, w = per_kernel(fetch, 'FETCH_SIZE'), per_kernel(write, 'WRITE_SIZE')
     layers, tot, launches = [], 0.0, 0
-    for key in f:
-        fv, wv = f[key][1:], w[key][1:]          # drop the warm-up launch
+    assert len(f) == len(w) and all(a[:2] == b[:2] and len(a[2]) == len(b[2]) for a, b in zip(f, w)), 'passes disagree'
+    for (kn, grid, fa), (_, _, wa) in zip(f, w):
+        key = (kn, grid)
+        fv, wv = fa[1:], wa[1:]                  # drop the warm-up launch
         fb, wb = 2.0 * sum(fv) / len(fv), sum(wv) / len(wv)
         layers.append({'kernel': key[0], 'grid': int(key[1]), 'launches_per_step': len(fv),
                        'fetch_bytes_x2_per_launch': fb, 'write_bytes_per_launch': wb})
