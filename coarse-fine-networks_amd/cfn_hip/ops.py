@@ -129,11 +129,24 @@ class ShortcutToken(object):
         self.acc, self.acc_stride, self.main_done = None, 1, False
 
 
+class TailLink(object):
+    """Couples a block tail (bn_add_relu) with the pointwise conv(s) whose raw outputs it consumes (conv3 as `y`, the
+    strided shortcut conv as `res`).  With a link the tail's backward writes ONE tensor g = (gout [+ gout2]) * relu' and
+    hands it out as the gradient of both inputs; the per-(n,c) factors A (for y) and Ar (for res) that turn it into the
+    true gradients are left here and applied by the convs' backward kernels when they load it (`gscale`).  The gradient
+    tensors of y / res are therefore only meaningful to those convs -- which is why the link must be given to both
+    sides."""
+
+    def __init__(self):
+        self.y_scale = self.res_scale = None
+        self.done = False
+
+
 class _PwConv(Function):
     """1x1x1 conv (optionally spatial stride 2) on fp32 MFMA; see include/cfn_hip.h cfn_pwconv_*."""
 
     @staticmethod
-    def forward(ctx, x, A, B, w, act, stride, want_stats, token, role):
+    def forward(ctx, x, A, B, w, act, stride, want_stats, token, role, tail=None, tail_role=None):
         x = check(x).contiguous()
         N, Cin, T, H, W = x.shape
         Cout = w.shape[0]
@@ -149,6 +162,7 @@ class _PwConv(Function):
         ctx.meta = (act, stride, tuple(w.shape))
         ctx.wparam = w
         ctx.token, ctx.role = token, role
+        ctx.tail, ctx.tail_role = tail, tail_role
         if not want_stats:
             return y, None, None
         return y, s, q
@@ -162,6 +176,9 @@ class _PwConv(Function):
         Cout = w2.shape[0]
         gy = torch.zeros_like(y) if gy is None else gy.contiguous()
         gs, gq = _opt(gs), _opt(gq)
+        gsc = None   # gy of a linked block tail is unscaled: the kernels apply the tail's per-(n,c) factor on load
+        if ctx.tail is not None and ctx.tail.done:
+            gsc = ctx.tail.y_scale if ctx.tail_role == 'y' else ctx.tail.res_scale
         gx = gA = gB = gw = None
         if ctx.needs_input_grad[0] or (A is not None and ctx.needs_input_grad[1]):
             if token is not None and role == 'short' and stride > 1 and not token.main_done:
@@ -169,34 +186,35 @@ class _PwConv(Function):
                 # conv1's data gradient consumes it
                 Ho, Wo = y.shape[3], y.shape[4]
                 da = torch.empty(N, Cin, T, Ho, Wo, dtype=torch.float32, device=x.device)
-                call('cfn_pwconv_bwd_data', gy, y, gs, gq, w2, None, None, None, ACT_NONE, da, None, None, N, Cin, Cout, T,
-                     Ho, Wo, 1)
+                call('cfn_pwconv_bwd_data_acc', gy, y, gs, gq, w2, None, None, None, ACT_NONE, da, None, None, N, Cin, Cout, T,
+                     Ho, Wo, 1, None, 1, gsc)
                 token.acc, token.acc_stride = da, stride
             else:
                 gx = torch.zeros_like(x) if stride != 1 else torch.empty_like(x)
                 ab = a64 = b64 = None
                 if A is not None:
                     ab, a64, b64 = _f64pair(N, Cin, x.device)
-                if token is not None and role == 'main' and token.acc is not None:
-                    call('cfn_pwconv_bwd_data_acc', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, Cin, Cout, T, H, W, stride,
-                         token.acc, token.acc_stride)
-                    token.acc = None
-                else:
-                    if token is not None and role == 'main':
+                acc, acc_stride = None, 1
+                if token is not None and role == 'main':
+                    if token.acc is not None:
+                        acc, acc_stride, token.acc = token.acc, token.acc_stride, None
+                    else:
                         token.main_done = True
-                    call('cfn_pwconv_bwd_data', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, Cin, Cout, T, H, W, stride)
+                call('cfn_pwconv_bwd_data_acc', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, Cin, Cout, T, H, W, stride,
+                     acc, acc_stride, gsc)
                 if A is not None:
                     gA, gB = ab[0], ab[1]
         if ctx.needs_input_grad[3]:
             g64, fin = _gw_buffers(ctx.wparam, Cout, Cin, x.device)
-            call('cfn_pwconv_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, Cin, Cout, T, H, W, stride)
+            call('cfn_pwconv_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, Cin, Cout, T, H, W, stride, gsc)
             gw = fin()
-        return gx, gA, gB, gw, None, None, None, None, None
+        return gx, gA, gB, gw, None, None, None, None, None, None, None
 
 
-def pwconv(x, w, A=None, B=None, act=ACT_NONE, stride=1, stats=True, token=None, role=None):
-    """returns (y, sum, sumsq); sum/sumsq are None when stats=False.  token / role ('main' | 'short'): see ShortcutToken"""
-    return _PwConv.apply(x, A, B, w, act, stride, stats, token, role)
+def pwconv(x, w, A=None, B=None, act=ACT_NONE, stride=1, stats=True, token=None, role=None, tail=None, tail_role=None):
+    """returns (y, sum, sumsq); sum/sumsq are None when stats=False.  token / role ('main' | 'short'): see ShortcutToken;
+    tail / tail_role ('y' | 'res'): see TailLink"""
+    return _PwConv.apply(x, A, B, w, act, stride, stats, token, role, tail, tail_role)
 
 
 class _DwConv3d(Function):
@@ -402,14 +420,20 @@ class _BnAddRelu(Function):
     kernel sums them on the fly instead of a 3-pass add kernel in between.  Nothing may write to either in place."""
 
     @staticmethod
-    def forward(ctx, y, A, B, res, Ar, Br, split):
+    def forward(ctx, y, A, B, res, Ar, Br, split, link):
         y, res = check(y).contiguous(), check(res).contiguous()
         N, C = y.shape[:2]
         vol = y[0, 0].numel()
         out = torch.empty_like(y)
         A, B, Ar, Br = _coef(A), _coef(B), _coef(Ar), _coef(Br)
-        call('cfn_bn_add_relu_fwd', y, A, B, res, Ar, Br, out, N * C, vol)
-        ctx.save_for_backward(y, A, res, Ar, out)
+        mask = None
+        if link is not None:   # ReLU bit mask for the one-tensor backward (1/32 of a tensor instead of re-reading out)
+            words = query('cfn_bn_add_relu_mask_words', N * C, vol)
+            if words > 0:
+                mask = torch.empty(words, dtype=torch.int32, device=y.device)
+        call('cfn_bn_add_relu_fwd', y, A, B, res, Ar, Br, out, mask, N * C, vol)
+        ctx.link, ctx.has_mask = link, mask is not None
+        ctx.save_for_backward(y, A, res, Ar, mask if mask is not None else out)
         if not split:
             return out
         alias = torch.empty(0, dtype=out.dtype, device=out.device).set_(out.untyped_storage(), out.storage_offset(),
@@ -424,19 +448,32 @@ class _BnAddRelu(Function):
         if gout is None:
             gout, gout2 = gout2, None
         if gout is None:
-            gout = torch.zeros_like(out)
-        gy, gres = torch.empty_like(y), torch.empty_like(res)
+            gout = torch.zeros_like(y)
+        gout2 = None if gout2 is None else gout2.contiguous()
         t3 = _arena.take(3 * N * C, y.device).view(3, N, C)
-        call('cfn_bn_add_relu_bwd', gout.contiguous(), None if gout2 is None else gout2.contiguous(), out, y, A, res, Ar, gy,
-             gres, t3[0], t3[1], t3[2] if Ar is not None else None, N * C, vol)
         gA, gB = t3[0], t3[1]
         gAr = t3[2] if Ar is not None else None
         gBr = gB if Ar is not None else None
-        return gy, gA, gB, gres, gAr, gBr, None
+        link = ctx.link
+        if link is not None:
+            g = torch.empty_like(y)
+            mask = out if ctx.has_mask else None
+            call('cfn_bn_add_relu_bwd_g', gout.contiguous(), gout2, None if ctx.has_mask else out, mask, y,
+                 res if Ar is not None else None, g, gA, gB, gAr, N * C, vol)
+            link.y_scale, link.res_scale, link.done = A, Ar, True
+            # one tensor, two consumers: a second tensor object over the same storage keeps autograd from accumulating
+            # into it in place
+            g2 = torch.empty(0, dtype=g.dtype, device=g.device).set_(g.untyped_storage(), g.storage_offset(), g.shape, g.stride())
+            return g, gA, gB, g2, gAr, gBr, None, None
+        gy, gres = torch.empty_like(y), torch.empty_like(res)
+        call('cfn_bn_add_relu_bwd', gout.contiguous(), gout2, out, y, A, res, Ar, gy, gres, gA, gB, gAr, N * C, vol)
+        return gy, gA, gB, gres, gAr, gBr, None, None
 
 
-def bn_add_relu(y, A, B, res, Ar=None, Br=None, split=False):
-    return _BnAddRelu.apply(y, A, B, res, Ar, Br, split)
+def bn_add_relu(y, A, B, res, Ar=None, Br=None, split=False, link=None):
+    """link (TailLink): one-tensor backward, see TailLink -- the producers of y (and of res when Ar is given) MUST be pwconv
+    calls carrying the same link"""
+    return _BnAddRelu.apply(y, A, B, res, Ar, Br, split, link)
 
 
 class _AffineAct(Function):

@@ -30,11 +30,12 @@ template <int VEC>
 __global__ __launch_bounds__(256) void bn_add_relu_fwd_kernel(const float* __restrict__ y, const double* __restrict__ A,
                                                               const double* __restrict__ B, const float* __restrict__ res,
                                                               const double* __restrict__ Ar, const double* __restrict__ Br,
-                                                              float* __restrict__ out, long vol) {
+                                                              float* __restrict__ out, unsigned* __restrict__ mask, long vol) {
     const long nc = blockIdx.y;
     const float a = A[nc], b = B[nc] + (Br ? Br[nc] : 0.0f), ar = Ar ? Ar[nc] : 1.0f;
     const long base = nc * vol;
     long i = ((long)blockIdx.x * 256 * EW_ITEMS + threadIdx.x) * VEC;
+    unsigned mw = 0;   // bit 4k+e: element e of this thread's k-th float4 is positive (VEC 4 only)
 #pragma unroll
     for (int k = 0; k < EW_ITEMS; ++k, i += 256 * VEC) {
         if (i >= vol) break;
@@ -45,9 +46,66 @@ __global__ __launch_bounds__(256) void bn_add_relu_fwd_kernel(const float* __res
             o.x = fmaxf(fmaf(yv.x, a, fmaf(rv.x, ar, b)), 0.f); o.y = fmaxf(fmaf(yv.y, a, fmaf(rv.y, ar, b)), 0.f);
             o.z = fmaxf(fmaf(yv.z, a, fmaf(rv.z, ar, b)), 0.f); o.w = fmaxf(fmaf(yv.w, a, fmaf(rv.w, ar, b)), 0.f);
             *reinterpret_cast<f4v*>(out + base + i) = o;
+            mw |= ((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u)) << (4 * k);
         } else {
             out[base + i] = fmaxf(fmaf(y[base + i], a, fmaf(res[base + i], ar, b)), 0.f);
         }
+    }
+    if (VEC == 4 && mask) mask[(nc * gridDim.x + blockIdx.x) * 256 + threadIdx.x] = mw;
+}
+
+// backward of the tail WITHOUT the per-channel scales:  g = (gout [+ gout2]) * (out > 0)  is written once and serves as
+// both d/dy (consumer applies A: cfn_pwconv_bwd_* `gscale`) and d/dres (identity shortcut: exact; conv shortcut: `gscale`
+// = Ar).  The ReLU mask comes from the forward's bit mask (1/32 of a tensor pass) or, without it, from `out`.
+//   gA += sum g*y;  gB += sum g;  gAr += sum g*res (when gAr != null)
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_add_relu_bwd_g_kernel(const float* __restrict__ gout, const float* __restrict__ gout2,
+                                                                const float* __restrict__ out, const unsigned* __restrict__ mask,
+                                                                const float* __restrict__ y, const float* __restrict__ res,
+                                                                float* __restrict__ g_out, double* __restrict__ gA,
+                                                                double* __restrict__ gB, double* __restrict__ gAr, long vol) {
+    __shared__ float sh[12];
+    const long nc = blockIdx.y;
+    const long base = nc * vol;
+    float acc[3] = {0.f, 0.f, 0.f};
+    long i = ((long)blockIdx.x * 256 * EW_ITEMS + threadIdx.x) * VEC;
+    const unsigned mw = (VEC == 4 && mask) ? mask[(nc * gridDim.x + blockIdx.x) * 256 + threadIdx.x] : 0u;
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k, i += 256 * VEC) {
+        if (i >= vol) break;
+        if (VEC == 4) {
+            f4v go = *reinterpret_cast<const f4v*>(gout + base + i);
+            if (gout2) go += *reinterpret_cast<const f4v*>(gout2 + base + i);
+            const f4v yv = *reinterpret_cast<const f4v*>(y + base + i);
+            unsigned m4;
+            if (mask) m4 = (mw >> (4 * k)) & 15u;
+            else {
+                const f4v ov = *reinterpret_cast<const f4v*>(out + base + i);
+                m4 = (ov.x > 0.f ? 1u : 0u) | (ov.y > 0.f ? 2u : 0u) | (ov.z > 0.f ? 4u : 0u) | (ov.w > 0.f ? 8u : 0u);
+            }
+            f4v g;
+            g.x = (m4 & 1u) ? go.x : 0.f; g.y = (m4 & 2u) ? go.y : 0.f;
+            g.z = (m4 & 4u) ? go.z : 0.f; g.w = (m4 & 8u) ? go.w : 0.f;
+            acc[0] += g.x * yv.x + g.y * yv.y + g.z * yv.z + g.w * yv.w;
+            acc[1] += g.x + g.y + g.z + g.w;
+            if (gAr) {
+                const f4v rv = *reinterpret_cast<const f4v*>(res + base + i);
+                acc[2] += g.x * rv.x + g.y * rv.y + g.z * rv.z + g.w * rv.w;
+            }
+            *reinterpret_cast<f4v*>(g_out + base + i) = g;
+        } else {
+            const float g = out[base + i] > 0.f ? gout[base + i] + (gout2 ? gout2[base + i] : 0.f) : 0.f;
+            acc[0] = fmaf(g, y[base + i], acc[0]);
+            acc[1] += g;
+            if (gAr) acc[2] = fmaf(g, res[base + i], acc[2]);
+            g_out[base + i] = g;
+        }
+    }
+    block_sum<3>(acc, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(&gA[nc], (double)acc[0]);
+        atomicAdd(&gB[nc], (double)acc[1]);
+        if (gAr) atomicAdd(&gAr[nc], (double)acc[2]);
     }
 }
 
@@ -288,16 +346,42 @@ static inline bool ew_vec4(long vol, const void* p0, const void* p1 = nullptr, c
 }
 #define CFN_NC_CHECK(NC) CFN_REQUIRE((NC) > 0 && (NC) <= 65535, "N*C = %ld exceeds grid.y limit", (long)(NC))
 
+// words of the ReLU bit mask cfn_bn_add_relu_fwd can emit for (NC, vol); 0 = no mask for this shape (vol % 4 != 0)
+extern "C" long cfn_bn_add_relu_mask_words(long NC, long vol) {
+    if (NC <= 0 || vol <= 0 || vol % 4 != 0) return 0;
+    return NC * (long)cfn_cdiv(vol, 256L * EW_ITEMS * 4) * 256;
+}
+
 extern "C" int cfn_bn_add_relu_fwd(const float* y, const double* A, const double* B, const float* res, const double* Ar,
-                                   const double* Br, float* out, long NC, long vol, void* stream) {
+                                   const double* Br, float* out, int* mask, long NC, long vol, void* stream) {
     CFN_REQUIRE(y && A && B && res && out, "cfn_bn_add_relu_fwd: null tensor");
     CFN_REQUIRE((Ar == nullptr) == (Br == nullptr), "cfn_bn_add_relu_fwd: Ar/Br mismatch");
     CFN_NC_CHECK(NC);
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_ELEMWISE, st, 12.0 * NC * vol);
-    if (ew_vec4(vol, y, res, out)) hipLaunchKernelGGL(bn_add_relu_fwd_kernel<4>, ew_grid(vol, NC, 4), dim3(256), 0, st, y, A, B, res, Ar, Br, out, vol);
-    else hipLaunchKernelGGL(bn_add_relu_fwd_kernel<1>, ew_grid(vol, NC, 1), dim3(256), 0, st, y, A, B, res, Ar, Br, out, vol);
+    const bool v4 = ew_vec4(vol, y, res, out);
+    CFN_REQUIRE(mask == nullptr || v4, "cfn_bn_add_relu_fwd: the bit mask needs vol %% 4 == 0 and 16-byte aligned tensors");
+    if (v4) hipLaunchKernelGGL(bn_add_relu_fwd_kernel<4>, ew_grid(vol, NC, 4), dim3(256), 0, st, y, A, B, res, Ar, Br, out, (unsigned*)mask, vol);
+    else hipLaunchKernelGGL(bn_add_relu_fwd_kernel<1>, ew_grid(vol, NC, 1), dim3(256), 0, st, y, A, B, res, Ar, Br, out, (unsigned*)nullptr, vol);
     return cfn_check_launch("bn_add_relu_fwd");
+}
+
+extern "C" int cfn_bn_add_relu_bwd_g(const float* gout, const float* gout2, const float* out, const int* mask, const float* y,
+                                     const float* res, float* g, double* gA, double* gB, double* gAr, long NC, long vol,
+                                     void* stream) {
+    CFN_REQUIRE(gout && y && g && gA && gB, "cfn_bn_add_relu_bwd_g: null tensor");
+    CFN_REQUIRE((out != nullptr) != (mask != nullptr), "cfn_bn_add_relu_bwd_g: exactly one of out / mask");
+    CFN_REQUIRE(gAr == nullptr || res != nullptr, "cfn_bn_add_relu_bwd_g: gAr needs res");
+    CFN_NC_CHECK(NC);
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_ELEMWISE, st, (12.0 + (gout2 ? 4.0 : 0.0) + (out ? 4.0 : 0.125) + (gAr ? 4.0 : 0.0)) * NC * vol);
+    const bool v4 = ew_vec4(vol, gout, out, y, gAr ? res : nullptr, g) && (((uintptr_t)gout2) & 15) == 0;
+    CFN_REQUIRE(mask == nullptr || v4, "cfn_bn_add_relu_bwd_g: the bit mask needs vol %% 4 == 0 and 16-byte aligned tensors");
+    if (v4)
+        hipLaunchKernelGGL(bn_add_relu_bwd_g_kernel<4>, ew_grid(vol, NC, 4), dim3(256), 0, st, gout, gout2, out, (const unsigned*)mask, y, res, g, gA, gB, gAr, vol);
+    else
+        hipLaunchKernelGGL(bn_add_relu_bwd_g_kernel<1>, ew_grid(vol, NC, 1), dim3(256), 0, st, gout, gout2, out, (const unsigned*)nullptr, y, res, g, gA, gB, gAr, vol);
+    return cfn_check_launch("bn_add_relu_bwd_g");
 }
 
 extern "C" int cfn_bn_add_relu_bwd(const float* gout, const float* gout2, const float* out, const float* y, const double* A, const float* res,

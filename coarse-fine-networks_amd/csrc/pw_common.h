@@ -16,6 +16,7 @@ struct PwArgs {
     const double* pb;
     const double* gs;    // DGRAD: d/d sum(y)   [n,k]  (may be null)
     const double* gq;    // DGRAD: d/d sum(y^2) [n,k]  (may be null)
+    const double* gsc;   // DGRAD: per-(n,k) scale of the incoming gradient: g' = gsc*gy + gs + 2*y*gq  (null = 1)
     const float* w;      // (Cout, Cin) row major
     float* dst;          // FWD: y (N,M,Q)                DGRAD: gx (N,M,Pin)
     const float* ex;     // DGRAD: forward input x raw (N,M,Pin) (needed when ea != null)
@@ -48,11 +49,12 @@ __device__ __forceinline__ float pw_bload(__amdgpu_buffer_rsrc_t r, int voff, in
 int pwd_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st);
 
 // pwwgrad.hip: direct-operand weight gradient for M, K >= 48 (stride 1); -1 = shape not handled.
-int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const double* pa,
-                         const double* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st);
-int pwd_wgrad_try_strided(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const double* pa,
-                          const double* pb, int act, double* gw, int N, int M, int K, int T, int Hi, int Wi, int stride,
-                          hipStream_t st);
+// gsc: per-(n,m) scale of gy (null = 1)
+int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const double* gsc, const float* x,
+                         const double* pa, const double* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st);
+int pwd_wgrad_try_strided(const float* gy, const float* y, const double* gs, const double* gq, const double* gsc, const float* x,
+                          const double* pa, const double* pb, int act, double* gw, int N, int M, int K, int T, int Hi, int Wi,
+                          int stride, hipStream_t st);
 int pwd_wgrad_try_dense(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const double* pa,
                         const double* pb, int act, double* gw, int N, int M, int Cimg, int T, int Hi, int Wi, const int* g,
                         hipStream_t st);

@@ -45,15 +45,16 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
     const int m0 = mtile * BM;
 
     float* As = smem;                                     // [kres][BM]
-    float2* sP = reinterpret_cast<float2*>(As + kres * BM);   // [Kpad + PW_UNIT] prologue coefficients
-    float2* sE = sP + Kpad + PW_UNIT;                     // [BM] epilogue coefficients (DGRAD)
+    float4* sP = reinterpret_cast<float4*>(As + kres * BM);   // [Kpad + PW_UNIT] prologue coefficients (FWD: A, B; DGRAD: gs, 2gq, gsc)
+    float2* sE = reinterpret_cast<float2*>(sP + Kpad + PW_UNIT);   // [BM] epilogue coefficients (DGRAD)
     float* sSt = reinterpret_cast<float*>(sE + BM);       // [BM][2]
     float* red = sSt + 2 * BM + wave * (32 * PW_RED_PITCH);
     int2* sK = reinterpret_cast<int2*>(sSt + 2 * BM + 4 * (32 * PW_RED_PITCH));   // [Kpad + PW_UNIT] im2col row table (STEM)
     const int KV = STEM ? a.kT * a.kH * a.kW : 1;
 
     for (int k = tid; k < Kpad + PW_UNIT; k += 256) {
-        float2 c;
+        float4 c;
+        c.z = 1.0f; c.w = 0.0f;
         if (STEM) {
             const int ci = k / KV, r = k - ci * KV;
             const int kt = r / (a.kH * a.kW), r2 = r - kt * a.kH * a.kW, kh = r2 / a.kW, kw = r2 - kh * a.kW;
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
         } else {
             c.x = (k < K && a.gs) ? (float)a.gs[(long)n * K + k] : 0.0f;
             c.y = (k < K && a.gq && a.src2) ? 2.0f * (float)a.gq[(long)n * K + k] : 0.0f;
+            c.z = (k < K && a.gsc) ? (float)a.gsc[(long)n * K + k] : 1.0f;
         }
         sP[k] = c;
     }
@@ -172,10 +174,14 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
 #pragma unroll
                 for (int j = 0; j < NU; ++j) {
                     const int kl = u + 2 * j + half;
-                    const float2 c = sP[kc0 + kl];
                     float v;
-                    if (MODE == PW_FWD) v = cfn_act<ACT>(fmaf(cur[j], c.x, c.y));
-                    else v = fmaf(cur2[j], c.y, cur[j] + c.x);
+                    if (MODE == PW_FWD) {
+                        const float2 c = *reinterpret_cast<const float2*>(&sP[kc0 + kl]);
+                        v = cfn_act<ACT>(fmaf(cur[j], c.x, c.y));
+                    } else {
+                        const float4 c = sP[kc0 + kl];
+                        v = fmaf(cur2[j], c.y, fmaf(cur[j], c.z, c.x));
+                    }
                     if (STEM) v = ((curm >> j) & 1u) ? v : 0.0f;   // zero padding is applied after the prologue
                     const float* ar = As + kl * BM + col;
 #pragma unroll
@@ -299,6 +305,7 @@ struct WgArgs {
     const float* gy;     // (N,M,Q)
     const float* y;      // (N,M,Q) raw conv output, for the gq term (may be null)
     const double* gs; const double* gq;   // [n,m] (may be null)
+    const double* gsc;                    // [n,m] scale of gy (null = 1)
     const float* x;      // (N,K,Pin) forward input raw
     const double* pa; const double* pb;     // forward prologue [n,k] (null = identity)
     double* gw;          // (M,K) fp64 accumulators, zero-filled by the caller
@@ -325,10 +332,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
     float* img0 = smem;                                // two images (double buffer)
     float* sCg = smem + 2 * IMG;                       // [BM][2]  (gs, 2gq)
     float* sCx = sCg + 2 * BM;                         // [BN][2]  (A, B)
+    float* sCz = sCx + 2 * BN;                         // [BM]     gsc
     for (int m = tid; m < BM; m += 256) {
         const bool ok = m0 + m < M;
         sCg[2 * m] = (ok && a.gs) ? (float)a.gs[(long)n * M + m0 + m] : 0.0f;
         sCg[2 * m + 1] = (ok && a.gq && a.y) ? 2.0f * (float)a.gq[(long)n * M + m0 + m] : 0.0f;
+        sCz[m] = (ok && a.gsc) ? (float)a.gsc[(long)n * M + m0 + m] : 1.0f;
     }
     for (int k = tid; k < BN; k += 256) {
         const bool ok = k0 + k < K && a.pa;
@@ -373,13 +382,13 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
 #pragma unroll
         for (int it = 0; it < NG; ++it) {
             const int row = it * 16 + lrow;
-            const float cs = sCg[2 * row], cq = sCg[2 * row + 1];
+            const float cs = sCg[2 * row], cq = sCg[2 * row + 1], cz = sCz[row];
             const bool ok = inq && (m0 + row < M);
             float* d = sG + row * WG_PITCH + c4;
-            d[0] = ok ? fmaf(py[it].x, cq, pg[it].x + cs) : 0.0f;
-            d[1] = ok ? fmaf(py[it].y, cq, pg[it].y + cs) : 0.0f;
-            d[2] = ok ? fmaf(py[it].z, cq, pg[it].z + cs) : 0.0f;
-            d[3] = ok ? fmaf(py[it].w, cq, pg[it].w + cs) : 0.0f;
+            d[0] = ok ? fmaf(py[it].x, cq, fmaf(pg[it].x, cz, cs)) : 0.0f;
+            d[1] = ok ? fmaf(py[it].y, cq, fmaf(pg[it].y, cz, cs)) : 0.0f;
+            d[2] = ok ? fmaf(py[it].z, cq, fmaf(pg[it].z, cz, cs)) : 0.0f;
+            d[3] = ok ? fmaf(py[it].w, cq, fmaf(pg[it].w, cz, cs)) : 0.0f;
         }
 #pragma unroll
         for (int it = 0; it < NX; ++it) {
@@ -403,10 +412,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
             if (chok) {
                 if (isg) {
                     const long base = ((long)n * M + ch) * Q + q0 + cc;
-                    const float cs = sCg[2 * row], cq = sCg[2 * row + 1];
+                    const float cs = sCg[2 * row], cq = sCg[2 * row + 1], cz = sCz[row];
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        if (q0 + cc + u < Q) v[u] = fmaf(a.y ? a.y[base + u] : 0.0f, cq, a.gy[base + u] + cs);
+                        if (q0 + cc + u < Q) v[u] = fmaf(a.y ? a.y[base + u] : 0.0f, cq, fmaf(a.gy[base + u], cz, cs));
                 } else {
                     const int kr = row - BM;
                     const float ca = sCx[2 * kr], cb = sCx[2 * kr + 1];
@@ -563,7 +572,7 @@ static int pw_plan(PwArgs& a, int& MT, unsigned& blocks, size_t& lds) {
     a.tpb = (int)tpb;
     a.nstrips = cfn_cdiv(tiles, tpb);
     blocks = (unsigned)((long)a.N * a.nstrips * a.mtiles);
-    lds = ((size_t)a.kres * BM + 2 * (a.Kpad + PW_UNIT) + 2 * BM + 2 * BM + 4 * 32 * PW_RED_PITCH + (a.stem ? 2 * (a.Kpad + PW_UNIT) : 0)) * sizeof(float);
+    lds = ((size_t)a.kres * BM + 4 * (a.Kpad + PW_UNIT) + 2 * BM + 2 * BM + 4 * 32 * PW_RED_PITCH + (a.stem ? 2 * (a.Kpad + PW_UNIT) : 0)) * sizeof(float);
     const long span = (long)a.K * (a.stem ? 1 : (a.src2 || a.gs || a.gq || a.ex ? a.Q : a.Pin)) * 4;
     if ((!a.stem && ((long)a.K * a.Pin * 4 >= (1L << 31) || (long)a.K * a.Q * 4 >= (1L << 31))) ||
         (long)a.M * a.Pin * 4 >= (1L << 31) || (long)a.M * a.Q * 4 >= (1L << 31))
@@ -606,7 +615,7 @@ extern "C" int cfn_pwconv_fwd(const float* x, const double* A, const double* B, 
 extern "C" int cfn_pwconv_bwd_data_acc(const float* gy, const float* y, const double* gsum, const double* gsumsq,
                                    const float* w, const float* x, const double* A, const double* B, int act, float* gx,
                                    double* gA, double* gB, int N, int Cin, int Cout, int T, int Hi, int Wi, int stride,
-                                   const float* acc, int acc_stride, void* stream) {
+                                   const float* acc, int acc_stride, const double* gscale, void* stream) {
     CFN_REQUIRE(gy && w && gx, "cfn_pwconv_bwd_data: null tensor");
     CFN_REQUIRE(stride == 1 || stride == 2, "cfn_pwconv_bwd_data: stride must be 1 or 2");
     CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pwconv_bwd_data: A/B mismatch");
@@ -614,7 +623,7 @@ extern "C" int cfn_pwconv_bwd_data_acc(const float* gy, const float* y, const do
     CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_pwconv_bwd_data: gsumsq needs y");
     CFN_REQUIRE(acc == nullptr || (stride == 1 && acc_stride >= 1), "cfn_pwconv_bwd_data_acc: acc needs stride 1");
     PwArgs a = {};
-    a.src = gy; a.src2 = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.w = w; a.dst = gx;
+    a.src = gy; a.src2 = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.gsc = gscale; a.w = w; a.dst = gx;
     a.ex = x; a.ea = A; a.eb = B; a.act = act; a.s1 = gA; a.s2 = gB;
     a.N = N; a.M = Cin; a.K = Cout; a.Cin = Cin;
     pw_geom(a, T, Hi, Wi, stride);
@@ -632,7 +641,7 @@ extern "C" int cfn_pwconv_bwd_data(const float* gy, const float* y, const double
                                    const float* w, const float* x, const double* A, const double* B, int act, float* gx,
                                    double* gA, double* gB, int N, int Cin, int Cout, int T, int Hi, int Wi, int stride,
                                    void* stream) {
-    return cfn_pwconv_bwd_data_acc(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, N, Cin, Cout, T, Hi, Wi, stride, nullptr, 1, stream);
+    return cfn_pwconv_bwd_data_acc(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, N, Cin, Cout, T, Hi, Wi, stride, nullptr, 1, nullptr, stream);
 }
 
 static void wg_plan(WgArgs& a, int& MTW, int& NTW) {
@@ -654,7 +663,7 @@ static void wg_plan(WgArgs& a, int& MTW, int& NTW) {
 
 static int wg_launch(const WgArgs& a, int MTW, int NTW, hipStream_t st) {
     const unsigned blocks = (unsigned)((long)a.N * a.nstrips * a.mtiles * a.ktiles);
-    size_t lds = ((size_t)2 * (32 * MTW + 32 * NTW) * WG_PITCH + 2 * (32 * MTW + 32 * NTW)) * sizeof(float);
+    size_t lds = ((size_t)2 * (32 * MTW + 32 * NTW) * WG_PITCH + 2 * (32 * MTW + 32 * NTW) + 32 * MTW) * sizeof(float);
     const size_t lds_cw = (size_t)4 * 32 * MTW * (32 * NTW + 1) * sizeof(float);
     if (lds_cw > lds) lds = lds_cw;
 #define CFN_WG_GO(MW, NW)                                                                                       \
@@ -679,13 +688,13 @@ static void wg_geom(WgArgs& a, int N, int Cin, int Cout, int T, int Hi, int Wi, 
 
 extern "C" int cfn_pwconv_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq,
                                      const float* x, const double* A, const double* B, int act, double* gw, int N,
-                                     int Cin, int Cout, int T, int Hi, int Wi, int stride, void* stream) {
+                                     int Cin, int Cout, int T, int Hi, int Wi, int stride, const double* gscale, void* stream) {
     CFN_REQUIRE(gy && x && gw, "cfn_pwconv_bwd_weight: null tensor");
     CFN_REQUIRE(stride == 1 || stride == 2, "cfn_pwconv_bwd_weight: stride must be 1 or 2");
     CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pwconv_bwd_weight: A/B mismatch");
     CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_pwconv_bwd_weight: gsumsq needs y");
     WgArgs a = {};
-    a.gy = gy; a.y = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.x = x; a.pa = A; a.pb = B; a.act = act;
+    a.gy = gy; a.y = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.gsc = gscale; a.x = x; a.pa = A; a.pb = B; a.act = act;
     a.gw = gw;
     wg_geom(a, N, Cin, Cout, T, Hi, Wi, stride);
     int MTW, NTW;
@@ -693,8 +702,8 @@ extern "C" int cfn_pwconv_bwd_weight(const float* gy, const float* y, const doub
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_WGRAD, st, 4.0 * N * ((double)Cout * a.Q * (a.y ? 2 : 1) + (double)Cin * a.Q));
     {
-        const int rc = stride == 1 ? pwd_wgrad_try_launch(gy, a.y, gsum, gsumsq, x, A, B, act, gw, N, Cout, Cin, a.Q, st)
-                                   : pwd_wgrad_try_strided(gy, a.y, gsum, gsumsq, x, A, B, act, gw, N, Cout, Cin, T, Hi, Wi, stride, st);
+        const int rc = stride == 1 ? pwd_wgrad_try_launch(gy, a.y, gsum, gsumsq, gscale, x, A, B, act, gw, N, Cout, Cin, a.Q, st)
+                                   : pwd_wgrad_try_strided(gy, a.y, gsum, gsumsq, gscale, x, A, B, act, gw, N, Cout, Cin, T, Hi, Wi, stride, st);
         if (rc >= 0) return rc;
     }
     return wg_launch(a, MTW, NTW, st);

@@ -25,19 +25,21 @@ __global__ __launch_bounds__(64 * PWD_WAVES) void pw_deep_kernel(const PwArgs a)
     const int m0 = mtile * BM;
 
     float* As = smem;                                         // [Kpad][BM]
-    float2* sP = reinterpret_cast<float2*>(As + Kpad * BM);   // [Kpad + PW_UNIT] prologue coefficients
-    float2* sE = sP + Kpad + PW_UNIT;                         // [BM] epilogue coefficients (DGRAD)
+    float4* sP = reinterpret_cast<float4*>(As + Kpad * BM);   // [Kpad + PW_UNIT] prologue coefficients (FWD: A, B; DGRAD: gs, 2gq, gsc)
+    float2* sE = reinterpret_cast<float2*>(sP + Kpad + PW_UNIT);   // [BM] epilogue coefficients (DGRAD)
     float* redbase = reinterpret_cast<float*>(sE + BM);       // [PWD_WAVES][32*33] transpose scratch, later wave slots
     float* red = redbase + wave * (32 * PW_RED_PITCH);
 
     for (int k = tid; k < Kpad + PW_UNIT; k += 64 * PWD_WAVES) {
-        float2 c;
+        float4 c;
+        c.z = 1.0f; c.w = 0.0f;
         if (MODE == PW_FWD) {
             c.x = (k < K && a.pa) ? a.pa[(long)n * K + k] : 1.0f;
             c.y = (k < K && a.pb) ? a.pb[(long)n * K + k] : 0.0f;
         } else {
             c.x = (k < K && a.gs) ? (float)a.gs[(long)n * K + k] : 0.0f;
             c.y = (k < K && a.gq && a.src2) ? 2.0f * (float)a.gq[(long)n * K + k] : 0.0f;
+            c.z = (k < K && a.gsc) ? (float)a.gsc[(long)n * K + k] : 1.0f;
         }
         sP[k] = c;
     }
@@ -168,9 +170,12 @@ __global__ __launch_bounds__(64 * PWD_WAVES) void pw_deep_kernel(const PwArgs a)
             for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i], v, acc[i], 0, 0, 0);
         };
         auto pro = [&](float x, float x2, int kl) -> float {
-            const float2 c = sP[kl];
-            if (MODE == PW_FWD) return cfn_act<ACT>(fmaf(x, c.x, c.y));
-            return fmaf(x2, c.y, x + c.x);
+            if (MODE == PW_FWD) {
+                const float2 c = *reinterpret_cast<const float2*>(&sP[kl]);
+                return cfn_act<ACT>(fmaf(x, c.x, c.y));
+            }
+            const float4 c = sP[kl];
+            return fmaf(x2, c.y, fmaf(x, c.z, c.x));
         };
         auto unit = [&](float (&r)[NU], float (&r2)[NU], int u) {   // entering: a0 = weights of k-pair (u, 0)
             const int k = u + half;
@@ -359,7 +364,8 @@ int pwd_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
     a.nstrips = (int)bpg;
     a.tpb = 0;
     const unsigned blocks = (unsigned)(groups * bpg);
-    const size_t lds = ((size_t)Kpad * BM + 2 * (Kpad + PW_UNIT) + 2 * BM + NW * 32 * PW_RED_PITCH) * sizeof(float);
+    const size_t lds = ((size_t)Kpad * BM + 4 * (Kpad + PW_UNIT) + 2 * BM + NW * 32 * PW_RED_PITCH) * sizeof(float);
+    if (lds > 160 * 1024) return -1;
     if (mode == PW_FWD) return stats ? pwd_act<PW_FWD, true>(a, MT, NW, blocks, lds, st) : pwd_act<PW_FWD, false>(a, MT, NW, blocks, lds, st);
     if (!stats) { a.act = CFN_ACT_NONE; return pwd_go<PW_DGRAD, false, CFN_ACT_NONE>(a, MT, NW, blocks, lds, st); }
     return pwd_act<PW_DGRAD, true>(a, MT, NW, blocks, lds, st);

@@ -16,6 +16,7 @@ struct WdArgs {
     const float* x; const double* pa; const double* pb;
     double* gw;
     int N, M, K, Q, act;
+    const double* gsc;                 // per-(n,m) scale of gy (null = 1)
     int mgroups, kgroups, nstrips;     // output tile groups (<= 3 tiles of 32 each way), workgroups per (group, sample)
     int mt32, kt32;                    // tiles of 32 rows / cols in total
     // XMODE 1: pointwise conv with spatial stride (x row pitch Pin, position map); XMODE 2: dense conv, x rows are
@@ -33,6 +34,8 @@ __device__ __forceinline__ void wd_split(int tiles, int groups, int g, int& firs
     first = g * base + min(g, rem);
     count = base + (g < rem ? 1 : 0);
 }
+
+__device__ __forceinline__ float wd_zfloor(float z) { return fabsf(z) < 1e-20f ? copysignf(1e-20f, z) : z; }
 
 template <int ACT, int XMODE, int WD_TM, int WD_TN>
 __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const WdArgs a) {
@@ -52,6 +55,10 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
     const int m0 = mt0 * 32, k0 = kt0 * 32;
 
     // per-lane prologue coefficients (lane <-> channel row of each tile)
+    // gy scale z (gsc): G' = z*gy + gs + 2*y*gq = z * (gy + gs/z + y*2gq/z): the loop runs on the bracket with pre-divided
+    // coefficients and row m of the result is multiplied by z when it leaves the workgroup -- a resident per-lane z makes
+    // the 3x3 variant spill (measured +20 % run time).  |z| is floored at 1e-20 (gamma == 0: the gy term then weighs
+    // 1e-20 instead of 0, far below fp32 resolution of the other two terms)
     float cs[WD_TM], cq[WD_TM], ca[WD_TN], cb[WD_TN];
 #pragma unroll
     for (int i = 0; i < WD_TM; ++i) {
@@ -59,6 +66,11 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
         const bool ok = i < mtn && m < M;
         cs[i] = (ok && a.gs) ? (float)a.gs[(long)n * M + m] : 0.0f;
         cq[i] = (ok && a.gq && a.y) ? 2.0f * (float)a.gq[(long)n * M + m] : 0.0f;
+        if (ok && a.gsc) {
+            const float rz = 1.0f / wd_zfloor((float)a.gsc[(long)n * M + m]);
+            cs[i] *= rz;
+            cq[i] *= rz;
+        }
     }
 #pragma unroll
     for (int i = 0; i < WD_TN; ++i) {
@@ -205,7 +217,10 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
 #pragma unroll
                     for (int w = 0; w < WD_WAVES; ++w) v += cw[w][ml * 33 + kl];
                     const int m = m0 + i * 32 + ml, k = k0 + j * 32 + kl;
-                    if (m < M && k < K) atomicAdd(&a.gw[(long)m * K + k], (double)v);
+                    if (m < M && k < K) {
+                        if (a.gsc) v *= wd_zfloor((float)a.gsc[(long)n * M + m]);
+                        atomicAdd(&a.gw[(long)m * K + k], (double)v);
+                    }
                 }
                 __syncthreads();
             }
@@ -244,11 +259,11 @@ static bool wd_common_ok(const float* gy, const float* y, const float* x, int ac
 }
 
 // contiguous pointwise conv (stride 1): M, K >= 48 (smaller layers are HBM bound and stay on the LDS-staged kernel)
-int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const double* pa,
-                         const double* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st) {
+int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const double* gsc, const float* x,
+                         const double* pa, const double* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st) {
     if (M < 48 || K < 48 || !wd_common_ok(gy, y, x, act, M, K, Q)) return -1;
     if (((uintptr_t)x & 15) || (long)K * Q * 4 >= (1L << 31) - 64) return -1;
-    WdArgs a = {gy, y, gs, gq, x, pa, pb, gw, N, M, K, Q, act};
+    WdArgs a = {gy, y, gs, gq, x, pa, pb, gw, N, M, K, Q, act, gsc};
     a.Pin = Q;
     {   // balanced groups never exceed 2 tiles either way (e.g. 108 x 48): the 2x2 variant needs half the registers
         const int mt = cfn_cdiv(M, 32), kt = cfn_cdiv(K, 32);
@@ -263,14 +278,14 @@ int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, cons
 }
 
 // pointwise conv with spatial stride 2 (shortcut convs): gathered x operand
-int pwd_wgrad_try_strided(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const double* pa,
-                          const double* pb, int act, double* gw, int N, int M, int K, int T, int Hi, int Wi, int stride,
-                          hipStream_t st) {
+int pwd_wgrad_try_strided(const float* gy, const float* y, const double* gs, const double* gq, const double* gsc, const float* x,
+                          const double* pa, const double* pb, int act, double* gw, int N, int M, int K, int T, int Hi, int Wi,
+                          int stride, hipStream_t st) {
     const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
     const int Q = T * Ho * Wo;
     if (Wo % 4 != 0 || !wd_common_ok(gy, y, x, act, M, K, Q)) return -1;
     if ((long)K * T * Hi * Wi * 4 >= (1L << 31) - 64) return -1;
-    WdArgs a = {gy, y, gs, gq, x, pa, pb, gw, N, M, K, Q, act};
+    WdArgs a = {gy, y, gs, gq, x, pa, pb, gw, N, M, K, Q, act, gsc};
     a.Pin = T * Hi * Wi; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = stride;
     return wd_launch<1, 3, 3>(a, st);
 }

@@ -184,17 +184,21 @@ class Bottleneck(nn.Module):
         # bn2 (+ SE: the global average of bn2(y2) is the bn2 affine of the per-sample mean of y2, x3d_fine.py:157-163)
         se = (self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias) if has_se else None
         A2, B2 = self.bn2.fold(s2, q2, _count(y2), n, se=se)
-        y3, s3, q3 = ops.pwconv(y2, self.conv3.weight, A2, B2, ACT_SWISH, 1, stats=tr)
+        # the tail's backward writes one unscaled gradient tensor; conv3 (and the shortcut conv) apply bn3's (the
+        # shortcut bn's) per-(n,c) factor when they load it
+        link = ops.TailLink()
+        y3, s3, q3 = ops.pwconv(y2, self.conv3.weight, A2, B2, ACT_SWISH, 1, stats=tr, tail=link, tail_role='y')
         A3, B3 = self.bn3.fold(s3, q3, _count(y3), n)
 
         if self.downsample is not None:
             if not isinstance(self.downsample, nn.Sequential):
                 raise NotImplementedError("shortcut_type 'A' is not on the accelerated path")
-            yd, sd, qd = ops.pwconv(xr, self.downsample[0].weight, xa, xb, xact, self.stride, stats=tr, token=tok, role='short')
+            yd, sd, qd = ops.pwconv(xr, self.downsample[0].weight, xa, xb, xact, self.stride, stats=tr, token=tok, role='short',
+                                    tail=link, tail_role='res')
             Ad, Bd = self.downsample[1].fold(sd, qd, _count(yd), n)
-            return ops.bn_add_relu(y3, A3, B3, yd, Ad, Bd, split=self.split_out)
+            return ops.bn_add_relu(y3, A3, B3, yd, Ad, Bd, split=self.split_out, link=link)
         res = x_res.materialize() if isinstance(x_res, Deferred) else x_res
-        return ops.bn_add_relu(y3, A3, B3, res, split=self.split_out)
+        return ops.bn_add_relu(y3, A3, B3, res, split=self.split_out, link=link)
 
 
 class ResNet(nn.Module):

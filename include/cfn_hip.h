@@ -74,13 +74,16 @@ int cfn_pwconv_bwd_data(const float* gy, const float* y, const double* gsum, con
                         const float* x, const double* A, const double* B, int act, float* gx, double* gA, double* gB, int N,
                         int Cin, int Cout, int T, int Hi, int Wi, int stride, void* stream);
 /* same, plus `acc`: compact gradient (N,Cin,T,ceil(Hi/acc_stride),ceil(Wi/acc_stride)) of a spatially strided shortcut conv
- * over the same input (x3d_fine.py:284-287), added on its lattice before the act' epilogue (requires stride == 1) */
+ * over the same input (x3d_fine.py:284-287), added on its lattice before the act' epilogue (requires stride == 1);
+ * and `gscale` (N,Cout) fp64, may be NULL: gy is the UNSCALED gradient of a block tail (cfn_bn_add_relu_bwd_g) and stands
+ * for gscale[n,c] * gy, i.e. g' = gscale*gy + gsum + 2*y*gsumsq */
 int cfn_pwconv_bwd_data_acc(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
                         const float* x, const double* A, const double* B, int act, float* gx, double* gA, double* gB, int N,
-                        int Cin, int Cout, int T, int Hi, int Wi, int stride, const float* acc, int acc_stride, void* stream);
+                        int Cin, int Cout, int T, int Hi, int Wi, int stride, const float* acc, int acc_stride,
+                        const double* gscale, void* stream);
 int cfn_pwconv_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* x,
                           const double* A, const double* B, int act, double* gw, int N, int Cin, int Cout, int T, int Hi,
-                          int Wi, int stride, void* stream);
+                          int Wi, int stride, const double* gscale, void* stream);
 
 /* ---- stem 1x3x3 stride (1,2,2) pad (0,1,1) dense conv: conv1_s x3d_fine.py:210-215 (im2col view on MFMA);
  * gw is fp64 (Cout, Cimg*9), zero-filled by caller.  The clip needs no gradient. ---- */
@@ -132,10 +135,18 @@ int cfn_fusion_gather_bwd(const float* gz, const float* z, const float* den, con
  * upstream gradient of the same output (the block output feeds the next conv1 AND the next residual); it is added to
  * gout on the fly. ---- */
 int cfn_bn_add_relu_fwd(const float* y, const double* A, const double* B, const float* res, const double* Ar, const double* Br,
-                        float* out, long NC, long vol, void* stream);
+                        float* out, int* mask, long NC, long vol, void* stream);
 int cfn_bn_add_relu_bwd(const float* gout, const float* gout2, const float* out, const float* y, const double* A, const float* res,
                         const double* Ar, float* gy, float* gres, double* gA, double* gB, double* gAr, long NC, long vol,
                         void* stream);
+/* The tail's backward as ONE output tensor: g = (gout [+ gout2]) * (out > 0) serves as d/dy (the conv3 backward applies A
+ * through `gscale`) and as d/dres (identity shortcut: exact; conv shortcut: `gscale` = Ar) -- 4 tensor passes instead of
+ * 6-7.  The ReLU mask is either `out` or the bit mask cfn_bn_add_relu_fwd wrote (`mask`, cfn_bn_add_relu_mask_words(NC,
+ * vol) 32-bit words, 0 = shape has no mask; bit layout private to the two kernels): exactly one of the two is given.
+ * gA += sum g*y, gB += sum g, gAr += sum g*res (gAr may be NULL). */
+long cfn_bn_add_relu_mask_words(long NC, long vol);
+int cfn_bn_add_relu_bwd_g(const float* gout, const float* gout2, const float* out, const int* mask, const float* y,
+                          const float* res, float* g, double* gA, double* gB, double* gAr, long NC, long vol, void* stream);
 
 /* ---- materialised prologue out = act(A x + B) (SubBatchNorm3d.forward on its own, x3d_fine.py:51-62) and
  * per-(n,c) sum / sumsq of a tensor (batch statistics of an arbitrary input) ---- */

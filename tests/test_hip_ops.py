@@ -162,6 +162,64 @@ def test_bn_add_relu(shape, affine_res):
         assert relerr(g[k].grad, c[k].grad) <= 2e-5, k
 
 
+@pytest.mark.parametrize('shortcut', ['identity', 'conv_s2', 'conv_s1'])
+@pytest.mark.parametrize('cfg', [(2, 54, 24, 4, 8, 8), (1, 108, 48, 3, 6, 6), (2, 216, 96, 2, 14, 14), (1, 20, 12, 3, 5, 7)])
+def test_linked_tail(cfg, shortcut):
+    """conv3 -> (stats) -> tail with a TailLink: the tail's backward hands ONE unscaled gradient tensor to conv3 and to the
+    shortcut conv, whose kernels apply the per-(n,c) factors (`gscale`); the forward emits the ReLU bit mask (or, for
+    volumes that are not a multiple of 4, the backward falls back to `out`).  Reference: plain torch autograd on the CPU."""
+    N, Cm, Co, T, H, W = cfg
+    s = 1 if shortcut != 'conv_s2' else 2
+    Hi, Wi = H * s, W * s
+    Cx = Co if shortcut == 'identity' else 10
+    vals = dict(x2=rnd(1, N, Cm, T, H, W), w3=0.2 * rnd(2, Co, Cm, 1, 1, 1), A2=1 + 0.2 * rnd(3, N, Cm), B2=0.1 * rnd(4, N, Cm),
+                A3=1 + 0.3 * rnd(5, N, Co), B3=0.2 * rnd(6, N, Co), xr=rnd(7, N, Cx, T, Hi, Wi))
+    if shortcut != 'identity':
+        vals.update(wd=0.3 * rnd(8, Co, Cx, 1, 1, 1), Ad=1 + 0.3 * rnd(9, N, Co), Bd=0.1 * rnd(10, N, Co))
+    vals['A3'][0, :3] = 0.0     # zero BN scale (gamma == 0): the weight-gradient kernels divide by a floored scale
+    vals['A3'][-1, -1] = -0.5
+    c = {k: v.clone().requires_grad_(True) for k, v in vals.items()}
+    g = {k: v.clone().to(DEV).requires_grad_(True) for k, v in vals.items()}
+
+    def ref(d):
+        shp = (N, -1, 1, 1, 1)
+        a2 = prologue_ref(d['x2'], d['A2'], d['B2'], 2)
+        y3 = F.conv3d(a2, d['w3'])
+        s3, q3 = stats_ref(y3)
+        z = y3 * d['A3'].view(shp) + d['B3'].view(shp)
+        if shortcut == 'identity':
+            r = d['xr']
+            extra = 0.0
+        else:
+            yd = F.conv3d(d['xr'], d['wd'], stride=(1, s, s))
+            sd, qd = stats_ref(yd)
+            r = yd * d['Ad'].view(shp) + d['Bd'].view(shp)
+            extra = (sd * 0.02).sum() + (qd * 0.003).sum()
+        return F.relu(z + r), (s3 * 0.03).sum() + (q3 * 0.004).sum() + extra
+
+    def hip(d):
+        o = ops()
+        link = o.TailLink()
+        y3, s3, q3 = o.pwconv(d['x2'], d['w3'], d['A2'], d['B2'], 2, 1, True, tail=link, tail_role='y')
+        if shortcut == 'identity':
+            out = o.bn_add_relu(y3, d['A3'], d['B3'], d['xr'], link=link)
+            extra = 0.0
+        else:
+            yd, sd, qd = o.pwconv(d['xr'], d['wd'], None, None, 0, s, True, tail=link, tail_role='res')
+            out = o.bn_add_relu(y3, d['A3'], d['B3'], yd, d['Ad'], d['Bd'], link=link)
+            extra = (sd * 0.02).sum() + (qd * 0.003).sum()
+        return out, (s3 * 0.03).sum() + (q3 * 0.004).sum() + extra
+
+    oc, ec = ref(c)
+    og, eg = hip(g)
+    assert relerr(og, oc) <= 1e-5
+    r = rnd(11, *oc.shape)
+    ((oc * r).sum() + ec).backward()
+    ((og * r.to(DEV)).sum() + eg.float()).backward()
+    for k in vals:
+        assert relerr(g[k].grad, c[k].grad) <= 5e-5, k
+
+
 @pytest.mark.parametrize('act', [0, 1, 2])
 def test_affine_act_and_stats(act):
     shape = (2, 5, 3, 6, 6)
