@@ -180,6 +180,8 @@ class _PwConv(Function):
         if ctx.tail is not None and ctx.tail.done:
             gsc = ctx.tail.y_scale if ctx.tail_role == 'y' else ctx.tail.res_scale
         gx = gA = gB = gw = None
+        g64 = fin = None
+        fused = False
         if ctx.needs_input_grad[0] or (A is not None and ctx.needs_input_grad[1]):
             if token is not None and role == 'short' and stride > 1 and not token.main_done:
                 # compact W^T g' at output resolution (a stride-1 data gradient over the strided grid, no epilogue);
@@ -200,13 +202,21 @@ class _PwConv(Function):
                         acc, acc_stride, token.acc = token.acc, token.acc_stride, None
                     else:
                         token.main_done = True
-                call('cfn_pwconv_bwd_data_acc', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, Cin, Cout, T, H, W, stride,
-                     acc, acc_stride, gsc)
+                # few channels (layer 1: HBM bound): data and weight gradient in one pass over gy, y, x
+                if stride == 1 and ctx.needs_input_grad[3]:
+                    g64, fin = _gw_buffers(ctx.wparam, Cout, Cin, x.device)
+                    fused = call_try('cfn_pwconv_bwd_fused', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, g64, N, Cin, Cout,
+                                     T, H, W, acc, acc_stride, gsc)
+                if not fused:
+                    call('cfn_pwconv_bwd_data_acc', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, Cin, Cout, T, H, W, stride,
+                         acc, acc_stride, gsc)
                 if A is not None:
                     gA, gB = ab[0], ab[1]
         if ctx.needs_input_grad[3]:
-            g64, fin = _gw_buffers(ctx.wparam, Cout, Cin, x.device)
-            call('cfn_pwconv_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, Cin, Cout, T, H, W, stride, gsc)
+            if g64 is None:
+                g64, fin = _gw_buffers(ctx.wparam, Cout, Cin, x.device)
+            if not fused:
+                call('cfn_pwconv_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, Cin, Cout, T, H, W, stride, gsc)
             gw = fin()
         return gx, gA, gB, gw, None, None, None, None, None, None, None
 

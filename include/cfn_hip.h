@@ -85,6 +85,15 @@ int cfn_pwconv_bwd_weight(const float* gy, const float* y, const double* gsum, c
                           const double* A, const double* B, int act, double* gw, int N, int Cin, int Cout, int T, int Hi,
                           int Wi, int stride, const double* gscale, void* stream);
 
+/* Data AND weight gradient of a stride-1 pointwise conv with few channels in ONE pass (Cin, Cout <= 64 and not both > 32:
+ * X3D layer 1, where the backward is HBM bound): gy, y, x leave HBM once for both products.  Same arguments and results
+ * as cfn_pwconv_bwd_data_acc (stride 1) + cfn_pwconv_bwd_weight; x is always required.  Returns -1 WITHOUT launching
+ * when the shape / alignment is not handled (callers then use the two separate entry points). */
+int cfn_pwconv_bwd_fused(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
+                         const float* x, const double* A, const double* B, int act, float* gx, double* gA, double* gB,
+                         double* gw, int N, int Cin, int Cout, int T, int Hi, int Wi, const float* acc, int acc_stride,
+                         const double* gscale, void* stream);
+
 /* ---- stem 1x3x3 stride (1,2,2) pad (0,1,1) dense conv: conv1_s x3d_fine.py:210-215 (im2col view on MFMA);
  * gw is fp64 (Cout, Cimg*9), zero-filled by caller.  The clip needs no gradient. ---- */
 int cfn_stem_conv_fwd(const float* x, const float* w, float* y, int N, int Cimg, int Cout, int T, int Hi, int Wi,

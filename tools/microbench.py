@@ -89,6 +89,10 @@ def bench_pw(T, bwd, NB=1, only=None):
                 torch.autograd.grad((y, sm, sq), (xr, wr, Ar, Br), (gy, gs, gq), retain_graph=True)
             d = devtime(f)
             md, mw = d.get('pwconv_bwd', 0.0), d.get('pwconv_wgrad', 0.0)
+            if mw == 0.0:
+                print('%-28s dgrad+wgrad fused %7.3f ms %7.1f GB/s (4 passes) %6.2f TF' %
+                      ('', md, 4.0 * (2 * ci + 2 * co) * Q / 1e6 / md, 4.0 * ci * co * Q / md / 1e9))
+                continue
             print('%-28s dgrad %7.3f ms %7.1f GB/s %6.2f TF | wgrad %7.3f ms %7.1f GB/s %6.2f TF' %
                   ('', md, 4.0 * (2 * ci + 2 * co) * Q / 1e6 / md, 2.0 * ci * co * Q / md / 1e9,
                    mw, 4.0 * (ci + 2 * co) * Q / 1e6 / mw, 2.0 * ci * co * Q / mw / 1e9))
