@@ -36,7 +36,7 @@ struct PfArgs {
 
 // ACT < 0: the forward conv had no prologue (gx = da, no statistics)
 template <int MTW, int NTW, int ACT>
-__global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PfArgs a) {
+__global__ __launch_bounds__(256, ACT < 0 ? 3 : 2) void pw_bwd_fused_kernel(const PfArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool EPI = ACT >= 0;
     constexpr int ACTV = EPI ? ACT : CFN_ACT_NONE;
