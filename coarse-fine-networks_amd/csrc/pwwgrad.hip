@@ -273,6 +273,9 @@ int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, cons
         if (mt <= 2 && kt == 4) return wd_launch<0, 2, 4>(a, st);
         if (mt == 4 && kt <= 2) return wd_launch<0, 4, 2>(a, st);
         if (gm <= 2 && gk <= 2) return wd_launch<0, 2, 2>(a, st);
+        // 7 row tiles x 3 column tiles (216 x 96): row groups of 3 leave a 1-tile group (7/9 of the MFMA slots used), groups
+        // of 2 use 7/8 (measured 0.363 -> 0.332 ms; the transposed 3 x 7 case shows no difference and stays on 3x3)
+        if (mt == 7 && kt == 3) return wd_launch<0, 2, 3>(a, st);
     }
     return wd_launch<0, 3, 3>(a, st);
 }
