@@ -186,7 +186,7 @@ class Bottleneck(nn.Module):
         A2, B2 = self.bn2.fold(s2, q2, _count(y2), n, se=se)
         # the tail's backward writes one unscaled gradient tensor; conv3 (and the shortcut conv) apply bn3's (the
         # shortcut bn's) per-(n,c) factor when they load it
-        link = ops.TailLink()
+        link = ops.TailLink() if torch.is_grad_enabled() else None
         y3, s3, q3 = ops.pwconv(y2, self.conv3.weight, A2, B2, ACT_SWISH, 1, stats=tr, tail=link, tail_role='y')
         A3, B3 = self.bn3.fold(s3, q3, _count(y3), n)
 
