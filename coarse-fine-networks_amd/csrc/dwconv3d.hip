@@ -87,7 +87,11 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     float* sR = sB + a.CG;                                     // reduction scratch: 27*CG floats
 
     for (int i = tid; i < 2 * bufsz; i += nthr) buf[i] = 0.0f;
-    for (int i = tid; i < a.CG * 27; i += nthr) sR[i] = 0.0f;
+    // reduction scratch: one slot set per WAVE (plain stores, summed in wave order: an LDS float atomic per wave would make
+    // the fp32 sum depend on the arrival order and the results differ from run to run)
+    const int nwv = nthr >> 6, wv = tid >> 6;
+    constexpr int KJ = MODE == DW_WGRAD ? 27 : 2;          // values per (wave, channel) slot
+    for (int i = tid; i < nwv * a.CG * KJ; i += nthr) sR[i] = 0.0f;
     if (tid < a.CG) {
         if (MODE == DW_DGRAD) {   // staged tensor is gy + gs + y * 2gq
             const bool ok = tid < ncg;
@@ -401,18 +405,24 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
 #pragma unroll
         for (int j = 0; j < 27; ++j) {
             const float r = seg_wave_sum(dwa[j], key, lane);
-            if (head) atomicAdd(&sR[c_local * 27 + j], r);
+            if (head) sR[(wv * a.CG + c_local) * 27 + j] = r;
         }
         __syncthreads();
-        for (int i = tid; i < ncg * 27; i += nthr) atomicAdd(&a.s1[(long)c0 * 27 + i], (double)sR[i]);
+        for (int i = tid; i < ncg * 27; i += nthr) {
+            float v = 0.0f;
+            for (int w = 0; w < nwv; ++w) v += sR[w * a.CG * 27 + i];
+            atomicAdd(&a.s1[(long)c0 * 27 + i], (double)v);
+        }
     } else if (a.s1 != nullptr) {
         const float r1 = seg_wave_sum(st1, key, lane);
         const float r2 = seg_wave_sum(st2, key, lane);
-        if (head) { atomicAdd(&sR[c_local * 2], r1); atomicAdd(&sR[c_local * 2 + 1], r2); }
+        if (head) { sR[(wv * a.CG + c_local) * KJ] = r1; sR[(wv * a.CG + c_local) * KJ + 1] = r2; }
         __syncthreads();
         if (tid < ncg) {
-            atomicAdd(&a.s1[(long)n * C + c0 + tid], (double)sR[tid * 2]);
-            atomicAdd(&a.s2[(long)n * C + c0 + tid], (double)sR[tid * 2 + 1]);
+            float v1 = 0.0f, v2 = 0.0f;
+            for (int w = 0; w < nwv; ++w) { v1 += sR[(w * a.CG + tid) * KJ]; v2 += sR[(w * a.CG + tid) * KJ + 1]; }
+            atomicAdd(&a.s1[(long)n * C + c0 + tid], (double)v1);
+            atomicAdd(&a.s2[(long)n * C + c0 + tid], (double)v2);
         }
     }
 }
@@ -464,7 +474,8 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, 2) void dw3d_bwd_fused_kernel(con
     float* sPb = sPa + a.CG;
     float* sR = sPb + a.CG;                // 27*CG (+ reuse for the 2*CG statistics)
     for (int i = tid; i < 4 * bufsz; i += nthr) smem[i] = 0.0f;
-    for (int i = tid; i < a.CG * 27; i += nthr) sR[i] = 0.0f;
+    const int nwv = nthr >> 6, wv = tid >> 6;             // per-wave reduction slots, see dw3d_kernel
+    for (int i = tid; i < nwv * a.CG * 27; i += nthr) sR[i] = 0.0f;
     if (tid < a.CG) {
         const bool ok = tid < ncg;
         const long nci = (long)n * C + c0 + tid;
@@ -683,21 +694,27 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, 2) void dw3d_bwd_fused_kernel(con
 #pragma unroll
     for (int j = 0; j < 27; ++j) {
         const float r = seg_wave_sum(dwa[j], key, lane);
-        if (head) atomicAdd(&sR[c_local * 27 + j], r);
+        if (head) sR[(wv * a.CG + c_local) * 27 + j] = r;
     }
     __syncthreads();
-    for (int i = tid; i < ncg * 27; i += nthr) atomicAdd(&a.gw[(long)c0 * 27 + i], (double)sR[i]);
+    for (int i = tid; i < ncg * 27; i += nthr) {
+        float v = 0.0f;
+        for (int w = 0; w < nwv; ++w) v += sR[w * a.CG * 27 + i];
+        atomicAdd(&a.gw[(long)c0 * 27 + i], (double)v);
+    }
     if (a.A && a.gA) {
         __syncthreads();
-        for (int i = tid; i < a.CG * 2; i += nthr) sR[i] = 0.0f;
+        for (int i = tid; i < nwv * a.CG * 27; i += nthr) sR[i] = 0.0f;
         __syncthreads();
         const float r1 = seg_wave_sum(st1, key, lane);
         const float r2 = seg_wave_sum(st2, key, lane);
-        if (head) { atomicAdd(&sR[c_local * 2], r1); atomicAdd(&sR[c_local * 2 + 1], r2); }
+        if (head) { sR[(wv * a.CG + c_local) * 27] = r1; sR[(wv * a.CG + c_local) * 27 + 1] = r2; }
         __syncthreads();
         if (tid < ncg) {
-            atomicAdd(&a.gA[(long)n * C + c0 + tid], (double)sR[tid * 2]);
-            atomicAdd(&a.gB[(long)n * C + c0 + tid], (double)sR[tid * 2 + 1]);
+            float v1 = 0.0f, v2 = 0.0f;
+            for (int w = 0; w < nwv; ++w) { v1 += sR[(w * a.CG + tid) * 27]; v2 += sR[(w * a.CG + tid) * 27 + 1]; }
+            atomicAdd(&a.gA[(long)n * C + c0 + tid], (double)v1);
+            atomicAdd(&a.gB[(long)n * C + c0 + tid], (double)v2);
         }
     }
 }
@@ -1094,7 +1111,7 @@ static int dw_plan_impl(DwArgs& a, int S, int mode, DwPlan& pl, bool allow_flat)
     a.TT = TT;
     a.nchunks = cfn_cdiv(a.T, TT);
     pl.HS = HS; pl.VEC = VEC; pl.MAXLD = MAXLD; pl.threads = threads;
-    pl.lds = ((size_t)2 * CG * a.RIN * a.WP + 2 * CG + 27 * CG) * sizeof(float);
+    pl.lds = ((size_t)2 * CG * a.RIN * a.WP + 2 * CG + (mode == DW_WGRAD ? 27 : 2) * CG * (threads / 64)) * sizeof(float);
     pl.blocks = (unsigned)(planes * a.nchunks);
     return CFN_OK;
 }
@@ -1268,7 +1285,7 @@ extern "C" int cfn_dwconv3d_bwd_fused(const float* gy, const float* y, const dou
                      N, C, T, H, W, act};
     f.TT = a.TT; f.nchunks = a.nchunks; f.CG = a.CG; f.ngroups = a.ngroups; f.GB = a.GB; f.nbands = a.nbands;
     f.IPCb = a.IPCb; f.IPCp = a.IPCp; f.RIN = a.RIN; f.WP = a.WP; f.XO = a.XO;
-    const size_t lds = ((size_t)4 * a.CG * a.RIN * a.WP + 4 * a.CG + 27 * a.CG) * sizeof(float);
+    const size_t lds = ((size_t)4 * a.CG * a.RIN * a.WP + 4 * a.CG + 27 * a.CG * (pl.threads / 64)) * sizeof(float);
     if (lds > 150 * 1024) return -1;
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_DWCONV_BWD, st, 4.0 * N * C * T * (double)H * W * (y ? 4 : 3));

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void conv3d_dense_bwd_data_kernel(const DenseB
 // saliency convs).  Weights live in LDS as [co][tap][ci] (ci fastest: one ds_read_b128 feeds 4 channels).
 template <int CI>
 __global__ __launch_bounds__(256) void conv3d_dense_bwd_data_allci_kernel(const DenseBwdArgs a) {
-    extern __shared__ float sg[];            // gs[Cout] | 2gq[Cout] | w[Cout][KV][CI] | red[2*CI]
+    extern __shared__ float sg[];            // gs[Cout] | 2gq[Cout] | w[Cout][KV][CI] | red[4 waves][2*CI]
     const int n = blockIdx.y;
     const int KV = a.kT * a.kH * a.kW;
     float* sw = sg + 2 * a.Cout;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void conv3d_dense_bwd_data_allci_kernel(const 
         const int ci = e % CI, r = e / CI, tap = r % KV, co = r / KV;
         sw[e] = ci < a.Cin ? a.w[((long)co * a.Cin + ci) * KV + tap] : 0.0f;
     }
-    for (int e = threadIdx.x; e < 2 * CI; e += 256) red[e] = 0.0f;
+    for (int e = threadIdx.x; e < 8 * CI; e += 256) red[e] = 0.0f;   // per-wave slots: fixed summation order
     __syncthreads();
     int cls = blockIdx.z;
     const int cw = cls % a.sW; cls /= a.sW;
@@ -176,15 +176,15 @@ __global__ __launch_bounds__(256) void conv3d_dense_bwd_data_allci_kernel(const 
             }
             if (a.A && a.gA) {
                 s1 = cfn_wave_sum(s1); s2 = cfn_wave_sum(s2);
-                if (lane == 0) { atomicAdd(&red[2 * i], s1); atomicAdd(&red[2 * i + 1], s2); }
+                if (lane == 0) { red[(threadIdx.x >> 6) * 2 * CI + 2 * i] = s1; red[(threadIdx.x >> 6) * 2 * CI + 2 * i + 1] = s2; }
             }
         }
     }
     if (a.A && a.gA) {
         __syncthreads();
         for (int i = threadIdx.x; i < a.Cin; i += 256) {
-            atomicAdd(&a.gA[(long)n * a.Cin + i], (double)red[2 * i]);
-            atomicAdd(&a.gB[(long)n * a.Cin + i], (double)red[2 * i + 1]);
+            atomicAdd(&a.gA[(long)n * a.Cin + i], (double)((red[2 * i] + red[2 * CI + 2 * i]) + (red[4 * CI + 2 * i] + red[6 * CI + 2 * i])));
+            atomicAdd(&a.gB[(long)n * a.Cin + i], (double)((red[2 * i + 1] + red[2 * CI + 2 * i + 1]) + (red[4 * CI + 2 * i + 1] + red[6 * CI + 2 * i + 1])));
         }
     }
 }
@@ -213,7 +213,7 @@ extern "C" int cfn_conv3d_dense_bwd_data(const float* gy, const float* y, const 
     const long pcls = (long)cfn_cdiv(T, a.sT) * cfn_cdiv(Hi, a.sH) * cfn_cdiv(Wi, a.sW);     // largest class
     {   // all-input-channels variant when the whole layer's weights fit in LDS
         const int CI = Cin <= 8 ? 8 : (Cin <= 24 ? 24 : 32);
-        const size_t lds_all = ((size_t)2 * Cout + (size_t)Cout * a.kT * a.kH * a.kW * CI + 2 * CI) * sizeof(float);
+        const size_t lds_all = ((size_t)2 * Cout + (size_t)Cout * a.kT * a.kH * a.kW * CI + 8 * CI) * sizeof(float);
         if (Cin <= 32 && lds_all <= 64 * 1024 && ncls <= 64 && N <= 65535) {
             const dim3 grid(cfn_cdiv(pcls, 256), N, ncls);
 #define CFN_DENSE_GO(CIV)                                                                                                 \

@@ -123,28 +123,65 @@ __global__ void interp1d_fwd_kernel(const float* __restrict__ x, const float* __
     if (ind) ind[i] = id;
 }
 
-// gradients of ynew = y0 + (y1-y0)/(eps+x1-x0) * (q-x0) with ind constant; fp32 atomics on
-// (B,N)-sized tensors (tiny)
+// gradients of ynew = y0 + (y1-y0)/(eps+x1-x0) * (q-x0) with ind constant.  Gather form: one thread per
+// OUTPUT element walks the queries in index order, so every sum has a fixed order (a scatter with fp32 atomics made the
+// Grid Pool gradients differ from run to run); the tensors are (B,N)/(B,Pq)-sized (tiny).  A broadcast x / y row (xrow /
+// yrow == 0) collects the queries of all B rows.
 __global__ void interp1d_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ y,
                                     const float* __restrict__ q, const long* __restrict__ ind, float* __restrict__ gx,
                                     float* __restrict__ gy, float* __restrict__ gq, int B, int N, int Pq, int xrow, int yrow,
                                     int qrow) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * Pq) return;
-    const int b = i / Pq, j = i - b * Pq;
-    const long xo = (long)(xrow ? b : 0) * N, yo = (long)(yrow ? b : 0) * N;
-    const int id = (int)ind[i];
-    const float x0 = x[xo + id], x1 = x[xo + id + 1], y0 = y[yo + id], y1 = y[yo + id + 1];
-    const float qv = q[(long)(qrow ? b : 0) * Pq + j];
-    const float den = 1.1920928955078125e-07f + (x1 - x0);
-    const float dy = y1 - y0, dq = qv - x0, slope = dy / den, gv = g[i];
-    if (gy) { atomicAdd(&gy[yo + id], gv * (1.0f - dq / den)); atomicAdd(&gy[yo + id + 1], gv * (dq / den)); }
-    if (gx) {
-        const float t = dy * dq / (den * den);
-        atomicAdd(&gx[xo + id], gv * (t - slope));
-        atomicAdd(&gx[xo + id + 1], gv * (-t));
+    auto terms = [&](int b, int j, float& gv, float& w1, float& t, float& slope) -> int {
+        const long xo = (long)(xrow ? b : 0) * N, yo = (long)(yrow ? b : 0) * N;
+        const int id = (int)ind[(long)b * Pq + j];
+        const float x0 = x[xo + id], x1 = x[xo + id + 1], y0 = y[yo + id], y1 = y[yo + id + 1];
+        const float qv = q[(long)(qrow ? b : 0) * Pq + j];
+        const float den = 1.1920928955078125e-07f + (x1 - x0);
+        const float dy = y1 - y0, dq = qv - x0;
+        slope = dy / den;
+        gv = g[(long)b * Pq + j];
+        w1 = dq / den;
+        t = dy * dq / (den * den);
+        return id;
+    };
+    // knot gradients: element (row r, knot k) <- queries whose bin is k (left knot) or k-1 (right knot)
+    if (i < B * N) {
+        const int r = i / N, k = i - r * N;
+        if (gy && (yrow || r == 0)) {
+            float acc = 0.0f;
+            for (int b = yrow ? r : 0; b < (yrow ? r + 1 : B); ++b)
+                for (int j = 0; j < Pq; ++j) {
+                    float gv, w1, t, sl;
+                    const int id = terms(b, j, gv, w1, t, sl);
+                    if (id == k) acc += gv * (1.0f - w1);
+                    else if (id + 1 == k) acc += gv * w1;
+                }
+            gy[(long)r * N + k] = acc;
+        }
+        if (gx && (xrow || r == 0)) {
+            float acc = 0.0f;
+            for (int b = xrow ? r : 0; b < (xrow ? r + 1 : B); ++b)
+                for (int j = 0; j < Pq; ++j) {
+                    float gv, w1, t, sl;
+                    const int id = terms(b, j, gv, w1, t, sl);
+                    if (id == k) acc += gv * (t - sl);
+                    else if (id + 1 == k) acc += gv * (-t);
+                }
+            gx[(long)r * N + k] = acc;
+        }
     }
-    if (gq) atomicAdd(&gq[(long)(qrow ? b : 0) * Pq + j], gv * slope);
+    // query gradients: one term per (b, j); a broadcast query row sums over b in order
+    if (gq && i < (qrow ? B : 1) * Pq) {
+        const int r = i / Pq, j = i - r * Pq;
+        float acc = 0.0f;
+        for (int b = qrow ? r : 0; b < (qrow ? r + 1 : B); ++b) {
+            float gv, w1, t, sl;
+            terms(b, j, gv, w1, t, sl);
+            acc += gv * sl;
+        }
+        gq[(long)r * Pq + j] = acc;
+    }
 }
 
 // ---- temporal linear resize: align_corners=True (F.interpolate 'linear' x3d_coarse.py:725 and the t-axis of
@@ -263,11 +300,12 @@ extern "C" int cfn_interp1d_fwd(const float* x, const float* y, const float* xne
     return cfn_check_launch("interp1d_fwd");
 }
 
-// gx / gy / gq must be zero-initialised by the caller (scatter-add); any of them may be null
+// gx (B or 1, N), gy (B or 1, N), gq (B or 1, Pq) are fully overwritten; any of them may be null
 extern "C" int cfn_interp1d_bwd(const float* g, const float* x, const float* y, const float* xnew, const long* ind, float* gx,
                                 float* gy, float* gq, int B, int N, int Pq, int xrow, int yrow, int qrow, void* stream) {
     CFN_REQUIRE(g && x && y && xnew && ind, "cfn_interp1d_bwd: null tensor");
-    hipLaunchKernelGGL(interp1d_bwd_kernel, dim3(cfn_cdiv((long)B * Pq, 256)), dim3(256), 0, (hipStream_t)stream, g, x, y, xnew, ind, gx, gy, gq, B, N, Pq, xrow, yrow, qrow);
+    const long work = (long)B * (N > Pq ? N : Pq);
+    hipLaunchKernelGGL(interp1d_bwd_kernel, dim3(cfn_cdiv(work, 256)), dim3(256), 0, (hipStream_t)stream, g, x, y, xnew, ind, gx, gy, gq, B, N, Pq, xrow, yrow, qrow);
     return cfn_check_launch("interp1d_bwd");
 }
 

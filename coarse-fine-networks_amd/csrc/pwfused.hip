@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, ACT < 0 ? 3 : 2) void pw_bwd_fused_kernel(cons
     float* sCg = smem + 2 * IMG;                       // [BM][2]  (gs, 2gq)
     float* sCz = sCg + 2 * BM;                         // [BM]     gsc
     float* sCx = sCz + BM;                             // [BN][2]  (A, B)
-    float* sSt = sCx + 2 * BN;                         // [BN][2]  statistics of this workgroup
+    float* sSt = sCx + 2 * BN;                         // [4 waves][BN][2]  statistics of this workgroup
     for (int m = tid; m < BM; m += 256) {
         const bool ok = m < M;
         sCg[2 * m] = (ok && a.gs) ? (float)a.gs[(long)n * M + m] : 0.0f;
@@ -66,7 +66,6 @@ __global__ __launch_bounds__(256, ACT < 0 ? 3 : 2) void pw_bwd_fused_kernel(cons
         const bool ok = EPI && k < K;
         sCx[2 * k] = ok ? (float)a.pa[(long)n * K + k] : 1.0f;
         sCx[2 * k + 1] = ok ? (float)a.pb[(long)n * K + k] : 0.0f;
-        sSt[2 * k] = 0.0f; sSt[2 * k + 1] = 0.0f;
     }
     // W^T operand of the data gradient, resident: lane (ci = t*16 + m16, co = 4s + kq)
     float wq[NT16][KS];
@@ -253,10 +252,10 @@ __global__ __launch_bounds__(256, ACT < 0 ? 3 : 2) void pw_bwd_fused_kernel(cons
                 float u = sa[t][r], v = sb[t][r];
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) { u += __shfl_xor(u, o, 64); v += __shfl_xor(v, o, 64); }
-                if (m16 == 0) {
+                if (m16 == 0) {                                // per-wave slot, plain store (fixed summation order below)
                     const int ci = t * 16 + 4 * kq + r;
-                    atomicAdd(&sSt[2 * ci], u);
-                    atomicAdd(&sSt[2 * ci + 1], v);
+                    sSt[(wave * BN + ci) * 2] = u;
+                    sSt[(wave * BN + ci) * 2 + 1] = v;
                 }
             }
     }
@@ -280,15 +279,17 @@ __global__ __launch_bounds__(256, ACT < 0 ? 3 : 2) void pw_bwd_fused_kernel(cons
         if (ml < M && kl < K) atomicAdd(&a.gw[(long)ml * K + kl], (double)v);
     }
     if (EPI && tid < K) {
-        atomicAdd(&a.gA[(long)n * K + tid], (double)sSt[2 * tid]);
-        atomicAdd(&a.gB[(long)n * K + tid], (double)sSt[2 * tid + 1]);
+        const float u = (sSt[2 * tid] + sSt[(BN + tid) * 2]) + (sSt[(2 * BN + tid) * 2] + sSt[(3 * BN + tid) * 2]);
+        const float v = (sSt[2 * tid + 1] + sSt[(BN + tid) * 2 + 1]) + (sSt[(2 * BN + tid) * 2 + 1] + sSt[(3 * BN + tid) * 2 + 1]);
+        atomicAdd(&a.gA[(long)n * K + tid], (double)u);
+        atomicAdd(&a.gB[(long)n * K + tid], (double)v);
     }
 }
 
 template <int MTW, int NTW>
 static int pf_launch(const PfArgs& a, int act, bool epi, unsigned blocks, hipStream_t st) {
     constexpr int BM = 32 * MTW, BN = 32 * NTW;
-    size_t lds = ((size_t)2 * (BM + BN) * PF_PITCH + 3 * BM + 4 * BN) * sizeof(float);
+    size_t lds = ((size_t)2 * (BM + BN) * PF_PITCH + 3 * BM + 10 * BN) * sizeof(float);
     const size_t lds_cw = (size_t)4 * BM * (BN + 1) * sizeof(float);
     if (lds_cw > lds) lds = lds_cw;
 #define CFN_PF_GO(ACTV)                                                                                         \

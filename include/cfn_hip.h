@@ -189,7 +189,7 @@ int cfn_time_sample_bwd(const float* g, const float* x, const float* cdf, float*
 
 /* ---- Interp1d.forward interp1d.py:8-147: x,y (B or 1 rows, N), xnew (B or 1 rows, Pq) -> ynew (B,Pq), ind int64
  * (searchsorted-left - 1, clamped to [0,N-2]).  *row flags: 1 = one row per batch entry, 0 = shared row.
- * bwd scatter-adds into zero-filled gx/gy/gq (any may be NULL). ---- */
+ * bwd overwrites gx/gy/gq (any may be NULL) in gather form: every sum has a fixed order (reproducible). ---- */
 int cfn_interp1d_fwd(const float* x, const float* y, const float* xnew, float* ynew, long* ind, int B, int N, int Pq,
                      int xrow, int yrow, int qrow, void* stream);
 int cfn_interp1d_bwd(const float* g, const float* x, const float* y, const float* xnew, const long* ind, float* gx, float* gy,

@@ -280,3 +280,32 @@ def test_coarse_train_fwd_bwd_vs_reference():
     for k in ('g_fc2_bias', 'g_rw6_at2_weight', 'g_mix5_conv_at2_weight'):
         name = [n for n in gn if ('g_' + n.replace('.', '_')) == k][0]
         assert relerr(thin(named[name].grad), z[k]) <= 1e-2, k
+
+
+def test_coarse_run_to_run_reproducibility():
+    """two identical train-mode passes of the full Coarse-Fine net: every reduction has a fixed order inside a workgroup and
+    fp64 accumulation of fp32 partials across workgroups, so logits and gradients normally repeat bit for bit (the loose
+    bounds only allow for a rare inexact fp64 sum, which train-mode BN would amplify)."""
+    x, feat, fm, meta, depth = _coarse_inputs(130, 2, 16, 12)
+    m = _coarse_model(depth, dropout=0.0)
+    m.train(True)
+    m.rw6.dropout.p = 0.0
+    from oracle import spec
+    r = spec.rand_input(131, (2, 157, 16)).to(DEV)
+    inp = [x.to(DEV), {k: v.to(DEV) for k, v in feat.items()}, fm.to(DEV), 0, meta.to(DEV)]
+    outs, grads = [], []
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        y = m(inp)
+        (y * r).sum().backward()
+        outs.append(y.detach().clone())
+        grads.append({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    d_out = float((outs[0] - outs[1]).abs().max() / outs[0].abs().max())
+    worst, where = 0.0, None
+    for k in grads[0]:
+        d = float((grads[0][k] - grads[1][k]).norm() / (grads[0][k].norm() + 1e-30))
+        if d > worst:
+            worst, where = d, k
+    print('coarse run-to-run: logits rel %.2e, worst gradient norm-rel %.2e (%s)' % (d_out, worst, where))
+    assert d_out <= 1e-3 and worst <= 5e-2

@@ -510,3 +510,31 @@ def test_interp1d_module_shape_rules(case):
     assert torch.equal(indg.cpu().view(indc.shape), indc), case
     assert torch.equal(yg.cpu(), yc), case
     assert torch.equal(out.cpu().view(yc.shape), yc), case
+
+
+@pytest.mark.parametrize('case', ['dw_s1', 'dw_s2', 'dw_small', 'pw_fused', 'pw_deep'])
+def test_bitwise_reproducible(case):
+    """Same inputs, three runs: outputs, statistics and gradients must be bit-identical.  Inside a workgroup every fp32
+    reduction has a fixed order (per-wave slots, no LDS float atomics); across workgroups fp32 partials are accumulated in
+    fp64, which is exact -- hence order independent -- as long as the partials of one sum lie within ~2^19 of each other."""
+    o = ops()
+    if case.startswith('dw'):
+        C, T, H, s = {'dw_s1': (6, 9, 28, 1), 'dw_s2': (5, 8, 28, 2), 'dw_small': (40, 12, 7, 1)}[case]
+        x, w = rnd(1, 2, C, T, H, H).to(DEV), (0.2 * rnd(2, C, 1, 3, 3, 3)).to(DEV)
+        A, B = (1 + 0.2 * rnd(3, 2, C)).to(DEV), (0.1 * rnd(4, 2, C)).to(DEV)
+        fn = lambda x_, w_, A_, B_: o.dwconv3d(x_, w_, A_, B_, 1, s, True)
+    else:
+        Ci, Co, T, H = (24, 54, 8, 16) if case == 'pw_fused' else (96, 216, 4, 14)
+        x, w = rnd(1, 2, Ci, T, H, H).to(DEV), (0.2 * rnd(2, Co, Ci, 1, 1, 1)).to(DEV)
+        A, B = (1 + 0.2 * rnd(3, 2, Ci)).to(DEV), (0.1 * rnd(4, 2, Ci)).to(DEV)
+        fn = lambda x_, w_, A_, B_: o.pwconv(x_, w_, A_, B_, 2, 1, True)
+    runs = []
+    for _ in range(3):
+        leaves = [v.clone().requires_grad_(True) for v in (x, w, A, B)]
+        y, sm, sq = fn(*leaves)
+        gy = rnd(9, *y.shape).to(DEV)
+        ((y * gy).sum() + (sm * 0.01).sum().float() + (sq * 0.001).sum().float()).backward()
+        runs.append([y.detach(), sm.detach(), sq.detach()] + [v.grad for v in leaves])
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert torch.equal(a, b)
