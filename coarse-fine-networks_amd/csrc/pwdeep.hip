@@ -358,7 +358,11 @@ int pwd_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
     const int NW = 8;
     const long wtiles = cfn_cdiv(a.Q, 32);
     const long groups = (long)a.N * a.mtiles;
-    long bpg = 256 / groups;
+    // two workgroups per CU where both fit (LDS <= 80 KiB, <= 128 VGPRs: 4 row tiles, or 2 with the act' epilogue): the
+    // HBM-bound layer-2 shapes gain (48->108 @28 dgrad 0.50 -> 0.42 ms); the big-image layers stay at one per CU
+    const size_t lds_probe = ((size_t)Kpad * BM + 4 * (Kpad + PW_UNIT) + 2 * BM + NW * 32 * PW_RED_PITCH) * sizeof(float);
+    const bool two = lds_probe <= 80 * 1024 && MT <= ((mode == PW_DGRAD && stats) ? 2 : 4);
+    long bpg = (two ? 512L : 256L) / groups;
     if (bpg < 1) bpg = 1;
     if (bpg > cfn_cdiv(wtiles, NW)) bpg = cfn_cdiv(wtiles, NW);
     a.nstrips = (int)bpg;
