@@ -565,9 +565,9 @@ static int pw_plan(PwArgs& a, int& MT, unsigned& blocks, size_t& lds) {
     a.mtiles = cfn_cdiv(a.M, 32 * MT);
     const int BM = 32 * MT;
     const long tiles = cfn_cdiv(a.Q, 128);
-    // ~3 workgroups per CU: long strips amortise the per-workgroup statistics atomics (all workgroups of one
+    // ~4 workgroups per CU (measured 512 / 768 / 1024 / 1536 / 2048: 24->54 @112 2.00 / 1.90 / 1.82 / 1.85 / 1.84 ms): long strips amortise the per-workgroup statistics atomics (all workgroups of one
     // (n, row) hit the same fp64 address) and the weight staging
-    long tpb = (tiles * a.N * a.mtiles + 767) / 768;
+    long tpb = (tiles * a.N * a.mtiles + 1023) / 1024;
     if (tpb < 1) tpb = 1;
     a.tpb = (int)tpb;
     a.nstrips = cfn_cdiv(tiles, tpb);
