@@ -327,9 +327,12 @@ extern "C" int cfn_pwconv_bwd_fused(const float* gy, const float* y, const doubl
     a.acc = acc; a.acc_s = acc ? acc_stride : 1; a.Hi = Hi; a.Wi = Wi; a.T = T;
     a.acc_Ho = (Hi - 1) / a.acc_s + 1; a.acc_Wo = (Wi - 1) / a.acc_s + 1;
     a.N = N; a.M = Cout; a.K = Cin; a.Q = (int)Ql;
-    // ~2.5 workgroups per CU over (samples x position strips), >= 4 stages per workgroup
+    // >= 4 stages per workgroup
     const long nst = cfn_cdiv(Ql, PF_PT);
-    long want = 640 / N;
+    // whole rounds of the chip: 2 workgroups per CU are resident with a prologue (3 without), so 1024 (1536) workgroups
+    // are 2 full rounds; 640 (= 1.25 rounds) cost 4.56 instead of 3.83 ms on 24->54 @112
+    const bool epi = A != nullptr;
+    long want = (epi ? 1024 : 1536) / N;
     if (want < 1) want = 1;
     long stages = cfn_cdiv(nst, want);
     if (stages < 4) stages = 4;
@@ -338,7 +341,6 @@ extern "C" int cfn_pwconv_bwd_fused(const float* gy, const float* y, const doubl
     const unsigned blocks = (unsigned)((long)N * a.nstrips);
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_BWD, st, 4.0 * N * ((double)Cout * Ql * (a.y ? 2 : 1) + (double)Cin * Ql * 2));
-    const bool epi = A != nullptr;
     if (Cout > 32) return pf_launch<2, 1>(a, act, epi, blocks, st);
     if (Cin > 32) return pf_launch<1, 2>(a, act, epi, blocks, st);
     return pf_launch<1, 1>(a, act, epi, blocks, st);
