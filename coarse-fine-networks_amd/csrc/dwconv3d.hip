@@ -1113,6 +1113,11 @@ static int dw_plan_impl(DwArgs& a, int S, int mode, DwPlan& pl, bool allow_flat)
     pl.HS = HS; pl.VEC = VEC; pl.MAXLD = MAXLD; pl.threads = threads;
     pl.lds = ((size_t)2 * CG * a.RIN * a.WP + 2 * CG + (mode == DW_WGRAD ? 27 : 2) * CG * (threads / 64)) * sizeof(float);
     pl.blocks = (unsigned)(planes * a.nchunks);
+    {   // CFN_DW_PLAN_DEBUG=1: print the launch plan (geometry audits)
+        static const int dbg = getenv("CFN_DW_PLAN_DEBUG") ? atoi(getenv("CFN_DW_PLAN_DEBUG")) : 0;
+        if (dbg) fprintf(stderr, "dw_plan mode %d S %d C %d %dx%d: HS %d VEC %d MAXLD %d UNIW %d thr %d CG %d TT %d chunks %d blocks %u per_cu %d lds %zu\n",
+                         mode, S, a.C, a.Hi, a.Wi, HS, VEC, MAXLD, (int)pl.UNIW, threads, CG, TT, a.nchunks, pl.blocks, per_cu, pl.lds);
+    }
     return CFN_OK;
 }
 
