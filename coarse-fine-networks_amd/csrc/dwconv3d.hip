@@ -731,6 +731,7 @@ struct DwS2Args {
     const float* gy; const float* y; const double* gs; const double* gq; const float* w;
     const float* x; const double* A; const double* B; float* gx; double* gA; double* gB;
     int C, T, Hi, Wi, Ho, Wo, act, TT, nchunks, pblocks;
+    int PBLK;            // positions per workgroup (the plane is split evenly over pblocks workgroups)
     int PB, CPB, NC;     // small planes: CPB channels of PB = Ho*Wo positions share a workgroup
 };
 
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
     // big planes: one (n,c) per blockIdx.y, 256 positions per workgroup; small planes (<= 128 positions): CPB channels
     // per workgroup so that the lanes stay busy (a 7x7 plane would fill 49 of 256 threads)
     const int cslot = PACKED ? threadIdx.x / a.PB : 0;
-    const int p = PACKED ? threadIdx.x - cslot * a.PB : pb * 256 + threadIdx.x;
+    const int p = PACKED ? threadIdx.x - cslot * a.PB : (threadIdx.x < a.PBLK ? pb * a.PBLK + threadIdx.x : Ho * Wo);
     const int ncr = PACKED ? blockIdx.y * a.CPB + cslot : blockIdx.y;
     const bool ok = (!PACKED || (cslot < a.CPB && ncr < a.NC)) && p < Ho * Wo;
     const int nc = (!PACKED || ncr < a.NC) ? ncr : a.NC - 1, c = nc % a.C;
@@ -892,7 +893,7 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_fast_kernel(const DwS2Args 
     const int Ho = a.Ho, Wo = a.Wo, Hi = a.Hi, Wi = a.Wi, T = a.T;
     const int chunk = blockIdx.x % a.nchunks, pb = blockIdx.x / a.nchunks;
     const int cslot = PACKED ? threadIdx.x / a.PB : 0;
-    const int p = PACKED ? threadIdx.x - cslot * a.PB : pb * 256 + threadIdx.x;
+    const int p = PACKED ? threadIdx.x - cslot * a.PB : (threadIdx.x < a.PBLK ? pb * a.PBLK + threadIdx.x : Ho * Wo);
     const int nc0 = PACKED ? blockIdx.y * a.CPB : blockIdx.y;            // first (n,c) of this workgroup
     const int ncr = nc0 + cslot;
     const bool ok = (!PACKED || (cslot < a.CPB && ncr < a.NC)) && p < Ho * Wo;
@@ -1208,6 +1209,9 @@ extern "C" int cfn_dwconv3d_bwd_data(const float* gy, const float* y, const doub
         a.PB = Ho * Wo;
         a.CPB = a.PB <= 128 ? 256 / a.PB : 1;
         a.pblocks = cfn_cdiv((long)Ho * Wo, 256);
+        // even split of the plane: 28x28 = 784 positions are 4 x 196, not 3 x 256 + a 16-thread straggler that streams all
+        // frames for 2 % of the work
+        a.PBLK = (a.PB % a.pblocks == 0 && (a.PB / a.pblocks) % 4 == 0) ? a.PB / a.pblocks : 256;   // (uneven splits measured slower)
         const int ygrid = cfn_cdiv(a.NC, a.CPB);
         CFN_REQUIRE(ygrid <= 65535, "cfn_dwconv3d_bwd_data: N*C exceeds grid.y");
         int TT = 64;
