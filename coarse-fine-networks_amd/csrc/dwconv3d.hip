@@ -1074,7 +1074,7 @@ static int dw_plan_impl(DwArgs& a, int S, int mode, DwPlan& pl, bool allow_flat)
     // workgroups, several of which fit on a CU (measured at 4 clips: 14x14 0.31 -> 0.25 ms, 7x7 0.25 -> 0.16 ms)
     // 4-wave workgroups (two per CU at this variant's register budget) beat one 8-wave workgroup everywhere except the
     // 7x7 forward (measured, 8 clips: 56->28 s2 fwd 0.80 -> 0.70 ms, 28->14 s2 0.42 -> 0.35, 14x14 wgrad 0.47 -> 0.45)
-    const int wg = (pl.UNIW || mode != DW_FWD || a.Ho * a.Wo > 64) ? 256 : 512;
+    const int wg = (pl.UNIW || mode != DW_FWD || a.Ho * a.Wo > 64 || S == 2) ? 256 : 512;
     int CG = wg / a.IPCp;
     if (CG < 1) CG = 1;
     if (CG > a.C) CG = a.C;
