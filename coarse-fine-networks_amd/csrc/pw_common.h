@@ -58,3 +58,6 @@ int pwd_wgrad_try_strided(const float* gy, const float* y, const double* gs, con
 int pwd_wgrad_try_dense(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const double* pa,
                         const double* pb, int act, double* gw, int N, int M, int Cimg, int T, int Hi, int Wi, const int* g,
                         hipStream_t st);
+
+// stem.hip: LDS-tiled forward of the 1x3x3 stride-(1,2,2) stem conv (Cimg == 3, Cout <= 32, Wi % 4 == 0, Hi even); -1 = not handled
+int stem_fwd_try_launch(const float* x, const float* w, float* y, int N, int Cimg, int Cout, int T, int Hi, int Wi, hipStream_t st);

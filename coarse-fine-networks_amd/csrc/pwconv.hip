@@ -782,6 +782,12 @@ static const int kStemGeom[9] = {1, 3, 3, 1, 2, 2, 0, 1, 1};
 
 extern "C" int cfn_stem_conv_fwd(const float* x, const float* w, float* y, int N, int Cimg, int Cout, int T, int Hi, int Wi,
                                  void* stream) {
+    CFN_REQUIRE(x && w && y, "cfn_stem_conv_fwd: null tensor");
+    CFN_REQUIRE(N > 0 && Cimg > 0 && Cout > 0 && T > 0 && Hi > 0 && Wi > 0, "cfn_stem_conv_fwd: bad shape");
+    {   // LDS-tiled kernel (stem.hip) for the X3D shape family; anything else runs as an implicit GEMM
+        const int rc = stem_fwd_try_launch(x, w, y, N, Cimg, Cout, T, Hi, Wi, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     return cfn_conv3d_dense_fwd(x, nullptr, nullptr, CFN_ACT_NONE, w, y, nullptr, nullptr, N, Cimg, Cout, T, Hi, Wi, kStemGeom, stream);
 }
 

@@ -128,7 +128,8 @@ def test_dwconv_t5(N, C, T, H, W):
                lambda a, w_: F.conv3d(a, w_, padding=(2, 0, 0), groups=C), x, w, None, None, 0)
 
 
-@pytest.mark.parametrize('N,T,H,W', [(2, 3, 16, 16), (1, 5, 30, 22), (1, 2, 17, 15)])
+@pytest.mark.parametrize('N,T,H,W', [(2, 3, 16, 16), (1, 5, 30, 22), (1, 2, 17, 15), (1, 2, 64, 48), (2, 1, 24, 40), (1, 3, 10, 12),
+                                     (1, 1, 224, 224)])
 def test_stem_conv(N, T, H, W):
     x, w = rnd(1, N, 3, T, H, W), rnd(2, 24, 3, 1, 3, 3, scale=0.3)
     wc, wg = w.clone().requires_grad_(True), w.clone().to(DEV).requires_grad_(True)
