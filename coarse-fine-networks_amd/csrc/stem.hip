@@ -31,14 +31,26 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
     // ---- stage the band: CI x RIN rows of Wi floats, float4 per thread, rows outside the image are zero -------------
     const int w4 = Wi >> 2, per_row = w4 + 1;                         // + one float4 slot that carries the left halo
     const int total = CI * RIN * per_row;
-    for (int e = tid; e < total; e += 256) {
-        const int rowid = e / per_row, c4 = e - rowid * per_row;
-        const int ci = rowid / RIN, r = rowid - ci * RIN;
-        const int ih = ih0 + r;
-        st4 v = (st4){0.f, 0.f, 0.f, 0.f};
-        if (c4 > 0 && ih >= 0 && ih < Hi)
-            v = *reinterpret_cast<const st4*>(a.x + (((long)n * CI + ci) * a.T + t) * (long)Hi * Wi + (long)ih * Wi + (c4 - 1) * 4);
-        *reinterpret_cast<st4*>(img + rowid * WPAD + c4 * 4) = v;    // c4 == 0: columns 0..3 (3 = halo of iw = -1) zero
+    // (all loads of a batch are issued before the first LDS write: a load -> store loop would pay one HBM round trip per
+    // iteration)
+    for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+        st4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 256;
+            const int rowid = e / per_row, c4 = e - rowid * per_row;
+            const int ci = rowid / RIN, r = rowid - ci * RIN;
+            const int ih = ih0 + r;
+            v[u] = (st4){0.f, 0.f, 0.f, 0.f};
+            if (e < total && c4 > 0 && ih >= 0 && ih < Hi)
+                v[u] = *reinterpret_cast<const st4*>(a.x + (((long)n * CI + ci) * a.T + t) * (long)Hi * Wi + (long)ih * Wi + (c4 - 1) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 256;
+            const int rowid = e / per_row, c4 = e - rowid * per_row;
+            if (e < total) *reinterpret_cast<st4*>(img + rowid * WPAD + c4 * 4) = v[u];   // c4 == 0: columns 0..3 (3 = halo of iw = -1) zero
+        }
     }
     // weight operand: lane (co = col, k = 2s + half)
     float wreg[KP];
