@@ -90,28 +90,48 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def call(name, *args):
-    """Invoke one C entry point: tensors -> device pointers, appends the current HIP stream."""
-    lib = load()
+def _marshal(name, args):
+    """tensors -> device pointers; checks element types against the header and that all tensors share ONE device.
+    Returns (converted args, that device or None)."""
     dts = _protos[name][2]
-    for i, a in enumerate(args):   # element types are part of the ABI (float* / double* / long*): refuse a mismatch
-        if isinstance(a, torch.Tensor) and dts[i] is not None and a.dtype != dts[i]:
-            raise RuntimeError('%s: argument %d must be a %s tensor, got %s' % (name, i, dts[i], a.dtype))
-    conv = [(_ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a) for a in args]
-    rc = getattr(lib, name)(*conv, stream())
+    dev = None
+    conv = []
+    for i, a in enumerate(args):
+        if isinstance(a, torch.Tensor):
+            if dts[i] is not None and a.dtype != dts[i]:   # element types are part of the ABI: refuse a mismatch
+                raise RuntimeError('%s: argument %d must be a %s tensor, got %s' % (name, i, dts[i], a.dtype))
+            if dev is None:
+                dev = a.device
+            elif a.device != dev:
+                raise RuntimeError('%s: tensors on different devices (%s and %s)' % (name, dev, a.device))
+            conv.append(_ptr(a))
+        else:
+            conv.append(a)
+    return conv, dev
+
+
+def _launch(name, args):
+    """Enqueue one entry point on the CURRENT stream of the device that owns the tensors (not of whatever device
+    happens to be current: the reference's caller is N threads in one process, one per device)."""
+    lib = load()
+    conv, dev = _marshal(name, args)
+    fn = getattr(lib, name)
+    if dev is None or dev.index == torch.cuda.current_device():
+        return fn(*conv, torch.cuda.current_stream().cuda_stream)
+    with torch.cuda.device(dev):
+        return fn(*conv, torch.cuda.current_stream(dev).cuda_stream)
+
+
+def call(name, *args):
+    """Invoke one C entry point: tensors -> device pointers, appends the tensors' device's current HIP stream."""
+    rc = _launch(name, args)
     if rc != 0:
         raise RuntimeError('%s failed (%d): %s' % (name, rc, last_error()))
 
 
 def call_try(name, *args):
     """like call(), for entry points that may decline a geometry: returns False (nothing was launched) on -1"""
-    lib = load()
-    dts = _protos[name][2]
-    for i, a in enumerate(args):
-        if isinstance(a, torch.Tensor) and dts[i] is not None and a.dtype != dts[i]:
-            raise RuntimeError('%s: argument %d must be a %s tensor, got %s' % (name, i, dts[i], a.dtype))
-    conv = [(_ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a) for a in args]
-    rc = getattr(lib, name)(*conv, stream())
+    rc = _launch(name, args)
     if rc > 0:
         raise RuntimeError('%s failed (%d): %s' % (name, rc, last_error()))
     return rc == 0

@@ -35,6 +35,19 @@ def init_from_env(backend=None):
     return rank, world, dev
 
 
+class _BucketHook(object):
+    """post-accumulate hook of GradReducer.  The marker tells cfn_hip.ops that this hook flushes the lazily cast weight
+    gradients before it reads them (ops._lazy_ok); any other post-accumulate hook disables the lazy cast for its
+    parameter."""
+    _cfn_flushes_grad_casts = True
+
+    def __init__(self, reducer):
+        self.reducer = reducer
+
+    def __call__(self, p):
+        self.reducer._on_grad(p)
+
+
 class GradReducer(object):
     """Bucketed, backward-overlapped gradient averaging for a replica's parameters."""
 
@@ -64,8 +77,9 @@ class GradReducer(object):
         self._stream = None
         self._hooks = []
         if self.world > 1 or self.force:
+            hook = _BucketHook(self)
             for p in self.params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                self._hooks.append(p.register_post_accumulate_grad_hook(hook))
 
     def _comm_stream(self, dev):
         if dev.type != 'cuda':
@@ -117,13 +131,81 @@ class GradReducer(object):
         self._pending = [len(b) for b in self.buckets]
 
 
-def global_mask_count(masks, group=None):
+def global_mask_count(masks, group=None, local=False):
     """sum(masks) over the GLOBAL batch: the loc-loss normaliser of train_fine.py:212 is taken over the
-    batch DataParallel gathered on GPU 0, so a sharded run has to all-reduce it."""
+    batch DataParallel gathered on GPU 0, so a sharded run has to all-reduce it.  local=True (evaluation: ranks hold
+    different numbers of videos, nothing is averaged across ranks) skips the collective."""
     tot = masks.sum().detach().clone()
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if not local and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(tot, group=group)
     return tot
+
+
+def _broadcast_flat(tensors, src, group):
+    """one collective per dtype instead of one per tensor"""
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for ts in by_dtype.values():
+        flat = torch.cat([t.detach().reshape(-1) for t in ts])
+        dist.broadcast(flat, src, group=group)
+        off = 0
+        with torch.no_grad():
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
+
+
+def sync_module(module, src=0, group=None):
+    """Make every replica identical to rank `src`: parameters AND buffers.  nn.DataParallel replicates ONE model each
+    iteration (train_fine.py:123); with one process per GPU the replicas are built independently, and anything not in the
+    pretrained checkpoint (`replace_logits`' fresh fc2, rw2-6, mix2-5, pool_1) would otherwise start different on every
+    rank -- gradient averaging alone never brings them together.  Call once after the model is complete."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    _broadcast_flat(list(module.parameters()) + list(module.buffers()), src, group)
+
+
+def all_agree(flag, device, group=None):
+    """True only if `flag` is true on EVERY rank (a collective: every rank must call it the same number of times).
+    Used for the reference's "skip a short last batch" rule (train_fine.py:180-181), so that no rank skips alone and
+    leaves the others waiting in a gradient all-reduce."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
+def gather_objects(obj, dst=0, group=None):
+    """list of every rank's `obj` on rank `dst` (None elsewhere); validation scores / targets / CSV rows"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [obj]
+    out = [None] * dist.get_world_size(group) if dist.get_rank(group) == dst else None
+    dist.gather_object(obj, out, dst=dst, group=group)
+    return out
+
+
+def mean_over_ranks(values, device, group=None):
+    """element-wise mean of a short list of python floats over the ranks (logging only)"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return list(values)
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(t, group=group)
+    return (t / dist.get_world_size(group)).tolist()
+
+
+def describe(group=None):
+    """one line for logs / bench output: world size as torch.distributed sees it, backend, RCCL version"""
+    if not dist.is_initialized():
+        return {'world_size': 1, 'backend': None}
+    out = {'world_size': dist.get_world_size(group), 'backend': dist.get_backend(group)}
+    try:
+        out['rccl'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        pass
+    return out
 
 
 def broadcast_buffers(module, src=0, group=None):
@@ -131,5 +213,4 @@ def broadcast_buffers(module, src=0, group=None):
     evaluation / checkpointing rank 0's buffers are the ones that survive in the reference."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    for b in module.buffers():
-        dist.broadcast(b, src, group=group)
+    _broadcast_flat(list(module.buffers()), src, group)

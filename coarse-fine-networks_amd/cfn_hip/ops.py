@@ -12,6 +12,7 @@ import torch
 from torch.autograd import Function
 
 import ctypes
+import threading
 
 from . import call, call_try, check, query, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID  # noqa: F401
 
@@ -36,31 +37,42 @@ class _ZeroArena(object):
         return self.buf[key][o:o + numel]
 
 
-_arena = _ZeroArena()
-
-
-def _f64(n, c, dev):
-    return _arena.take(n * c, dev).view(n, c)
-
-
-def _f64pair(n, c, dev):
-    """two adjacent (n,c) accumulators, returned together so one cast converts both"""
-    t = _arena.take(2 * n * c, dev).view(2, n, c)
-    return t, t[0], t[1]
-
-
 class _GradCast(object):
     """fp64 weight-gradient accumulators -> fp32 gradients with ONE cast kernel per backward pass.
 
     The wgrad kernels accumulate into fp64 (zero-filled) buffers.  Casting each of the ~110 buffers on its own costs a
     ~6 us kernel apiece, so the accumulators of one backward pass are carved out of one fp64 chunk that is mirrored
     by an fp32 chunk of the same layout; backward returns views of the fp32 chunk and a callback queued on the
-    autograd engine fills it with a single copy when the pass ends.  Only used when nobody can read the gradient
-    before that (leaf parameter without an existing .grad, no create_graph); GradReducer calls flush() before it
-    packs a bucket."""
+    autograd engine fills it with a single copy when the pass ends.
+
+    A view is only handed out when nobody can read the gradient before that copy (`_gw_buffers`): leaf parameter
+    without an existing .grad, no create_graph, no tensor hooks, no post-accumulate hooks other than GradReducer's (which
+    flushes before it packs a bucket), and the FIRST gradient of that parameter in the running pass (a parameter used
+    twice in one graph would have its two unfilled views summed by autograd mid-pass).  State is per (thread, backward
+    pass): a pass that died with an exception cannot leave `scheduled` set, because the next pass is recognised by its
+    graph-task id and starts from scratch."""
 
     def __init__(self):
-        self.cur, self.live, self.scheduled, self.last_total = {}, [], False, 0
+        self._reset()
+        self.last_total = 0
+
+    def _reset(self):
+        self.cur, self.live, self.scheduled, self.seen, self.task = {}, [], False, set(), None
+
+    def begin(self):
+        """called before every hand-out: a new autograd graph task means a new pass"""
+        tid = torch._C._current_graph_task_id()
+        if tid != self.task:
+            if self.live:      # the previous pass never reached its end-of-backward callback (exception): make what it
+                self.flush()   # handed out valid, then forget it
+            self._reset()
+            self.task = tid
+
+    def first_use(self, w):
+        if id(w) in self.seen:
+            return False
+        self.seen.add(id(w))
+        return True
 
     def take(self, numel, shape, dev):
         al = (numel + 3) & ~3
@@ -89,22 +101,59 @@ class _GradCast(object):
         self.flush()
         self.last_total = max(sum(ch['off'] for ch in self.live), 1)
         # the fp32 chunk now belongs to the gradients that view it; the next pass gets fresh chunks
-        self.cur, self.live, self.scheduled = {}, [], False
+        self._reset()
 
 
-_gradcast = _GradCast()
+class _PerThread(threading.local):
+    """scratch state is per calling thread (the reference's DataParallel drives one thread per device; the autograd
+    engine runs backward on per-device worker threads) and, inside it, per device"""
+
+    def __init__(self):
+        self.arena = _ZeroArena()
+        self.gradcast = _GradCast()
+
+
+_tls = _PerThread()
+LAZY_GRAD_CAST = True     # set False to cast every weight gradient immediately (one small kernel each)
+
+
+def _f64(n, c, dev):
+    return _tls.arena.take(n * c, dev).view(n, c)
+
+
+def _f64pair(n, c, dev):
+    """two adjacent (n,c) accumulators, returned together so one cast converts both"""
+    t = _tls.arena.take(2 * n * c, dev).view(2, n, c)
+    return t, t[0], t[1]
 
 
 def flush_grad_casts():
     """make every weight gradient handed out so far in the running backward pass valid (see _GradCast)"""
-    _gradcast.flush()
+    _tls.gradcast.flush()
+
+
+def _lazy_ok(w):
+    if not LAZY_GRAD_CAST or w is None or not w.is_leaf or w.grad is not None or torch.is_grad_enabled():
+        return False
+    if w._backward_hooks:
+        return False
+    hooks = getattr(w, '_post_accumulate_grad_hooks', None)
+    if hooks and not all(getattr(h, '_cfn_flushes_grad_casts', False) for h in hooks.values()):
+        return False      # somebody else (DDP, FSDP, optimizer-in-backward) would read the gradient before the flush
+    return True
 
 
 def _gw_buffers(w, rows, cols, dev):
     """(fp64 accumulator (rows, cols), finish() -> fp32 gradient shaped like w)"""
-    if w is not None and w.is_leaf and w.grad is None and not torch.is_grad_enabled() and not w._backward_hooks:
-        g64, g32 = _gradcast.take(rows * cols, tuple(w.shape), dev)
-        return g64.view(rows, cols), (lambda: g32)
+    gc = _tls.gradcast
+    if _lazy_ok(w):
+        gc.begin()
+        if gc.first_use(w):
+            g64, g32 = gc.take(rows * cols, tuple(w.shape), dev)
+            return g64.view(rows, cols), (lambda: g32)
+        # second gradient of the same parameter in this pass: autograd is about to ADD it to the view handed out for the
+        # first one -- fill that view now (its accumulation was enqueued before this call), and cast this one eagerly
+        gc.flush()
     g64 = _f64(rows, cols, dev)
     return g64, (lambda: g64.float().view(tuple(w.shape)))
 
@@ -460,7 +509,7 @@ class _BnAddRelu(Function):
         if gout is None:
             gout = torch.zeros_like(y)
         gout2 = None if gout2 is None else gout2.contiguous()
-        t3 = _arena.take(3 * N * C, y.device).view(3, N, C)
+        t3 = _tls.arena.take(3 * N * C, y.device).view(3, N, C)
         gA, gB = t3[0], t3[1]
         gAr = t3[2] if Ar is not None else None
         gBr = gB if Ar is not None else None
@@ -760,32 +809,100 @@ def conv3d_dense(x, w, kernel, stride, padding, A=None, B=None, act=ACT_NONE, st
 
 
 class _FusionGather(Function):
-    """z[b,c,k,p] = sum_t x[b,c,t,p] at[b,t,p] gm[b,t,k] / (sum_t at gm + 1e-6)   (cfn_fusion_gather_*)"""
+    """z[r,c,k,p] = sum_t x[b] at[b] GX[r] mask[b] / (sum_t at GX mask + 1e-6), at = sigmoid(at_raw + at_bias), r = b*crops + j
+    (cfn_fusion_gather_*)"""
 
     @staticmethod
-    def forward(ctx, x, at, gm):
-        x, at, gm = check(x).contiguous(), check(at).contiguous(), check(gm).contiguous()
+    def forward(ctx, x, at_raw, at_bias, GX, mask, crops):
+        x, at_raw, GX, mask = check(x).contiguous(), check(at_raw).contiguous(), check(GX).contiguous(), check(mask).contiguous()
         B, C, Tf, P = x.shape
-        K = gm.shape[2]
-        z = torch.empty(B, C, K, P, dtype=torch.float32, device=x.device)
-        den = torch.empty(B, K, P, dtype=torch.float32, device=x.device)
-        call('cfn_fusion_gather_fwd', x, at, gm, z, den, B, C, Tf, K, P)
-        ctx.save_for_backward(x, at, gm, z, den)
+        K = GX.shape[2]
+        if GX.shape[0] != B * crops or GX.shape[1] != Tf or tuple(mask.shape) != (B, Tf) or tuple(at_raw.shape) != (B, Tf, P):
+            raise RuntimeError('fusion_gather: inconsistent shapes x %s at %s GX %s mask %s crops %d'
+                               % (tuple(x.shape), tuple(at_raw.shape), tuple(GX.shape), tuple(mask.shape), crops))
+        z = torch.empty(B * crops, C, K, P, dtype=torch.float32, device=x.device)
+        den = torch.empty(B * crops, K, P, dtype=torch.float32, device=x.device)
+        call('cfn_fusion_gather_fwd', x, at_raw, at_bias, GX, mask, z, den, B, crops, C, Tf, K, P)
+        ctx.save_for_backward(x, at_raw, at_bias, GX, mask, z, den)
+        ctx.crops = crops
         return z
 
     @staticmethod
     def backward(ctx, gz):
-        x, at, gm, z, den = ctx.saved_tensors
+        x, at_raw, at_bias, GX, mask, z, den = ctx.saved_tensors
         B, C, Tf, P = x.shape
-        K = gm.shape[2]
-        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty(B, Tf, K, P, dtype=torch.float32, device=x.device)
-        call('cfn_fusion_gather_bwd', gz.contiguous(), z, den, x, at, gm, gx, dw, B, C, Tf, K, P)
-        gat = torch.einsum('btkp,btk->btp', dw, gm) if ctx.needs_input_grad[1] else None
-        ggm = torch.einsum('btkp,btp->btk', dw, at) if ctx.needs_input_grad[2] else None
-        return gx, gat, ggm
+        K, crops = GX.shape[2], ctx.crops
+        need = ctx.needs_input_grad
+        gx = torch.empty_like(x) if need[0] else None
+        want_at = need[1] or (at_bias is not None and need[2])
+        gat = torch.empty_like(at_raw) if want_at else None
+        gGX = torch.empty_like(GX) if need[3] else None
+        dw = torch.empty(B * crops, Tf, K, P, dtype=torch.float32, device=x.device)
+        call('cfn_fusion_gather_bwd', gz.contiguous(), z, den, x, at_raw, at_bias, GX, mask, gx, gat, gGX, dw, B, crops, C, Tf, K, P)
+        gb = gat.sum().view(at_bias.shape) if (at_bias is not None and need[2]) else None
+        return gx, (gat if need[1] else None), gb, gGX, None, None
 
 
-def fusion_gather(x, at, gm):
-    """x (B,C,Tf,P), at (B,Tf,P), gm (B,Tf,K) -> (B,C,K,P)"""
-    return _FusionGather.apply(x, at, gm)
+def fusion_gather(x, at_raw, at_bias, GX, mask, crops=1):
+    """x (B,C,Tf,P), at_raw (B,Tf,P), at_bias (1,) or None, GX (B*crops,Tf,K), mask (B,Tf) -> (B*crops,C,K,P)"""
+    return _FusionGather.apply(x, at_raw, at_bias, GX, mask, crops)
+
+
+class _GaussAlign(Function):
+    """Gaussian.forward (x3d_coarse.py:256-286) as one kernel; gradient w.r.t. the CDF knots only."""
+
+    @staticmethod
+    def forward(ctx, meta, mask, gx, tx, ratio, crops, K):
+        meta, mask = meta.contiguous(), check(mask).contiguous()
+        if meta.dtype != torch.int64:
+            meta = meta.to(torch.int64)
+        B, Tf = mask.shape
+        if gx is not None:
+            gx = check(gx).contiguous()
+        GX = torch.empty(B * crops, Tf, K, dtype=torch.float32, device=mask.device)
+        call('cfn_gauss_align_fwd', meta, mask, gx, float(tx), float(ratio), GX, B, crops, Tf, K)
+        ctx.save_for_backward(meta, mask, gx)
+        ctx.cfg = (float(tx), float(ratio), crops, K)
+        return GX
+
+    @staticmethod
+    def backward(ctx, gGX):
+        meta, mask, gx = ctx.saved_tensors
+        tx, ratio, crops, K = ctx.cfg
+        ggx = None
+        if gx is not None and ctx.needs_input_grad[2]:
+            B, Tf = mask.shape
+            ggx = torch.empty_like(gx)
+            call('cfn_gauss_align_bwd', gGX.contiguous(), meta, mask, gx, tx, ratio, ggx, B, crops, Tf, K)
+        return None, None, ggx, None, None, None, None
+
+
+def gauss_align(meta, mask, gx, tx, ratio, crops, K):
+    """meta (B,4) int64, mask (B,Tf), gx (B*crops,K) or None (then tl = arange(K)) -> GX (B*crops,Tf,K)"""
+    return _GaussAlign.apply(meta, mask, gx, 1.0 if tx is None else tx, ratio, crops, K)
+
+
+class _GridCdf(Function):
+    """saliency logits (B,Kin) (+ scalar bias) -> CDF knots (B,Kin+1)   (cfn_grid_cdf_*)"""
+
+    @staticmethod
+    def forward(ctx, g, bias):
+        g = check(g).contiguous()
+        B, Kin = g.shape
+        cdf = torch.empty(B, Kin + 1, dtype=torch.float32, device=g.device)
+        call('cfn_grid_cdf_fwd', g, bias, cdf, B, Kin)
+        ctx.save_for_backward(g, bias)
+        return cdf
+
+    @staticmethod
+    def backward(ctx, gcdf):
+        g, bias = ctx.saved_tensors
+        B, Kin = g.shape
+        gg = torch.empty_like(g)
+        call('cfn_grid_cdf_bwd', gcdf.contiguous(), g, bias, gg, B, Kin)
+        gb = gg.sum().view(bias.shape) if (bias is not None and ctx.needs_input_grad[1]) else None
+        return gg, gb
+
+
+def grid_cdf(g, bias=None):
+    return _GridCdf.apply(g, bias)

@@ -235,84 +235,227 @@ extern "C" int cfn_conv3d_dense_bwd_data(const float* gy, const float* y, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// fusion gather.  x (B,C,Tf,P) fine features, at (B,Tf,P) attention, gm (B,Tf,K) = Gaussian alignment * mask.
-//   w[b,t,k,p] = at[b,t,p] * gm[b,t,k];  den[b,k,p] = sum_t w + 1e-6;  z[b,c,k,p] = sum_t x*w / den
+// Gaussian temporal alignment (Gaussian.forward, x3d_coarse.py:256-286).  One thread per (row r of b2 = B*crops, knot k):
+//   mu = (tl + st) / ratio,  tl = gx[r,k]*tx (grid mode) or k,  st = meta[b,0] + meta[b,3]*crop  (:264-266)
+//   f[t] = exp(-((t - mu)^2 / (2 std^2 + 1e-16))),  std = sum(mask[b,:]) / 8,   GX[r,t,k] = f[t] / (max_t f + 1e-16)
+// same operation order as the reference's tensor expression; backward = autograd of it (the max passes its
+// gradient to the first arg-max frame, like torch.max(dim)).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fusion_gather_fwd_kernel(const float* __restrict__ x, const float* __restrict__ at,
-                                                                const float* __restrict__ gm, float* __restrict__ z,
-                                                                float* __restrict__ den, int C, int Tf, int K, int P, long total) {
+__device__ __forceinline__ float gauss_f(int t, float mu, float den) {
+    const float d = (float)t - mu;
+    return expf(-((d * d) / den));
+}
+
+__global__ __launch_bounds__(256) void gauss_align_fwd_kernel(const long* __restrict__ meta, const float* __restrict__ mask,
+                                                              const float* __restrict__ gx, float tx, float ratio,
+                                                              float* __restrict__ GX, int crops, int Tf, int K, int total) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int k = e % K, r = e / K, b = r / crops, crop = r - b * crops;
+    float msum = 0.f;
+    for (int t = 0; t < Tf; ++t) msum += mask[(long)b * Tf + t];
+    const float std = 0.125f * msum;
+    const float den = 2.0f * (std * std) + 1e-16f;
+    const float st = (float)meta[b * 4] + (float)meta[b * 4 + 3] * (float)crop;
+    const float tl = gx ? gx[(long)r * K + k] * tx : (float)k;
+    const float mu = (tl + st) / ratio;
+    float m = 0.f;
+    for (int t = 0; t < Tf; ++t) m = fmaxf(m, gauss_f(t, mu, den));
+    const float dn = m + 1e-16f;
+    for (int t = 0; t < Tf; ++t) GX[((long)r * Tf + t) * K + k] = gauss_f(t, mu, den) / dn;
+}
+
+__global__ __launch_bounds__(256) void gauss_align_bwd_kernel(const float* __restrict__ gGX, const long* __restrict__ meta,
+                                                              const float* __restrict__ mask, const float* __restrict__ gx,
+                                                              float tx, float ratio, float* __restrict__ ggx, int crops, int Tf,
+                                                              int K, int total) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int k = e % K, r = e / K, b = r / crops, crop = r - b * crops;
+    float msum = 0.f;
+    for (int t = 0; t < Tf; ++t) msum += mask[(long)b * Tf + t];
+    const float std = 0.125f * msum;
+    const float den = 2.0f * (std * std) + 1e-16f;
+    const float st = (float)meta[b * 4] + (float)meta[b * 4 + 3] * (float)crop;
+    const float mu = (gx[(long)r * K + k] * tx + st) / ratio;
+    float m = -1.f;
+    int tm = 0;
+    for (int t = 0; t < Tf; ++t) { const float f = gauss_f(t, mu, den); if (f > m) { m = f; tm = t; } }
+    const float dn = m + 1e-16f;
+    // y_t = f_t / dn:  d/df_t = g_t / dn ;  d/dm = -sum_t g_t f_t / dn^2 (lands on frame tm) ;  df_t/dmu = f_t * 2 (t - mu) / den
+    float gm = 0.f, gmu = 0.f;
+    for (int t = 0; t < Tf; ++t) {
+        const float g = gGX[((long)r * Tf + t) * K + k], f = gauss_f(t, mu, den);
+        gm -= g * f;
+        gmu += (g / dn) * f * (2.0f * ((float)t - mu) / den);
+    }
+    gmu += (gm / (dn * dn)) * m * (2.0f * ((float)tm - mu) / den);
+    ggx[(long)r * K + k] = gmu / ratio * tx;
+}
+
+extern "C" int cfn_gauss_align_fwd(const long* meta, const float* mask, const float* gx, double tx, double ratio, float* GX,
+                                   int B, int crops, int Tf, int K, void* stream) {
+    CFN_REQUIRE(meta && mask && GX, "cfn_gauss_align_fwd: null tensor");
+    CFN_REQUIRE(B > 0 && crops > 0 && Tf > 0 && K > 0 && ratio != 0.0, "cfn_gauss_align_fwd: bad sizes");
+    const int total = B * crops * K;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_FUSION, st, 4.0 * B * crops * (double)Tf * K);
+    hipLaunchKernelGGL(gauss_align_fwd_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, st, meta, mask, gx, (float)tx, (float)ratio,
+                       GX, crops, Tf, K, total);
+    return cfn_check_launch("gauss_align_fwd");
+}
+
+extern "C" int cfn_gauss_align_bwd(const float* gGX, const long* meta, const float* mask, const float* gx, double tx, double ratio,
+                                   float* ggx, int B, int crops, int Tf, int K, void* stream) {
+    CFN_REQUIRE(gGX && meta && mask && gx && ggx, "cfn_gauss_align_bwd: null tensor");
+    const int total = B * crops * K;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_FUSION, st, 4.0 * B * crops * (double)Tf * K);
+    hipLaunchKernelGGL(gauss_align_bwd_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, st, gGX, meta, mask, gx, (float)tx,
+                       (float)ratio, ggx, crops, Tf, K, total);
+    return cfn_check_launch("gauss_align_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fusion gather.  x (B,C,Tf,P) fine features (shared by the `crops` rows r = b*crops + j of a video), at_raw (B,Tf,P)
+// attention logits (at = sigmoid(at_raw + at_bias[0]), x3d_coarse.py:219), GX (B*crops,Tf,K) Gaussian alignment, mask (B,Tf):
+//   w[r,t,k,p] = at[b,t,p] * GX[r,t,k] * mask[b,t];  den[r,k,p] = sum_t w + 1e-6;  z[r,c,k,p] = sum_t x[b,c,t,p]*w / den
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fusion_gather_fwd_kernel(const float* __restrict__ x, const float* __restrict__ at_raw,
+                                                                const float* __restrict__ at_bias, const float* __restrict__ GX,
+                                                                const float* __restrict__ mask, float* __restrict__ z,
+                                                                float* __restrict__ den, int crops, int C, int Tf, int K, int P,
+                                                                long total) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int p = (int)(e % P), k = (int)((e / P) % K), c = (int)((e / ((long)P * K)) % C);
-    const long b = e / ((long)P * K * C);
+    const long r = e / ((long)P * K * C), b = r / crops;
     const float* xp = x + ((b * C + c) * Tf) * (long)P + p;
-    const float* ap = at + b * Tf * (long)P + p;
-    const float* gp = gm + b * Tf * (long)K + k;
+    const float* ap = at_raw + b * Tf * (long)P + p;
+    const float* gp = GX + r * Tf * (long)K + k;
+    const float* mp = mask + b * Tf;
+    const float ab = at_bias ? at_bias[0] : 0.0f;
     float num = 0.f, d = 0.f;
     for (int t = 0; t < Tf; ++t) {
-        const float w = ap[(long)t * P] * gp[(long)t * K];
+        const float a = 1.0f / (1.0f + expf(-(ap[(long)t * P] + ab)));
+        const float w = a * (gp[(long)t * K] * mp[t]);
         num = fmaf(xp[(long)t * P], w, num);
         d += w;
     }
     d += 1e-6f;
     z[e] = num / d;
-    if (c == 0) den[(b * K + k) * (long)P + p] = d;
+    if (c == 0) den[(r * K + k) * (long)P + p] = d;
 }
 
-// gx[b,c,t,p] = sum_k (gz/den)[b,c,k,p] * w[b,t,k,p]
+// gx[b,c,t,p] = at[b,t,p] mask[b,t] sum_{crop} sum_k (gz/den)[r,c,k,p] * GX[r,t,k]
 __global__ __launch_bounds__(256) void fusion_gather_bwd_x_kernel(const float* __restrict__ gz, const float* __restrict__ den,
-                                                                  const float* __restrict__ at, const float* __restrict__ gm,
-                                                                  float* __restrict__ gx, int C, int Tf, int K, int P, long total) {
+                                                                  const float* __restrict__ at_raw, const float* __restrict__ at_bias,
+                                                                  const float* __restrict__ GX, const float* __restrict__ mask,
+                                                                  float* __restrict__ gx, int crops, int C, int Tf, int K, int P,
+                                                                  long total) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int p = (int)(e % P), t = (int)((e / P) % Tf), c = (int)((e / ((long)P * Tf)) % C);
     const long b = e / ((long)P * Tf * C);
-    const float a0 = at[(b * Tf + t) * (long)P + p];
-    const float* gp = gm + (b * Tf + t) * (long)K;
-    const float* zp = gz + ((b * C + c) * K) * (long)P + p;
-    const float* dp = den + b * K * (long)P + p;
+    const float ab = at_bias ? at_bias[0] : 0.0f;
+    const float a0 = mask[b * Tf + t] / (1.0f + expf(-(at_raw[(b * Tf + t) * (long)P + p] + ab)));
     float acc = 0.f;
-    for (int k = 0; k < K; ++k) acc = fmaf(zp[(long)k * P] / dp[(long)k * P], gp[k], acc);
+    for (int j = 0; j < crops; ++j) {
+        const long r = b * crops + j;
+        const float* gp = GX + (r * Tf + t) * (long)K;
+        const float* zp = gz + ((r * C + c) * K) * (long)P + p;
+        const float* dp = den + r * K * (long)P + p;
+        for (int k = 0; k < K; ++k) acc = fmaf(zp[(long)k * P] / dp[(long)k * P], gp[k], acc);
+    }
     gx[e] = acc * a0;
 }
 
-// dw[b,t,k,p] = sum_c (gz/den)[b,c,k,p] * (x[b,c,t,p] - z[b,c,k,p])      (d num and d den together)
+// dw[r,t,k,p] = sum_c (gz/den)[r,c,k,p] * (x[b,c,t,p] - z[r,c,k,p])      (d num and d den together)
 __global__ __launch_bounds__(256) void fusion_gather_bwd_w_kernel(const float* __restrict__ gz, const float* __restrict__ z,
                                                                   const float* __restrict__ den, const float* __restrict__ x,
-                                                                  float* __restrict__ dw, int C, int Tf, int K, int P, long total) {
+                                                                  float* __restrict__ dw, int crops, int C, int Tf, int K, int P,
+                                                                  long total) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int p = (int)(e % P), k = (int)((e / P) % K), t = (int)((e / ((long)P * K)) % Tf);
-    const long b = e / ((long)P * K * Tf);
-    const float id = 1.0f / den[(b * K + k) * (long)P + p];
+    const long r = e / ((long)P * K * Tf), b = r / crops;
+    const float id = 1.0f / den[(r * K + k) * (long)P + p];
     float acc = 0.f;
     for (int c = 0; c < C; ++c) {
-        const long o = ((b * C + c) * K + k) * (long)P + p;
+        const long o = ((r * C + c) * K + k) * (long)P + p;
         acc = fmaf(gz[o], x[((b * C + c) * Tf + t) * (long)P + p] - z[o], acc);
     }
     dw[e] = acc * id;
 }
 
-extern "C" int cfn_fusion_gather_fwd(const float* x, const float* at, const float* gm, float* z, float* den, int B, int C,
-                                     int Tf, int K, int P, void* stream) {
-    CFN_REQUIRE(x && at && gm && z && den, "cfn_fusion_gather_fwd: null tensor");
-    const long total = (long)B * C * K * P;
+// One workgroup per (b, t): the two contractions of dw that autograd of `at * GX * mask` needs, in a fixed order:
+//   g_at_raw[b,t,p] = at (1 - at) mask[b,t] * sum_{crop,k} dw[r,t,k,p] GX[r,t,k]          (through the sigmoid)
+//   gGX[r,t,k]      = mask[b,t] * sum_p dw[r,t,k,p] at[b,t,p]
+__global__ __launch_bounds__(256) void fusion_gather_bwd_reduce_kernel(const float* __restrict__ dw, const float* __restrict__ at_raw,
+                                                                       const float* __restrict__ at_bias, const float* __restrict__ GX,
+                                                                       const float* __restrict__ mask, float* __restrict__ gat,
+                                                                       float* __restrict__ gGX, int crops, int Tf, int K, int P) {
+    extern __shared__ float sat[];     // at[b,t,:]
+    const long b = blockIdx.x / Tf;
+    const int t = blockIdx.x % Tf;
+    const float mk = mask[b * Tf + t];
+    const float ab = at_bias ? at_bias[0] : 0.0f;
+    for (int p = threadIdx.x; p < P; p += 256) sat[p] = 1.0f / (1.0f + expf(-(at_raw[(b * Tf + t) * (long)P + p] + ab)));
+    __syncthreads();
+    if (gat) {
+        for (int p = threadIdx.x; p < P; p += 256) {
+            float acc = 0.f;
+            for (int j = 0; j < crops; ++j) {
+                const long r = b * crops + j;
+                const float* dp = dw + ((r * Tf + t) * (long)K) * P + p;
+                const float* gp = GX + (r * Tf + t) * (long)K;
+                for (int k = 0; k < K; ++k) acc = fmaf(dp[(long)k * P], gp[k], acc);
+            }
+            const float a = sat[p];
+            gat[(b * Tf + t) * (long)P + p] = acc * mk * a * (1.0f - a);
+        }
+    }
+    if (gGX) {
+        for (int e = threadIdx.x; e < crops * K; e += 256) {
+            const int j = e / K, k = e - j * K;
+            const long r = b * crops + j;
+            const float* dp = dw + ((r * Tf + t) * (long)K + k) * P;
+            float acc = 0.f;
+            for (int p = 0; p < P; ++p) acc = fmaf(dp[p], sat[p], acc);
+            gGX[(r * Tf + t) * (long)K + k] = acc * mk;
+        }
+    }
+}
+
+extern "C" int cfn_fusion_gather_fwd(const float* x, const float* at_raw, const float* at_bias, const float* GX, const float* mask,
+                                     float* z, float* den, int B, int crops, int C, int Tf, int K, int P, void* stream) {
+    CFN_REQUIRE(x && at_raw && GX && mask && z && den, "cfn_fusion_gather_fwd: null tensor");
+    CFN_REQUIRE(crops >= 1, "cfn_fusion_gather_fwd: crops must be >= 1");
+    const long total = (long)B * crops * C * K * P;
     hipStream_t st = (hipStream_t)stream;
-    CfnProfScope prof(CFN_K_FUSION, st, 4.0 * B * ((double)C * Tf * P + (double)C * K * P));
-    hipLaunchKernelGGL(fusion_gather_fwd_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, st, x, at, gm, z, den, C, Tf, K, P, total);
+    CfnProfScope prof(CFN_K_FUSION, st, 4.0 * B * ((double)C * Tf * P + (double)crops * C * K * P));
+    hipLaunchKernelGGL(fusion_gather_fwd_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, st, x, at_raw, at_bias, GX, mask, z, den,
+                       crops, C, Tf, K, P, total);
     return cfn_check_launch("fusion_gather_fwd");
 }
 
-extern "C" int cfn_fusion_gather_bwd(const float* gz, const float* z, const float* den, const float* x, const float* at,
-                                     const float* gm, float* gx, float* dw, int B, int C, int Tf, int K, int P, void* stream) {
-    CFN_REQUIRE(gz && z && den && x && at && gm && dw, "cfn_fusion_gather_bwd: null tensor");
+extern "C" int cfn_fusion_gather_bwd(const float* gz, const float* z, const float* den, const float* x, const float* at_raw,
+                                     const float* at_bias, const float* GX, const float* mask, float* gx, float* gat, float* gGX,
+                                     float* dw, int B, int crops, int C, int Tf, int K, int P, void* stream) {
+    CFN_REQUIRE(gz && z && den && x && at_raw && GX && mask && dw, "cfn_fusion_gather_bwd: null tensor");
     hipStream_t st = (hipStream_t)stream;
-    CfnProfScope prof(CFN_K_FUSION, st, 4.0 * B * ((double)C * Tf * P * 2 + (double)C * K * P * 2));
+    CfnProfScope prof(CFN_K_FUSION, st, 4.0 * B * ((double)C * Tf * P * 2 + (double)crops * C * K * P * 2));
     if (gx) {
         const long total = (long)B * C * Tf * P;
-        hipLaunchKernelGGL(fusion_gather_bwd_x_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, st, gz, den, at, gm, gx, C, Tf, K, P, total);
+        hipLaunchKernelGGL(fusion_gather_bwd_x_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, st, gz, den, at_raw, at_bias, GX, mask,
+                           gx, crops, C, Tf, K, P, total);
     }
-    const long total = (long)B * Tf * K * P;
-    hipLaunchKernelGGL(fusion_gather_bwd_w_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, st, gz, z, den, x, dw, C, Tf, K, P, total);
+    if (gat || gGX) {
+        const long total = (long)B * crops * Tf * K * P;
+        hipLaunchKernelGGL(fusion_gather_bwd_w_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, st, gz, z, den, x, dw, crops, C, Tf, K,
+                           P, total);
+        hipLaunchKernelGGL(fusion_gather_bwd_reduce_kernel, dim3(B * Tf), dim3(256), P * sizeof(float), st, dw, at_raw, at_bias, GX,
+                           mask, gat, gGX, crops, Tf, K, P);
+    }
     return cfn_check_launch("fusion_gather_bwd");
 }

@@ -324,3 +324,71 @@ extern "C" int cfn_time_resize_bwd(const float* g, float* gx, long BC, int Kin, 
     hipLaunchKernelGGL(time_resize_bwd_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, g, gx, Kin, Lout, P, total, align_corners);
     return cfn_check_launch("time_resize_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// saliency logits -> CDF knots (GridPoolLayer.forward x3d_coarse.py:384-392), one thread per row:
+//   q = 1 - sigmoid(0.5 (g + bias));  p = q / (sum q + 1e-16);  cdf = [0, cumsum(p)]
+// fp32 element arithmetic in the reference's operation order (contraction off), cumsum accumulated in fp64 and rounded
+// per knot like ATen's CPU cumsum; the row sum is a plain left-to-right fp32 sum (ATen's vectorised CPU sum order depends
+// on the host's vector ISA and cannot be a contract).  Backward = autograd of the same expression.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cdf_q(float g) {
+#pragma clang fp contract(off)
+    return 1.0f - 1.0f / (1.0f + expf(-(g * 0.5f)));
+}
+
+__global__ void grid_cdf_fwd_kernel(const float* __restrict__ g, const float* __restrict__ bias, float* __restrict__ cdf, int B, int Kin) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float bs = bias ? bias[0] : 0.0f;
+    const float* gr = g + (long)b * Kin;
+    float S = 0.0f;
+    for (int i = 0; i < Kin; ++i) S += cdf_q(gr[i] + bs);
+    const float dn = S + 1e-16f;
+    double c = 0.0;
+    float* o = cdf + (long)b * (Kin + 1);
+    o[0] = 0.0f;
+    for (int i = 0; i < Kin; ++i) {
+        c += (double)(cdf_q(gr[i] + bs) / dn);
+        o[i + 1] = (float)c;
+    }
+}
+
+__global__ void grid_cdf_bwd_kernel(const float* __restrict__ gc, const float* __restrict__ g, const float* __restrict__ bias,
+                                    float* __restrict__ gg, int B, int Kin) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float bs = bias ? bias[0] : 0.0f;
+    const float* gr = g + (long)b * Kin;
+    const float* gcr = gc + (long)b * (Kin + 1);
+    float S = 0.0f;
+    for (int i = 0; i < Kin; ++i) S += cdf_q(gr[i] + bs);
+    const float dn = S + 1e-16f;
+    // gp_i = sum_{k > i} gc_k (suffix sums);  dot = sum_j gp_j q_j
+    double suf = 0.0, dot = 0.0;
+    for (int i = Kin - 1; i >= 0; --i) {
+        suf += (double)gcr[i + 1];
+        dot += suf * (double)cdf_q(gr[i] + bs);
+    }
+    suf = 0.0;
+    const double idn = 1.0 / (double)dn;
+    for (int i = Kin - 1; i >= 0; --i) {
+        suf += (double)gcr[i + 1];
+        const float q = cdf_q(gr[i] + bs), s = 1.0f - q;
+        const double gq = suf * idn - dot * idn * idn;
+        gg[(long)b * Kin + i] = (float)(gq * (double)(-0.5f * s * (1.0f - s)));
+    }
+}
+
+extern "C" int cfn_grid_cdf_fwd(const float* g, const float* bias, float* cdf, int B, int Kin, void* stream) {
+    CFN_REQUIRE(g && cdf && B > 0 && Kin > 0, "cfn_grid_cdf_fwd: bad arguments");
+    hipLaunchKernelGGL(grid_cdf_fwd_kernel, dim3(cfn_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, g, bias, cdf, B, Kin);
+    return cfn_check_launch("grid_cdf_fwd");
+}
+
+extern "C" int cfn_grid_cdf_bwd(const float* gcdf, const float* g, const float* bias, float* gg, int B, int Kin, void* stream) {
+    CFN_REQUIRE(gcdf && g && gg && B > 0 && Kin > 0, "cfn_grid_cdf_bwd: bad arguments");
+    hipLaunchKernelGGL(grid_cdf_bwd_kernel, dim3(cfn_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, gcdf, g, bias, gg, B, Kin);
+    return cfn_check_launch("grid_cdf_bwd");
+}

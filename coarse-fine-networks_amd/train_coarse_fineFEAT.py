@@ -72,26 +72,18 @@ def _mean_ap(apm):
     return float(v.mean()) if torch.is_tensor(v) else float(v)
 
 
-def detection_loss(per_frame_logits, labels, masks, group=None):
-    """train_coarse_fineFEAT.py:226-240; loc-loss normaliser over the GLOBAL batch (see train_fine.detection_loss)"""
-    if per_frame_logits.is_cuda:   # ATen's upsample_linear1d backward is a 17 ms atomic scatter at batch 16: own kernels
-        from cfn_hip import ops
-        logits = ops.time_resize(per_frame_logits, labels.size(2), False)
-    else:
-        logits = F.interpolate(per_frame_logits, labels.size(2), mode='linear')
-    probs = torch.sigmoid(logits) * masks.unsqueeze(1)
-    cls_loss = F.binary_cross_entropy(torch.max(probs, dim=2)[0], torch.max(labels, dim=2)[0])
-    world = torch.distributed.get_world_size(group) if torch.distributed.is_initialized() else 1
-    norm = cdist.global_mask_count(masks, group) * labels.shape[1]
-    loc_loss = F.binary_cross_entropy(probs, labels, reduction='sum') / norm * world
-    return cls_loss, loc_loss, probs
+def detection_loss(per_frame_logits, labels, masks, group=None, crops=1, local_norm=False):
+    """train_coarse_fineFEAT.py:226-240 (F.interpolate WITHOUT align_corners); multi-crop / normaliser conventions as in
+    train_fine.detection_loss"""
+    from train_fine import detection_loss as _loss
+    return _loss(per_frame_logits, labels, masks, False, group, crops, local_norm)
 
 
 def build_model(device, n_classes=NUM_CLASSES, pretrained=None, dropout=0.5):
     net = x3d_coarse.generate_model(x3d_version=X3D_VERSION, n_classes=400, n_input_channels=3, feat_depth=FEAT_DEPTH,
                                     task='loc', dropout=dropout, base_bn_splits=1, learnedMixing=True, isMixing=True,
                                     t_pool='grid')
-    if pretrained and os.path.exists(pretrained):
+    if pretrained:      # a missing file raises, as in the reference (train_coarse_fineFEAT.py:112)
         ckpt = torch.load(pretrained, map_location='cpu')
         state = net.state_dict()
         state.update(ckpt['model_state_dict'])
@@ -121,14 +113,31 @@ def forward_video(net, inputs, feat, feat_masks, i, meta, t_lim=1000):
     return torch.cat(outs, dim=2)
 
 
-def train_step(net, reducer, optimizer, inputs, labels, masks, feat, feat_masks, meta, i=0):
+def train_step(net, reducer, optimizer, inputs, labels, masks, feat, feat_masks, meta, i=0, pre_step=None):
     logits = net([inputs, feat, feat_masks, i, meta])
     cls_loss, loc_loss, probs = detection_loss(logits, labels, masks)
     ((cls_loss + loc_loss) / 2).backward()
     reducer.finish()
+    if pre_step is not None:       # warm-up learning rate is set before optimizer.step() (train_coarse_fineFEAT.py:274-277)
+        pre_step()
     optimizer.step()
     optimizer.zero_grad(set_to_none=True)
     return cls_loss.detach(), loc_loss.detach(), probs.detach()
+
+
+def localize_rows(probs, labels, valid_t, names, dur):
+    """Charades_v1_localize rows (:249-263): 25 equally spaced frames per video.
+    -> list of (csv rows [name, time, '157 scores'], scores (25,157), targets (25,157))"""
+    out = []
+    for bb in range(labels.shape[0]):
+        v = int(valid_t[bb])
+        step = max(int(v / 25.), 1)
+        p1 = probs[bb][:, :v][:, 1::step][:, :25]
+        l1 = labels[bb][:, :v][:, 1::step][:, :25]
+        a = p1.transpose(0, 1).cpu().numpy()
+        rows = [[names[0], 1 + r * float(dur[bb]) / 25., ' '.join(str(s) for s in a[r])] for r in range(a.shape[0])]
+        out.append((rows, a, l1.transpose(0, 1).cpu().numpy()))
+    return out
 
 
 def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, train_split=None,
@@ -144,6 +153,7 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
         dataloaders = {'train': SyntheticCoarse(local_bs, iters, clip_frames, seed=rank),
                        'val': SyntheticCoarse(1, CHARADES_VAL_SIZE // world, clip_frames, seed=1000 + rank)}
     net = build_model(dev, pretrained=pretrained)
+    cdist.sync_module(net)   # rw2-6, mix2-5, pool_1 and the new fc2 are not in the checkpoint: rank 0's draw everywhere
     optimizer = optim.SGD(param_groups(net, init_lr), lr=init_lr, momentum=0.9, weight_decay=1e-5)
     lr_sched = optim.lr_scheduler.MultiStepLR(optimizer, [15, 25, 35])
     reducer = cdist.GradReducer(net.parameters())
@@ -164,18 +174,22 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
                 net.aggregate_sub_bn_stats()
             tot_loc = tot_cls = 0.0
             n_it = 0
+            val_rows = []
             for i, (inputs, labels, masks, feat, feat_masks, meta, name, dur) in enumerate(dataloaders[phase]):
-                if train and inputs.shape[0] != local_bs:
-                    continue
-                b, n = inputs.shape[:2]
+                if train:     # collective skip of a short last batch (:193-194)
+                    ok = inputs.shape[0] == local_bs
+                    if not (cdist.all_agree(ok, dev) if world > 1 else ok):
+                        continue
+                b, n = inputs.shape[:2]            # n crops per video at validation time (:198-201)
                 inputs = inputs.view((b * n,) + tuple(inputs.shape[2:])).to(dev, non_blocking=True)
                 labels, masks, feat_masks, meta = labels.to(dev), masks.to(dev), feat_masks.to(dev), meta.to(dev)
                 feat = {k: v.to(dev) for k, v in feat.items()}
                 valid_t = masks.sum(1).int()
                 n_it += 1
                 if train:
-                    cls_loss, loc_loss, probs = train_step(net, reducer, optimizer, inputs, labels, masks, feat, feat_masks, meta, i)
-                    lr_warmup(init_lr, steps, warmup_steps, optimizer)
+                    warm = (lambda: lr_warmup(init_lr, steps, warmup_steps, optimizer))
+                    cls_loss, loc_loss, probs = train_step(net, reducer, optimizer, inputs, labels, masks, feat, feat_masks, meta,
+                                                           i, pre_step=warm)
                     steps += 1
                     for bb in range(labels.shape[0]):
                         v = int(valid_t[bb])
@@ -183,22 +197,15 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
                 else:
                     with torch.no_grad():
                         logits = forward_video(net, inputs, feat, feat_masks, i, meta)
-                        cls_loss, loc_loss, probs = detection_loss(logits, labels, masks)
-                    for bb in range(labels.shape[0]):     # 25 equally spaced frames per video (:249-263)
-                        v = int(valid_t[bb])
-                        sc = v / 25.
-                        p1 = probs[bb][:, :v][:, 1::max(int(sc), 1)][:, :25]
-                        l1 = labels[bb][:, :v][:, 1::max(int(sc), 1)][:, :25]
-                        a = p1.transpose(0, 1).cpu().numpy()
-                        if writer is not None:
-                            for r in range(a.shape[0]):
-                                writer.writerow([name[0], 1 + r * float(dur[bb]) / 25., ' '.join(str(s) for s in a[r])])
-                        val_apm.add(a, l1.transpose(0, 1).cpu().numpy())
+                        cls_loss, loc_loss, probs = detection_loss(logits, labels, masks, crops=n, local_norm=True)
+                    val_rows.extend(localize_rows(probs, labels, valid_t, name, dur))
                 tot_cls += float(cls_loss)
                 tot_loc += float(loc_loss)
-                if train and steps % max(iters // 2, 1) == 0 and rank == 0:
-                    log(' Epoch:{} {} steps: {} Loc Loss: {:.4f} Cls Loss: {:.4f} mAP: {:.4f}'.format(
-                        epochs, phase, steps, tot_loc / n_it, tot_cls / n_it, _mean_ap(tr_apm)))
+                if train and steps % max(iters // 2, 1) == 0:
+                    m_loc, m_cls = cdist.mean_over_ranks([tot_loc / n_it, tot_cls / n_it], dev)
+                    if rank == 0:
+                        log(' Epoch:{} {} steps: {} Loc Loss: {:.4f} Cls Loss: {:.4f} mAP: {:.4f}'.format(
+                            epochs, phase, steps, m_loc, m_cls, _mean_ap(tr_apm)))
                     tr_apm.reset()
                 if train and steps % 1000 == 0 and rank == 0:
                     os.makedirs(os.path.dirname(save_model) or '.', exist_ok=True)
@@ -209,12 +216,22 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
                         write_file.close()
                     return net
             if not train:
+                # each rank evaluated its shard of the videos; rank 0 writes the CSV and the mAP for ALL of them
+                gathered = cdist.gather_objects((val_rows, tot_loc, tot_cls, n_it))
+                if rank == 0:
+                    g_loc = g_cls = 0.0
+                    g_it = 0
+                    for rows_r, r_loc, r_cls, r_it in gathered:
+                        for rows, sc, tg in rows_r:
+                            if writer is not None:
+                                writer.writerows(rows)
+                            val_apm.add(sc, tg)
+                        g_loc, g_cls, g_it = g_loc + r_loc, g_cls + r_cls, g_it + r_it
+                    log(' Epoch:{} val Loc Loss: {:.4f} Cls Loss: {:.4f} mAP: {:.4f}'.format(
+                        epochs, g_loc / max(g_it, 1), g_cls / max(g_it, 1), _mean_ap(val_apm)))
                 if write_file:          # the reference closes the CSV after the first val phase (:295)
                     write_file.close()
                     write_file = writer = None
-                if rank == 0:
-                    log(' Epoch:{} val Loc Loss: {:.4f} Cls Loss: {:.4f} mAP: {:.4f}'.format(
-                        epochs, tot_loc / max(n_it, 1), tot_cls / max(n_it, 1), _mean_ap(val_apm)))
                 val_apm.reset()
                 lr_sched.step()
     return net

@@ -58,21 +58,30 @@ class SyntheticCharades(object):
             yield x, labels, masks, ['synthetic_%d' % i] * self.bs
 
 
-def detection_loss(per_frame_logits, labels, masks, align_corners=True, group=None):
+def detection_loss(per_frame_logits, labels, masks, align_corners=True, group=None, crops=1, local_norm=False):
     """cls + loc loss of train_fine.py:199-213 for one rank's shard.
 
     ``loc_loss`` is normalised by the GLOBAL sum(masks) and multiplied by the world size, so that the
-    average of the ranks' gradients equals the gradient of the reference's gathered-batch loss."""
+    average of the ranks' gradients equals the gradient of the reference's gathered-batch loss.
+    crops = n > 1: validation-time multi-crop, logits are (b*n, C, T) against (b, ...) labels / masks; the per-frame
+    probability is the max over the n crops of a video (train_fine.py:204-207).  local_norm=True (evaluation): this
+    rank's own sum(masks) and no world factor -- no collective, ranks may hold different numbers of videos."""
     tl = labels.size(2)
     if per_frame_logits.is_cuda:
         from cfn_hip import ops
         logits = ops.time_resize(per_frame_logits, tl, align_corners)   # = F.interpolate(mode='linear', align_corners=...)
     else:
         logits = F.interpolate(per_frame_logits, tl, mode='linear', align_corners=align_corners)
-    probs = torch.sigmoid(logits) * masks.unsqueeze(1)
+    if crops > 1:
+        logits = logits.view(labels.shape[0], crops, logits.shape[1], tl)
+        probs = torch.max(torch.sigmoid(logits), dim=1)[0] * masks.unsqueeze(1)
+    else:
+        probs = torch.sigmoid(logits) * masks.unsqueeze(1)
     cls_loss = F.binary_cross_entropy(torch.max(probs, dim=2)[0], torch.max(labels, dim=2)[0])
-    world = torch.distributed.get_world_size(group) if torch.distributed.is_initialized() else 1
-    norm = cdist.global_mask_count(masks, group) * labels.shape[1]
+    world = 1
+    if not local_norm and torch.distributed.is_initialized():
+        world = torch.distributed.get_world_size(group)
+    norm = cdist.global_mask_count(masks, group, local=local_norm) * labels.shape[1]
     loc_loss = F.binary_cross_entropy(probs, labels, reduction='sum') / norm * world
     return cls_loss, loc_loss, probs
 
@@ -93,7 +102,7 @@ def lr_warmup(init_lr, cur_steps, warmup_steps, opt):
 def build_model(device, n_classes=NUM_CLASSES, pretrained=None, dropout=0.5):
     net = x3d_fine.generate_model(x3d_version=X3D_VERSION, n_classes=400, n_input_channels=3, task='loc',
                                   dropout=dropout, base_bn_splits=1, t_downsample=False, extract_feat=False)
-    if pretrained and os.path.exists(pretrained):      # partial state.update as train_fine.py:104-107
+    if pretrained:      # partial state.update as train_fine.py:104-107; a missing file raises, as in the reference
         ckpt = torch.load(pretrained, map_location='cpu')
         state = net.state_dict()
         state.update(ckpt['model_state_dict'])
@@ -102,17 +111,30 @@ def build_model(device, n_classes=NUM_CLASSES, pretrained=None, dropout=0.5):
     return net.to(device)
 
 
-def train_step(net, reducer, optimizer, inputs, labels, masks, gamma_tau=5):
-    """one optimisation step on this rank's shard; returns (cls_loss, loc_loss, probs)"""
+def train_step(net, reducer, optimizer, inputs, labels, masks, gamma_tau=5, pre_step=None):
+    """one optimisation step on this rank's shard; returns (cls_loss, loc_loss, probs).  pre_step() runs between the
+    gradient reduction and optimizer.step() -- where the reference adjusts the warm-up learning rate
+    (train_fine.py:241-244)."""
     masks_clip = masks[:, ::gamma_tau * 2]
     logits = net([inputs, masks_clip])
     cls_loss, loc_loss, probs = detection_loss(logits, labels, masks, True)
     loss = (cls_loss + loc_loss) / 2
     loss.backward()
     reducer.finish()
+    if pre_step is not None:
+        pre_step()
     optimizer.step()
     optimizer.zero_grad(set_to_none=True)
     return cls_loss.detach(), loc_loss.detach(), probs.detach()
+
+
+def _ap_rows(probs, labels, valid_t):
+    """per video: (scores (v,157), targets (v,157)) numpy over the valid frames -- what APMeter.add takes"""
+    rows = []
+    for i in range(labels.shape[0]):
+        v = int(valid_t[i])
+        rows.append((probs[i][:, :v].transpose(0, 1).cpu().numpy(), labels[i][:, :v].transpose(0, 1).cpu().numpy()))
+    return rows
 
 
 def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, train_split=None,
@@ -130,6 +152,7 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
         dataloaders = {'train': SyntheticCharades(local_bs, iters, clip_frames, crop, gamma_tau * 2, seed=rank),
                        'val': SyntheticCharades(val_bs, val_iters, clip_frames, crop, gamma_tau * 2, seed=1000 + rank)}
     net = build_model(dev, pretrained=pretrained)
+    cdist.sync_module(net)        # one model on every rank (DataParallel replicates rank 0's; fc2 was just re-drawn)
     optimizer = optim.SGD(net.parameters(), lr=init_lr, momentum=0.9, weight_decay=1e-5)
     lr_sched = optim.lr_scheduler.MultiStepLR(optimizer, [15, 20, 25])
     reducer = cdist.GradReducer(net.parameters())
@@ -146,33 +169,37 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
                 net.aggregate_sub_bn_stats()
             tot_loc = tot_cls = 0.0
             n_it = 0
+            val_rows = []
             for inputs, labels, masks, _name in dataloaders[phase]:
                 want = local_bs if train else val_bs
-                if inputs.shape[0] != want:
+                ok = inputs.shape[0] == want
+                if train:      # the skip is a collective decision: no rank may leave the others alone in an all-reduce
+                    ok = cdist.all_agree(ok, dev) if world > 1 else ok
+                if not ok:
                     continue
-                b, n = inputs.shape[:2]
+                b, n = inputs.shape[:2]          # n crops per video (1 in training, train_fine.py:176-185)
                 inputs = inputs.view((b * n,) + tuple(inputs.shape[2:])).to(dev, non_blocking=True)
                 labels, masks = labels.to(dev), masks.to(dev)
                 valid_t = masks.sum(1).int()
                 n_it += 1
                 if train:
-                    cls_loss, loc_loss, probs = train_step(net, reducer, optimizer, inputs, labels, masks, gamma_tau)
-                    lr_warmup(init_lr, steps, warmup_steps, optimizer)
+                    warm = (lambda: lr_warmup(init_lr, steps, warmup_steps, optimizer))
+                    cls_loss, loc_loss, probs = train_step(net, reducer, optimizer, inputs, labels, masks, gamma_tau, pre_step=warm)
                     steps += 1
-                    apm = tr_apm
+                    for sc, tg in _ap_rows(probs, labels, valid_t):
+                        tr_apm.add(sc, tg)
                 else:
                     with torch.no_grad():
                         logits = net([inputs, masks[:, ::gamma_tau * 2]])
-                        cls_loss, loc_loss, probs = detection_loss(logits, labels, masks, True)
-                    apm = val_apm
+                        cls_loss, loc_loss, probs = detection_loss(logits, labels, masks, True, crops=n, local_norm=True)
+                    val_rows.extend(_ap_rows(probs, labels, valid_t))
                 tot_cls += float(cls_loss)
                 tot_loc += float(loc_loss)
-                for i in range(labels.shape[0]):
-                    v = int(valid_t[i])
-                    apm.add(probs[i][:, :v].transpose(0, 1).cpu().numpy(), labels[i][:, :v].transpose(0, 1).cpu().numpy())
-                if train and steps % max(iters // 2, 1) == 0 and rank == 0:
-                    log(' Epoch:{} {} steps: {} Loc Loss: {:.4f} Cls Loss: {:.4f} mAP: {:.4f}'.format(
-                        epochs, phase, steps, tot_loc / n_it, tot_cls / n_it, _mean_ap(tr_apm)))
+                if train and steps % max(iters // 2, 1) == 0:
+                    m_loc, m_cls = cdist.mean_over_ranks([tot_loc / n_it, tot_cls / n_it], dev)
+                    if rank == 0:
+                        log(' Epoch:{} {} steps: {} Loc Loss: {:.4f} Cls Loss: {:.4f} mAP: {:.4f}'.format(
+                            epochs, phase, steps, m_loc, m_cls, _mean_ap(tr_apm)))
                     tr_apm.reset()
                 if train and steps % 1000 == 0 and rank == 0:
                     os.makedirs(os.path.dirname(save_model) or '.', exist_ok=True)
@@ -181,9 +208,17 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
                 if max_steps is not None and steps >= max_steps:
                     return net
             if not train:
+                # every rank validated its own shard: the reported mAP / losses cover the WHOLE validation set
+                gathered = cdist.gather_objects((val_rows, tot_loc, tot_cls, n_it))
                 if rank == 0:
+                    g_loc = g_cls = 0.0
+                    g_it = 0
+                    for rows, r_loc, r_cls, r_it in gathered:
+                        for sc, tg in rows:
+                            val_apm.add(sc, tg)
+                        g_loc, g_cls, g_it = g_loc + r_loc, g_cls + r_cls, g_it + r_it
                     log(' Epoch:{} val Loc Loss: {:.4f} Cls Loss: {:.4f} mAP: {:.4f}'.format(
-                        epochs, tot_loc / max(n_it, 1), tot_cls / max(n_it, 1), _mean_ap(val_apm)))
+                        epochs, g_loc / max(g_it, 1), g_cls / max(g_it, 1), _mean_ap(val_apm)))
                 val_apm.reset()
                 lr_sched.step()
     return net

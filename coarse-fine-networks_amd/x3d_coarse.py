@@ -63,20 +63,17 @@ class RewightLayer(nn.Module):
         return out                                                  # raw: the bias of `second` is still to be added
 
     def gather(self, x, b2, mask, GX):
-        """fine features (B,C,T',7,7) -> aligned (b2,C,K,7,7)  (x3d_coarse.py:204-223 at native resolution)"""
+        """fine features (B,C,T',7,7) -> aligned (b2,C,K,7,7)  (x3d_coarse.py:204-223 at native resolution).  b2 = n*B at
+        multi-crop validation (:209-211): the crops of a video share its features / mask / attention and differ in GX."""
         b, c, t, h, w = x.shape
         if mask.shape[1] != t:
             mask = F.adaptive_max_pool1d(mask.unsqueeze(1), t).squeeze(1)
             GX = F.adaptive_avg_pool2d(GX.unsqueeze(1), (t, None)).squeeze(1)
-        if b != b2:      # multi-crop testing
-            x = x.unsqueeze(1).repeat(1, b2 // b, 1, 1, 1, 1).view(b2, c, t, h, w)
-            mask = mask.unsqueeze(1).repeat(1, b2 // b, 1).view(b2, t)
         y1, _, _ = ops.pwconv(x, _w5(self.at1), stats=False)
-        one = torch.ones(b2, c, device=x.device)
-        y2, _, _ = ops.pwconv(y1, _w5(self.at2), one, _rows(self.at1.bias, b2), ACT_RELU, stats=False)
-        at = torch.sigmoid(y2.view(b2, t, h * w) + self.at2.bias)
-        gm = GX * mask.unsqueeze(2)
-        z = ops.fusion_gather(x.reshape(b2, c, t, h * w), at, gm)
+        one = torch.ones(b, c, device=x.device)
+        y2, _, _ = ops.pwconv(y1, _w5(self.at2), one, _rows(self.at1.bias, b), ACT_RELU, stats=False)
+        # sigmoid(at2 + bias), the mask multiply and the per-crop repeat happen inside the gather kernel
+        z = ops.fusion_gather(x.reshape(b, c, t, h * w), y2.view(b, t, h * w), self.at2.bias, GX, mask, b2 // b)
         return z.view(b2, c, GX.shape[2], h, w)
 
     def forward7(self, x, b2, mask, GX, is_mixing):
@@ -114,7 +111,10 @@ def _upsample(v, height):
 
 
 class Gaussian(nn.Module):
-    """Temporal Gaussian alignment weights (x3d_coarse.py:251-286); (B,T',K) tensors, plain device-side torch."""
+    """Temporal Gaussian alignment weights (x3d_coarse.py:251-286): [meta (B,4), mask (B,T'), gx, tx] -> GX (b2,T',K).
+    gx is the CDF (b2,K) with tx the coarse clip length (grid mode), or any tensor whose dim 2 is the coarse length with
+    tx=None.  b2 = n*B at multi-crop validation: crop j of a video starts at start + step*j (:264-266).  One HIP kernel
+    (cfn_gauss_align_*); the CDF receives its gradient through it."""
 
     def __init__(self, ratio=1):
         super(Gaussian, self).__init__()
@@ -122,26 +122,10 @@ class Gaussian(nn.Module):
 
     def forward(self, inp):
         meta, mask, gx, tx = inp
-        dev = gx.device
-        st, step = meta[:, 0].to(torch.float32), meta[:, 3]
-        b, b2, len_f = meta.shape[0], gx.shape[0], mask.shape[1]
-        if b2 != b:
-            offset = step.view(-1, 1) * torch.arange(0, b2 // b, device=dev).to(torch.float32).view(1, -1).repeat(b, 1)
-            st = (st.view(-1, 1).repeat(1, b2 // b) + offset).view(-1, 1)
+        b, b2 = meta.shape[0], gx.shape[0]
         if tx is not None:
-            len_x = gx.shape[1]
-            tl = (gx * tx).unsqueeze(1)
-        else:
-            len_x = gx.shape[2]
-            tl = torch.arange(0, len_x, device=dev).to(torch.float32).view(1, 1, -1).repeat(b2, 1, 1)
-        mu = (tl + st.view(b2, 1, 1)) / self.ratio
-        t = torch.arange(0, len_f, device=dev).to(torch.float32).view(1, -1, 1).repeat(b2, 1, 1)
-        std = (1 / 8 * torch.sum(mask, dim=1)).view(-1, 1).repeat(1, b2 // b).view(-1, 1)
-        t = t - mu
-        f = t ** 2 / (2 * (std ** 2).view(b2, 1, 1).repeat(1, len_f, len_x) + 1e-16)
-        f = torch.exp(-f)
-        f = f / (torch.max(f, dim=1)[0].view(b2, 1, len_x) + 1e-16)
-        return f.view(b2, len_f, len_x)
+            return ops.gauss_align(meta, mask, gx, tx, self.ratio, b2 // b, gx.shape[1])
+        return ops.gauss_align(meta, mask, None, None, self.ratio, b2 // b, gx.shape[2])
 
 
 class MixingLayer(nn.Module):
@@ -217,19 +201,16 @@ class GridPoolLayer(nn.Module):
         y2, A2, B2 = self._conv_bn(y1, self.conv2, self.bn2, A1, B1, ACT_RELU)
         y3, _, _ = ops.conv3d_dense(y2, self.conv3.weight, (1, 3, 3), (1, 2, 2), (0, 1, 1), A2, B2, ACT_RELU, stats=False)
         g = ops.pool_hw(y3, 1, 1)
-        return g.view(g.shape[0], g.shape[2]) + self.conv3.bias
+        return g.view(g.shape[0], g.shape[2])          # conv3's bias is added by the CDF kernel
 
     @staticmethod
-    def cdf(g):
-        """saliency logits -> CDF knots (B, K) (x3d_coarse.py:384-392); cumsum accumulates in fp64 like the CPU op"""
-        p = 1. - torch.sigmoid(g * 5e-1)
-        p = p / (torch.sum(p, dim=1, keepdim=True) + 1e-16)
-        c = torch.cumsum(p.double(), dim=1).float()
-        return torch.cat([torch.zeros(c.shape[0], 1, device=c.device), c], dim=1)
+    def cdf(g, bias=None):
+        """saliency logits (+ bias) -> CDF knots (B, K) (x3d_coarse.py:384-392): one kernel, cumsum accumulated in fp64"""
+        return ops.grid_cdf(g, bias)
 
     def forward(self, inp):
         x = inp.materialize() if isinstance(inp, Deferred) else inp
-        gx_out = self.cdf(self.saliency(x))
+        gx_out = self.cdf(self.saliency(x), self.conv3.bias)
         return ops.time_sample(x, gx_out), gx_out
 
 

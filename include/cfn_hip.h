@@ -130,14 +130,27 @@ int cfn_conv3d_dense_bwd_weight(const float* gy, const float* y, const double* g
                                 const double* A, const double* B, int act, double* gw, int N, int Cin, int Cout, int T, int Hi,
                                 int Wi, const int* geom, void* stream);
 
-/* ---- Multi-stage Fusion temporal-alignment gather: RewightLayer.forward x3d_coarse.py:213-223 at the fine
- * features' native resolution.  x (B,C,Tf,P) fine features, at (B,Tf,P) attention (after sigmoid), gm (B,Tf,K) =
- * Gaussian alignment x mask;  z[b,c,k,p] = sum_t x at gm / (sum_t at gm + 1e-6), den (B,K,P) saved for the backward.
- * bwd: gx (B,C,Tf,P) (may be NULL) and dw (B,Tf,K,P) = d loss / d (at*gm)[b,t,k,p]. ---- */
-int cfn_fusion_gather_fwd(const float* x, const float* at, const float* gm, float* z, float* den, int B, int C, int Tf, int K,
-                          int P, void* stream);
-int cfn_fusion_gather_bwd(const float* gz, const float* z, const float* den, const float* x, const float* at, const float* gm,
-                          float* gx, float* dw, int B, int C, int Tf, int K, int P, void* stream);
+/* ---- Gaussian temporal alignment: Gaussian.forward x3d_coarse.py:256-286 (called at :651 / :657).
+ * meta (B,4) int64 [start, frames, nf, step] (only columns 0 and 3 are read), mask (B,Tf), gx (B*crops,K) CDF knots or NULL
+ * (tl = arange(K), the non-grid modes); tx = coarse clip length.  crops > 1 = validation-time multi-crop: row r = b*crops + j
+ * starts at meta[b,0] + meta[b,3]*j (:264-266).  GX (B*crops,Tf,K).  bwd: ggx (B*crops,K) = d loss / d gx. ---- */
+int cfn_gauss_align_fwd(const long* meta, const float* mask, const float* gx, double tx, double ratio, float* GX, int B, int crops,
+                        int Tf, int K, void* stream);
+int cfn_gauss_align_bwd(const float* gGX, const long* meta, const float* mask, const float* gx, double tx, double ratio,
+                        float* ggx, int B, int crops, int Tf, int K, void* stream);
+
+/* ---- Multi-stage Fusion temporal-alignment gather: RewightLayer.forward x3d_coarse.py:209-223 at the fine
+ * features' native resolution, with the attention sigmoid (:219), the mask multiply (:213-216) and the multi-crop
+ * repeat (:209-211) folded in.  x (B,C,Tf,P) fine features, at_raw (B,Tf,P) attention logits (at = sigmoid(at_raw +
+ * at_bias[0]); at_bias may be NULL), GX (B*crops,Tf,K), mask (B,Tf);  row r = b*crops + j:
+ *   z[r,c,k,p] = sum_t x[b] at[b] GX[r] mask[b] / (sum_t at GX mask + 1e-6), den (B*crops,K,P) saved for the backward.
+ * bwd: gx (B,C,Tf,P), gat (B,Tf,P) = d loss / d at_raw, gGX (B*crops,Tf,K) (each may be NULL);
+ * dw (B*crops,Tf,K,P) is scratch. ---- */
+int cfn_fusion_gather_fwd(const float* x, const float* at_raw, const float* at_bias, const float* GX, const float* mask, float* z,
+                          float* den, int B, int crops, int C, int Tf, int K, int P, void* stream);
+int cfn_fusion_gather_bwd(const float* gz, const float* z, const float* den, const float* x, const float* at_raw,
+                          const float* at_bias, const float* GX, const float* mask, float* gx, float* gat, float* gGX, float* dw,
+                          int B, int crops, int C, int Tf, int K, int P, void* stream);
 
 /* ---- block tail  out = relu(A y + B + (Ar res + Br)) : bn3 + (downsample bn) + `out += residual` + relu,
  * x3d_fine.py:167-173.  Ar/Br NULL = identity shortcut.  vol = T*H*W, NC = N*C.  bwd: gout2 (may be NULL) is a second
@@ -183,6 +196,10 @@ int cfn_film_bwd(const float* g, const float* x, const float* m, float* gx, floa
  * x (B,C,Tin,P), cdf (B,K) -> out (B,C,K,P).  bwd: gx (B,C,Tin,P) fully written, gcdf (B,K) fp64 zero-filled
  * by the caller; either may be NULL. ---- */
 int cfn_grid_time_index(const float* cdf, int n, int Tin, int* i0, float* w1, void* stream);
+/* saliency logits g (B,Kin) (+ bias[0], may be NULL) -> CDF knots (B,Kin+1): x3d_coarse.py:384-392
+ * (1 - sigmoid(g/2), normalise, cumsum in fp64, leading 0).  bwd: gg (B,Kin) from gcdf (B,Kin+1). */
+int cfn_grid_cdf_fwd(const float* g, const float* bias, float* cdf, int B, int Kin, void* stream);
+int cfn_grid_cdf_bwd(const float* gcdf, const float* g, const float* bias, float* gg, int B, int Kin, void* stream);
 int cfn_time_sample_fwd(const float* x, const float* cdf, float* out, int B, int C, int Tin, int K, long P, void* stream);
 int cfn_time_sample_bwd(const float* g, const float* x, const float* cdf, float* gx, double* gcdf, int B, int C, int Tin,
                         int K, long P, void* stream);

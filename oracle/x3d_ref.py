@@ -372,12 +372,16 @@ def x3d_coarse_forward(sd, inp, version='M', training=False, splits=1, is_mixing
 # --------------------------------------------------------------------------------------
 # loss + AP (harness pieces needed for parity statements)
 # --------------------------------------------------------------------------------------
-def detection_loss(logits, labels, masks, align_corners):
+def detection_loss(logits, labels, masks, align_corners, crops=1):
     """cls/loc loss of train_fine.py:199-213 (align_corners=True) and
-    train_coarse_fineFEAT.py:226-240 (align_corners=False)."""
+    train_coarse_fineFEAT.py:226-240 (align_corners=False).  crops = n > 1: the validation branch
+    (train_fine.py:204-207, train_coarse_fineFEAT.py:231-235): logits (b*n, C, T), max over the n crops."""
     tl = labels.shape[2]
     lg = F.interpolate(logits, tl, mode='linear', align_corners=align_corners)
-    probs = torch.sigmoid(lg) * masks.unsqueeze(1)
+    if crops > 1:
+        probs = torch.max(torch.sigmoid(lg.view(labels.shape[0], crops, -1, tl)), dim=1)[0] * masks.unsqueeze(1)
+    else:
+        probs = torch.sigmoid(lg) * masks.unsqueeze(1)
     cls = F.binary_cross_entropy(torch.max(probs, dim=2)[0], torch.max(labels, dim=2)[0])
     loc = F.binary_cross_entropy(probs, labels, reduction='sum') / (torch.sum(masks) * labels.shape[1])
     return cls, loc, probs

@@ -346,10 +346,83 @@ def case_keys():
     save('state_keys', fine=keys_json(m), coarse=keys_json(c), fine_s2=keys_json(m2))
 
 
+def case_multicrop():
+    """validation-time multi-crop (b2 = n*b): Gaussian offsets `st` by step*crop (x3d_coarse.py:264-266), RewightLayer
+    repeats the fine features / mask per crop (:209-211), the loss takes the max over the crops of a video
+    (train_fine.py:204-207)."""
+    rs = np.random.RandomState(141)
+    B, n, Tf, K, T = 2, 2, 20, 9, 32
+    cdf = torch.from_numpy(make_cdf(rs, B * n, K, [np.float32(1)] * (B * n)))
+    mask = torch.ones(B, Tf)
+    mask[1, 14:] = 0
+    meta = torch.tensor([[0, 32, 20, 3], [5, 32, 14, 2]], dtype=torch.int64)      # step (col 3) != 1: the crop offset shows
+    GX = ref_coarse.Gaussian(ratio=1)([meta, mask, cdf, T])
+    save('gaussian_multicrop', cdf=cdf, mask=mask, meta=meta, T=np.array(T), GX=GX)
+    C = 8
+    for is_mix in (True, False):
+        m = ref_coarse.RewightLayer(channels=6, g_channels=6, depth=C, height=14)
+        spec.fill_module_(m)
+        m.eval()
+        xf = spec.rand_input(142, (B, C, Tf, 7, 7), nonneg=True)
+        lx = torch.zeros(B * n, 6, K, 14, 14)
+        with torch.no_grad():
+            b_, s_ = m([xf, lx, mask, None, 0, GX, is_mix])
+        save('rewight_multicrop_%s' % ('mix' if is_mix else 'nomix'), keys=keys_json(m), xf=xf, mask=mask, GX=GX,
+             bias=b_, scale=s_)
+    # loss with n = 3 crops per video, both align_corners conventions (the val branch of both training scripts)
+    b, ncrop, tl = 2, 3, 40
+    lg = spec.rand_input(143, (b * ncrop, 157, 16))
+    labels = torch.from_numpy((np.random.RandomState(144).uniform(size=(b, 157, tl)) < 0.05).astype(np.float32))
+    masks = torch.ones(b, tl)
+    masks[0, 33:] = 0
+    out = {}
+    for ac in (True, False):
+        pl = F.interpolate(lg, tl, mode='linear', align_corners=ac).view(b, ncrop, -1, tl)
+        probs = torch.max(torch.sigmoid(pl), dim=1)[0] * masks.unsqueeze(1)
+        out['cls_%d' % ac] = torch.nn.BCELoss(reduction='mean')(torch.max(probs, dim=2)[0], torch.max(labels, dim=2)[0])
+        out['loc_%d' % ac] = torch.nn.BCELoss(reduction='sum')(probs, labels) / (torch.sum(masks) * labels.shape[1])
+        out['probs_%d' % ac] = probs[:, ::13]
+    save('loss_multicrop', logits=lg, labels=labels, masks=masks, crops=np.array(ncrop), **out)
+
+
+def case_collate():
+    """the two `mt_collate_fn` batch builders (charades_fine.py:201-224, charades_coarse_fineFEAT.py:208-252) on ragged
+    samples.  The dataset modules import h5py / torchvision / cv2 at module level (absent here, and unused by the collate
+    functions): empty placeholder modules satisfy those imports; the functions themselves run unmodified."""
+    import types
+    for name in ('h5py', 'torchvision', 'cv2', 'accimage'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    import charades_fine as ref_cf
+    import charades_coarse_fineFEAT as ref_cc
+    rs = np.random.RandomState(151)
+    lens = [(6, 60), (9, 90), (4, 37)]
+    fine_batch = [(rs.standard_normal((2, 3, t, 4, 5)).astype(np.float32),
+                   (rs.uniform(size=(7, tl)) < 0.3).astype(np.float32), 'vid%d' % i) for i, (t, tl) in enumerate(lens)]
+    clips, label, mask, vids = ref_cf.mt_collate_fn(fine_batch)
+    save('collate_fine', clips=clips, label=label, mask=mask, vids=json.dumps(list(vids)),
+         **{'in%d_%s' % (i, k): v for i, b in enumerate(fine_batch) for k, v in (('clips', b[0]), ('label', b[1]))})
+    chans = {'layer1': 3, 'conv5': 5}
+    flens = [100, 140, 128]       # one sample beyond the 128-frame cap
+    coarse_batch = []
+    for i, ((t, tl), tf) in enumerate(zip(lens, flens)):
+        feat = {k: np.abs(rs.standard_normal((c, tf, 2, 2))).astype(np.float32) for k, c in chans.items()}
+        coarse_batch.append((rs.standard_normal((1, 3, t, 4, 5)).astype(np.float32),
+                             (rs.uniform(size=(7, tl)) < 0.3).astype(np.float32), feat,
+                             np.array([i, t, tf, 1]), 'vid%d' % i, 10.5 + i))
+    clips, label, mask, feat, fmask, meta, vids, dur = ref_cc.mt_collate_fn(coarse_batch)
+    ins = {}
+    for i, b in enumerate(coarse_batch):
+        ins['in%d_clips' % i], ins['in%d_label' % i], ins['in%d_meta' % i] = b[0], b[1], b[3]
+        for k in chans:
+            ins['in%d_feat_%s' % (i, k)] = b[2][k]
+    save('collate_coarse', clips=clips, label=label, mask=mask, fmask=fmask, meta=meta, dur=dur,
+         vids=json.dumps(list(vids)), **{'feat_' + k: v for k, v in feat.items()}, **ins)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     cases = [case_keys, case_interp1d, case_gridpool, case_gridunpool, case_gaussian, case_rewight, case_mixing,
-             case_subbn, case_bottleneck, case_loss_ap, case_fine, case_coarse]
+             case_subbn, case_bottleneck, case_loss_ap, case_fine, case_coarse, case_multicrop, case_collate]
     for c in cases:
         if only and c.__name__[5:] not in only:
             continue

@@ -94,3 +94,104 @@ def test_param_groups_follow_the_reference_rule():
     n_rw = sum(p.numel() for p in groups[1]['params'])
     assert groups[1]['lr'] == pytest.approx(0.2)
     assert n_rw == 1204447 and n_base + n_rw == 4532327
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# replicas start identical: unseeded construction on every rank, then sync_module
+# ---------------------------------------------------------------------------------------------------------------------
+def _worker_sync(rank, port, out):
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD), LOCAL_RANK=str(rank))
+    from cfn_hip import dist as cdist
+    import train_fine
+    cdist.init_from_env(backend='gloo')
+    torch.manual_seed(100 + rank)                     # every rank draws DIFFERENT initial weights (as replace_logits does)
+    net = nn.Sequential(nn.Conv1d(6, 16, 1), nn.BatchNorm1d(16), nn.ReLU(), nn.Conv1d(16, 5, 1))
+    before = torch.cat([p.detach().flatten() for p in net.parameters()]).clone()
+    cdist.sync_module(net)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
+    reducer = cdist.GradReducer(net.parameters(), bucket_bytes=128)
+    x, labels, masks = _batch()
+    sl = slice(rank * 2, rank * 2 + 2)
+    for _ in range(3):
+        cls, loc, _ = train_fine.detection_loss(net(x[sl]), labels[sl], masks[sl], align_corners=False)
+        ((cls + loc) / 2).backward()
+        reducer.finish()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    agree_all = cdist.all_agree(True, torch.device('cpu'))
+    agree_one = cdist.all_agree(rank == 0, torch.device('cpu'))       # rank 1 has a short batch -> everybody skips
+    gathered = cdist.gather_objects({'rank': rank, 'rows': [rank] * (rank + 1)})
+    means = cdist.mean_over_ranks([float(rank), 10.0], torch.device('cpu'))
+    out[rank] = (before, torch.cat([p.detach().flatten() for p in net.parameters()]),
+                 net[1].running_mean.clone(), agree_all, agree_one, gathered, means, cdist.describe())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_identical_after_sync_and_training():
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker_sync, args=(port, out), nprocs=WORLD, join=True)
+    assert not torch.equal(out[0][0], out[1][0])               # the ranks really started from different draws
+    assert torch.equal(out[0][1], out[1][1])                   # ... and hold ONE model after sync + 3 averaged steps
+    for rank in range(WORLD):
+        _b, _p, _rm, agree_all, agree_one, gathered, means, desc = out[rank]
+        assert agree_all is True and agree_one is False
+        assert means == [0.5, 10.0]
+        assert desc['world_size'] == WORLD and desc['backend'] == 'gloo'
+    assert out[1][5] is None and [g['rank'] for g in out[0][5]] == [0, 1] and out[0][5][1]['rows'] == [1, 1]
+
+
+def test_bucket_plan_on_the_real_parameter_sets():
+    """GradReducer over the REAL x3d_fine / x3d_coarse parameter lists (CPU tensors, shapes only): every trainable
+    parameter lands in exactly one bucket, buckets follow reverse registration order (the order backward produces
+    gradients in), all but the last reach the size threshold."""
+    sys.path.insert(0, PKG)
+    from cfn_hip import dist as cdist
+    import train_fine
+    import train_coarse_fineFEAT as tc
+    for net, total in ((train_fine.build_model('cpu'), 3296415),
+                       (tc.build_model('cpu'), 4532327)):
+        params = [p for p in net.parameters() if p.requires_grad]
+        assert sum(p.numel() for p in params) == total
+        red = cdist.GradReducer(params, bucket_bytes=4 << 20)
+        flat = [p for b in red.buckets for p in b]
+        assert len(flat) == len(params) and len(set(map(id, flat))) == len(params)
+        assert [id(p) for p in flat] == [id(p) for p in reversed(params)]
+        sizes = [sum(p.numel() * 4 for p in b) for b in red.buckets]
+        assert all(s >= (4 << 20) for s in sizes[:-1]) and 3 <= len(sizes) <= 6, sizes
+        assert red._pending == [len(b) for b in red.buckets]
+
+
+def _worker_partial(rank, port, out):
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD), LOCAL_RANK=str(rank))
+    from cfn_hip import dist as cdist
+    cdist.init_from_env(backend='gloo')
+    torch.manual_seed(0)
+    used, unused = nn.Linear(4, 3), nn.Linear(4, 3)        # `unused` never contributes to the loss: no gradient at all
+    params = list(used.parameters()) + list(unused.parameters())
+    reducer = cdist.GradReducer(params, bucket_bytes=1 << 20)      # ONE bucket holding used and unused parameters
+    x = torch.full((2, 4), float(rank + 1))
+    res = []
+    for _ in range(2):
+        for p in params:
+            p.grad = None
+        used(x).sum().backward()
+        reducer.finish()                                    # the half-filled bucket must still be reduced, every step
+        res.append(used.weight.grad.clone())
+    out[rank] = (res, unused.weight.grad)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_finish_reduces_buckets_with_gradientless_parameters():
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker_partial, args=(port, out), nprocs=WORLD, join=True)
+    for rank in range(WORLD):
+        res, unused_grad = out[rank]
+        assert unused_grad is None
+        for g in res:                                       # mean over ranks of 2 * (rank + 1) = 3
+            assert torch.allclose(g, torch.full((3, 4), 3.0))

@@ -1,0 +1,72 @@
+"""The lazily cast weight gradients of cfn_hip.ops (_GradCast) on CPU tensors: the hand-out rules that keep a gradient from
+being read before it is filled.  No HIP calls: a stand-in autograd Function uses the same buffers the
+conv ops use."""
+import pytest
+import torch
+
+from cfn_hip import ops
+
+
+class _Scale(torch.autograd.Function):
+    """y = w * x with the weight gradient produced the way the conv ops do: fp64 accumulator + deferred fp32 view"""
+
+    @staticmethod
+    def forward(ctx, x, w, boom):
+        ctx.save_for_backward(x)
+        ctx.wparam, ctx.boom = w, boom
+        return x * w
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        g64, fin = ops._gw_buffers(ctx.wparam, 1, x.numel(), x.device)
+        g64.view(-1).add_((gy * x).double().view(-1))
+        if ctx.boom:
+            raise RuntimeError('backward failed')
+        return gy * ctx.wparam, fin(), None
+
+
+def test_lazy_view_is_filled_at_end_of_backward():
+    w = torch.nn.Parameter(torch.tensor([1.0, 2.0, 3.0]))
+    x = torch.tensor([2.0, 2.0, 2.0], requires_grad=True)
+    _Scale.apply(x, w, False).sum().backward()
+    assert torch.equal(w.grad, torch.tensor([2.0, 2.0, 2.0]))
+
+
+def test_weight_used_twice_in_one_graph_sums_both_terms():
+    """autograd adds the two gradients mid-pass: the second use must not get an unfilled view"""
+    w = torch.nn.Parameter(torch.tensor([1.0, 2.0, 3.0]))
+    x1 = torch.tensor([2.0, 2.0, 2.0], requires_grad=True)
+    x2 = torch.tensor([5.0, 6.0, 7.0], requires_grad=True)
+    (_Scale.apply(x1, w, False).sum() + _Scale.apply(x2, w, False).sum()).backward()
+    assert torch.equal(w.grad, torch.tensor([7.0, 8.0, 9.0]))
+
+
+def test_foreign_post_accumulate_hook_sees_a_valid_gradient():
+    w = torch.nn.Parameter(torch.tensor([1.0, 2.0, 3.0]))
+    seen = []
+    w.register_post_accumulate_grad_hook(lambda p: seen.append(p.grad.clone()))
+    x = torch.tensor([2.0, 3.0, 4.0], requires_grad=True)
+    _Scale.apply(x, w, False).sum().backward()
+    assert torch.equal(seen[0], torch.tensor([2.0, 3.0, 4.0]))
+
+
+def test_failed_backward_does_not_poison_the_next_pass():
+    w = torch.nn.Parameter(torch.tensor([1.0, 2.0, 3.0]))
+    x = torch.tensor([2.0, 2.0, 2.0], requires_grad=True)
+    with pytest.raises(RuntimeError):
+        _Scale.apply(x, w, True).sum().backward()
+    w.grad = None
+    _Scale.apply(x, w, False).sum().backward()
+    assert torch.equal(w.grad, torch.tensor([2.0, 2.0, 2.0]))
+
+
+def test_eager_cast_switch():
+    ops.LAZY_GRAD_CAST = False
+    try:
+        w = torch.nn.Parameter(torch.tensor([1.0, 2.0]))
+        x = torch.tensor([3.0, 4.0], requires_grad=True)
+        _Scale.apply(x, w, False).sum().backward()
+        assert torch.equal(w.grad, torch.tensor([3.0, 4.0]))
+    finally:
+        ops.LAZY_GRAD_CAST = True

@@ -157,6 +157,9 @@ def test_gridpool_layer_vs_reference(tag, depth, mode):
     # index contract: identical CDF in => identical frame indices out (bit exact)
     i0, _ = ops.grid_time_index(t(z['cdf']).to(DEV), x.shape[2])
     assert torch.equal(i0.cpu(), t(z['i0']))
+    # ... and the indices the layer derives from ITS OWN CDF (saliency convs + CDF kernel on the GPU) are the reference's
+    i_own, _ = ops.grid_time_index(cdf, x.shape[2])
+    assert torch.equal(i_own.cpu(), t(z['i0'])), (i_own.cpu() != t(z['i0'])).sum()
     assert maxdiff(y, z['y']) <= 1e-4
     if mode == 'train':
         assert maxdiff(m.bn1.split_bn.running_mean, z['rm1']) <= 1e-5
@@ -175,11 +178,27 @@ def test_gridunpool_vs_reference():
     assert maxdiff(yf, z['yf']) <= 2e-5
 
 
-def test_gaussian_vs_reference():
+@pytest.mark.parametrize('name', ['gaussian', 'gaussian_multicrop'])
+def test_gaussian_vs_reference(name):
+    """Gaussian module = one HIP kernel; 'gaussian_multicrop': b2 = 2b, crop j starts at start + step*j (x3d_coarse.py:264-266)"""
     import x3d_coarse
-    z = load_golden('gaussian')
+    z = load_golden(name)
     g = x3d_coarse.Gaussian(ratio=1)([t(z['meta']).to(DEV), t(z['mask']).to(DEV), t(z['cdf']).to(DEV), int(z['T'])])
-    assert maxdiff(g, z['GX']) <= 1e-6
+    assert tuple(g.shape) == z['GX'].shape and maxdiff(g, z['GX']) <= 1e-6
+
+
+@pytest.mark.parametrize('mix', [True, False])
+def test_rewight_multicrop_vs_reference(mix):
+    """b2 = 2b (validation-time multi-crop, x3d_coarse.py:209-211): fine features / mask of a video are shared by its crops"""
+    import x3d_coarse
+    z = load_golden('rewight_multicrop_%s' % ('mix' if mix else 'nomix'))
+    m = _load(x3d_coarse.RewightLayer(channels=6, g_channels=6, depth=8, height=14), golden_sd(z)).eval()
+    b2, K = z['GX'].shape[0], z['GX'].shape[2]
+    lx = torch.zeros(b2, 6, K, 14, 14, device=DEV)
+    with torch.no_grad():
+        b_, s_ = m([t(z['xf']).to(DEV), lx, t(z['mask']).to(DEV), None, 0, t(z['GX']).to(DEV), mix])
+    assert b_.shape[0] == 2 * z['xf'].shape[0]
+    assert maxdiff(b_, z['bias']) <= 1e-5 and maxdiff(s_, z['scale']) <= 1e-5
 
 
 @pytest.mark.parametrize('name,hgt,mix,pool', [('rewight_h7_mix', 7, True, False), ('rewight_h7_nomix', 7, False, False),
@@ -249,8 +268,16 @@ def test_coarse_eval_logits_vs_reference():
     m = _coarse_model(depth).eval()
     with torch.no_grad():
         y = m([x.to(DEV), {k: v.to(DEV) for k, v in feat.items()}, fm.to(DEV), 0, meta.to(DEV)])
+        _, cdf = m.pool_1(m.layer1(m._stem(x.to(DEV))))
     assert y.shape == (1, 157, 16)
     assert maxdiff(y, z['logits']) <= 1e-3
+    # Grid Pool frame indices from the model's OWN CDF == those of the reference's CDF (north_star: indices bit exact)
+    from cfn_hip import ops
+    from oracle import x3d_ref as R
+    assert maxdiff(cdf, z['cdf']) <= 2e-6
+    i_own, _ = ops.grid_time_index(cdf, 16)
+    i_ref, _ = R.grid_sample_time_index(t(z['cdf']), 16)
+    assert torch.equal(i_own.cpu(), i_ref), (i_own.cpu(), i_ref)
 
 
 def test_coarse_train_fwd_bwd_vs_reference():

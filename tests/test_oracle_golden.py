@@ -91,6 +91,31 @@ def test_rewight(name, hgt, mix, pool):
     assert maxdiff(s_, z['scale']) <= 2e-6
 
 
+def test_gaussian_multicrop():
+    """b2 = 2b: crop j of video i is offset by step_i * j (x3d_coarse.py:264-266)"""
+    z = load_golden('gaussian_multicrop')
+    g = R.gaussian(t(z['meta']), t(z['mask']), t(z['cdf']), int(z['T']))
+    assert g.shape == (4, 20, 9) and maxdiff(g, z['GX']) <= 1e-7
+
+
+@pytest.mark.parametrize('mix', [True, False])
+def test_rewight_multicrop(mix):
+    z = load_golden('rewight_multicrop_%s' % ('mix' if mix else 'nomix'))
+    sd = {'rw.' + k: v for k, v in golden_sd(z).items()}
+    b2, K = z['GX'].shape[0], z['GX'].shape[2]
+    b_, s_ = R.rewight(sd, 'rw', t(z['xf']), (b2, 0, K, 14, 14), t(z['mask']), t(z['GX']), mix, 14)
+    assert b_.shape[0] == 2 * z['xf'].shape[0]
+    assert maxdiff(b_, z['bias']) <= 2e-6 and maxdiff(s_, z['scale']) <= 2e-6
+
+
+def test_loss_multicrop():
+    z = load_golden('loss_multicrop')
+    for ac in (1, 0):
+        cls, loc, probs = R.detection_loss(t(z['logits']), t(z['labels']), t(z['masks']), bool(ac), crops=int(z['crops']))
+        assert abs(float(cls) - float(z['cls_%d' % ac])) <= 1e-7 and abs(float(loc) - float(z['loc_%d' % ac])) <= 1e-7
+        assert maxdiff(probs[:, ::13], z['probs_%d' % ac]) <= 1e-7
+
+
 @pytest.mark.parametrize('li,h', [(0, 14), (3, 7)])
 def test_mixing(li, h):
     z = load_golden('mixing_l%d' % li)
