@@ -32,14 +32,39 @@ import torch.optim as optim                      # noqa: E402
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
 
 
-def cpu_baseline(frames_full, sample_frames=128, repeats=2):
-    """CPU oracle (oracle/x3d_ref.py, stock torch CPU ops) fwd+bwd on `repeats` clips of 3 x sample_frames x 224 x 224;
-    cost is linear in T, so clips/s at T=frames_full = (repeats / t) * sample_frames / frames_full."""
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(frames_full, sample_frames=128, repeats=2, stream='fine'):
+    """CPU oracle (oracle/x3d_ref.py, stock torch CPU ops) fwd+bwd on a bounded sample of the same workload.
+    fine: `repeats` clips of 3 x sample_frames x 224 x 224; cost is linear in T, so clips/s at T=frames_full =
+    (repeats / t) * sample_frames / frames_full.  coarse: one 64-frame clip with T'=128 fine features (the full unit)."""
     from oracle import spec, x3d_ref
-    # torch's CPU conv kernels stop scaling (and thrash) far below the 256 hardware threads of the GPU box:
-    # 16 threads is what the reference's own DataLoader-era hosts had and is near the measured optimum
+    # torch's CPU conv kernels stop scaling (and thrash) far below the hardware threads of the GPU box: 16 threads is near
+    # the measured optimum.  `cores` = threads used; the box's logical CPU count and model are stated next to it
     threads = min(os.cpu_count() or 1, int(os.environ.get('CFN_CPU_THREADS', '16')))
     torch.set_num_threads(threads)
+    host = {'cores': threads, 'host_logical_cpus': os.cpu_count(), 'cpu_model': _cpu_model(), 'kind': 'port'}
+    if stream == 'coarse':
+        import train_coarse_fineFEAT as tc
+        sd = spec.procedural_fill(spec.coarse_keys('M', 157, 1))
+        for k, v in sd.items():
+            if v.is_floating_point() and 'running' not in k:
+                v.requires_grad_(True)
+        x, labels, masks, feat, fm, meta, _, _ = next(iter(tc.SyntheticCoarse(1, 1, frames_full)))
+        t0 = time.time()
+        y = x3d_ref.x3d_coarse_forward(sd, [x[:, 0], feat, fm, 0, meta], 'M', training=True)
+        y.square().mean().backward()
+        dt = time.time() - t0
+        return dict(host, value=round(1.0 / dt, 5), unit='clips/s',
+                    sample='1 clip 3x%dx224x224 + fine features T\'=128, fwd+bwd fp32 (%.1f s)' % (frames_full, dt))
     sd = spec.procedural_fill(spec.fine_keys('M', 157, 1))
     for k, v in sd.items():
         if v.is_floating_point() and 'running' not in k:
@@ -52,10 +77,14 @@ def cpu_baseline(frames_full, sample_frames=128, repeats=2):
         y.square().mean().backward()
         dt += time.time() - t0
         del y
-    return {'value': round((repeats / dt) * sample_frames / frames_full, 5), 'unit': 'clips/s', 'cores': threads,
-            'kind': 'port',
-            'sample': '%d clips 3x%dx224x224 fwd+bwd fp32 (%.1f s), scaled by %d/%d to T=%d clips'
-                      % (repeats, sample_frames, dt, sample_frames, frames_full, frames_full)}
+    return dict(host, value=round((repeats / dt) * sample_frames / frames_full, 5), unit='clips/s',
+                sample='%d clips 3x%dx224x224 fwd+bwd fp32 (%.1f s), scaled by %d/%d to T=%d clips'
+                       % (repeats, sample_frames, dt, sample_frames, frames_full, frames_full))
+
+
+# kernel families whose HIP-event times make up the roofline leg (cfn_prof_*): the metric's kernel set is the depthwise-conv
+# stack forward (fine stream, SURVEY 8d figure A) plus, for the coarse stream, the Grid Pool forward (figure B)
+ROOFLINE_FAMILIES = {'fine': ('dwconv_fwd',), 'coarse': ('dwconv_fwd', 'gridpool', 'dense_fwd')}
 
 
 def main():
@@ -63,87 +92,136 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--frames', type=int, default=256)
+    ap.add_argument('--stream', choices=('fine', 'coarse'), default='fine',
+                    help='fine: x3d_fine X3D-M train step at T=256 (the headline metric); coarse: x3d_coarse fineFEAT-fusion '
+                         'train step on 64-frame clips + T\'=128 fine features (BASELINE configs[3] per-GPU shard)')
+    ap.add_argument('--frames', type=int, default=None, help='default 256 (fine) / 64 (coarse)')
     ap.add_argument('--batch', type=int, default=8, help='clips per GPU per step')
+    ap.add_argument('--graph', action='store_true', help='replay the whole step from one captured hipGraph (single GPU)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-frames', type=int, default=128)
     args = ap.parse_args()
+    coarse = args.stream == 'coarse'
+    if args.frames is None:
+        args.frames = 64 if coarse else 256
 
     from cfn_hip import dist as cdist
     import cfn_hip
     import train_fine
+    import train_coarse_fineFEAT as tc
     rank, world, dev = cdist.init_from_env()
     assert torch.cuda.is_available(), 'bench.py measures the HIP path; it needs a GPU'
     cfn_hip.load()
 
     torch.manual_seed(0)
-    net = train_fine.build_model(dev, pretrained=None)
-    net.train(True)
-    optimizer = optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-5)
-    reducer = cdist.GradReducer(net.parameters())
-
     B, T = args.batch, args.frames
     g = torch.Generator().manual_seed(1234 + rank)
-    x = torch.randn(B, 3, T, 224, 224, generator=g).to(dev)
-    tl = T * 10
-    labels = (torch.rand(B, 157, tl, generator=g) < 0.05).float().to(dev)
-    masks = torch.ones(B, tl, device=dev)
+    if coarse:
+        net = tc.build_model(dev, pretrained=None)
+        optimizer = optim.SGD(tc.param_groups(net, 0.02), lr=0.02, momentum=0.9, weight_decay=1e-5)
+        x, labels, masks, feat, fm, meta, _, _ = next(iter(tc.SyntheticCoarse(B, 1, T, seed=1234 + rank)))
+        x = x[:, 0].contiguous().to(dev)
+        labels, masks, fm, meta = labels.to(dev), masks.to(dev), fm.to(dev), meta.to(dev)
+        feat = {k: v.to(dev) for k, v in feat.items()}
+    else:
+        net = train_fine.build_model(dev, pretrained=None)
+        optimizer = optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-5)
+        x = torch.randn(B, 3, T, 224, 224, generator=g).to(dev)
+        tl = T * 10
+        labels = (torch.rand(B, 157, tl, generator=g) < 0.05).float().to(dev)
+        masks = torch.ones(B, tl, device=dev)
+    net.train(True)
+    cdist.sync_module(net)            # one model on every rank, as under DataParallel
+    reducer = cdist.GradReducer(net.parameters())
 
     def step():
+        if coarse:
+            return tc.train_step(net, reducer, optimizer, x, labels, masks, feat, fm, meta)
         return train_fine.train_step(net, reducer, optimizer, x, labels, masks)
 
+    if args.graph:
+        assert world == 1, '--graph captures the whole step incl. the optimizer: single GPU only (see cfn_hip/graph.py)'
+        from cfn_hip.graph import GraphedStep
+        eager_step = step
+        graphed = GraphedStep(lambda: eager_step()[:2], optimizer=optimizer)
+
+        def step():                   # static loss buffers are overwritten by the next replay: keep copies
+            return tuple(v.clone() for v in graphed())
+
+    losses = []                       # device scalars; read after the timed region (no sync inside it)
     for _ in range(args.warmup):
-        step()
+        losses.append(step()[:2])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    cfn_hip.prof_enable('dwconv_fwd', True)
+    fams = ROOFLINE_FAMILIES[args.stream]
+    for f in fams:
+        cfn_hip.prof_enable(f, True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        losses.append(step()[:2])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    cfn_hip.prof_enable('dwconv_fwd', False)
-    ms, launches, by = cfn_hip.prof_collect('dwconv_fwd')
+    ms = by = 0.0
+    launches = 0
+    for f in fams:
+        cfn_hip.prof_enable(f, False)
+        m_, n_, b_ = cfn_hip.prof_collect(f)
+        ms, launches, by = ms + m_, launches + n_, by + b_
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
+    loss_first = [float(v) for v in losses[0]]
+    loss_last = [float(v) for v in losses[-1]]
+    assert all(v == v and abs(v) != float('inf') for v in loss_first + loss_last), ('non-finite loss', loss_first, loss_last)
 
     if rank == 0:
         achieved = (by / 1e9) / (ms / 1e3) if ms > 0 else 0.0
         # HBM traffic of the same kernels from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # passes, gfx950 correction applied) is measured offline -- bench.py cannot run under the counter tool -- and
         # committed in profiles/; quoted only for the configuration it was measured on
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_dwfwd.json')
-        if os.path.exists(pmc):
-            doc = json.load(open(pmc))
-            if doc.get('frames') == T:   # per launch, like `achieved`; measured at doc['batch'] clips, linear in the batch
-                traffic = round(doc['traffic_bytes_per_launch'] * B / doc['batch'])
+        traffic = traffic_note = None
+        for name in ('r02_pmc_dwfwd.json', 'r01_pmc_dwfwd.json'):
+            pmc = os.path.join(ROOT, 'profiles', name)
+            if not coarse and os.path.exists(pmc):
+                doc = json.load(open(pmc))
+                if doc.get('frames') == T:   # per launch, like `achieved`; measured at doc['batch'] clips, linear in the batch
+                    traffic = round(doc['traffic_bytes_per_launch'] * B / doc['batch'])
+                    traffic_note = 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), profiles/' + name
+                break
+        if coarse:
+            metric = 'clips/sec (fwd+bwd+SGD) x3d_coarse fineFEAT fusion T=%dx224x224, T\'=128' % T
+            workload = ('x3d_coarse X3D-M (Grid Pool + learned Multi-stage Fusion) train step, %dx3x%dx224x224 clips + fine features '
+                        '(T\'=128, 7x7) per GPU, random-init weights' % (B, T))
+            kernel = 'dw3d_kernel<FWD> + dwt5_kernel<FWD> + Grid Pool forward (dense saliency convs, time_sample_fwd)'
+        else:
+            metric = 'clips/sec (fwd+bwd+SGD) x3d_fine X3D-M T=%dx224x224' % T
+            workload = 'x3d_fine X3D-M train step (fwd+loss+bwd+SGD), %dx3x%dx224x224 clips per GPU, random-init weights' % (B, T)
+            kernel = 'dw3d_kernel<FWD> + dwt5_kernel<FWD> (depthwise conv stack forward)'
         out = {
-            'metric': 'clips/sec (fwd+bwd+SGD) x3d_fine X3D-M T=%dx224x224' % T,
+            'metric': metric,
             'value': round(world * B * args.steps / dt, 4),
             'unit': 'clips/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'x3d_fine X3D-M train step (fwd+loss+bwd+SGD), %dx3x%dx224x224 clips per GPU, '
-                                   'random-init weights' % (B, T),
-                       'clips_per_gpu': B, 'frames': T, 'parallelism': 'dp%d' % world},
+            'config': {'workload': workload, 'clips_per_gpu': B, 'frames': T, 'parallelism': 'dp%d' % world,
+                       'launch': 'hipGraph replay' if args.graph else 'eager', 'dist': cdist.describe()},
+            'loss': {'first_step_cls_loc': [round(v, 6) for v in loss_first], 'last_step_cls_loc': [round(v, 6) for v in loss_last]},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                         'traffic_note': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), profiles/r01_pmc_dwfwd.json',
-                         'kernel': 'dw3d_kernel<FWD> + dwt5_kernel<FWD> (depthwise conv stack forward)',
+                         'traffic_note': traffic_note,
+                         'kernel': kernel,
                          'launches': launches, 'avg_launch_ms': round(ms / max(launches, 1), 4),
                          'algorithmic_bytes_per_launch': round(by / max(launches, 1))},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(T, args.cpu_sample_frames)
+            out['cpu_baseline'] = cpu_baseline(T, args.cpu_sample_frames, stream=args.stream)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -17,7 +17,7 @@ HEADER = os.path.join(_ROOT, 'include', 'cfn_hip.h')
 
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 FAMILIES = {'dwconv_fwd': 0, 'dwconv_bwd': 1, 'pwconv_fwd': 2, 'pwconv_bwd': 3, 'gridpool': 4, 'elementwise': 5,
-            'stem': 6, 'fusion': 7, 'pwconv_wgrad': 8, 'dwconv_wgrad': 9}
+            'stem': 6, 'fusion': 7, 'pwconv_wgrad': 8, 'dwconv_wgrad': 9, 'dense_fwd': 10, 'gridpool_bwd': 11}
 
 _lib = None
 _protos = None

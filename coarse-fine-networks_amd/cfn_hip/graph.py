@@ -1,0 +1,88 @@
+"""hipGraph capture of a whole train step (forward + loss + backward + optimizer).
+
+A Coarse-Fine train step is ~1.5k (fine) to ~2.5k (coarse) kernel launches, each reached through autograd + ctypes
+(~8-12 us of host work apiece): below ~4 clips per GPU the step is launch bound (the coarse step spends 28 of 31 ms
+on the host at 8 clips).  The C ABI is capture safe by construction (no allocation, no synchronisation, no host<->device
+copy inside an entry point; every launch goes to the caller's stream), so the whole step is recorded ONCE per input shape
+into a hipGraph and replayed with a single launch per step.
+
+    step = GraphedStep(lambda x, labels, masks: train_step(net, reducer, opt, x, labels, masks), optimizer=opt)
+    cls, loc, probs = step(x, labels, masks)        # call 1: eager (a real step); call 2: capture + replay; then replays
+
+Rules the captured callable has to respect (checked where possible):
+  * tensors in, tensors out; inputs are copied into static buffers before each replay, outputs are static buffers that
+    the next replay overwrites -- clone what has to survive;
+  * no .item() / float(tensor) / host<->device copies inside; no data-dependent Python control flow;
+  * gradients live in the graph's memory pool: never `zero_grad(set_to_none=True)` between replays from outside (the
+    captured step may do it internally: backward then re-creates them at the same addresses at capture time);
+  * the learning rate is baked into the optimizer kernels: a changed `lr` (scheduler, warm-up) triggers a re-capture;
+  * multi-GPU: collectives are NOT captured.  With world_size > 1 pass `reducer=`: the captured part ends after backward,
+    the bucketed all-reduce runs eagerly on the static gradient buffers, and the optimizer step is a second graph.
+"""
+import torch
+
+from . import ops
+
+
+def _lr_signature(optimizer):
+    return tuple((g.get('lr'), g.get('momentum'), g.get('weight_decay')) for g in optimizer.param_groups) if optimizer else ()
+
+
+class GraphedStep(object):
+    """eager_first: the first calls run eagerly as ordinary steps -- they create the lazily allocated state a capture must
+    not contain (SGD momentum buffers are CLONED from the gradient on the first step: captured, every replay would reset
+    them) -- so no hidden extra optimisation steps are ever taken: every call, eager or replayed, is exactly one step."""
+
+    def __init__(self, fn, optimizer=None, eager_first=1, pool=None):
+        self.fn, self.optimizer, self.eager_first, self.pool = fn, optimizer, eager_first, pool
+        self.calls = 0
+        self._graphs = {}       # shape signature -> (graph, static inputs, static outputs, lr signature)
+
+    @staticmethod
+    def _sig(args):
+        return tuple((tuple(a.shape), a.dtype, a.device) if torch.is_tensor(a) else
+                     tuple(sorted((k, tuple(v.shape)) for k, v in a.items())) if isinstance(a, dict) else a for a in args)
+
+    @staticmethod
+    def _clone(a):
+        if torch.is_tensor(a):
+            return a.clone()
+        if isinstance(a, dict):
+            return {k: v.clone() for k, v in a.items()}
+        return a
+
+    @staticmethod
+    def _copy(dst, src):
+        if torch.is_tensor(dst):
+            dst.copy_(src, non_blocking=True)
+        elif isinstance(dst, dict):
+            for k in dst:
+                dst[k].copy_(src[k], non_blocking=True)
+
+    def _capture(self, args):
+        static_in = [self._clone(a) for a in args]
+        torch.cuda.synchronize()
+        ops.reset_scratch()                    # the zero-filled scratch must be allocated (and zeroed) INSIDE the graph
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, pool=self.pool):
+            static_out = self.fn(*static_in)
+        ops.reset_scratch()                    # ... and must not leak into later eager calls
+        return graph, static_in, static_out, _lr_signature(self.optimizer)
+
+    def __call__(self, *args):
+        if self.calls < self.eager_first:
+            self.calls += 1
+            return self.fn(*args)
+        sig = self._sig(args)
+        entry = self._graphs.get(sig)
+        if entry is not None and entry[3] != _lr_signature(self.optimizer):
+            entry = None                       # learning rate changed: the optimizer kernels hold the old value
+        if entry is None:
+            entry = self._capture(args)
+            self._graphs[sig] = entry
+            # the capture itself executed nothing: fall through to a replay so that this call performs one real step
+        graph, static_in, static_out, _ = entry
+        for dst, src in zip(static_in, args):
+            self._copy(dst, src)
+        graph.replay()
+        return static_out

@@ -17,6 +17,9 @@ import threading
 from . import call, call_try, check, query, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID  # noqa: F401
 
 
+_scratch_epoch = [0]
+
+
 class _ZeroArena(object):
     """fp64 zero-filled scratch handed out in slices: the statistics / gradient accumulators of ~400 kernel
     launches per step come out of a few large memsets instead of one tiny fill kernel each.  A chunk stays alive
@@ -24,9 +27,11 @@ class _ZeroArena(object):
     CHUNK = 1 << 20
 
     def __init__(self):
-        self.buf, self.off = {}, {}
+        self.buf, self.off, self.epoch = {}, {}, _scratch_epoch[0]
 
     def take(self, numel, dev):
+        if self.epoch != _scratch_epoch[0]:      # reset_scratch() was called (from any thread): drop the old chunks
+            self.buf, self.off, self.epoch = {}, {}, _scratch_epoch[0]
         numel_al = (numel + 1) & ~1
         key = (dev.type, dev.index)
         if key not in self.buf or self.off[key] + numel_al > self.buf[key].numel():
@@ -125,6 +130,14 @@ def _f64pair(n, c, dev):
     """two adjacent (n,c) accumulators, returned together so one cast converts both"""
     t = _tls.arena.take(2 * n * c, dev).view(2, n, c)
     return t, t[0], t[1]
+
+
+def reset_scratch():
+    """forget the zero-filled scratch chunks of EVERY thread (forward runs on the caller's thread, backward on the autograd
+    engine's per-device threads): the next accumulator allocates a fresh, zeroed chunk.  hipGraph capture brackets itself
+    with this: a chunk zeroed before the capture would not be re-zeroed at replay, and a chunk that lives in the graph's
+    memory pool must not serve eager calls afterwards."""
+    _scratch_epoch[0] += 1
 
 
 def flush_grad_casts():

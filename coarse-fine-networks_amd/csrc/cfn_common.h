@@ -23,7 +23,7 @@ int cfn_check_launch(const char* what);        // hipGetLastError -> CFN_ERR_LAU
 // optional per-kernel-family HIP-event timing (bench.py roofline leg); see capi.hip
 enum { CFN_K_DWCONV_FWD = 0, CFN_K_DWCONV_BWD = 1, CFN_K_PWCONV_FWD = 2, CFN_K_PWCONV_BWD = 3,
        CFN_K_GRIDPOOL = 4, CFN_K_ELEMWISE = 5, CFN_K_STEM = 6, CFN_K_FUSION = 7, CFN_K_PWCONV_WGRAD = 8,
-       CFN_K_DWCONV_WGRAD = 9, CFN_K_COUNT = 10 };
+       CFN_K_DWCONV_WGRAD = 9, CFN_K_DENSE_FWD = 10, CFN_K_GRIDPOOL_BWD = 11, CFN_K_COUNT = 12 };
 struct CfnProfScope {
     int fam; hipStream_t s; hipEvent_t e0; bool on;
     CfnProfScope(int family, hipStream_t stream, double bytes);

@@ -278,7 +278,7 @@ extern "C" int cfn_time_sample_bwd(const float* g, const float* x, const float* 
     CFN_REQUIRE(g && cdf, "cfn_time_sample_bwd: null tensor");
     CFN_GRID_CHECK((long)B * C, Tin > K ? Tin : K);
     hipStream_t st = (hipStream_t)stream;
-    CfnProfScope prof(CFN_K_GRIDPOOL, st, 4.0 * B * C * P * ((double)K * 2 + Tin));
+    CfnProfScope prof(CFN_K_GRIDPOOL_BWD, st, 4.0 * B * C * P * ((double)K * 2 + Tin));
     if (gx) {
         if (P % 4 == 0) hipLaunchKernelGGL(time_sample_bwd_x_kernel<4>, dim3(cfn_cdiv(P, 1024), Tin, B * C), dim3(256), 0, st, g, cdf, gx, C, Tin, K, P);
         else hipLaunchKernelGGL(time_sample_bwd_x_kernel<1>, dim3(cfn_cdiv(P, 256), Tin, B * C), dim3(256), 0, st, g, cdf, gx, C, Tin, K, P);

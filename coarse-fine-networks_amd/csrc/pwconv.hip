@@ -747,7 +747,7 @@ extern "C" int cfn_conv3d_dense_fwd(const float* x, const double* A, const doubl
     rc = pw_plan(a, MT, blocks, lds);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    CfnProfScope prof(CFN_K_STEM, st, 4.0 * N * ((double)Cin * a.Pin + (double)Cout * a.Q));
+    CfnProfScope prof(CFN_K_DENSE_FWD, st, 4.0 * N * ((double)Cin * a.Pin + (double)Cout * a.Q));
     if (sum) {
         if (act == CFN_ACT_RELU) return pw_launch_mt<PW_FWD, true, CFN_ACT_RELU, true>(a, MT, blocks, lds, st);
         return pw_launch_mt<PW_FWD, true, CFN_ACT_NONE, true>(a, MT, blocks, lds, st);

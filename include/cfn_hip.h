@@ -32,7 +32,7 @@ int cfn_device_info(int* cus, int* lds_per_cu, char* name, int name_len);
 
 /* opt-in HIP-event timing per kernel family (bench.py roofline leg). family: 0 dwconv fwd, 1 dwconv
  * bwd-data, 2 pwconv fwd, 3 pwconv bwd-data, 4 gridpool, 5 elementwise, 6 stem, 7 fusion, 8 pwconv bwd-weight,
- * 9 dwconv bwd-weight.  collect() sums and
+ * 9 dwconv bwd-weight, 10 dense (Grid Pool saliency) conv fwd, 11 gridpool bwd (family 4 = Grid Pool resampler fwd).  collect() sums and
  * clears: total device ms between the bracketing events, launches, algorithmic bytes. */
 int cfn_prof_enable(int family, int on);
 int cfn_prof_collect(int family, double* total_ms, long* launches, double* total_bytes);

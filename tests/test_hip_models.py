@@ -158,8 +158,11 @@ def test_gridpool_layer_vs_reference(tag, depth, mode):
     i0, _ = ops.grid_time_index(t(z['cdf']).to(DEV), x.shape[2])
     assert torch.equal(i0.cpu(), t(z['i0']))
     # ... and the indices the layer derives from ITS OWN CDF (saliency convs + CDF kernel on the GPU) are the reference's
+    # (interior knots exactly; the last knot's cdf[-1] in {1-2^-24, 1, 1+2^-23} spells the same frame as T-2 (w=1) or T-1
+    # (w=0), decided by one ulp of the row sum -- tests/test_hip_ops.py::test_grid_index_mismatch_rate_vs_cpu_reference)
     i_own, _ = ops.grid_time_index(cdf, x.shape[2])
-    assert torch.equal(i_own.cpu(), t(z['i0'])), (i_own.cpu() != t(z['i0'])).sum()
+    assert torch.equal(i_own.cpu()[:, :-1], t(z['i0'])[:, :-1])
+    assert int((i_own.cpu()[:, -1] - t(z['i0'])[:, -1]).abs().max()) <= 1
     assert maxdiff(y, z['y']) <= 1e-4
     if mode == 'train':
         assert maxdiff(m.bn1.split_bn.running_mean, z['rm1']) <= 1e-5
@@ -277,7 +280,8 @@ def test_coarse_eval_logits_vs_reference():
     assert maxdiff(cdf, z['cdf']) <= 2e-6
     i_own, _ = ops.grid_time_index(cdf, 16)
     i_ref, _ = R.grid_sample_time_index(t(z['cdf']), 16)
-    assert torch.equal(i_own.cpu(), i_ref), (i_own.cpu(), i_ref)
+    assert torch.equal(i_own.cpu()[:, :-1], i_ref[:, :-1]), (i_own.cpu(), i_ref)
+    assert int((i_own.cpu()[:, -1] - i_ref[:, -1]).abs().max()) <= 1     # last knot: T-2 (w=1) == T-1 (w=0), see test_hip_ops
 
 
 def test_coarse_train_fwd_bwd_vs_reference():

@@ -521,11 +521,15 @@ def test_grid_cdf_kernel(B, Kin):
 
 
 def test_grid_index_mismatch_rate_vs_cpu_reference():
-    """End-to-end index statement: 10k random saliency rows through the CDF kernel + the index kernel
-    against the reference's CPU expression + ATen index arithmetic.  The CDF can differ from the CPU one in the last ulp
-    (ATen's vectorised sigmoid / sum are host-ISA specific), which moves floor(i_t) only when i_t lies within an ulp of an
-    integer: the mismatch rate is reported and bounded; the contract that IS bit exact is identical CDF -> identical indices
-    (test_grid_time_index_bit_exact, tests/test_oracle_c.py)."""
+    """End-to-end index statement: 10k random saliency rows (T=256, K=65) through the CDF kernel + the index
+    kernel against the reference's CPU expression + ATen index arithmetic.
+
+    What is bit exact is the contract `identical CDF in -> identical indices out`.  End to end, the CDF itself is only equal
+    to ~1e-7 (ATen's vectorised CPU sigmoid / sum are host-ISA specific, the GPU convs differ in the last bits), which moves
+    floor(i_t) only where i_t sits within an ulp of an integer.  Interior knots: essentially never.  The LAST knot: always --
+    cdf[-1] = fl(sum p) is 1-2^-24, 1 or 1+2^-23 according to the rounding error of the row sum S (SURVEY 7 measured 39 % != 1
+    on the CPU itself), so i0[-1] is T-2 (weight ~1 on frame T-1) or T-1 (weight 0 on the out-of-range frame T): the same
+    resampled frame, two spellings.  Measured here: interior 0 of 640k, last knot ~41 %."""
     from oracle import x3d_ref as R
     rows, Kin, T = 10000, 64, 256
     g0 = rnd(21, rows, Kin, scale=1.5)
@@ -534,14 +538,16 @@ def test_grid_index_mismatch_rate_vs_cpu_reference():
     cdf = ops().grid_cdf(g0.to(DEV))
     i0, _ = ops().grid_time_index(cdf, T)
     mism = (i0.cpu() != i_ref)
-    rate_all = float(mism.float().mean())
+    rate_inner = float(mism[:, :-1].float().mean())
     rate_last = float(mism[:, -1].float().mean())
-    print('grid index mismatch vs CPU reference: %.2e of all indices, %.2e of last-knot indices' % (rate_all, rate_last))
-    assert maxdiff(cdf, ref_cdf) <= 2.5e-7
-    assert rate_all <= 2e-2
-    # a mismatching index is always the neighbouring frame with the complementary weight: the resampled value is continuous
-    d = (i0.cpu() - i_ref).abs()
-    assert int(d.max()) <= 1
+    print('grid index mismatch vs CPU reference: %.2e of interior indices, %.2e of last-knot indices' % (rate_inner, rate_last))
+    assert maxdiff(cdf, ref_cdf) <= 1e-6
+    assert rate_inner <= 1e-4
+    assert int((i0.cpu() - i_ref).abs().max()) <= 1          # a flipped index is the neighbouring frame ...
+    x = rnd(22, 64, 1, T, 3)                                 # ... and resamples to the same value (continuity of the lerp)
+    ya = ops().time_sample(x.to(DEV), cdf[:64].contiguous())
+    yb = ops().time_sample(x.to(DEV), ref_cdf[:64].to(DEV))
+    assert maxdiff(ya, yb) <= 2e-3                         # |d cdf| (1e-6) x 255 frames x |x| (~4)
     # same CDF in -> same indices out, bit for bit
     i_same, _ = ops().grid_time_index(ref_cdf.to(DEV), T)
     assert torch.equal(i_same.cpu(), i_ref)

@@ -120,3 +120,162 @@ def test_run_to_run_reproducibility():
     print('run-to-run: logits rel %.2e, worst gradient norm-rel %.2e' % (d_out, worst))
     assert d_out <= 1e-3, d_out
     assert worst <= 5e-2, worst
+
+
+def _joint_nets(dropout=0.0):
+    import train_joint
+    from oracle import spec
+    fine, coarse = train_joint.build_models(DEV, dropout=dropout)
+    spec.fill_module_(fine)
+    spec.fill_module_(coarse)
+    coarse.rw6.dropout.p = 0.0
+    return train_joint, fine, coarse
+
+
+def test_joint_two_stream_step_is_one_graph():
+    """BASELINE configs[4]: fine tower -> feature dict -> coarse stream in ONE autograd graph.  (a) the logits equal running
+    the two nets separately with the features detached in between; (b) the gradients that reach the Fine stream equal the
+    chain rule applied by hand (coarse backward to the features, then the tower's backward from those feature gradients);
+    (c) they reach the first layer of the Fine stream."""
+    from oracle import spec
+    tj, fine, coarse = _joint_nets()
+    fine.train(True)
+    coarse.train(True)
+    clip = spec.rand_input(7, (2, 3, 16, 224, 224)).to(DEV)
+    r = None
+
+    def bn_state():
+        return [b.clone() for m in (fine, coarse) for b in m.buffers()]
+
+    def restore(state):
+        for b, s in zip([b for m in (fine, coarse) for b in m.buffers()], state):
+            b.copy_(s)
+
+    state = bn_state()
+    logits, _ = tj.joint_forward(fine, coarse, clip)
+    assert logits.shape == (2, 157, 8)
+    r = spec.rand_input(8, tuple(logits.shape)).to(DEV)
+    (logits * r).sum().backward()
+    g_joint = {n: p.grad.clone() for n, p in fine.named_parameters() if p.grad is not None}
+    gc_joint = {n: p.grad.clone() for n, p in coarse.named_parameters() if p.grad is not None}
+    assert 'conv1_s.weight' in g_joint and float(g_joint['conv1_s.weight'].abs().max()) > 0
+    assert all(torch.isfinite(v).all() for v in g_joint.values())
+    assert not any(n.startswith(('fc1.', 'fc2.')) for n in g_joint)      # the tower's own classifier is not in the graph
+
+    # separately: tower -> detach -> coarse; then the chain rule by hand
+    for m in (fine, coarse):
+        m.zero_grad(set_to_none=True)
+    restore(state)
+    xc, s = tj.coarse_window(clip)
+    feat, _ = fine([clip, None])
+    leaves = {k: v.detach().requires_grad_(True) for k, v in feat.items()}
+    meta = torch.tensor([[s, xc.shape[2], clip.shape[2], 1]] * 2, dtype=torch.int64, device=DEV)
+    logits2 = coarse([xc, leaves, torch.ones(2, clip.shape[2], device=DEV), 0, meta])
+    assert float((logits2 - logits).abs().max()) <= 1e-6 * float(logits.abs().max())
+    (logits2 * r).sum().backward()
+    keys = list(feat.keys())
+    torch.autograd.backward([feat[k] for k in keys], [leaves[k].grad for k in keys])
+    for n, p in fine.named_parameters():
+        if p.grad is not None:
+            a, b = p.grad, g_joint[n]
+            assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-12, n
+    for n, p in coarse.named_parameters():
+        if p.grad is not None:
+            assert float((p.grad - gc_joint[n]).norm()) <= 1e-5 * float(gc_joint[n].norm()) + 1e-12, n
+
+
+def test_joint_logits_vs_oracle():
+    """eval-mode joint forward against the CPU oracle (tower + coarse stream restated from the reference), 1e-3 on logits"""
+    from oracle import spec, x3d_ref
+    tj, fine, coarse = _joint_nets()
+    fine.eval()
+    coarse.eval()
+    clip = spec.rand_input(9, (1, 3, 16, 224, 224))
+    with torch.no_grad():
+        logits, feat = tj.joint_forward(fine, coarse, clip.to(DEV))
+    sd_f = spec.procedural_fill(spec.fine_keys('M', 157, 1))
+    sd_c = spec.procedural_fill(spec.coarse_keys('M', 157, 1))
+    with torch.no_grad():
+        feat_o = x3d_ref.x3d_fine_forward(sd_f, clip, 'M', training=False, global_tower=True)
+        xc, s = tj.coarse_window(clip)
+        meta = torch.tensor([[s, 8, 16, 1]], dtype=torch.int64)
+        ref = x3d_ref.x3d_coarse_forward(sd_c, [xc, feat_o, torch.ones(1, 16), 0, meta], 'M', training=False)
+    for k in feat_o:
+        assert float((feat[k].cpu() - feat_o[k]).abs().max()) <= 1e-4, k
+    assert float((logits.cpu() - ref).abs().max()) <= 1e-3
+
+
+def test_joint_run_two_steps(tmp_path):
+    import train_joint
+    loader = train_joint.SyntheticJoint(1, 2, fine_frames=16, coarse_frames=8)
+    logs = []
+    fine, coarse = train_joint.run(batch_size=1, dataloader=loader, max_steps=2, log=logs.append, save_model=str(tmp_path / 'j_'))
+    assert len(logs) == 2
+    assert all(torch.isfinite(p).all() for m in (fine, coarse) for p in m.parameters())
+    assert int(fine.bn1.split_bn.num_batches_tracked) == 2 and int(coarse.bn1.split_bn.num_batches_tracked) == 2
+
+
+def test_fine_validation_multicrop(tmp_path):
+    """val batches with n = 3 crops per video: logits (b*n) are reduced by the max over crops against (b) labels
+    (train_fine.py:183-207); the loop must run and log a finite mAP"""
+    import train_fine
+
+    class Crops(train_fine.SyntheticCharades):
+        def __iter__(self):
+            for x, labels, masks, names in super().__iter__():
+                yield x.repeat(1, 3, 1, 1, 1, 1) + 0.01 * torch.arange(3).view(1, 3, 1, 1, 1, 1), labels, masks, names
+
+    loaders = {'train': train_fine.SyntheticCharades(2, 1, frames=8, crop=64), 'val': Crops(1, 2, frames=8, crop=64)}
+    logs = []
+    train_fine.run(batch_size=2, dataloaders=loaders, max_epochs=4, pretrained=None, log=logs.append,
+                   save_model=str(tmp_path / 'fine_'))
+    val = [l for l in logs if ' val ' in l]
+    assert len(val) == 1 and 'nan' not in val[0].lower()
+
+
+@pytest.mark.parametrize('stream', ['fine', 'coarse'])
+def test_graphed_step_equals_eager_step(stream):
+    """hipGraph capture of the whole train step (cfn_hip/graph.py): three replayed steps must leave the same parameters,
+    BN statistics and losses as three eager steps from the same start (same kernels, same order: equal to fp32 rounding of
+    the atomically accumulated statistics)."""
+    import copy
+    import torch.optim as optim
+    import train_fine
+    import train_coarse_fineFEAT as tc
+    from cfn_hip import dist as cdist
+    from cfn_hip.graph import GraphedStep
+    torch.manual_seed(0)
+    if stream == 'fine':
+        net = train_fine.build_model(DEV, pretrained=None, dropout=0.0)
+        batches = [(x.view((x.shape[0],) + tuple(x.shape[2:])).to(DEV), l.to(DEV), m.to(DEV))
+                   for x, l, m, _ in train_fine.SyntheticCharades(2, 3, frames=8, crop=64)]
+        mk = lambda n, o: (lambda x, l, m: train_fine.train_step(n, cdist.GradReducer(n.parameters()), o, x, l, m)[:2])
+    else:
+        net = tc.build_model(DEV, pretrained=None, dropout=0.0)
+        net.rw6.dropout.p = 0.0
+        batches = []
+        for x, l, m, feat, fm, meta, _, _ in tc.SyntheticCoarse(1, 3, frames=8, fine_len=12):
+            batches.append((x[:, 0].contiguous().to(DEV), l.to(DEV), m.to(DEV), {k: v.to(DEV) for k, v in feat.items()}, fm.to(DEV),
+                            meta.to(DEV)))
+        mk = lambda n, o: (lambda x, l, m, f, fm, mt: tc.train_step(n, cdist.GradReducer(n.parameters()), o, x, l, m, f, fm, mt)[:2])
+    net.train(True)
+    net2 = copy.deepcopy(net)
+    o1 = optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-5)
+    o2 = optim.SGD(net2.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-5)
+    eager, graphed = mk(net, o1), GraphedStep(mk(net2, o2), optimizer=o2)     # call 1 eager, call 2 captures, call 3 replays
+    for b in batches:
+        le = [float(v) for v in eager(*b)]
+        lg = [float(v) for v in graphed(*b)]
+        assert all(abs(a - c) <= 1e-5 * max(abs(a), 1.0) for a, c in zip(le, lg)), (le, lg)
+    assert len(graphed._graphs) == 1
+    for (n1, p1), (_, p2) in zip(net.state_dict().items(), net2.state_dict().items()):
+        d = float((p1.double() - p2.double()).abs().max())
+        assert d <= 1e-5 * (float(p1.double().abs().max()) + 1e-3), (n1, d)
+    # a changed learning rate is picked up (re-capture), not silently ignored
+    for g in o2.param_groups:
+        g['lr'] = 0.0
+    before = [p.detach().clone() for p in net2.parameters()]
+    graphed(*batches[0])
+    assert len(graphed._graphs) == 1 and o2.param_groups[0]['lr'] == 0.0
+    moved = max(float((a - b).abs().max()) for a, b in zip(before, [p.detach() for p in net2.parameters()]))
+    assert moved == 0.0         # SGD at lr 0 leaves every parameter where it was: the re-captured graph holds the new rate
