@@ -36,6 +36,7 @@ class GraphedStep(object):
     def __init__(self, fn, optimizer=None, eager_first=1, pool=None):
         self.fn, self.optimizer, self.eager_first, self.pool = fn, optimizer, eager_first, pool
         self.calls = 0
+        self.stream = None      # side stream shared by the eager first steps and every capture (see _on_side_stream)
         self._graphs = {}       # shape signature -> (graph, static inputs, static outputs, lr signature)
 
     @staticmethod
@@ -59,12 +60,29 @@ class GraphedStep(object):
             for k in dst:
                 dst[k].copy_(src[k], non_blocking=True)
 
+    def _side_stream(self, args):
+        """Autograd remembers the stream an AccumulateGrad node was created on and synchronises with it in every later
+        backward; a node born on the default stream would drag the (uncapturable) default stream into the capture.  So the
+        eager first steps run on the same side stream the captures use."""
+        if self.stream is None:
+            dev = next(a.device for a in args if torch.is_tensor(a)) if any(torch.is_tensor(a) for a in args) else None
+            self.stream = torch.cuda.Stream(device=dev)
+        return self.stream
+
+    def _eager(self, args):
+        st = self._side_stream(args)
+        st.wait_stream(torch.cuda.current_stream(st.device))
+        with torch.cuda.stream(st):
+            out = self.fn(*args)
+        torch.cuda.current_stream(st.device).wait_stream(st)
+        return out
+
     def _capture(self, args):
         static_in = [self._clone(a) for a in args]
         torch.cuda.synchronize()
         ops.reset_scratch()                    # the zero-filled scratch must be allocated (and zeroed) INSIDE the graph
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, pool=self.pool):
+        with torch.cuda.graph(graph, pool=self.pool, stream=self._side_stream(args)):
             static_out = self.fn(*static_in)
         ops.reset_scratch()                    # ... and must not leak into later eager calls
         return graph, static_in, static_out, _lr_signature(self.optimizer)
@@ -72,7 +90,7 @@ class GraphedStep(object):
     def __call__(self, *args):
         if self.calls < self.eager_first:
             self.calls += 1
-            return self.fn(*args)
+            return self._eager(args)
         sig = self._sig(args)
         entry = self._graphs.get(sig)
         if entry is not None and entry[3] != _lr_signature(self.optimizer):
