@@ -38,7 +38,8 @@ def header_prototypes(path=HEADER):
                 if '*' in a:
                     at.append(ctypes.c_void_p)
                     base = a.replace('const', '').split('*')[0].strip()
-                    dt[-1] = {'float': torch.float32, 'double': torch.float64, 'long': torch.int64, 'int': torch.int32}.get(base)
+                    dt[-1] = {'float': torch.float32, 'double': torch.float64, 'long': torch.int64, 'int': torch.int32,
+                               'unsigned short': torch.bfloat16}.get(base)
                 elif a.startswith('long'):
                     at.append(ctypes.c_long)
                 elif a.startswith('double'):
@@ -143,7 +144,8 @@ def query(name, *args):
 
 
 def check(t, dtype=torch.float32):
-    if t is not None and t.dtype != dtype:
+    """activation tensors are fp32 or bf16 (the *_bf16 entry points); anything else is refused"""
+    if t is not None and t.dtype != dtype and not (dtype == torch.float32 and t.dtype == torch.bfloat16):
         raise RuntimeError('expected %s tensor, got %s' % (dtype, t.dtype))
     return t
 

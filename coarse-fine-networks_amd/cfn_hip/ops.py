@@ -204,8 +204,21 @@ class TailLink(object):
         self.done = False
 
 
+def _bf(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
+def subsample_hw(x, s):
+    """x[..., ::s, ::s] of a bf16 (N,C,T,H,W) tensor (cfn_subsample_hw_bf16); no autograd (used inside the conv ops)"""
+    N, C, T, H, W = x.shape
+    out = torch.empty(N, C, T, (H - 1) // s + 1, (W - 1) // s + 1, dtype=x.dtype, device=x.device)
+    call('cfn_subsample_hw_bf16', x, out, N * C * T, H, W, s)
+    return out
+
+
 class _PwConv(Function):
-    """1x1x1 conv (optionally spatial stride 2) on fp32 MFMA; see include/cfn_hip.h cfn_pwconv_*."""
+    """1x1x1 conv (optionally spatial stride 2); fp32 MFMA for fp32 tensors (cfn_pwconv_*), bf16 MFMA with fp32 accumulation
+    for bf16 tensors (cfn_pwconv_*_bf16: a strided conv is a gather + the stride-1 contraction on the compact tensor)."""
 
     @staticmethod
     def forward(ctx, x, A, B, w, act, stride, want_stats, token, role, tail=None, tail_role=None):
@@ -213,14 +226,19 @@ class _PwConv(Function):
         N, Cin, T, H, W = x.shape
         Cout = w.shape[0]
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-        y = torch.empty(N, Cout, T, Ho, Wo, dtype=torch.float32, device=x.device)
+        y = torch.empty(N, Cout, T, Ho, Wo, dtype=x.dtype, device=x.device)
         s = q = None
         if want_stats:
             s, q = _f64(N, Cout, x.device), _f64(N, Cout, x.device)
         w2 = w.reshape(Cout, Cin).contiguous()
         A, B = _coef(A), _coef(B)
-        call('cfn_pwconv_fwd', x, A, B, act, w2, y, s, q, N, Cin, Cout, T, H, W, stride)
-        ctx.save_for_backward(x, A, B, w2, y)
+        xs = None
+        if _bf(x):
+            xs = subsample_hw(x, stride) if stride > 1 else x
+            call('cfn_pwconv_fwd_bf16', xs, A, B, act, w2, y, s, q, N, Cin, Cout, T * Ho * Wo)
+        else:
+            call('cfn_pwconv_fwd', x, A, B, act, w2, y, s, q, N, Cin, Cout, T, H, W, stride)
+        ctx.save_for_backward(x, A, B, w2, y, xs if stride > 1 else None)
         ctx.meta = (act, stride, tuple(w.shape))
         ctx.wparam = w
         ctx.token, ctx.role = token, role
@@ -231,7 +249,7 @@ class _PwConv(Function):
 
     @staticmethod
     def backward(ctx, gy, gs, gq):
-        x, A, B, w2, y = ctx.saved_tensors
+        x, A, B, w2, y, xs = ctx.saved_tensors
         act, stride, wshape = ctx.meta
         token, role = ctx.token, ctx.role
         N, Cin, T, H, W = x.shape
@@ -241,6 +259,8 @@ class _PwConv(Function):
         gsc = None   # gy of a linked block tail is unscaled: the kernels apply the tail's per-(n,c) factor on load
         if ctx.tail is not None and ctx.tail.done:
             gsc = ctx.tail.y_scale if ctx.tail_role == 'y' else ctx.tail.res_scale
+        if _bf(x):
+            return _PwConv._backward_bf16(ctx, gy, gs, gq, gsc)
         gx = gA = gB = gw = None
         g64 = fin = None
         fused = False
@@ -282,11 +302,60 @@ class _PwConv(Function):
             gw = fin()
         return gx, gA, gB, gw, None, None, None, None, None, None, None
 
+    @staticmethod
+    def _backward_bf16(ctx, gy, gs, gq, gsc):
+        """bf16 tensors: data gradient and weight gradient as two bf16-MFMA kernels; a strided conv works on the compact
+        (subsampled) input saved by the forward"""
+        x, A, B, w2, y, xs = ctx.saved_tensors
+        act, stride, wshape = ctx.meta
+        token, role = ctx.token, ctx.role
+        N, Cin, T, H, W = x.shape
+        Cout = w2.shape[0]
+        Ho, Wo = y.shape[3], y.shape[4]
+        xin = xs if stride > 1 else x
+        gx = gA = gB = gw = None
+        if ctx.needs_input_grad[0] or (A is not None and ctx.needs_input_grad[1]):
+            if token is not None and role == 'short' and stride > 1 and not token.main_done:
+                da = torch.empty(N, Cin, T, Ho, Wo, dtype=x.dtype, device=x.device)      # compact, no epilogue
+                call('cfn_pwconv_bwd_data_bf16', gy, y, gs, gq, w2, None, None, None, ACT_NONE, da, None, None, N, Cin, Cout, T,
+                     Ho, Wo, None, 1, gsc)
+                token.acc, token.acc_stride = da, stride
+            else:
+                ab = a64 = b64 = None
+                if A is not None:
+                    ab, a64, b64 = _f64pair(N, Cin, x.device)
+                acc, acc_stride = None, 1
+                if token is not None and role == 'main':
+                    if token.acc is not None:
+                        acc, acc_stride, token.acc = token.acc, token.acc_stride, None
+                    else:
+                        token.main_done = True
+                gxc = torch.empty_like(xin)
+                call('cfn_pwconv_bwd_data_bf16', gy, y, gs, gq, w2, xin, A, B, act, gxc, a64, b64, N, Cin, Cout, T, Ho, Wo,
+                     acc, acc_stride, gsc)
+                if stride > 1:      # only reached when conv1's backward ran before the shortcut's: scatter onto the lattice
+                    gx = torch.zeros_like(x)
+                    gx[:, :, :, ::stride, ::stride] = gxc
+                else:
+                    gx = gxc
+                if A is not None:
+                    gA, gB = ab[0], ab[1]
+        if ctx.needs_input_grad[3]:
+            g64, fin = _gw_buffers(ctx.wparam, Cout, Cin, x.device)
+            call('cfn_pwconv_bwd_weight_bf16', gy, y, gs, gq, xin, A, B, act, g64, N, Cin, Cout, T * Ho * Wo, gsc)
+            gw = fin()
+        return gx, gA, gB, gw, None, None, None, None, None, None, None
+
 
 def pwconv(x, w, A=None, B=None, act=ACT_NONE, stride=1, stats=True, token=None, role=None, tail=None, tail_role=None):
     """returns (y, sum, sumsq); sum/sumsq are None when stats=False.  token / role ('main' | 'short'): see ShortcutToken;
     tail / tail_role ('y' | 'res'): see TailLink"""
     return _PwConv.apply(x, A, B, w, act, stride, stats, token, role, tail, tail_role)
+
+
+def _sfx(t):
+    """entry-point suffix for the element type of an activation tensor"""
+    return '_bf16' if t.dtype == torch.bfloat16 else ''
 
 
 class _DwConv3d(Function):
@@ -297,13 +366,13 @@ class _DwConv3d(Function):
         x = check(x).contiguous()
         N, C, T, H, W = x.shape
         Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
-        y = torch.empty(N, C, T, Ho, Wo, dtype=torch.float32, device=x.device)
+        y = torch.empty(N, C, T, Ho, Wo, dtype=x.dtype, device=x.device)
         s = q = None
         if want_stats:
             s, q = _f64(N, C, x.device), _f64(N, C, x.device)
         w2 = w.reshape(C, 27).contiguous()
         A, B = _coef(A), _coef(B)
-        call('cfn_dwconv3d_fwd', x, A, B, act, w2, y, s, q, N, C, T, H, W, stride)
+        call('cfn_dwconv3d_fwd' + _sfx(x), x, A, B, act, w2, y, s, q, N, C, T, H, W, stride)
         ctx.save_for_backward(x, A, B, w2, y)
         ctx.meta = (act, stride, tuple(w.shape))
         ctx.wparam = w
@@ -329,13 +398,14 @@ class _DwConv3d(Function):
         if want_w:
             g64, fin = _gw_buffers(ctx.wparam, C, 27, x.device)
         # stride 1, big planes: data and weight gradient in ONE pass over gy, y, x (declines small planes)
-        fused = want_x and want_w and stride == 1 and call_try('cfn_dwconv3d_bwd_fused', gy, y, gs, gq, w2, x, A, B, act, gx,
-                                                             a64, b64, g64, N, C, T, H, W)
+        sfx = _sfx(x)
+        fused = want_x and want_w and stride == 1 and call_try('cfn_dwconv3d_bwd_fused' + sfx, gy, y, gs, gq, w2, x, A, B, act,
+                                                             gx, a64, b64, g64, N, C, T, H, W)
         if not fused:
             if want_x:
-                call('cfn_dwconv3d_bwd_data', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, C, T, H, W, stride)
+                call('cfn_dwconv3d_bwd_data' + sfx, gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, C, T, H, W, stride)
             if want_w:
-                call('cfn_dwconv3d_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, C, T, H, W, stride)
+                call('cfn_dwconv3d_bwd_weight' + sfx, gy, y, gs, gq, x, A, B, act, g64, N, C, T, H, W, stride)
         if want_x and A is not None:
             gA, gB = ab[0], ab[1]
         if want_w:
@@ -351,15 +421,15 @@ class _DwConvT5(Function):
     """depthwise 5x1x1 temporal conv of the stem; see cfn_dwconv_t5_*."""
 
     @staticmethod
-    def forward(ctx, x, w, want_stats):
-        x = check(x).contiguous()
+    def forward(ctx, x, w, want_stats, out_dtype=None):
+        x = check(x, torch.float32).contiguous()       # the stem conv's output stays fp32 in both precisions
         N, C, T, H, W = x.shape
-        y = torch.empty_like(x)
+        y = torch.empty_like(x, dtype=out_dtype or x.dtype)
         s = q = None
         if want_stats:
             s, q = _f64(N, C, x.device), _f64(N, C, x.device)
         w2 = w.reshape(C, 5).contiguous()
-        call('cfn_dwconv_t5_fwd', x, w2, y, s, q, N, C, T, H * W)
+        call('cfn_dwconv_t5_fwd' + _sfx(y), x, w2, y, s, q, N, C, T, H * W)
         ctx.save_for_backward(x, w2, y)
         ctx.wshape = tuple(w.shape)
         ctx.wparam = w
@@ -376,16 +446,17 @@ class _DwConvT5(Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            call('cfn_dwconv_t5_bwd_data', gy, y, gs, gq, w2, gx, N, C, T, H * W)
+            call('cfn_dwconv_t5_bwd_data' + _sfx(y), gy, y, gs, gq, w2, gx, N, C, T, H * W)
         if ctx.needs_input_grad[1]:
             g64, fin = _gw_buffers(ctx.wparam, C, 5, x.device)
-            call('cfn_dwconv_t5_bwd_weight', gy, y, gs, gq, x, g64, N, C, T, H * W)
+            call('cfn_dwconv_t5_bwd_weight' + _sfx(y), gy, y, gs, gq, x, g64, N, C, T, H * W)
             gw = fin()
-        return gx, gw, None
+        return gx, gw, None, None
 
 
-def dwconv_t5(x, w, stats=True):
-    return _DwConvT5.apply(x, w, stats)
+def dwconv_t5(x, w, stats=True, out_dtype=None):
+    """out_dtype=torch.bfloat16: the bf16 activation path starts here (fp32 in, bf16 out)"""
+    return _DwConvT5.apply(x, w, stats, out_dtype)
 
 
 class _StemConv(Function):
@@ -499,11 +570,12 @@ class _BnAddRelu(Function):
         out = torch.empty_like(y)
         A, B, Ar, Br = _coef(A), _coef(B), _coef(Ar), _coef(Br)
         mask = None
+        sfx = _sfx(y)
         if link is not None:   # ReLU bit mask for the one-tensor backward (1/32 of a tensor instead of re-reading out)
-            words = query('cfn_bn_add_relu_mask_words', N * C, vol)
+            words = query('cfn_bn_add_relu_mask_words' + sfx, N * C, vol)
             if words > 0:
                 mask = torch.empty(words, dtype=torch.int32, device=y.device)
-        call('cfn_bn_add_relu_fwd', y, A, B, res, Ar, Br, out, mask, N * C, vol)
+        call('cfn_bn_add_relu_fwd' + sfx, y, A, B, res, Ar, Br, out, mask, N * C, vol)
         ctx.link, ctx.has_mask = link, mask is not None
         ctx.save_for_backward(y, A, res, Ar, mask if mask is not None else out)
         if not split:
@@ -530,13 +602,20 @@ class _BnAddRelu(Function):
         if link is not None:
             g = torch.empty_like(y)
             mask = out if ctx.has_mask else None
-            call('cfn_bn_add_relu_bwd_g', gout.contiguous(), gout2, None if ctx.has_mask else out, mask, y,
+            call('cfn_bn_add_relu_bwd_g' + _sfx(y), gout.contiguous(), gout2, None if ctx.has_mask else out, mask, y,
                  res if Ar is not None else None, g, gA, gB, gAr, N * C, vol)
             link.y_scale, link.res_scale, link.done = A, Ar, True
             # one tensor, two consumers: a second tensor object over the same storage keeps autograd from accumulating
             # into it in place
             g2 = torch.empty(0, dtype=g.dtype, device=g.device).set_(g.untyped_storage(), g.storage_offset(), g.shape, g.stride())
             return g, gA, gB, g2, gAr, gBr, None, None
+        if _bf(y):   # no link (a tail used on its own): one-tensor kernel, then the two per-(n,c) scalings as tensor ops
+            g = torch.empty_like(y)
+            call('cfn_bn_add_relu_bwd_g_bf16', gout.contiguous(), gout2, out, None, y, res if Ar is not None else None, g, gA, gB,
+                 gAr, N * C, vol)
+            shp = (N, C) + (1,) * (y.dim() - 2)
+            gres = g if Ar is None else (g.float() * Ar.float().view(shp)).to(y.dtype)
+            return (g.float() * A.float().view(shp)).to(y.dtype), gA, gB, gres, gAr, gBr, None, None
         gy, gres = torch.empty_like(y), torch.empty_like(res)
         call('cfn_bn_add_relu_bwd', gout.contiguous(), gout2, out, y, A, res, Ar, gy, gres, gA, gB, gAr, N * C, vol)
         return gy, gA, gB, gres, gAr, gBr, None, None
@@ -610,9 +689,9 @@ class _PoolHW(Function):
     def forward(ctx, x, A, B, act, OH, OW):
         x = check(x).contiguous()
         N, C, T, H, W = x.shape
-        out = torch.empty(N, C, T, OH, OW, dtype=torch.float32, device=x.device)
+        out = torch.empty(N, C, T, OH, OW, dtype=torch.float32, device=x.device)     # pooled tensors are fp32 in both precisions
         A, B = _coef(A), _coef(B)
-        call('cfn_pool_hw_fwd', x, A, B, act, out, N * C, T, H, W, OH, OW)
+        call('cfn_pool_hw_fwd' + _sfx(x), x, A, B, act, out, N * C, T, H, W, OH, OW)
         ctx.save_for_backward(x, A, B)
         ctx.meta = (act, OH, OW)
         return out
@@ -626,7 +705,7 @@ class _PoolHW(Function):
         a64 = b64 = None
         if A is not None:
             a64, b64 = _f64(N, C, x.device), _f64(N, C, x.device)
-        call('cfn_pool_hw_bwd', gout.contiguous(), x, A, B, act, gx, a64, b64, N * C, T, H, W, OH, OW)
+        call('cfn_pool_hw_bwd' + _sfx(x), gout.contiguous(), x, A, B, act, gx, a64, b64, N * C, T, H, W, OH, OW)
         if A is None:
             return gx, None, None, None, None, None
         return gx, a64, b64, None, None, None

@@ -18,20 +18,73 @@
 // find their halo frames in that XCD's L2.
 #include "cfn_common.h"
 
+// Element type of the activation tensors.  This file is compiled twice: as is (fp32 storage) and through
+// dwconv3d_bf16.hip (#define DW_BF16: bf16 storage, identical fp32 arithmetic, entry points suffixed _bf16, argument
+// structs renamed so that the kernel symbols differ).  Every global-memory access of a tensor goes through the helpers
+// below; byte offsets use DW_ES.
+#ifdef DW_BF16
+typedef unsigned short dwe_t;
+#define DW_ES 2
+#define DWN(name) name##_bf16
+#else
+typedef float dwe_t;
+#define DW_ES 4
+#define DWN(name) name
+#endif
+typedef float __attribute__((ext_vector_type(4))) dw_f4;
+typedef float __attribute__((ext_vector_type(2))) dw_f2;
+#ifdef DW_BF16
+typedef __bf16 __attribute__((ext_vector_type(2))) dw_b2;
+__device__ __forceinline__ float dw_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float dw_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ unsigned dw_pk(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((dw_f2){a, b}, dw_b2)); }
+__device__ __forceinline__ float dw_ld(const dwe_t* p) { return dw_lo(*p); }
+__device__ __forceinline__ void dw_st(dwe_t* p, float v) { *p = (unsigned short)(dw_pk(v, 0.0f) & 0xffffu); }
+__device__ __forceinline__ void dw_st2(dwe_t* p, dw_f2 v) { *reinterpret_cast<unsigned*>(p) = dw_pk(v.x, v.y); }
+__device__ __forceinline__ dw_f2 dw_ld2(const dwe_t* p) { const unsigned u = *reinterpret_cast<const unsigned*>(p); return (dw_f2){dw_lo(u), dw_hi(u)}; }
+__device__ __forceinline__ dw_f4 dw_ld4(const dwe_t* p) { const uint2 u = *reinterpret_cast<const uint2*>(p); return (dw_f4){dw_lo(u.x), dw_hi(u.x), dw_lo(u.y), dw_hi(u.y)}; }
+__device__ __forceinline__ float dw_bld1(__amdgpu_buffer_rsrc_t r, int vo, int so) { return dw_lo((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, vo, so, 0)); }
+__device__ __forceinline__ dw_f2 dw_bld2(__amdgpu_buffer_rsrc_t r, int vo, int so) { const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0); return (dw_f2){dw_lo(u), dw_hi(u)}; }
+__device__ __forceinline__ dw_f4 dw_bld4(__amdgpu_buffer_rsrc_t r, int vo, int so) {
+    typedef unsigned __attribute__((ext_vector_type(2))) u2;
+    const u2 u = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0));
+    return (dw_f4){dw_lo(u.x), dw_hi(u.x), dw_lo(u.y), dw_hi(u.y)};
+}
+__device__ __forceinline__ void dw_bst1(float v, __amdgpu_buffer_rsrc_t r, int vo, int so) { __builtin_amdgcn_raw_buffer_store_b16((short)(dw_pk(v, 0.0f) & 0xffffu), r, vo, so, 0); }
+__device__ __forceinline__ void dw_bst2(dw_f2 v, __amdgpu_buffer_rsrc_t r, int vo, int so) { __builtin_amdgcn_raw_buffer_store_b32(dw_pk(v.x, v.y), r, vo, so, 0); }
+// value as the consumer will read it back (statistics are taken over stored values)
+__device__ __forceinline__ float dw_rt(float v) { return dw_lo(dw_pk(v, 0.0f)); }
+#else
+__device__ __forceinline__ float dw_ld(const dwe_t* p) { return *p; }
+__device__ __forceinline__ void dw_st(dwe_t* p, float v) { *p = v; }
+__device__ __forceinline__ void dw_st2(dwe_t* p, dw_f2 v) { *reinterpret_cast<dw_f2*>(p) = v; }
+__device__ __forceinline__ dw_f2 dw_ld2(const dwe_t* p) { return *reinterpret_cast<const dw_f2*>(p); }
+__device__ __forceinline__ dw_f4 dw_ld4(const dwe_t* p) { return *reinterpret_cast<const dw_f4*>(p); }
+__device__ __forceinline__ float dw_bld1(__amdgpu_buffer_rsrc_t r, int vo, int so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0)); }
+__device__ __forceinline__ dw_f2 dw_bld2(__amdgpu_buffer_rsrc_t r, int vo, int so) { return __builtin_bit_cast(dw_f2, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0)); }
+__device__ __forceinline__ dw_f4 dw_bld4(__amdgpu_buffer_rsrc_t r, int vo, int so) { return __builtin_bit_cast(dw_f4, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0)); }
+__device__ __forceinline__ void dw_bst1(float v, __amdgpu_buffer_rsrc_t r, int vo, int so) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, so, 0); }
+__device__ __forceinline__ void dw_bst2(dw_f2 v, __amdgpu_buffer_rsrc_t r, int vo, int so) {
+    typedef int __attribute__((ext_vector_type(2))) i2v;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i2v, v), r, vo, so, 0);
+}
+__device__ __forceinline__ float dw_rt(float v) { return v; }
+#endif
+
 enum { DW_FWD = 0, DW_DGRAD = 1, DW_WGRAD = 2 };
 
 struct DwArgs {
-    const float* src;    // FWD/WGRAD: x raw (N,C,T,Hi,Wi)      DGRAD: gy (N,C,T,H,W)
-    const float* src2;   // DGRAD: y (raw conv output) for the 2*y*gq term, may be null
+    const dwe_t* src;    // FWD/WGRAD: x raw (N,C,T,Hi,Wi)      DGRAD: gy (N,C,T,H,W)
+    const dwe_t* src2;   // DGRAD: y (raw conv output) for the 2*y*gq term, may be null
     const double* A;      // per-(n,c) prologue scale of the forward input (null = identity)
     const double* B;
     const double* gs;    // DGRAD/WGRAD: d loss / d sum(y)   per (n,c), may be null
     const double* gq;    // DGRAD/WGRAD: d loss / d sum(y^2) per (n,c), may be null
     const float* w;      // (C,27)
-    float* dst;          // FWD: y     DGRAD: gx
-    const float* xin;    // DGRAD: forward input x raw (for act' and the A/B gradients)
-    const float* gy;     // WGRAD: upstream gradient at output resolution
-    const float* yout;   // WGRAD: raw conv output (for the 2*y*gq term), may be null
+    dwe_t* dst;          // FWD: y     DGRAD: gx
+    const dwe_t* xin;    // DGRAD: forward input x raw (for act' and the A/B gradients)
+    const dwe_t* gy;     // WGRAD: upstream gradient at output resolution
+    const dwe_t* yout;   // WGRAD: raw conv output (for the 2*y*gq term), may be null
     double* s1;          // FWD: sum(y)      DGRAD: sum(dz*x)     WGRAD: gw (C,27) accumulators
     double* s2;          // FWD: sum(y*y)    DGRAD: sum(dz)
     int N, C, T, Hi, Wi, Ho, Wo, act;
@@ -148,20 +201,20 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     constexpr bool UNC = MODE == DW_DGRAD || (MODE == DW_FWD && LV == 4);
     constexpr int OOB = 0x7ffffff0;
     const long gi0 = ((long)n * C + c0) * T * plane_i, go0 = ((long)n * C + c0) * T * plane_o;
-    const unsigned span_i = (unsigned)((long)ncg * T * plane_i * 4), span_o = (unsigned)((long)ncg * T * plane_o * 4);
-    __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src + gi0), 0, span_i, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((MODE == DW_DGRAD && a.src2 ? a.src2 : a.src) + gi0), 0, span_i, 0x00020000);
+    const unsigned span_i = (unsigned)((long)ncg * T * plane_i * DW_ES), span_o = (unsigned)((long)ncg * T * plane_o * DW_ES);
+    __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<dwe_t*>(a.src + gi0), 0, span_i, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<dwe_t*>((MODE == DW_DGRAD && a.src2 ? a.src2 : a.src) + gi0), 0, span_i, 0x00020000);
     // per-thread operands / results at output resolution: FWD/DGRAD dst, DGRAD xin, WGRAD gy / yout
-    const float* po1 = MODE == DW_WGRAD ? a.gy : (MODE == DW_DGRAD && a.xin ? a.xin : a.src);
-    const float* po2 = MODE == DW_WGRAD && a.yout ? a.yout : po1;
-    __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(po1 + go0), 0, span_o, 0x00020000);
-    __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(po2 + go0), 0, span_o, 0x00020000);
-    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((MODE == DW_WGRAD ? const_cast<float*>(a.src) : a.dst) + (MODE == DW_WGRAD ? gi0 : go0), 0,
+    const dwe_t* po1 = MODE == DW_WGRAD ? a.gy : (MODE == DW_DGRAD && a.xin ? a.xin : a.src);
+    const dwe_t* po2 = MODE == DW_WGRAD && a.yout ? a.yout : po1;
+    __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<dwe_t*>(po1 + go0), 0, span_o, 0x00020000);
+    __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<dwe_t*>(po2 + go0), 0, span_o, 0x00020000);
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((MODE == DW_WGRAD ? const_cast<dwe_t*>(a.src) : a.dst) + (MODE == DW_WGRAD ? gi0 : go0), 0,
                                                                    MODE == DW_WGRAD ? 0u : span_o, 0x00020000);
-    const int ovo = active ? (int)(((long)c_local * T * plane_o + (long)hrow0 * Wo + wo) * 4) : OOB;   // this thread's first output
+    const int ovo = active ? (int)(((long)c_local * T * plane_o + (long)hrow0 * Wo + wo) * DW_ES) : OOB;   // this thread's first output
     int relb[MAXLD];
 #pragma unroll
-    for (int k = 0; k < MAXLD; ++k) relb[k] = rel[k] >= 0 ? rel[k] * 4 : OOB;
+    for (int k = 0; k < MAXLD; ++k) relb[k] = rel[k] >= 0 ? rel[k] * DW_ES : OOB;
 
     float wr[27];
     if (MODE != DW_WGRAD) {
@@ -208,22 +261,22 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
 #pragma unroll
             for (int k = 0; k < MAXLD; ++k) {
                 if (rel[k] >= 0) {
-                    if (LV == 4) pf[k] = *reinterpret_cast<const f4*>(a.src + base + rel[k]);
-                    else pf[k].x = a.src[base + rel[k]];
+                    if (LV == 4) pf[k] = dw_ld4(a.src + base + rel[k]);
+                    else pf[k].x = dw_ld(a.src + base + rel[k]);
                 }
             }
             return;
         }
-        const int so = fvd ? f * (int)plane_i * 4 : 0;
+        const int so = fvd ? f * (int)plane_i * DW_ES : 0;
 #pragma unroll
         for (int k = 0; k < MAXLD; ++k) {
             const int vo = fvd ? relb[k] : OOB;
             if (LV == 4) {
-                pf[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, so, 0));
-                if (MODE == DW_DGRAD && two_src) pf2[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs2, vo, so, 0));
+                pf[k] = dw_bld4(rs1, vo, so);
+                if (MODE == DW_DGRAD && two_src) pf2[k] = dw_bld4(rs2, vo, so);
             } else {
-                pf[k].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, vo, so, 0));
-                if (MODE == DW_DGRAD && two_src) pf2[k].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, vo, so, 0));
+                pf[k].x = dw_bld1(rs1, vo, so);
+                if (MODE == DW_DGRAD && two_src) pf2[k].x = dw_bld1(rs2, vo, so);
             }
         }
     };
@@ -280,8 +333,8 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
             const long o = (nc * T + t) * plane_o + (long)hrow0 * Wo + wo;
 #pragma unroll
             for (int i = 0; i < HS; ++i) {
-                gnn[i] = a.gy[o + (long)i * Wo];
-                if (a.yout) gny[i] = a.yout[o + (long)i * Wo];
+                gnn[i] = dw_ld(a.gy + o + (long)i * Wo);
+                if (a.yout) gny[i] = dw_ld(a.yout + o + (long)i * Wo);
             }
         }
     };
@@ -333,9 +386,9 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
         prefetch(f + 1 + DEPTH, nx, nx2);
         if (MODE == DW_DGRAD && a.A) {
             const bool want = to + 1 >= t0 && to + 1 < t1;
-            const int vo = want ? ovo : OOB, so = want ? (to + 1) * (int)plane_o * 4 : 0;
+            const int vo = want ? ovo : OOB, so = want ? (to + 1) * (int)plane_o * DW_ES : 0;
 #pragma unroll
-            for (int i = 0; i < HS; ++i) xen[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ro1, vo + i * Wo * 4, so, 0));
+            for (int i = 0; i < HS; ++i) xen[i] = dw_bld1(ro1, vo + i * Wo * DW_ES, so);
         }
         if (MODE == DW_WGRAD) load_g(f + 2);
         const float* tbp = tb + par * bufsz;
@@ -368,12 +421,13 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
         }
 
         if (MODE != DW_WGRAD) {
-            const int vo = emit ? ovo : OOB, so = emit ? to * (int)plane_o * 4 : 0;
+            const int vo = emit ? ovo : OOB, so = emit ? to * (int)plane_o * DW_ES : 0;
             const float em = emit ? 1.0f : 0.0f;
 #pragma unroll
             for (int i = 0; i < HS; ++i) {
                 float v = acc[2][i];
                 if (MODE == DW_FWD) {
+                    v = dw_rt(v);
                     st1 = fmaf(v, em, st1);
                     st2 = fmaf(v * em, v, st2);
                 } else if (a.A) {
@@ -383,8 +437,8 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
                     st2 += dz;
                     v = dz * eA;
                 }
-                if (UNC) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, vo + i * Wo * 4, so, 0);
-                else if (emit) a.dst[go0 + (long)c_local * T * plane_o + (long)to * plane_o + (long)hrow0 * Wo + wo + (long)i * Wo] = v;
+                if (UNC) dw_bst1(v, rd, vo + i * Wo * DW_ES, so);
+                else if (emit) dw_st(a.dst + go0 + (long)c_local * T * plane_o + (long)to * plane_o + (long)hrow0 * Wo + wo + (long)i * Wo, v);
             }
 #pragma unroll
             for (int i = 0; i < HS; ++i) { acc[2][i] = acc[1][i]; acc[1][i] = acc[0][i]; acc[0][i] = 0.0f; }
@@ -438,8 +492,8 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
 // one step ahead).  DW_WGRAD's t_out = fa - kt + 1 pairing with fa = f-1.
 // ---------------------------------------------------------------------------------------------
 struct DwFusedArgs {
-    const float* gy; const float* y; const double* gs; const double* gq; const float* w; const float* x;
-    const double* A; const double* B; float* gx; double* gA; double* gB; double* gw;
+    const dwe_t* gy; const dwe_t* y; const double* gs; const double* gq; const float* w; const dwe_t* x;
+    const double* A; const double* B; dwe_t* gx; double* gA; double* gB; double* gw;
     int N, C, T, H, W, act;
     int TT, nchunks, CG, ngroups, GB, nbands, IPCb, IPCp, RIN, WP, XO;
 };
@@ -537,11 +591,11 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, 2) void dw3d_bwd_fused_kernel(con
         for (int k = 0; k < MAXLD; ++k) {
             if (rel[k] >= 0) {
                 if (VEC == 4) {
-                    pfG[k] = *reinterpret_cast<const f4*>(a.gy + base + rel[k]);
-                    if (has_y) pfY[k] = *reinterpret_cast<const f4*>(a.y + base + rel[k]);
+                    pfG[k] = dw_ld4(a.gy + base + rel[k]);
+                    if (has_y) pfY[k] = dw_ld4(a.y + base + rel[k]);
                 } else {
-                    pfG[k].x = a.gy[base + rel[k]];
-                    if (has_y) pfY[k].x = a.y[base + rel[k]];
+                    pfG[k].x = dw_ld(a.gy + base + rel[k]);
+                    if (has_y) pfY[k].x = dw_ld(a.y + base + rel[k]);
                 }
             }
         }
@@ -552,8 +606,8 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, 2) void dw3d_bwd_fused_kernel(con
 #pragma unroll
         for (int k = 0; k < MAXLD; ++k) {
             if (rel[k] >= 0) {
-                if (VEC == 4) pfX[k] = *reinterpret_cast<const f4*>(a.x + base + rel[k]);
-                else pfX[k].x = a.x[base + rel[k]];
+                if (VEC == 4) pfX[k] = dw_ld4(a.x + base + rel[k]);
+                else pfX[k].x = dw_ld(a.x + base + rel[k]);
             }
         }
     };
@@ -622,7 +676,7 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, 2) void dw3d_bwd_fused_kernel(con
         if (a.A && to + 1 >= t0 && to + 1 < t1 && active) {
             const long o = (nc * T + to + 1) * plane + (long)hrow0 * W + wo;
 #pragma unroll
-            for (int i = 0; i < HS; ++i) xen[i] = a.x[o + (long)i * W];
+            for (int i = 0; i < HS; ++i) xen[i] = dw_ld(a.x + o + (long)i * W);
         }
         // ---- data gradient from the G window, g' centres for the weight gradient ----------------------------
 #pragma unroll
@@ -679,7 +733,7 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, 2) void dw3d_bwd_fused_kernel(con
                     st2 += dz;
                     v = dz * eA;
                 }
-                a.gx[o + (long)i * W] = v;
+                dw_st(a.gx + o + (long)i * W, v);
             }
         }
 #pragma unroll
@@ -728,8 +782,8 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, 2) void dw3d_bwd_fused_kernel(con
 // kh in {0,2}; same along w  =>  27 FMAs per 2x2 block per frame.
 // ---------------------------------------------------------------------------------------------
 struct DwS2Args {
-    const float* gy; const float* y; const double* gs; const double* gq; const float* w;
-    const float* x; const double* A; const double* B; float* gx; double* gA; double* gB;
+    const dwe_t* gy; const dwe_t* y; const double* gs; const double* gq; const float* w;
+    const dwe_t* x; const double* A; const double* B; dwe_t* gx; double* gA; double* gB;
     int C, T, Hi, Wi, Ho, Wo, act, TT, nchunks, pblocks;
     int PBLK;            // positions per workgroup (the plane is split evenly over pblocks workgroups)
     int PB, CPB, NC;     // small planes: CPB channels of PB = Ho*Wo positions share a workgroup
@@ -758,8 +812,8 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
     for (int k = 0; k < 27; ++k) w[k] = a.w[c * 27 + k];
     const float pa = a.A ? a.A[nc] : 1.0f, pb2 = a.A ? a.B[nc] : 0.0f;
     const long po = (long)Ho * Wo, pi = (long)Hi * Wi;
-    const float* gyb = a.gy + (long)nc * T * po + (long)i * Wo + j;
-    const float* yb = a.y ? a.y + (long)nc * T * po + (long)i * Wo + j : nullptr;
+    const dwe_t* gyb = a.gy + (long)nc * T * po + (long)i * Wo + j;
+    const dwe_t* yb = a.y ? a.y + (long)nc * T * po + (long)i * Wo + j : nullptr;
 
     const int t0 = chunk * a.TT, t1 = min(t0 + a.TT, T);
     // g'[f] at (i,j) (i,j+1) (i+1,j) (i+1,j+1), zero outside.  Software pipelined: ld_raw only issues the loads
@@ -768,15 +822,15 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
         const bool v = ok && f >= 0 && f < T;
         if (v) {
             const long o = (long)f * po;
-            g[0] = gyb[o];
-            if (j1) g[1] = gyb[o + 1];
-            if (i1) g[2] = gyb[o + Wo];
-            if (i1 && j1) g[3] = gyb[o + Wo + 1];
+            g[0] = dw_ld(gyb + o);
+            if (j1) g[1] = dw_ld(gyb + o + 1);
+            if (i1) g[2] = dw_ld(gyb + o + Wo);
+            if (i1 && j1) g[3] = dw_ld(gyb + o + Wo + 1);
             if (yb) {
-                y[0] = yb[o];
-                if (j1) y[1] = yb[o + 1];
-                if (i1) y[2] = yb[o + Wo];
-                if (i1 && j1) y[3] = yb[o + Wo + 1];
+                y[0] = dw_ld(yb + o);
+                if (j1) y[1] = dw_ld(yb + o + 1);
+                if (i1) y[2] = dw_ld(yb + o + Wo);
+                if (i1 && j1) y[3] = dw_ld(yb + o + Wo + 1);
             }
         }
         return v;
@@ -796,14 +850,14 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
         if (!(a.A && ok && t < t1)) return;
         const long o = ((long)nc * T + t) * pi + (long)(2 * i) * Wi + 2 * j;
         if (pair) {
-            const f2 u = *reinterpret_cast<const f2*>(a.x + o);
+            const f2 u = dw_ld2(a.x + o);
             xv[0] = u.x; xv[1] = u.y;
-            if (r1) { const f2 d = *reinterpret_cast<const f2*>(a.x + o + Wi); xv[2] = d.x; xv[3] = d.y; }
+            if (r1) { const f2 d = dw_ld2(a.x + o + Wi); xv[2] = d.x; xv[3] = d.y; }
         } else {
-            xv[0] = a.x[o];
-            if (c1) xv[1] = a.x[o + 1];
-            if (r1) xv[2] = a.x[o + Wi];
-            if (r1 && c1) xv[3] = a.x[o + Wi + 1];
+            xv[0] = dw_ld(a.x + o);
+            if (c1) xv[1] = dw_ld(a.x + o + 1);
+            if (r1) xv[2] = dw_ld(a.x + o + Wi);
+            if (r1 && c1) xv[3] = dw_ld(a.x + o + Wi + 1);
         }
     };
     float G[3][4], rg[4], ry[4], xn[4];
@@ -849,13 +903,13 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
                 }
             }
             if (pair) {
-                *reinterpret_cast<f2*>(a.gx + o) = (f2){v[0], v[1]};
-                if (r1) *reinterpret_cast<f2*>(a.gx + o + Wi) = (f2){v[2], v[3]};
+                dw_st2(a.gx + o, (f2){v[0], v[1]});
+                if (r1) dw_st2(a.gx + o + Wi, (f2){v[2], v[3]});
             } else {
-                a.gx[o] = v[0];
-                if (c1) a.gx[o + 1] = v[1];
-                if (r1) a.gx[o + Wi] = v[2];
-                if (r1 && c1) a.gx[o + Wi + 1] = v[3];
+                dw_st(a.gx + o, v[0]);
+                if (c1) dw_st(a.gx + o + 1, v[1]);
+                if (r1) dw_st(a.gx + o + Wi, v[2]);
+                if (r1 && c1) dw_st(a.gx + o + Wi + 1, v[3]);
             }
         }
     }
@@ -910,26 +964,26 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_fast_kernel(const DwS2Args 
     const int po = Ho * Wo, pi = Hi * Wi;
     constexpr int OOB = 0x7ffffff0;
     const int nch = PACKED ? min(a.CPB, a.NC - nc0) : 1;
-    __amdgpu_buffer_rsrc_t rgy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy + (long)nc0 * T * po), 0, (unsigned)((long)nch * T * po * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.y + (long)nc0 * T * po), 0, (unsigned)((long)nch * T * po * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)nc0 * T * pi), 0, (unsigned)((long)nch * T * pi * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t rgx = __builtin_amdgcn_make_buffer_rsrc(a.gx + (long)nc0 * T * pi, 0, (unsigned)((long)nch * T * pi * 4), 0x00020000);
-    const int gb = (cslot * T * po + i * Wo + j) * 4;
-    const int go[4] = {ok ? gb : OOB, ok && j1 ? gb + 4 : OOB, ok && i1 ? gb + Wo * 4 : OOB, ok && i1 && j1 ? gb + (Wo + 1) * 4 : OOB};
-    const int xb = (cslot * T * pi + 2 * i * Wi + 2 * j) * 4;
-    const int xo[2] = {ok ? xb : OOB, ok && r1 ? xb + Wi * 4 : OOB};
+    __amdgpu_buffer_rsrc_t rgy = __builtin_amdgcn_make_buffer_rsrc(const_cast<dwe_t*>(a.gy + (long)nc0 * T * po), 0, (unsigned)((long)nch * T * po * DW_ES), 0x00020000);
+    __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<dwe_t*>(a.y + (long)nc0 * T * po), 0, (unsigned)((long)nch * T * po * DW_ES), 0x00020000);
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<dwe_t*>(a.x + (long)nc0 * T * pi), 0, (unsigned)((long)nch * T * pi * DW_ES), 0x00020000);
+    __amdgpu_buffer_rsrc_t rgx = __builtin_amdgcn_make_buffer_rsrc(a.gx + (long)nc0 * T * pi, 0, (unsigned)((long)nch * T * pi * DW_ES), 0x00020000);
+    const int gb = (cslot * T * po + i * Wo + j) * DW_ES;
+    const int go[4] = {ok ? gb : OOB, ok && j1 ? gb + DW_ES : OOB, ok && i1 ? gb + Wo * DW_ES : OOB, ok && i1 && j1 ? gb + (Wo + 1) * DW_ES : OOB};
+    const int xb = (cslot * T * pi + 2 * i * Wi + 2 * j) * DW_ES;
+    const int xo[2] = {ok ? xb : OOB, ok && r1 ? xb + Wi * DW_ES : OOB};
     const int t0 = chunk * a.TT, t1 = min(t0 + a.TT, T);
 
     typedef float __attribute__((ext_vector_type(2))) f2;
     typedef int __attribute__((ext_vector_type(2))) i2;
     auto ld_raw = [&](int f, float (&g)[4], float (&y)[4]) -> bool {
         const bool fv = f >= 0 && f < T;
-        const int so = fv ? f * po * 4 : 0;
+        const int so = fv ? f * po * DW_ES : 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int vo = fv ? go[k] : OOB;
-            g[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rgy, vo, so, 0));
-            y[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, vo, so, 0));
+            g[k] = dw_bld1(rgy, vo, so);
+            y[k] = dw_bld1(ry, vo, so);
         }
         return ok && fv;
     };
@@ -940,9 +994,9 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_fast_kernel(const DwS2Args 
     };
     auto ld_x = [&](int t, float (&xv)[4]) {
         const bool want = t < t1;
-        const int so = want ? t * pi * 4 : 0;
-        const f2 u = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rx, want ? xo[0] : OOB, so, 0));
-        const f2 d = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rx, want ? xo[1] : OOB, so, 0));
+        const int so = want ? t * pi * DW_ES : 0;
+        const f2 u = dw_bld2(rx, want ? xo[0] : OOB, so);
+        const f2 d = dw_bld2(rx, want ? xo[1] : OOB, so);
         xv[0] = u.x; xv[1] = u.y; xv[2] = d.x; xv[3] = d.y;
     };
     float G[3][4], rg[4], ryv[4], xn[4];
@@ -979,9 +1033,9 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_fast_kernel(const DwS2Args 
             s2 += dz;
             v[k] = dz * pa;
         }
-        const int so = t * pi * 4;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i2, (f2){v[0], v[1]}), rgx, xo[0], so, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i2, (f2){v[2], v[3]}), rgx, xo[1], so, 0);
+        const int so = t * pi * DW_ES;
+        dw_bst2((f2){v[0], v[1]}, rgx, xo[0], so);
+        dw_bst2((f2){v[2], v[3]}, rgx, xo[1], so);
     }
     if (a.gA) {
         __shared__ float sh[8];
@@ -1087,7 +1141,7 @@ static int dw_plan_impl(DwArgs& a, int S, int mode, DwPlan& pl, bool allow_flat)
     }
     if ((long)CG * a.RIN * a.Wi > (long)LVh * 8 * threads)
         return cfn_fail(CFN_ERR_UNSUPPORTED, "dwconv3d: loader capacity exceeded for plane %dx%d", a.Hi, a.Wi);
-    if ((long)CG * a.T * a.Hi * a.Wi * 4 >= 0x7ffffff0L)
+    if ((long)CG * a.T * a.Hi * a.Wi * DW_ES >= 0x7ffffff0L)
         return cfn_fail(CFN_ERR_UNSUPPORTED, "dwconv3d: %d channels x %d frames of a %dx%d plane exceed the 2 GiB buffer range", CG, a.T, a.Hi, a.Wi);
     a.CG = CG;
     a.ngroups = cfn_cdiv(a.C, CG);
@@ -1167,10 +1221,10 @@ static int dw_launch(const DwArgs& a, const DwPlan& pl, hipStream_t st) {
 }
 
 static double dw_bytes(const DwArgs& a, int tensors_in, int tensors_out) {
-    return 4.0 * a.N * a.C * a.T * ((double)tensors_in * a.Hi * a.Wi + (double)tensors_out * a.Ho * a.Wo);
+    return (double)DW_ES * a.N * a.C * a.T * ((double)tensors_in * a.Hi * a.Wi + (double)tensors_out * a.Ho * a.Wo);
 }
 
-extern "C" int cfn_dwconv3d_fwd(const float* x, const double* A, const double* B, int act, const float* w, float* y,
+extern "C" int DWN(cfn_dwconv3d_fwd)(const dwe_t* x, const double* A, const double* B, int act, const float* w, dwe_t* y,
                                 double* sum, double* sumsq, int N, int C, int T, int Hi, int Wi, int stride,
                                 void* stream) {
     CFN_REQUIRE(x && w && y, "cfn_dwconv3d_fwd: null tensor");
@@ -1185,13 +1239,13 @@ extern "C" int cfn_dwconv3d_fwd(const float* x, const double* A, const double* B
     int rc = dw_plan(a, stride, DW_FWD, pl);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    CfnProfScope prof(CFN_K_DWCONV_FWD, st, 4.0 * N * C * T * ((double)Hi * Wi + (double)a.Ho * a.Wo) + 4.0 * C * 27);
+    CfnProfScope prof(CFN_K_DWCONV_FWD, st, (double)DW_ES * N * C * T * ((double)Hi * Wi + (double)a.Ho * a.Wo) + 4.0 * C * 27);
     return stride == 1 ? dw_launch<DW_FWD, 1>(a, pl, st) : dw_launch<DW_FWD, 2>(a, pl, st);
 }
 
-extern "C" int cfn_dwconv3d_bwd_data(const float* gy, const float* y, const double* gsum, const double* gsumsq,
-                                     const float* w, const float* x, const double* A, const double* B, int act,
-                                     float* gx, double* gA, double* gB, int N, int C, int T, int Hi, int Wi,
+extern "C" int DWN(cfn_dwconv3d_bwd_data)(const dwe_t* gy, const dwe_t* y, const double* gsum, const double* gsumsq,
+                                     const float* w, const dwe_t* x, const double* A, const double* B, int act,
+                                     dwe_t* gx, double* gA, double* gB, int N, int C, int T, int Hi, int Wi,
                                      int stride, void* stream) {
     CFN_REQUIRE(gy && w && gx, "cfn_dwconv3d_bwd_data: null tensor");
     CFN_REQUIRE(stride == 1 || stride == 2, "cfn_dwconv3d_bwd_data: stride must be 1 or 2");
@@ -1218,7 +1272,7 @@ extern "C" int cfn_dwconv3d_bwd_data(const float* gy, const float* y, const doub
         while (TT > 8 && (long)ygrid * a.pblocks * cfn_cdiv(T, TT) < 2048) TT >>= 1;
         a.TT = TT > T ? T : TT;
         a.nchunks = cfn_cdiv(T, a.TT);
-        const bool fast = (Wi % 2 == 0) && A && a.y && a.gq && gA && (long)a.CPB * T * Hi * Wi * 4 < 0x7ffffff0L;
+        const bool fast = (Wi % 2 == 0) && A && a.y && a.gq && gA && (long)a.CPB * T * Hi * Wi * DW_ES < 0x7ffffff0L;
         const dim3 grid(a.pblocks * a.nchunks, ygrid);
         if (fast && a.CPB > 1) hipLaunchKernelGGL(dw3d_dgrad_s2_fast_kernel<true>, grid, dim3(256), 0, st, a);
         else if (fast) hipLaunchKernelGGL(dw3d_dgrad_s2_fast_kernel<false>, grid, dim3(256), 0, st, a);
@@ -1236,8 +1290,8 @@ extern "C" int cfn_dwconv3d_bwd_data(const float* gy, const float* y, const doub
     return dw_launch<DW_DGRAD, 1>(a, pl, st);
 }
 
-extern "C" int cfn_dwconv3d_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq,
-                                       const float* x, const double* A, const double* B, int act, double* gw, int N,
+extern "C" int DWN(cfn_dwconv3d_bwd_weight)(const dwe_t* gy, const dwe_t* y, const double* gsum, const double* gsumsq,
+                                       const dwe_t* x, const double* A, const double* B, int act, double* gw, int N,
                                        int C, int T, int Hi, int Wi, int stride, void* stream) {
     CFN_REQUIRE(gy && x && gw, "cfn_dwconv3d_bwd_weight: null tensor");
     CFN_REQUIRE(stride == 1 || stride == 2, "cfn_dwconv3d_bwd_weight: stride must be 1 or 2");
@@ -1269,8 +1323,8 @@ static int dwf_launch_hs(const DwFusedArgs& f, const DwPlan& pl, size_t lds, hip
     return cfn_check_launch("dwconv3d_bwd_fused");
 }
 
-extern "C" int cfn_dwconv3d_bwd_fused(const float* gy, const float* y, const double* gsum, const double* gsumsq,
-                                      const float* w, const float* x, const double* A, const double* B, int act, float* gx,
+extern "C" int DWN(cfn_dwconv3d_bwd_fused)(const dwe_t* gy, const dwe_t* y, const double* gsum, const double* gsumsq,
+                                      const float* w, const dwe_t* x, const double* A, const double* B, int act, dwe_t* gx,
                                       double* gA, double* gB, double* gw, int N, int C, int T, int H, int W, void* stream) {
     CFN_REQUIRE(gy && w && x && gx && gw, "cfn_dwconv3d_bwd_fused: null tensor");
     CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_dwconv3d_bwd_fused: A/B mismatch");
@@ -1297,7 +1351,7 @@ extern "C" int cfn_dwconv3d_bwd_fused(const float* gy, const float* y, const dou
     const size_t lds = ((size_t)4 * a.CG * a.RIN * a.WP + 4 * a.CG + 27 * a.CG * (pl.threads / 64)) * sizeof(float);
     if (lds > 150 * 1024) return -1;
     hipStream_t st = (hipStream_t)stream;
-    CfnProfScope prof(CFN_K_DWCONV_BWD, st, 4.0 * N * C * T * (double)H * W * (y ? 4 : 3));
+    CfnProfScope prof(CFN_K_DWCONV_BWD, st, (double)DW_ES * N * C * T * (double)H * W * (y ? 4 : 3));
     switch (pl.HS) {
         case 7: return dwf_launch_hs<7>(f, pl, lds, st);
         case 4: return dwf_launch_hs<4>(f, pl, lds, st);

@@ -10,21 +10,43 @@
 typedef float __attribute__((ext_vector_type(4))) f4v;
 enum { T5_FWD = 0, T5_DGRAD = 1, T5_WGRAD = 2 };
 
+// BF (bf16 activation path): the conv OUTPUT side (y, gy) is bf16, the input side (x, gx) stays fp32 -- the stem conv
+// that produces x and consumes gx runs in fp32 (its 3-channel input clip is fp32), so only conv1_t's output is narrowed.
 struct T5Args {
-    const float* src;    // FWD/WGRAD: x (N,C,T,P)    DGRAD: gy
-    const float* src2;   // DGRAD: y (for gq) or null
+    const void* src;     // FWD/WGRAD: x (N,C,T,P) fp32    DGRAD: gy (fp32 | bf16)
+    const void* src2;    // DGRAD: y (for gq) or null
     const double* gs; const double* gq;
     const float* w;      // (C,5)
-    float* dst;
-    const float* gy;     // WGRAD
-    const float* yout;   // WGRAD: y (for gq) or null
+    void* dst;           // FWD: y (fp32 | bf16)   DGRAD: gx fp32
+    const void* gy;      // WGRAD (fp32 | bf16)
+    const void* yout;    // WGRAD: y (for gq) or null
     double* s1; double* s2;
     int C, T, TT, nchunks, pchunks;
     long plane;
 };
 
-template <int MODE, int VEC>
+__device__ __forceinline__ f4v t5_ld(const void* ptr, long idx, bool b16, int vec) {
+    f4v v = {0.f, 0.f, 0.f, 0.f};
+    if (b16) {
+        const unsigned short* p = static_cast<const unsigned short*>(ptr) + idx;
+        if (vec == 4) {
+            const uint2 u = *reinterpret_cast<const uint2*>(p);
+            v.x = __builtin_bit_cast(float, u.x << 16); v.y = __builtin_bit_cast(float, u.x & 0xffff0000u);
+            v.z = __builtin_bit_cast(float, u.y << 16); v.w = __builtin_bit_cast(float, u.y & 0xffff0000u);
+        } else v.x = __builtin_bit_cast(float, (unsigned)p[0] << 16);
+    } else {
+        const float* p = static_cast<const float*>(ptr) + idx;
+        if (vec == 4) v = *reinterpret_cast<const f4v*>(p);
+        else v.x = p[0];
+    }
+    return v;
+}
+
+template <int MODE, int VEC, bool BF>
 __global__ __launch_bounds__(256) void dwt5_kernel(const T5Args a) {
+    typedef __bf16 __attribute__((ext_vector_type(4))) bf4;
+    constexpr bool SRC16 = BF && MODE == T5_DGRAD;      // element type of src / src2
+    constexpr bool DST16 = BF && MODE == T5_FWD;        // element type of dst
     __shared__ float sh[20];
     const long nc = blockIdx.y;
     const int c = (int)(nc % a.C);
@@ -40,14 +62,12 @@ __global__ __launch_bounds__(256) void dwt5_kernel(const T5Args a) {
     const float gsv = (MODE != T5_FWD && a.gs) ? (float)a.gs[nc] : 0.0f;
     const float gqv = (MODE != T5_FWD && a.gq) ? 2.0f * (float)a.gq[nc] : 0.0f;
 
-    auto ld = [&](const float* ptr, int t) -> f4v {
+    auto ldt = [&](const void* ptr, int t, bool b16) -> f4v {
         f4v v = {0.f, 0.f, 0.f, 0.f};
-        if (ok && t >= 0 && t < a.T) {
-            if (VEC == 4) v = *reinterpret_cast<const f4v*>(ptr + base + (long)t * a.plane);
-            else v.x = ptr[base + (long)t * a.plane];
-        }
+        if (ok && t >= 0 && t < a.T) v = t5_ld(ptr, base + (long)t * a.plane, b16, VEC);
         return v;
     };
+    auto ld = [&](const void* ptr, int t) -> f4v { return ldt(ptr, t, SRC16); };
     auto ld_src = [&](int t) -> f4v {   // staged tensor of the window
         f4v v = ld(a.src, t);
         if (MODE == T5_DGRAD && ok && t >= 0 && t < a.T) {
@@ -83,7 +103,7 @@ __global__ __launch_bounds__(256) void dwt5_kernel(const T5Args a) {
     const bool wy = MODE == T5_WGRAD && a.yout != nullptr;
     if (MODE == T5_WGRAD) {
 #pragma unroll
-        for (int k = 0; k < PF; ++k) { gr4[k] = ld(a.gy, t0 + k); yr4[k] = wy ? ld(a.yout, t0 + k) : zero; }
+        for (int k = 0; k < PF; ++k) { gr4[k] = ldt(a.gy, t0 + k, BF); yr4[k] = wy ? ldt(a.yout, t0 + k, BF) : zero; }
     }
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float st1 = 0.f, st2 = 0.f;
@@ -101,8 +121,8 @@ __global__ __launch_bounds__(256) void dwt5_kernel(const T5Args a) {
             if (MODE == T5_WGRAD) {
                 f4v g = zero;
                 if (ok) { g = gr4[u] + gsv; if (wy) g += yr4[u] * gqv; }    // t < t1 <= T here
-                gr4[u] = (t + PF < t1) ? ld(a.gy, t + PF) : zero;
-                if (wy) yr4[u] = (t + PF < t1) ? ld(a.yout, t + PF) : zero;
+                gr4[u] = (t + PF < t1) ? ldt(a.gy, t + PF, BF) : zero;
+                if (wy) yr4[u] = (t + PF < t1) ? ldt(a.yout, t + PF, BF) : zero;
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
                     const f4v pr = g * win[k];
@@ -111,8 +131,17 @@ __global__ __launch_bounds__(256) void dwt5_kernel(const T5Args a) {
             } else {
                 f4v y = win[0] * wk[0] + win[1] * wk[1] + win[2] * wk[2] + win[3] * wk[3] + win[4] * wk[4];
                 if (ok) {
-                    if (VEC == 4) *reinterpret_cast<f4v*>(a.dst + base + (long)t * a.plane) = y;
-                    else a.dst[base + (long)t * a.plane] = y.x;
+                    if (DST16) {      // statistics are taken over the rounded values the consumer will read
+                        const bf4 yb = __builtin_convertvector(y, bf4);
+                        unsigned short* dp = static_cast<unsigned short*>(a.dst) + base + (long)t * a.plane;
+                        if (VEC == 4) *reinterpret_cast<bf4*>(dp) = yb;
+                        else dp[0] = __builtin_bit_cast(unsigned short, yb.x);
+                        y = __builtin_convertvector(yb, f4v);
+                    } else {
+                        float* dp = static_cast<float*>(a.dst) + base + (long)t * a.plane;
+                        if (VEC == 4) *reinterpret_cast<f4v*>(dp) = y;
+                        else dp[0] = y.x;
+                    }
                     if (MODE == T5_FWD) {
                         if (VEC == 4) { st1 += y.x + y.y + y.z + y.w; st2 += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w; }
                         else { st1 += y.x; st2 = fmaf(y.x, y.x, st2); }
@@ -141,7 +170,7 @@ __global__ __launch_bounds__(256) void dwt5_kernel(const T5Args a) {
     }
 }
 
-template <int MODE>
+template <int MODE, bool BF = false>
 static int t5_launch(T5Args& a, int N, hipStream_t st) {
     const long NC = (long)N * a.C;
     CFN_REQUIRE(NC <= 65535, "dwconv_t5: N*C = %ld exceeds grid.y", NC);
@@ -154,8 +183,8 @@ static int t5_launch(T5Args& a, int N, hipStream_t st) {
     a.TT = TT;
     a.nchunks = cfn_cdiv(a.T, TT);
     dim3 grid((unsigned)(a.pchunks * a.nchunks), (unsigned)NC);
-    if (v4) hipLaunchKernelGGL((dwt5_kernel<MODE, 4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((dwt5_kernel<MODE, 1>), grid, dim3(256), 0, st, a);
+    if (v4) hipLaunchKernelGGL((dwt5_kernel<MODE, 4, BF>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dwt5_kernel<MODE, 1, BF>), grid, dim3(256), 0, st, a);
     return cfn_check_launch("dwconv_t5");
 }
 
@@ -190,4 +219,40 @@ extern "C" int cfn_dwconv_t5_bwd_weight(const float* gy, const float* y, const d
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_DWCONV_BWD, st, 4.0 * N * C * T * plane * (a.yout ? 3 : 2));
     return t5_launch<T5_WGRAD>(a, N, st);
+}
+
+// ---- bf16 activation path: y / gy bf16, x / gx fp32 (see T5Args) ----------------------------------------------------
+extern "C" int cfn_dwconv_t5_fwd_bf16(const float* x, const float* w, unsigned short* y, double* sum, double* sumsq, int N, int C,
+                                      int T, long plane, void* stream) {
+    CFN_REQUIRE(x && w && y, "cfn_dwconv_t5_fwd_bf16: null tensor");
+    CFN_REQUIRE((sum == nullptr) == (sumsq == nullptr), "cfn_dwconv_t5_fwd_bf16: sum/sumsq mismatch");
+    T5Args a = {};
+    a.src = x; a.w = w; a.dst = y; a.s1 = sum; a.s2 = sumsq; a.C = C; a.T = T; a.plane = plane;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DWCONV_FWD, st, 6.0 * N * C * T * plane);
+    return t5_launch<T5_FWD, true>(a, N, st);
+}
+
+extern "C" int cfn_dwconv_t5_bwd_data_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum,
+                                           const double* gsumsq, const float* w, float* gx, int N, int C, int T, long plane,
+                                           void* stream) {
+    CFN_REQUIRE(gy && w && gx, "cfn_dwconv_t5_bwd_data_bf16: null tensor");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv_t5_bwd_data_bf16: gsumsq needs y");
+    T5Args a = {};
+    a.src = gy; a.src2 = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.w = w; a.dst = gx; a.C = C; a.T = T; a.plane = plane;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DWCONV_BWD, st, N * (double)C * T * plane * (a.src2 ? 8.0 : 6.0));
+    return t5_launch<T5_DGRAD, true>(a, N, st);
+}
+
+extern "C" int cfn_dwconv_t5_bwd_weight_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum,
+                                             const double* gsumsq, const float* x, double* gw, int N, int C, int T, long plane,
+                                             void* stream) {
+    CFN_REQUIRE(gy && x && gw, "cfn_dwconv_t5_bwd_weight_bf16: null tensor");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv_t5_bwd_weight_bf16: gsumsq needs y");
+    T5Args a = {};
+    a.src = x; a.gy = gy; a.yout = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.s1 = gw; a.C = C; a.T = T; a.plane = plane;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DWCONV_BWD, st, N * (double)C * T * plane * (a.yout ? 8.0 : 6.0));
+    return t5_launch<T5_WGRAD, true>(a, N, st);
 }

@@ -99,9 +99,10 @@ def lr_warmup(init_lr, cur_steps, warmup_steps, opt):
             pg['lr'] = lr_scale * init_lr
 
 
-def build_model(device, n_classes=NUM_CLASSES, pretrained=None, dropout=0.5):
+def build_model(device, n_classes=NUM_CLASSES, pretrained=None, dropout=0.5, act_dtype=None):
     net = x3d_fine.generate_model(x3d_version=X3D_VERSION, n_classes=400, n_input_channels=3, task='loc',
-                                  dropout=dropout, base_bn_splits=1, t_downsample=False, extract_feat=False)
+                                  dropout=dropout, base_bn_splits=1, t_downsample=False, extract_feat=False,
+                                  act_dtype=act_dtype)
     if pretrained:      # partial state.update as train_fine.py:104-107; a missing file raises, as in the reference
         ckpt = torch.load(pretrained, map_location='cpu')
         state = net.state_dict()

@@ -206,7 +206,8 @@ class ResNet(nn.Module):
 
     def __init__(self, block, layers, block_inplanes, n_input_channels=3, conv1_t_size=7, conv1_t_stride=1,
                  shortcut_type='B', widen_factor=1.0, dropout=0.5, n_classes=400, base_bn_splits=8, task='class',
-                 extract_feat=False, global_tower=False, t_downsample=False, aux_losses=None, _skip_module_init=False):
+                 extract_feat=False, global_tower=False, t_downsample=False, aux_losses=None, _skip_module_init=False,
+                 act_dtype=None):
         if not _skip_module_init:      # x3d_coarse registers pool_1 before the trunk, like the reference
             super(ResNet, self).__init__()
         block_inplanes = [(int(x * widen_factor), int(y * widen_factor)) for x, y in block_inplanes]
@@ -216,6 +217,12 @@ class ResNet(nn.Module):
         self.extract_feat = extract_feat
         self.global_tower = global_tower
         self.t_downsample = t_downsample
+        # storage type of the activations and their gradients in HBM (an addition to the reference's signature): None /
+        # 'f32' = fp32 (the reference's precision), 'bf16' = bf16 storage + bf16 MFMA with fp32 accumulation, fp32 master
+        # weights, fp32/fp64 statistics (BASELINE configs[1]).  The clip, the stem conv output and everything after the
+        # spatial pooling of the head stay fp32.
+        self.act_dtype = {None: torch.float32, 'f32': torch.float32, 'fp32': torch.float32, torch.float32: torch.float32,
+                          'bf16': torch.bfloat16, torch.bfloat16: torch.bfloat16}[act_dtype]
         self.in_planes = block_inplanes[0][1]
 
         self.conv1_s = nn.Conv3d(n_input_channels, self.in_planes, kernel_size=(1, 3, 3), stride=(1, 2, 2),
@@ -287,7 +294,7 @@ class ResNet(nn.Module):
     def _stem(self, x):
         """conv1_s -> conv1_t -> bn1 -> relu (x3d_fine.py:334-337); bn1+relu stay deferred."""
         y = ops.stem_conv(x, self.conv1_s.weight)
-        y, s, q = ops.dwconv_t5(y, self.conv1_t.weight, stats=self.training)
+        y, s, q = ops.dwconv_t5(y, self.conv1_t.weight, stats=self.training, out_dtype=self.act_dtype)
         A, B = self.bn1.fold(s, q, _count(y), y.shape[0])
         return Deferred(y, A, B, ACT_RELU)
 

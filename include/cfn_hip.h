@@ -6,7 +6,8 @@
  * ctypes binding a maintainer of the reference would add.
  *
  * Conventions
- *   - plain pointers to DEVICE memory + sizes; no torch types.  Tensors are dense NCDHW fp32.
+ *   - plain pointers to DEVICE memory + sizes; no torch types.  Tensors are dense NCDHW fp32 (the *_bf16 entry points
+ *     at the end of this file take bf16 activations as `unsigned short*`).
  *   - `stream` is a hipStream_t passed as void* (0 = default stream); kernels are enqueued on it and
  *     the call returns immediately; no allocation, no synchronisation, no host<->device copy inside
  *     (graph-capture safe).
@@ -217,6 +218,68 @@ int cfn_interp1d_bwd(const float* g, const float* x, const float* y, const float
  * x (BC,Kin,P) -> out (BC,Lout,P) ---- */
 int cfn_time_resize_fwd(const float* x, float* out, long BC, int Kin, int Lout, long P, int align_corners, void* stream);
 int cfn_time_resize_bwd(const float* g, float* gx, long BC, int Kin, int Lout, long P, int align_corners, void* stream);
+
+/* =====================================================================================================================
+ * bf16 activation path (BASELINE.json configs[1] "X3D-M fwd+bwd bf16"; the reference itself is fp32 only: these entry
+ * points are the same call sites with activations and activation gradients stored as bf16 in HBM).
+ *   - `unsigned short*` = bf16 tensor (round to nearest even on store); weights, prologue coefficients, statistics and
+ *     every reduction stay fp32 / fp64 exactly as in the fp32 entry points; all arithmetic is fp32.
+ *   - pointwise contractions run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; BN statistics are taken over the
+ *     ROUNDED outputs (what the consumer reads back).
+ *   - the stem conv (fp32 clip in) keeps an fp32 output; conv1_t (cfn_dwconv_t5_*_bf16) reads fp32 and writes bf16, and
+ *     returns an fp32 input gradient.  Pooled head / feature-tower tensors are fp32 (cfn_pool_hw_*_bf16 leaves the
+ *     bf16 domain).
+ *   - shape limits: pointwise needs T*H*W even (fwd / bwd_data) and a multiple of 8 (bwd_weight); a spatially strided
+ *     pointwise conv = cfn_subsample_hw_bf16 + the stride-1 contraction on the compact tensor.
+ * ===================================================================================================================== */
+/* conv1x1x1 x3d_fine.py:100-105 (stride 1; Q = T*H*W positions per (n, channel) row) */
+int cfn_pwconv_fwd_bf16(const unsigned short* x, const double* A, const double* B, int act, const float* w, unsigned short* y,
+                        double* sum, double* sumsq, int N, int Cin, int Cout, long Q, void* stream);
+/* as cfn_pwconv_bwd_data_acc: acc = compact (N,Cin,T,ceil(H/s),ceil(W/s)) gradient of a strided second consumer, gscale (N,Cout) */
+int cfn_pwconv_bwd_data_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                             const float* w, const unsigned short* x, const double* A, const double* B, int act,
+                             unsigned short* gx, double* gA, double* gB, int N, int Cin, int Cout, int T, int H, int W,
+                             const unsigned short* acc, int acc_stride, const double* gscale, void* stream);
+int cfn_pwconv_bwd_weight_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                               const unsigned short* x, const double* A, const double* B, int act, double* gw, int N, int Cin,
+                               int Cout, long Q, const double* gscale, void* stream);
+/* x[..., ::s, ::s] of (planes = N*C*T, H, W): the gather in front of a strided shortcut conv (x3d_fine.py:284-287) */
+int cfn_subsample_hw_bf16(const unsigned short* x, unsigned short* out, long planes, int H, int W, int s, void* stream);
+
+/* conv3x3x3 depthwise x3d_fine.py:89-97: cfn_dwconv3d_* with bf16 tensors (same kernels compiled for 2-byte elements) */
+int cfn_dwconv3d_fwd_bf16(const unsigned short* x, const double* A, const double* B, int act, const float* w, unsigned short* y,
+                          double* sum, double* sumsq, int N, int C, int T, int Hi, int Wi, int stride, void* stream);
+int cfn_dwconv3d_bwd_data_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                               const float* w, const unsigned short* x, const double* A, const double* B, int act,
+                               unsigned short* gx, double* gA, double* gB, int N, int C, int T, int Hi, int Wi, int stride,
+                               void* stream);
+int cfn_dwconv3d_bwd_weight_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                                 const unsigned short* x, const double* A, const double* B, int act, double* gw, int N, int C,
+                                 int T, int Hi, int Wi, int stride, void* stream);
+int cfn_dwconv3d_bwd_fused_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                                const float* w, const unsigned short* x, const double* A, const double* B, int act,
+                                unsigned short* gx, double* gA, double* gB, double* gw, int N, int C, int T, int H, int W,
+                                void* stream);
+
+/* conv1_t depthwise 5x1x1 x3d_fine.py:216-222: x / gx fp32, y / gy bf16 */
+int cfn_dwconv_t5_fwd_bf16(const float* x, const float* w, unsigned short* y, double* sum, double* sumsq, int N, int C, int T,
+                           long plane, void* stream);
+int cfn_dwconv_t5_bwd_data_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                                const float* w, float* gx, int N, int C, int T, long plane, void* stream);
+int cfn_dwconv_t5_bwd_weight_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                                  const float* x, double* gw, int N, int C, int T, long plane, void* stream);
+
+/* block tail x3d_fine.py:167-173 (cfn_bn_add_relu_fwd / _bwd_g) and spatial pooling :255,:345-366 (bf16 in, fp32 pooled) */
+long cfn_bn_add_relu_mask_words_bf16(long NC, long vol);
+int cfn_bn_add_relu_fwd_bf16(const unsigned short* y, const double* A, const double* B, const unsigned short* res,
+                             const double* Ar, const double* Br, unsigned short* out, int* mask, long NC, long vol, void* stream);
+int cfn_bn_add_relu_bwd_g_bf16(const unsigned short* gout, const unsigned short* gout2, const unsigned short* out, const int* mask,
+                               const unsigned short* y, const unsigned short* res, unsigned short* g, double* gA, double* gB,
+                               double* gAr, long NC, long vol, void* stream);
+int cfn_pool_hw_fwd_bf16(const unsigned short* x, const double* A, const double* B, int act, float* out, long NC, int T, int H,
+                         int W, int OH, int OW, void* stream);
+int cfn_pool_hw_bwd_bf16(const float* gout, const unsigned short* x, const double* A, const double* B, int act,
+                         unsigned short* gx, double* gA, double* gB, long NC, int T, int H, int W, int OH, int OW, void* stream);
 
 #ifdef __cplusplus
 }
