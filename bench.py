@@ -97,11 +97,15 @@ def main():
                          'train step on 64-frame clips + T\'=128 fine features (BASELINE configs[3] per-GPU shard)')
     ap.add_argument('--frames', type=int, default=None, help='default 256 (fine) / 64 (coarse)')
     ap.add_argument('--batch', type=int, default=8, help='clips per GPU per step')
+    ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32',
+                    help='storage type of activations / activation gradients (fine stream): f32 = the reference precision (the '
+                         'headline), bf16 = BASELINE configs[1] (bf16 MFMA pointwise, fp32 accumulation and statistics)')
     ap.add_argument('--graph', action='store_true', help='replay the whole step from one captured hipGraph (single GPU)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-frames', type=int, default=128)
     args = ap.parse_args()
     coarse = args.stream == 'coarse'
+    assert not (coarse and args.dtype != 'f32'), 'the bf16 activation path covers the fine stream'
     if args.frames is None:
         args.frames = 64 if coarse else 256
 
@@ -124,7 +128,7 @@ def main():
         labels, masks, fm, meta = labels.to(dev), masks.to(dev), fm.to(dev), meta.to(dev)
         feat = {k: v.to(dev) for k, v in feat.items()}
     else:
-        net = train_fine.build_model(dev, pretrained=None)
+        net = train_fine.build_model(dev, pretrained=None, act_dtype=args.dtype)
         optimizer = optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-5)
         x = torch.randn(B, 3, T, 224, 224, generator=g).to(dev)
         tl = T * 10
@@ -187,7 +191,7 @@ def main():
         traffic = traffic_note = None
         for name in ('r02_pmc_dwfwd.json', 'r01_pmc_dwfwd.json'):
             pmc = os.path.join(ROOT, 'profiles', name)
-            if not coarse and os.path.exists(pmc):
+            if not coarse and args.dtype == 'f32' and os.path.exists(pmc):
                 doc = json.load(open(pmc))
                 if doc.get('frames') == T:   # per launch, like `achieved`; measured at doc['batch'] clips, linear in the batch
                     traffic = round(doc['traffic_bytes_per_launch'] * B / doc['batch'])
@@ -209,7 +213,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': workload, 'clips_per_gpu': B, 'frames': T, 'parallelism': 'dp%d' % world,
                        'launch': 'hipGraph replay' if args.graph else 'eager', 'dist': cdist.describe()},
             'loss': {'first_step_cls_loc': [round(v, 6) for v in loss_first], 'last_step_cls_loc': [round(v, 6) for v in loss_last]},

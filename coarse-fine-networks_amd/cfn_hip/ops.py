@@ -533,6 +533,8 @@ class _BnFold(Function):
         if training:
             gs = torch.empty(N, C, dtype=torch.float64, device=dev)
             gq = torch.empty_like(gs)
+        elif Wd:     # eval mode: the statistics are constants, but the SE gate still depends on sum(y) (x3d_fine.py:158)
+            gs = torch.empty(N, C, dtype=torch.float64, device=dev)
         gg = gbt = None
         if gamma is not None:
             gg, gbt = torch.empty(C, device=dev), torch.empty(C, device=dev)

@@ -251,7 +251,7 @@ extern "C" int cfn_bn_fold_bwd(const double* gA, const double* gB, const double*
     CFN_REQUIRE(gA && gB && mean && rstd, "cfn_bn_fold_bwd: null tensor");
     CFN_REQUIRE(Wd <= 0 || (s && A0 && B0 && gate && hbuf && pooled && w1 && w2 && gw1 && gb1 && gw2 && gb2 && tA && tB),
                 "cfn_bn_fold_bwd: SE needs its tensors");
-    CFN_REQUIRE((gs == nullptr) == (gq == nullptr), "cfn_bn_fold_bwd: gs/gq mismatch");
+    CFN_REQUIRE(!training || ((gs == nullptr) == (gq == nullptr)), "cfn_bn_fold_bwd: gs/gq mismatch");   // eval + SE: gs alone
     BnFoldBwdArgs a = {gA, gB, s, gamma, mean, rstd, A0, B0, gate, hbuf, pooled, w1, w2, training, N, C, S, Wd, count,
                        pool_count, gs, gq, ggamma, gbeta, gw1, gb1, gw2, gb2, tA, tB};
     const size_t lds = Wd > 0 ? ((size_t)Wd * C + (size_t)C * (Wd + 1) + 2 * BNF_NB * (size_t)(C + Wd)) * sizeof(float) : 0;

@@ -217,10 +217,17 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_kernel(const PwbArgs a) {
 
         // ---- epilogue: C layout of the 32x32 tile: column = lane & 31 (position pair j), row = (r & 3) + 8 (r >> 2) + 4 kg
         const int cvo = cv ? (q0 + 2 * j) * 2 : PWB_OOB;
-        int ao = PWB_OOB;                                                    // offset into the compact lattice tensor (even element only)
+        // offsets into the compact lattice tensor for the two positions of the pair (OOB = not on the lattice): with an even
+        // width only the even position can be on it
+        int ao = PWB_OOB, ao2 = PWB_OOB;
+        const bool odd_w = MODE == PWB_DGRAD && a.acc && (a.W & 1);
         if (MODE == PWB_DGRAD && a.acc && cv) {
-            const int q = q0 + 2 * j, w_ = q % a.W, h_ = (q / a.W) % a.H, t_ = q / (a.W * a.H);
-            if ((h_ % a.acc_s) == 0 && (w_ % a.acc_s) == 0) ao = ((t_ * a.aHo + h_ / a.acc_s) * a.aWo + w_ / a.acc_s) * 2;
+            auto lat = [&](int q) {
+                const int w_ = q % a.W, h_ = (q / a.W) % a.H, t_ = q / (a.W * a.H);
+                return ((h_ % a.acc_s) == 0 && (w_ % a.acc_s) == 0) ? ((t_ * a.aHo + h_ / a.acc_s) * a.aWo + w_ / a.acc_s) * 2 : PWB_OOB;
+            };
+            ao = lat(q0 + 2 * j);
+            if (odd_w) ao2 = lat(q0 + 2 * j + 1);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -243,7 +250,10 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_kernel(const PwbArgs a) {
                             t1[hh] = e + o; t2[hh] = fmaf(e, e, o * o);
                         }
                     } else {
-                        if (a.acc) e += pwb_lo((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rac, ao + row * (int)accP * 2, 0, 0));
+                        if (a.acc) {
+                            e += pwb_lo((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rac, ao + row * (int)accP * 2, 0, 0));
+                            if (odd_w) o += pwb_lo((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rac, ao2 + row * (int)accP * 2, 0, 0));
+                        }
                         if (STATS) {                                         // act' epilogue + prologue-coefficient gradients
                             const unsigned xp = __builtin_amdgcn_raw_buffer_load_b32(rx, cvo + row * Q * 2, 0, 0);
                             const float2 c = sE[row];
@@ -375,7 +385,6 @@ extern "C" int cfn_pwconv_bwd_data_bf16(const uint16_t* gy, const uint16_t* y, c
     a.aHo = (H - 1) / a.acc_s + 1; a.aWo = (W - 1) / a.acc_s + 1;
     a.N = N; a.M = Cin; a.K = Cout; a.Q = T * H * W; a.Cin = Cin; a.Cout = Cout;
     CFN_REQUIRE((long)T * H * W < 0x7fffffffL, "cfn_pwconv_bwd_data_bf16: too many positions");
-    CFN_REQUIRE(acc == nullptr || W % 2 == 0, "cfn_pwconv_bwd_data_bf16: lattice add needs an even width");
     int MT; unsigned blocks; size_t lds;
     int rc = pwb_plan(a, MT, blocks, lds, 64);
     if (rc) return rc;

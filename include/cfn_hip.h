@@ -107,7 +107,8 @@ int cfn_stem_conv_bwd_weight(const float* gy, const float* x, double* gw, int N,
  * training: s,q (N,C) fp64 sums over `count` positions; run_mean/run_var = split_bn buffers (S*C) updated in place,
  * nbt = num_batches_tracked.  eval: run_mean/run_var = bn buffers (C).  Wd>0 enables SE (fc1 (Wd,C), fc2 (C,Wd),
  * pool_count = positions of the SE average).  Saved tensors (mean,rstd (S,C) fp64; A0,B0,gate,pooled (N,C); hbuf (N,Wd))
- * feed cfn_bn_fold_bwd, which returns gs,gq (N,C) fp64 and the parameter gradients (all overwritten). ---- */
+ * feed cfn_bn_fold_bwd, which returns gs,gq (N,C) fp64 (eval mode with SE: gs alone -- the gate still depends on sum(y) --,
+ * gq NULL) and the parameter gradients (all overwritten). ---- */
 int cfn_bn_fold_fwd(const double* s, const double* q, const float* gamma, const float* beta, float* run_mean, float* run_var,
                     long* nbt, int training, int N, int C, int S, double count, double eps, double momentum, const float* w1,
                     const float* b1, const float* w2, const float* b2, int Wd, double pool_count, double* A, double* B,

@@ -59,8 +59,12 @@ def run_pair(hip_fn, ref_fn, x, w, A, B, act, tol_y=1e-2, tol_gx=2e-2, tol_gw=1e
     e_s = relerr(sg, ycq.double().sum(d)) if sg is not None else 0.0
     e_q = relerr(qg, (ycq.double() ** 2).sum(d)) if qg is not None else 0.0
     r = q(rnd(7, *yc.shape))
-    (yc * r).sum().backward()
-    (yg.float() * r.to(DEV)).sum().backward()
+    # the loss also depends on the statistics outputs (as batch norm does): exercises the gs / gq terms of the backward
+    # kernels, g' = gy + gs + 2 y gq.  The CPU statistics are those of the rounded output, like the kernel's
+    sc, qc = yc.sum(d) + (ycq - yc.detach()).sum(d), (yc * yc).sum(d) + (ycq * ycq - yc.detach() ** 2).sum(d)
+    rs, rq = rnd(8, *sc.shape).double(), rnd(9, *sc.shape).double() * 0.1
+    ((yc * r).sum() + (sc.double() * rs).sum() + (qc.double() * rq).sum()).backward()
+    ((yg.float() * r.to(DEV)).sum() + (sg * rs.to(DEV)).sum() + (qg * rq.to(DEV)).sum()).backward()
     errs = {'y': e_y, 's': e_s, 'q': e_q, 'gx': relerr(lg[0].grad.float(), lc[0].grad), 'gw': relerr(lg[1].grad, lc[1].grad)}
     if A is not None:
         errs['gA'], errs['gB'] = relerr(lg[2].grad, lc[2].grad), relerr(lg[3].grad, lc[3].grad)
@@ -161,13 +165,40 @@ def test_tail_and_pool_bf16():
     assert xg.grad.dtype == BF and relerr(xg.grad.float(), xc.grad) <= 5e-3
 
 
+def _oracle_bottleneck(z, tag_args, quant):
+    """(y, gx, {param: grad}) of the CPU oracle on the fixture's inputs; quant=True: with bf16 storage emulated"""
+    from oracle import spec, x3d_ref as R
+    from bf16_emul import bf16_storage, RoundBf16
+    index, stride, cin = tag_args
+    sd = {'b.' + k: v.clone() for k, v in golden_sd(z).items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running' not in k:
+            v.requires_grad_(True)
+    x = F.relu(spec.rand_input(91, (2, cin, 4, 8, 8)))
+    if quant:
+        x = q(x)
+    x.requires_grad_(True)
+    if quant:
+        with bf16_storage():
+            y = RoundBf16.apply(R.bottleneck(x, sd, 'b', stride, index, True, 1))
+    else:
+        y = R.bottleneck(x, sd, 'b', stride, index, True, 1)
+    (y * spec.rand_input(92, tuple(y.shape))).sum().backward()
+    return y.detach(), x.grad, {k[2:]: v.grad for k, v in sd.items() if v.grad is not None}
+
+
 @pytest.mark.parametrize('tag,index,stride,cin,planes', [('even_s1', 0, 1, 24, (54, 24)), ('odd_s1', 1, 1, 24, (54, 24)),
                                                          ('even_s2', 0, 2, 24, (54, 48)), ('odd_s2', 1, 2, 48, (108, 48))])
 def test_bottleneck_bf16_vs_reference(tag, index, stride, cin, planes):
     """whole bottleneck (train mode: batch statistics, SE, Swish, shortcut conv, tail) on bf16 tensors against the vectors the
-    fp32 REFERENCE produced (tests/golden/bottleneck_*): output within 3e-2 of max|y|, gradients 6e-2 relative."""
+    fp32 REFERENCE produced (tests/golden/bottleneck_*).  Output: <= 1e-2 of max|y|.  Gradients pass through three
+    train-mode batch norms over 512 positions: bf16 STORAGE alone (the CPU oracle with every conv output / gradient rounded
+    to bf16 and the operands of the pointwise products rounded to bf16, tests/bf16_emul.py) moves them by 5-16 % (norm) on this
+    fixture; the HIP path has to stay within 1.5x of that floor, measured against the same fp32 reference (observed: equal
+    to the floor to two digits)."""
     import x3d_fine
     from oracle import spec
+    from bf16_emul import nrel
     z = load_golden('bottleneck_' + tag)
     ds = None
     if stride != 1 or cin != planes[1]:
@@ -179,17 +210,23 @@ def test_bottleneck_bf16_vs_reference(tag, index, stride, cin, planes):
     x = F.relu(spec.rand_input(91, (2, cin, 4, 8, 8))).to(BF).to(DEV).requires_grad_(True)
     y = m(x)
     assert y.dtype == BF
-    e_y = relerr(y.float(), z['y'])
     (y.float() * spec.rand_input(92, tuple(y.shape)).to(DEV)).sum().backward()
-    e_gx = relerr(x.grad.float(), z['gx'])
     named = dict(m.named_parameters())
-    worst = 0.0
-    for k in z:
-        if k.startswith('g_'):
-            name = k[2:].replace('_weight', '.weight').replace('_bias', '.bias').replace('downsample_', 'downsample.')
-            worst = max(worst, relerr(named[name].grad, z[k]))
-    print('bottleneck bf16 %s: y %.2e gx %.2e worst param grad %.2e' % (tag, e_y, e_gx, worst))
-    assert e_y <= 3e-2 and e_gx <= 6e-2 and worst <= 6e-2
+    yr, gxr, gr = _oracle_bottleneck(z, (index, stride, cin), False)       # fp32 oracle == reference (pinned elsewhere)
+    ye, gxe, ge = _oracle_bottleneck(z, (index, stride, cin), True)        # bf16-storage floor
+    assert maxdiff(yr, z['y']) <= 5e-6
+    e_y, f_y = relerr(y.float(), z['y']), relerr(ye, z['y'])
+    e_gx, f_gx = nrel(x.grad.float(), gxr), nrel(gxe, gxr)
+    worst = (0.0, 0.0, '')
+    for k, g_ref in gr.items():
+        e, f = nrel(named[k].grad, g_ref), nrel(ge[k], g_ref)
+        if e - 1.5 * f > worst[0] - 1.5 * worst[1] or not worst[2]:
+            worst = (e, f, k)
+    print('bottleneck bf16 %s: y %.2e (floor %.2e)  gx %.2e (floor %.2e)  worst param grad %s %.2e (floor %.2e)'
+          % (tag, e_y, f_y, e_gx, f_gx, worst[2], worst[0], worst[1]))
+    assert e_y <= 1e-2
+    assert e_gx <= 1.5 * f_gx + 1e-2
+    assert worst[0] <= 1.5 * worst[1] + 1e-2, worst
 
 
 def _fine_pair(act_dtype):
@@ -202,43 +239,79 @@ def _fine_pair(act_dtype):
 
 def test_fine_cfg2_bf16_vs_fp32_oracle():
     """BASELINE.json configs[1]: X3D-M fwd+bwd in bf16 on 8x3x16x224x224 against the fp32 CPU oracle.
-    Eval-mode logits (running statistics): <= 2e-2 of max|logit| (north_star's fp32 bar is 1e-3; bf16 carries 2^-9 per stored
-    tensor through 26 blocks).  Train mode (batch statistics): logits <= 5e-2 of max, head gradient tight, trunk gradients
-    by norm and direction as in the fp32 whole-net test (conditioning)."""
+
+    (a) Eval mode (running statistics), forward: logits within 1e-2 of max|logit| (measured 4e-3; north_star's fp32 bar is
+        1e-3).
+    (b) Eval mode, backward on 2 of the clips (well conditioned): every compared gradient within 1.5x of the bf16 floor
+        (the CPU oracle with each conv / block output and its gradient rounded to bf16 and bf16 pointwise operands,
+        tests/bf16_emul.py) + 2e-2,
+        norm-relative, direction cosine >= 0.98.
+    (c) Train mode (batch statistics) on all 8 clips.  With random procedural weights this network is chaotic: the fp32
+        oracle's own deep gradients move by tens of percent under a 1e-6 input perturbation, and bf16
+        storage alone moves the logits by ~10 % (norm) and decorrelates the trunk gradients (floor: norm-rel 1.2, measured
+        on the CPU emulation).  What can be, and is, asserted: the HIP bf16 path is AS accurate as bf16 storage permits --
+        logits and every compared gradient within 1.3x of the floor + 2e-2 against the same fp32 oracle -- and the head
+        gradients keep their direction."""
     from oracle import spec, x3d_ref
+    from bf16_emul import bf16_storage, nrel
     x = spec.rand_input(11, (8, 3, 16, 224, 224))
     m = _fine_pair('bf16')
-    sd = spec.procedural_fill(spec.fine_keys('M', 157, 1))
+    keys = ('conv1_s.weight', 'layer1.0.conv2.weight', 'layer2.1.conv1.weight', 'layer3.4.conv3.weight', 'layer4.6.conv2.weight',
+            'conv5.weight', 'fc1.weight', 'fc2.weight')
+    named = dict(m.named_parameters())
+
+    def oracle(xin, r, training, quant):
+        sd = spec.procedural_fill(spec.fine_keys('M', 157, 1))
+        for k, v in sd.items():
+            if v.is_floating_point() and 'running' not in k:
+                v.requires_grad_(True)
+        if quant:
+            with bf16_storage():
+                yo_ = x3d_ref.x3d_fine_forward(sd, q(xin), 'M', training=training)
+        else:
+            yo_ = x3d_ref.x3d_fine_forward(sd, xin, 'M', training=training)
+        (yo_ * r).sum().backward()
+        return yo_.detach(), {k: sd[k].grad for k in keys}
+
+    def hip(xin, r, training):
+        m.train(training)
+        m.zero_grad(set_to_none=True)
+        y = m([xin.to(DEV), None])
+        assert y.dtype == torch.float32
+        (y * r.to(DEV)).sum().backward()
+        return y.detach(), {k: named[k].grad.detach().clone() for k in keys}
+
+    def compare(tag, xin, r, training, factor, min_cos):
+        y, g = hip(xin, r, training)
+        y_ref, g_ref = oracle(xin, r, training, False)
+        y_em, g_em = oracle(xin, r, training, True)
+        e_y, f_y = nrel(y, y_ref), nrel(y_em, y_ref)
+        e_max = float((y.cpu() - y_ref).abs().max() / y_ref.abs().max())
+        rows = {}
+        for k in keys:
+            a_, b_ = g[k].cpu().flatten().double(), g_ref[k].flatten().double()
+            rows[k] = (nrel(g[k], g_ref[k]), nrel(g_em[k], g_ref[k]), float(torch.dot(a_, b_) / (a_.norm() * b_.norm())))
+        print('cfg2 bf16 %s: logits rel-max %.2e, norm-rel %.2e (bf16-storage floor %.2e)' % (tag, e_max, e_y, f_y))
+        print('cfg2 bf16 %s grads (norm-rel, floor, cosine):' % tag, {k: ('%.2e' % a, '%.2e' % b, '%.4f' % c) for k, (a, b, c) in rows.items()})
+        assert e_y <= factor * f_y + 1e-2, (tag, e_y, f_y)
+        for k, (e, f, c) in rows.items():
+            assert e <= factor * f + 2e-2, (tag, k, e, f)
+            if min_cos.get(k, min_cos.get('*')) is not None:
+                assert c >= min_cos.get(k, min_cos.get('*')), (tag, k, c)
+        return e_max
+
+    # (a) + (b): eval mode.  forward on all 8 clips against the oracle on 2 of them (the CPU cost is the oracle's)
     m.eval()
     with torch.no_grad():
-        y = m([x.to(DEV), None])
-        yo = x3d_ref.x3d_fine_forward(sd, x[:2], 'M', training=False)
-    e_eval = float((y[:2].cpu() - yo).abs().max() / yo.abs().max())
-    # train mode fwd + bwd
-    m.train(True)
-    for k, v in sd.items():
-        if v.is_floating_point() and 'running' not in k:
-            v.requires_grad_(True)
-    y = m([x.to(DEV), None])
-    assert y.shape == (8, 157, 16) and y.dtype == torch.float32
-    r = spec.rand_input(12, tuple(y.shape))
-    (y * r.to(DEV)).sum().backward()
-    yo = x3d_ref.x3d_fine_forward(sd, x, 'M', training=True)
-    (yo * r).sum().backward()
-    e_train = float((y.detach().cpu() - yo.detach()).abs().max() / yo.detach().abs().max())
-    named = dict(m.named_parameters())
-    gh, gho = named['fc2.weight'].grad.cpu(), sd['fc2.weight'].grad
-    e_head = float((gh - gho).abs().max() / gho.abs().max())
-    stats = {}
-    for k in ('conv1_s.weight', 'layer1.0.conv2.weight', 'layer2.1.conv1.weight', 'layer3.4.conv3.weight', 'layer4.6.conv2.weight',
-              'conv5.weight', 'fc1.weight'):
-        g, go = named[k].grad.cpu().flatten().double(), sd[k].grad.flatten().double()
-        stats[k] = (float(torch.dot(g, go) / (g.norm() * go.norm())), float(g.norm() / go.norm()))
-    print('cfg2 bf16: eval logits rel %.2e, train logits rel %.2e, fc2 grad rel %.2e' % (e_eval, e_train, e_head))
-    print('cfg2 bf16 grads (cosine, norm ratio):', {k: ('%.4f' % c, '%.3f' % n) for k, (c, n) in stats.items()})
-    assert e_eval <= 2e-2 and e_train <= 5e-2 and e_head <= 5e-2
-    for k, (c, n) in stats.items():
-        assert c >= 0.95 and 0.8 <= n <= 1.25, (k, c, n)
+        y8 = m([x.to(DEV), None])
+    assert y8.shape == (8, 157, 16)
+    r2 = spec.rand_input(12, (2, 157, 16))
+    e_eval = compare('eval', x[:2], r2, False, 1.5, {'*': 0.98})
+    assert e_eval <= 1e-2
+    with torch.no_grad():
+        assert maxdiff(m.eval()([x[:2].to(DEV), None]), y8[:2]) <= 1e-5 * float(y8.abs().max())     # samples are independent in eval mode
+    # (c) train mode, all 8 clips
+    compare('train', x, spec.rand_input(13, (8, 157, 16)), True, 1.3, {'*': None, 'fc2.weight': 0.98, 'fc1.weight': 0.9})
 
 
 def test_fine_bf16_train_step_runs_and_is_finite():

@@ -140,6 +140,39 @@ def test_fine_eval_matches_oracle_at_224():
     assert maxdiff(y, yo) <= 1e-3
 
 
+def test_fine_eval_mode_backward_vs_oracle():
+    """eval-mode (running statistics) forward + backward of X3D-M against the CPU oracle: well conditioned, so the gradients
+    are compared tightly (norm-relative 2e-3), including the depthwise weights of squeeze-excite blocks, whose gradient
+    has a term through the SE average pool even when the BN statistics are constants"""
+    import x3d_fine
+    from oracle import spec, x3d_ref
+    m = x3d_fine.generate_model('M', n_classes=157, task='loc', base_bn_splits=1, dropout=0.0)
+    spec.fill_module_(m)
+    m.to(DEV).eval()
+    x = spec.rand_input(21, (1, 3, 8, 112, 112))
+    y = m([x.to(DEV), None])
+    r = spec.rand_input(22, tuple(y.shape))
+    (y * r.to(DEV)).sum().backward()
+    sd = spec.procedural_fill(spec.fine_keys('M', 157, 1))
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running' not in k:
+            v.requires_grad_(True)
+    yo = x3d_ref.x3d_fine_forward(sd, x, 'M', training=False)
+    (yo * r).sum().backward()
+    assert maxdiff(y, yo) <= 1e-3
+    named = dict(m.named_parameters())
+    worst = ('', 0.0)
+    for k in ('conv1_s.weight', 'conv1_t.weight', 'layer1.0.conv2.weight', 'layer1.0.fc1.weight', 'layer1.1.conv2.weight',
+              'layer2.0.downsample.0.weight', 'layer2.2.bn2.weight', 'layer3.4.conv3.weight', 'layer4.6.conv2.weight',
+              'layer4.6.fc2.bias', 'layer4.5.conv1.weight', 'conv5.weight', 'bn5.bias', 'fc1.weight', 'fc2.weight'):
+        a, b = named[k].grad.cpu().double().flatten(), sd[k].grad.double().flatten()
+        e = float((a - b).norm() / b.norm())
+        if e > worst[1]:
+            worst = (k, e)
+    print('eval-mode backward vs oracle: worst norm-rel %.2e (%s)' % (worst[1], worst[0]))
+    assert worst[1] <= 2e-3, worst
+
+
 # ---- coarse stream -----------------------------------------------------------------------------------
 @pytest.mark.parametrize('tag,depth', [('d4', 4), ('d24', 24)])
 @pytest.mark.parametrize('mode', ['eval', 'train'])
