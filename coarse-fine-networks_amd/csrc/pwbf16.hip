@@ -82,7 +82,9 @@ __device__ __forceinline__ float pwb_rowsum(const float (&a)[8], int lane) {
     return d;
 }
 
-template <int MT, int MODE, bool STATS, int ACT>
+// TWO (DGRAD): the 2*y*gq term is present, i.e. a second tensor is streamed.  A template parameter, not a runtime flag: a load
+// under a (even uniform) branch makes the compiler wait with vmcnt(0), which would serialise the k-block prefetch.
+template <int MT, int MODE, bool STATS, int ACT, bool TWO>
 __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_kernel(const PwbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = 32 * MT;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_kernel(const PwbArgs a) {
     }
     __syncthreads();
 
-    const bool two_src = MODE == PWB_DGRAD && a.src2 != nullptr;
+    constexpr bool two_src = MODE == PWB_DGRAD && TWO;
     const long src_n = (long)n * K * Q, dst_n = (long)n * M * Q;
     __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.src + src_n), 0, (unsigned)((long)K * Q * 2), 0x00020000);
     __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>((two_src ? a.src2 : a.src) + src_n), 0, (unsigned)((long)K * Q * 2), 0x00020000);
@@ -163,6 +165,27 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_kernel(const PwbArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f16v)0.0f; acc[mt][1] = (f16v)0.0f; }
 
+        const int cvo = cv ? (q0 + 2 * j) * 2 : PWB_OOB;
+        // offsets into the compact lattice tensor for the two positions of the pair (OOB = not on the lattice): with an even
+        // width only the even position can be on it
+        int ao = PWB_OOB, ao2 = PWB_OOB;
+        const bool odd_w = MODE == PWB_DGRAD && a.acc && (a.W & 1);
+        if (MODE == PWB_DGRAD && a.acc && cv) {
+            auto lat = [&](int q) {
+                const int w_ = q % a.W, h_ = (q / a.W) % a.H, t_ = q / (a.W * a.H);
+                return ((h_ % a.acc_s) == 0 && (w_ % a.acc_s) == 0) ? ((t_ * a.aHo + h_ / a.acc_s) * a.aWo + w_ / a.acc_s) * 2 : PWB_OOB;
+            };
+            ao = lat(q0 + 2 * j);
+            if (odd_w) ao2 = lat(q0 + 2 * j + 1);
+        }
+        // DGRAD epilogue operands (forward input x of the output rows, for act'): 16 row loads per 32-row tile, issued as ONE
+        // batch one phase ahead of their use (tile 0 here, behind the first k-block; tile mt+1 before the epilogue of tile mt)
+        // -- issued next to their consumers they would cost one HBM round trip EACH
+        // Row addressing: the lane part (column pair, kg's 4-row offset) sits in the vector offset, the wave-uniform row base
+        // in the scalar offset; a row base beyond the slab's valid rows would push the scalar offset past the range (which
+        // wraps instead of failing the check), so such rows are switched off through the vector offset.
+        const int cvk = cv ? (q0 + 2 * j) * 2 + 4 * kg * Q * 2 : PWB_OOB;
+        auto rowbase = [&](int mt, int r) { return mt * 32 + (r & 3) + 8 * (r >> 2); };
         unsigned ld[2][8], ld2[2][8];
         // unconditional loads (exact vmcnt waits).  The hardware checks  voffset >= num_records - soffset: the scalar part
         // must never exceed the range (it would wrap), so a k-block that starts beyond K is switched off through the lane
@@ -216,22 +239,27 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_kernel(const PwbArgs a) {
         }
 
         // ---- epilogue: C layout of the 32x32 tile: column = lane & 31 (position pair j), row = (r & 3) + 8 (r >> 2) + 4 kg
-        const int cvo = cv ? (q0 + 2 * j) * 2 : PWB_OOB;
-        // offsets into the compact lattice tensor for the two positions of the pair (OOB = not on the lattice): with an even
-        // width only the even position can be on it
-        int ao = PWB_OOB, ao2 = PWB_OOB;
-        const bool odd_w = MODE == PWB_DGRAD && a.acc && (a.W & 1);
-        if (MODE == PWB_DGRAD && a.acc && cv) {
-            auto lat = [&](int q) {
-                const int w_ = q % a.W, h_ = (q / a.W) % a.H, t_ = q / (a.W * a.H);
-                return ((h_ % a.acc_s) == 0 && (w_ % a.acc_s) == 0) ? ((t_ * a.aHo + h_ / a.acc_s) * a.aWo + w_ / a.acc_s) * 2 : PWB_OOB;
-            };
-            ao = lat(q0 + 2 * j);
-            if (odd_w) ao2 = lat(q0 + 2 * j + 1);
-        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             if (m0 + mt * 32 >= M) continue;
+            // DGRAD epilogue operands: the 16 row loads of this 32-row tile go out as ONE batch (next to their consumers
+            // they would cost one HBM round trip each)
+            unsigned xq[16];
+            if (MODE == PWB_DGRAD && STATS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool live = rowbase(mt, r) < mrows;
+                    xq[r] = __builtin_amdgcn_raw_buffer_load_b32(rx, live ? cvk : PWB_OOB, live ? rowbase(mt, r) * Q * 2 : 0, 0);
+                }
+            }
+            if (MODE == PWB_DGRAD && a.acc) {      // compact gradient of the strided second consumer, added on its lattice
+                unsigned ap[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ap[r] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rac, ao + (rowbase(mt, r) + 4 * kg) * (int)accP * 2, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][0][r] += pwb_lo(ap[r]);
+            }
             float f1[8], f2[8];
 #pragma unroll
             for (int rp = 0; rp < 8; ++rp) {
@@ -244,18 +272,15 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_kernel(const PwbArgs a) {
                     t1[hh] = t2[hh] = 0.0f;
                     if (MODE == PWB_FWD) {
                         const unsigned p = pwb_pack(e, o);
-                        __builtin_amdgcn_raw_buffer_store_b32(p, rd, cvo + row * Q * 2, 0, 0);      // rows >= M: beyond the range, dropped
+                        __builtin_amdgcn_raw_buffer_store_b32(p, rd, rowbase(mt, r) < mrows ? cvk : PWB_OOB, rowbase(mt, r) < mrows ? rowbase(mt, r) * Q * 2 : 0, 0);
                         if (STATS) {                                         // statistics of what the consumer will read
                             e = cv ? pwb_lo(p) : 0.0f; o = cv ? pwb_hi(p) : 0.0f;
                             t1[hh] = e + o; t2[hh] = fmaf(e, e, o * o);
                         }
                     } else {
-                        if (a.acc) {
-                            e += pwb_lo((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rac, ao + row * (int)accP * 2, 0, 0));
-                            if (odd_w) o += pwb_lo((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rac, ao2 + row * (int)accP * 2, 0, 0));
-                        }
+                        if (odd_w) o += pwb_lo((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rac, ao2 + row * (int)accP * 2, 0, 0));
                         if (STATS) {                                         // act' epilogue + prologue-coefficient gradients
-                            const unsigned xp = __builtin_amdgcn_raw_buffer_load_b32(rx, cvo + row * Q * 2, 0, 0);
+                            const unsigned xp = xq[r];
                             const float2 c = sE[row];
                             const float xe = pwb_lo(xp), xo = pwb_hi(xp);
                             const float de = cv ? e * cfn_act_grad<ACT>(fmaf(xe, c.x, c.y)) : 0.0f;
@@ -263,7 +288,7 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_kernel(const PwbArgs a) {
                             t1[hh] = fmaf(de, xe, dn * xo); t2[hh] = de + dn;
                             e = de * c.x; o = dn * c.x;
                         }
-                        __builtin_amdgcn_raw_buffer_store_b32(pwb_pack(e, o), rd, cvo + row * Q * 2, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(pwb_pack(e, o), rd, rowbase(mt, r) < mrows ? cvk : PWB_OOB, rowbase(mt, r) < mrows ? rowbase(mt, r) * Q * 2 : 0, 0);
                     }
                 }
                 if (STATS) { f1[rp] = pwb_fold16(t1[0], t1[1], lane); f2[rp] = pwb_fold16(t2[0], t2[1], lane); }
@@ -321,11 +346,11 @@ static int pwb_plan(PwbArgs& a, int& MT, unsigned& blocks, size_t& lds, int max_
     return CFN_OK;
 }
 
-template <int MODE, bool STATS, int ACT>
+template <int MODE, bool STATS, int ACT, bool TWO>
 static int pwb_launch_mt(const PwbArgs& a, int MT, unsigned blocks, size_t lds, hipStream_t st) {
 #define PWB_GO(MTV)                                                                                                        \
     do {                                                                                                                   \
-        auto k = pwb_kernel<MTV, MODE, STATS, ACT>;                                                                        \
+        auto k = pwb_kernel<MTV, MODE, STATS, ACT, TWO>;                                                                        \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * PWB_WAVES), lds, st, a);                                             \
     } while (0)
@@ -343,12 +368,12 @@ static int pwb_launch_mt(const PwbArgs& a, int MT, unsigned blocks, size_t lds, 
     return cfn_check_launch("pwconv bf16");
 }
 
-template <int MODE, bool STATS>
+template <int MODE, bool STATS, bool TWO = false>
 static int pwb_launch(const PwbArgs& a, int MT, unsigned blocks, size_t lds, hipStream_t st) {
     switch (a.act) {
-        case CFN_ACT_RELU: return pwb_launch_mt<MODE, STATS, CFN_ACT_RELU>(a, MT, blocks, lds, st);
-        case CFN_ACT_SWISH: return pwb_launch_mt<MODE, STATS, CFN_ACT_SWISH>(a, MT, blocks, lds, st);
-        default: return pwb_launch_mt<MODE, STATS, CFN_ACT_NONE>(a, MT, blocks, lds, st);
+        case CFN_ACT_RELU: return pwb_launch_mt<MODE, STATS, CFN_ACT_RELU, TWO>(a, MT, blocks, lds, st);
+        case CFN_ACT_SWISH: return pwb_launch_mt<MODE, STATS, CFN_ACT_SWISH, TWO>(a, MT, blocks, lds, st);
+        default: return pwb_launch_mt<MODE, STATS, CFN_ACT_NONE, TWO>(a, MT, blocks, lds, st);
     }
 }
 
@@ -390,7 +415,8 @@ extern "C" int cfn_pwconv_bwd_data_bf16(const uint16_t* gy, const uint16_t* y, c
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_BWD, st, 2.0 * N * ((double)Cout * a.Q * (a.src2 ? 2 : 1) + (double)Cin * a.Q * (A ? 2 : 1)));
-    return A ? pwb_launch<PWB_DGRAD, true>(a, MT, blocks, lds, st) : pwb_launch<PWB_DGRAD, false>(a, MT, blocks, lds, st);
+    if (a.src2) return A ? pwb_launch<PWB_DGRAD, true, true>(a, MT, blocks, lds, st) : pwb_launch<PWB_DGRAD, false, true>(a, MT, blocks, lds, st);
+    return A ? pwb_launch<PWB_DGRAD, true, false>(a, MT, blocks, lds, st) : pwb_launch<PWB_DGRAD, false, false>(a, MT, blocks, lds, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -406,7 +432,7 @@ struct PwbWgArgs {
     int N, M, K, Q, act, mblocks, kblocks, strips;
 };
 
-template <int MTW, int NTW, int ACT>
+template <int MTW, int NTW, int ACT, bool HASY>
 __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_wgrad_kernel(const PwbWgArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* red = reinterpret_cast<float*>(smem);                           // [PWB_WAVES][MTW*NTW][64*16]  (one tile set per wave)
@@ -422,7 +448,7 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_wgrad_kernel(const PwbWgAr
     // per-lane row coefficients: A-operand rows m0 + 32 i + r (gs, 2 gq, gsc), B-operand rows k0 + 32 i + r (A, B)
     float cgs[MTW], cgq[MTW], cgc[MTW], cpa[NTW], cpb[NTW];
     int offm[MTW], offk[NTW];
-    const bool has_y = a.y != nullptr && a.gq != nullptr;
+    constexpr bool has_y = HASY;
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
         const int m = m0 + 32 * i + r;
@@ -455,18 +481,23 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_wgrad_kernel(const PwbWgAr
     const int nsteps = (Q + 15) >> 4;
     const int per = (nsteps + a.strips * PWB_WAVES - 1) / (a.strips * PWB_WAVES);
     const int s0 = (strip * PWB_WAVES + wave) * per, s1 = min(s0 + per, nsteps);
-    for (int s = s0; s < s1; ++s) {
+    // software pipeline: the operand loads of step s+1 are in flight while step s is converted and multiplied
+    // (unconditional buffer loads; a step beyond the strip reads nothing: out-of-range offsets)
+    u4v ga[2][MTW], ya[2][MTW], xb[2][NTW];
+    auto issue = [&](int s, u4v (&g)[MTW], u4v (&yy)[MTW], u4v (&xx)[NTW]) {
         const int p0 = s << 4;
-        const bool pv = p0 + kg * 8 < Q;
-        const int so = p0 * 2;
-        u4v ga[MTW], ya[MTW], xb[NTW];
+        const bool pv = s < s1 && p0 + kg * 8 < Q;
+        const int so = pv ? p0 * 2 : 0;
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
-            ga[i] = __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rg, pv ? offm[i] : PWB_OOB, so, 0));
-            if (has_y) ya[i] = __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(ry, pv ? offm[i] : PWB_OOB, so, 0));
+            g[i] = __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rg, pv ? offm[i] : PWB_OOB, so, 0));
+            if (has_y) yy[i] = __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(ry, pv ? offm[i] : PWB_OOB, so, 0));
         }
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) xb[i] = __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rx, pv ? offk[i] : PWB_OOB, so, 0));
+        for (int i = 0; i < NTW; ++i) xx[i] = __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rx, pv ? offk[i] : PWB_OOB, so, 0));
+    };
+    auto compute = [&](int s, const u4v (&g)[MTW], const u4v (&yy)[MTW], const u4v (&xx)[NTW]) {
+        const bool pv = (s << 4) + kg * 8 < Q;
         bf16x8 Aop[MTW], Bop[NTW];
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
@@ -474,8 +505,8 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_wgrad_kernel(const PwbWgAr
             const bool live = pv && offm[i] != PWB_OOB;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float lo = fmaf(pwb_lo(ga[i][e]), cgc[i], cgs[i]), hi = fmaf(pwb_hi(ga[i][e]), cgc[i], cgs[i]);
-                if (has_y) { lo = fmaf(pwb_lo(ya[i][e]), cgq[i], lo); hi = fmaf(pwb_hi(ya[i][e]), cgq[i], hi); }
+                float lo = fmaf(pwb_lo(g[i][e]), cgc[i], cgs[i]), hi = fmaf(pwb_hi(g[i][e]), cgc[i], cgs[i]);
+                if (has_y) { lo = fmaf(pwb_lo(yy[i][e]), cgq[i], lo); hi = fmaf(pwb_hi(yy[i][e]), cgq[i], hi); }
                 o[e] = live ? pwb_pack(lo, hi) : 0u;                       // masked rows / positions contribute nothing
             }
             Aop[i] = __builtin_bit_cast(bf16x8, o);
@@ -486,7 +517,7 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_wgrad_kernel(const PwbWgAr
             const bool live = pv && offk[i] != PWB_OOB;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float lo = cfn_act<ACT>(fmaf(pwb_lo(xb[i][e]), cpa[i], cpb[i])), hi = cfn_act<ACT>(fmaf(pwb_hi(xb[i][e]), cpa[i], cpb[i]));
+                const float lo = cfn_act<ACT>(fmaf(pwb_lo(xx[i][e]), cpa[i], cpb[i])), hi = cfn_act<ACT>(fmaf(pwb_hi(xx[i][e]), cpa[i], cpb[i]));
                 o[e] = live ? pwb_pack(lo, hi) : 0u;
             }
             Bop[i] = __builtin_bit_cast(bf16x8, o);
@@ -495,6 +526,13 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_wgrad_kernel(const PwbWgAr
         for (int i = 0; i < MTW; ++i)
 #pragma unroll
             for (int jn = 0; jn < NTW; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aop[i], Bop[jn], acc[i][jn], 0, 0, 0);
+    };
+    issue(s0, ga[0], ya[0], xb[0]);
+    for (int s = s0; s < s1; s += 2) {
+        issue(s + 1, ga[1], ya[1], xb[1]);
+        compute(s, ga[0], ya[0], xb[0]);
+        issue(s + 2, ga[0], ya[0], xb[0]);
+        if (s + 1 < s1) compute(s + 1, ga[1], ya[1], xb[1]);
     }
 
     // combine the 8 waves (fixed order) and add into gw: tile element (row = (e & 3) + 8 (e >> 2) + 4 kg, col = r)
@@ -544,7 +582,11 @@ extern "C" int cfn_pwconv_bwd_weight_bf16(const uint16_t* gy, const uint16_t* y,
     const dim3 grid((unsigned)(groups * strips));
 #define PWB_WG_GO(MV, NV, AV)                                                                                              \
     do {                                                                                                                   \
-        auto k = pwb_wgrad_kernel<MV, NV, AV>;                                                                             \
+        if (a.y) PWB_WG_GO2(MV, NV, AV, true); else PWB_WG_GO2(MV, NV, AV, false);                                         \
+    } while (0)
+#define PWB_WG_GO2(MV, NV, AV, HY)                                                                                         \
+    do {                                                                                                                   \
+        auto k = pwb_wgrad_kernel<MV, NV, AV, HY>;                                                                             \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(k, grid, dim3(64 * PWB_WAVES), lds, st, a);                                                     \
     } while (0)
@@ -560,6 +602,7 @@ extern "C" int cfn_pwconv_bwd_weight_bf16(const uint16_t* gy, const uint16_t* y,
     else PWB_WG_ACT(2, 2);
 #undef PWB_WG_ACT
 #undef PWB_WG_GO
+#undef PWB_WG_GO2
     return cfn_check_launch("pwconv wgrad bf16");
 }
 
