@@ -308,8 +308,12 @@ def test_fine_cfg2_bf16_vs_fp32_oracle():
     r2 = spec.rand_input(12, (2, 157, 16))
     e_eval = compare('eval', x[:2], r2, False, 1.5, {'*': 0.98})
     assert e_eval <= 1e-2
+    # Samples are independent in eval mode, but only up to rounding: the SE average of a block is summed per workgroup chunk,
+    # and the chunking follows the batch size, so the gate differs in the last fp32 bit between an 8-clip and a 2-clip launch
+    # (fp32 path: logits differ by 1.8e-6).  In bf16 that bit flips the rounding of a few stored elements (one bf16 ulp =
+    # 4e-3 relative each): the same clips inside a different batch agree to bf16 accuracy, not bit for bit.
     with torch.no_grad():
-        assert maxdiff(m.eval()([x[:2].to(DEV), None]), y8[:2]) <= 1e-5 * float(y8.abs().max())     # samples are independent in eval mode
+        assert maxdiff(m.eval()([x[:2].to(DEV), None]), y8[:2]) <= 5e-3 * float(y8.abs().max())
     # (c) train mode, all 8 clips
     compare('train', x, spec.rand_input(13, (8, 157, 16)), True, 1.3, {'*': None, 'fc2.weight': 0.98, 'fc1.weight': 0.9})
 
