@@ -24,6 +24,12 @@ def init_from_env(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     use_cuda = torch.cuda.is_available()
+    # CFN_DIST_BACKEND / CFN_SHARE_GPU: test hooks -- several ranks on ONE GPU over gloo (RCCL needs one device per rank), so
+    # that the whole multi-rank path (parameter sync, bucketed all-reduce behind backward, global loss normaliser) can be
+    # exercised with the real kernels on a one-GPU box
+    backend = backend or os.environ.get('CFN_DIST_BACKEND') or None
+    if use_cuda and os.environ.get('CFN_SHARE_GPU'):
+        local = local % torch.cuda.device_count()
     dev = torch.device('cuda', local) if use_cuda else torch.device('cpu')
     if use_cuda:
         torch.cuda.set_device(dev)

@@ -279,3 +279,26 @@ def test_graphed_step_equals_eager_step(stream):
     assert len(graphed._graphs) == 1 and o2.param_groups[0]['lr'] == 0.0
     moved = max(float((a - b).abs().max()) for a, b in zip(before, [p.detach() for p in net2.parameters()]))
     assert moved == 0.0         # SGD at lr 0 leaves every parameter where it was: the re-captured graph holds the new rate
+
+
+def test_bench_two_ranks_sharing_the_gpu(tmp_path):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), with the two
+    ranks sharing the box's single GPU over gloo (RCCL needs a device per rank): parameter sync from rank 0, the bucketed
+    all-reduce queued behind backward on a side stream, the global loss normaliser, max-over-ranks timing and the one JSON
+    line are all exercised with the real kernels.  Small clips keep it short."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, CFN_DIST_BACKEND='gloo', CFN_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29541', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--frames', '16',
+           '--batch', '2']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    doc = json.loads(lines[0])
+    assert doc['n_gpus'] == 2 and doc['config']['dist']['world_size'] == 2 and doc['config']['parallelism'] == 'dp2'
+    assert doc['value'] > 0 and all(v == v for v in doc['loss']['last_step_cls_loc'])
+    assert 'cpu_baseline' not in doc          # N > 1: no CPU leg
