@@ -773,6 +773,35 @@ def time_sample(x, cdf):
     return _TimeSample.apply(x, cdf)
 
 
+class _TimePool(Function):
+    """t_pool 'avg' / 'max': (B,C,T,H,W) -> (B,C,T//R,H,W)   (cfn_time_pool_*)"""
+
+    @staticmethod
+    def forward(ctx, x, mode, R):
+        x = check(x, torch.float32).contiguous()
+        B, C, T = x.shape[:3]
+        P = x[0, 0, 0].numel()
+        out = torch.empty((B, C, T // R) + tuple(x.shape[3:]), dtype=torch.float32, device=x.device)
+        call('cfn_time_pool_fwd', x, out, mode, B * C, T, R, P)
+        ctx.save_for_backward(x)
+        ctx.meta = (mode, R)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        mode, R = ctx.meta
+        B, C, T = x.shape[:3]
+        gx = torch.empty_like(x)
+        call('cfn_time_pool_bwd', g.contiguous(), x, gx, mode, B * C, T, R, x[0, 0, 0].numel())
+        return gx, None, None
+
+
+def time_pool(x, mode, R=4):
+    """mode 'avg' | 'max'"""
+    return _TimePool.apply(x, {'avg': 0, 'max': 1}[mode], R)
+
+
 def grid_time_index(cdf, Tin):
     """(i0 int32, w1 fp32) the resampler derives from a CDF (bit-exact ATen index arithmetic)."""
     cdf = check(cdf).contiguous()

@@ -392,3 +392,62 @@ extern "C" int cfn_grid_cdf_bwd(const float* gcdf, const float* g, const float* 
     hipLaunchKernelGGL(grid_cdf_bwd_kernel, dim3(cfn_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, gcdf, g, bias, gg, B, Kin);
     return cfn_check_launch("grid_cdf_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Fixed temporal pooling of the coarse stream, t_pool = 'avg' | 'max' (nn.AvgPool3d / nn.MaxPool3d((4,1,1), stride (4,1,1)),
+// x3d_coarse.py:489-492, applied at :640-643): out[bc,k,p] = mean / max of x[bc, R k .. R k + R - 1, p], K = floor(T / R).
+// bwd: avg spreads g / R; max routes g to the first maximal frame (ATen's tie rule); frames beyond R*K get zero.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int mode, int Tin, int K,
+                                                            int R, long P) {
+    const long bc = blockIdx.z;
+    const int k = blockIdx.y;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const float* xp = x + (bc * Tin + (long)k * R) * P + p;
+    float v = xp[0];
+    for (int i = 1; i < R; ++i) v = mode == 0 ? v + xp[(long)i * P] : fmaxf(v, xp[(long)i * P]);
+    out[(bc * K + k) * P + p] = mode == 0 ? v / (float)R : v;
+}
+
+__global__ __launch_bounds__(256) void time_pool_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ gx,
+                                                            int mode, int Tin, int K, int R, long P) {
+    const long bc = blockIdx.z;
+    const int t = blockIdx.y;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int k = t / R;
+    float r = 0.0f;
+    if (k < K) {
+        const float gv = g[(bc * K + k) * P + p];
+        if (mode == 0) r = gv / (float)R;
+        else {
+            const float* xp = x + (bc * Tin + (long)k * R) * P + p;
+            int arg = 0;
+            float m = xp[0];
+            for (int i = 1; i < R; ++i) { const float v = xp[(long)i * P]; if (v > m) { m = v; arg = i; } }
+            r = (t - k * R) == arg ? gv : 0.0f;
+        }
+    }
+    gx[(bc * Tin + t) * P + p] = r;
+}
+
+extern "C" int cfn_time_pool_fwd(const float* x, float* out, int mode, long BC, int Tin, int R, long P, void* stream) {
+    CFN_REQUIRE(x && out && (mode == 0 || mode == 1) && R >= 1 && Tin >= R, "cfn_time_pool_fwd: bad arguments");
+    const int K = Tin / R;
+    CFN_GRID_CHECK(BC, K);
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_GRIDPOOL, st, 4.0 * BC * P * ((double)K * R + K));
+    hipLaunchKernelGGL(time_pool_fwd_kernel, dim3(cfn_cdiv(P, 256), K, (unsigned)BC), dim3(256), 0, st, x, out, mode, Tin, K, R, P);
+    return cfn_check_launch("time_pool_fwd");
+}
+
+extern "C" int cfn_time_pool_bwd(const float* g, const float* x, float* gx, int mode, long BC, int Tin, int R, long P, void* stream) {
+    CFN_REQUIRE(g && gx && (mode == 0 || (mode == 1 && x)) && R >= 1 && Tin >= R, "cfn_time_pool_bwd: bad arguments");
+    const int K = Tin / R;
+    CFN_GRID_CHECK(BC, Tin);
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_GRIDPOOL_BWD, st, 4.0 * BC * P * ((double)Tin * (mode ? 2 : 1) + K));
+    hipLaunchKernelGGL(time_pool_bwd_kernel, dim3(cfn_cdiv(P, 256), Tin, (unsigned)BC), dim3(256), 0, st, g, x, gx, mode, Tin, K, R, P);
+    return cfn_check_launch("time_pool_bwd");
+}

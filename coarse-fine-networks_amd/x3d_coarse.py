@@ -240,10 +240,11 @@ class ResNet(x3d_fine.ResNet):
         self.feat_depth, self.learnedMixing, self.isMixing, self.t_pool = feat_depth, learnedMixing, isMixing, t_pool
         nn.Module.__init__(self)
         planes = [(int(x * widen_factor), int(y * widen_factor)) for x, y in block_inplanes]
-        if t_pool in ('avg', 'max'):
-            raise NotImplementedError("t_pool='%s' is never used by the reference scripts and is not on the accelerated "
-                                      "path (use 'grid', 'stride' or None)" % t_pool)
-        if t_pool == 'grid':
+        if t_pool == 'avg':       # parameter-free holders as in the reference (x3d_coarse.py:489-492); the op is cfn_time_pool_*
+            self.pool_1 = nn.AvgPool3d((4, 1, 1), stride=(4, 1, 1))
+        elif t_pool == 'max':
+            self.pool_1 = nn.MaxPool3d((4, 1, 1), stride=(4, 1, 1))
+        elif t_pool == 'grid':
             self.pool_1 = GridPoolLayer(ratio=4, depth=planes[0][1])      # registered first, as in the reference
         x3d_fine.ResNet.__init__(self, block, layers, block_inplanes, n_input_channels=n_input_channels,
                                  shortcut_type=shortcut_type, widen_factor=widen_factor, dropout=dropout,
@@ -279,6 +280,8 @@ class ResNet(x3d_fine.ResNet):
         else:
             if self.t_pool == 'stride':
                 x = x[:, :, ::4].contiguous()
+            elif self.t_pool in ('avg', 'max'):
+                x = ops.time_pool(x.materialize() if isinstance(x, Deferred) else x, self.t_pool, 4)
             GX = self.gauss([meta, feat_masks, x, None])
         b2 = x.shape[0]
         levels = (('layer1', self.rw2), ('layer2', self.rw3), ('layer3', self.rw4), ('layer4', self.rw5))

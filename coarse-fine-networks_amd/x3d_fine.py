@@ -114,16 +114,19 @@ class Swish(nn.Module):
 
 
 def conv3x3x3(in_planes, out_planes, stride=1, t_downsample=False):
-    if t_downsample:
-        raise NotImplementedError('t_downsample=True is not on the accelerated path (unused by the reference scripts)')
-    return nn.Conv3d(in_planes, out_planes, kernel_size=3, stride=(1, stride, stride), padding=1, bias=False,
-                     groups=in_planes)
+    """depthwise 3x3x3 (x3d_fine.py:89-97); t_downsample: the stride also applies along t"""
+    return nn.Conv3d(in_planes, out_planes, kernel_size=3, stride=stride if t_downsample else (1, stride, stride), padding=1,
+                     bias=False, groups=in_planes)
 
 
 def conv1x1x1(in_planes, out_planes, stride=1, t_downsample=False):
-    if t_downsample:
-        raise NotImplementedError('t_downsample=True is not on the accelerated path (unused by the reference scripts)')
-    return nn.Conv3d(in_planes, out_planes, kernel_size=1, stride=(1, stride, stride), bias=False)
+    return nn.Conv3d(in_planes, out_planes, kernel_size=1, stride=stride if t_downsample else (1, stride, stride), bias=False)
+
+
+def _every(x, s):
+    """x[:, :, ::s] as a dense tensor (temporal stride of the never-default t_downsample option: the kernels stride H and W
+    only; the frame selection is an indexing op around them)"""
+    return x if s == 1 else x[:, :, ::s].contiguous()
 
 
 def _count(y):
@@ -154,6 +157,7 @@ class Bottleneck(nn.Module):
             self.sigmoid = nn.Sigmoid()
         self.downsample = downsample
         self.stride = stride
+        self.t_stride = stride if t_downsample else 1
         # set by ResNet._make_layer when the next module is an identity-shortcut Bottleneck: the output is then
         # returned as a pair so that its two gradients (conv1 data gradient, residual) meet inside the tail kernel
         self.split_out = False
@@ -176,11 +180,18 @@ class Bottleneck(nn.Module):
         tr = self.training
         has_se = self.index % 2 == 0
 
+        ts = self.t_stride
         # stage-first block: conv1 and the strided shortcut conv read the same input; their data gradients are fused
-        tok = ops.ShortcutToken() if (isinstance(self.downsample, nn.Sequential) and self.stride > 1) else None
+        # (same frames only: with a temporal stride the shortcut sees every ts-th frame and the plain path is used)
+        tok = ops.ShortcutToken() if (isinstance(self.downsample, nn.Sequential) and self.stride > 1 and ts == 1) else None
         y1, s1, q1 = ops.pwconv(xr, self.conv1.weight, xa, xb, xact, 1, stats=tr, token=tok, role='main')
         A1, B1 = self.bn1.fold(s1, q1, _count(y1), n)
-        y2, s2, q2 = ops.dwconv3d(y1, self.conv2.weight, A1, B1, ACT_RELU, self.stride, stats=tr or has_se)
+        if ts == 1:
+            y2, s2, q2 = ops.dwconv3d(y1, self.conv2.weight, A1, B1, ACT_RELU, self.stride, stats=tr or has_se)
+        else:   # t_downsample (x3d_fine.py:93): a kernel-3 / pad-1 conv at temporal stride ts = every ts-th frame of the stride-1 result
+            y2f, _, _ = ops.dwconv3d(y1, self.conv2.weight, A1, B1, ACT_RELU, self.stride, stats=False)
+            y2 = _every(y2f, ts)
+            s2, q2 = ops.channel_stats(y2) if (tr or has_se) else (None, None)
         # bn2 (+ SE: the global average of bn2(y2) is the bn2 affine of the per-sample mean of y2, x3d_fine.py:157-163)
         se = (self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias) if has_se else None
         A2, B2 = self.bn2.fold(s2, q2, _count(y2), n, se=se)
@@ -192,8 +203,15 @@ class Bottleneck(nn.Module):
 
         if self.downsample is not None:
             if not isinstance(self.downsample, nn.Sequential):
-                raise NotImplementedError("shortcut_type 'A' is not on the accelerated path")
-            yd, sd, qd = ops.pwconv(xr, self.downsample[0].weight, xa, xb, xact, self.stride, stats=tr, token=tok, role='short',
+                # shortcut type 'A' (x3d_fine.py:266-275): avg_pool3d(kernel 1, stride s) = every s-th sample along t, h, w, zero
+                # channels appended, and -- `out.data` -- cut out of the autograd graph
+                _, planes_out, s_ = self.downsample
+                xm = x_res.materialize() if isinstance(x_res, Deferred) else x_res
+                res = xm.detach()[:, :, ::s_, ::s_, ::s_]
+                if planes_out > res.shape[1]:
+                    res = torch.cat([res, res.new_zeros((res.shape[0], planes_out - res.shape[1]) + tuple(res.shape[2:]))], dim=1)
+                return ops.bn_add_relu(y3, A3, B3, res.contiguous(), split=self.split_out, link=link)
+            yd, sd, qd = ops.pwconv(_every(xr, ts), self.downsample[0].weight, xa, xb, xact, self.stride, stats=tr, token=tok, role='short',
                                     tail=link, tail_role='res')
             Ad, Bd = self.downsample[1].fold(sd, qd, _count(yd), n)
             return ops.bn_add_relu(y3, A3, B3, yd, Ad, Bd, split=self.split_out, link=link)
@@ -254,11 +272,13 @@ class ResNet(nn.Module):
         downsample = None
         if stride != 1 or self.in_planes != planes[1]:
             if shortcut_type == 'A':
-                raise NotImplementedError("shortcut_type 'A' (x3d_fine.py:266-275) is never used by the reference "
-                                          "scripts and is not on the accelerated path")
-            downsample = nn.Sequential(
-                conv1x1x1(self.in_planes, planes[1], stride, t_downsample=self.t_downsample),
-                SubBatchNorm3d(num_splits=self.base_bn_splits, num_features=planes[1], affine=True))
+                # parameter-free shortcut; the reference's own 'A' strides t as well, so it only fits t_downsample=True
+                # (x3d_fine.py:266-275: with the default temporal stride 1 its `out += residual` fails on the T axis)
+                downsample = ('A', planes[1], stride)
+            else:
+                downsample = nn.Sequential(
+                    conv1x1x1(self.in_planes, planes[1], stride, t_downsample=self.t_downsample),
+                    SubBatchNorm3d(num_splits=self.base_bn_splits, num_features=planes[1], affine=True))
         layers = [block(in_planes=self.in_planes, planes=planes, stride=stride, downsample=downsample,
                         index=self.index, base_bn_splits=self.base_bn_splits, t_downsample=self.t_downsample)]
         self.in_planes = planes[1]

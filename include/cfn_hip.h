@@ -206,6 +206,11 @@ int cfn_time_sample_fwd(const float* x, const float* cdf, float* out, int B, int
 int cfn_time_sample_bwd(const float* g, const float* x, const float* cdf, float* gx, double* gcdf, int B, int C, int Tin,
                         int K, long P, void* stream);
 
+/* ---- fixed temporal pooling t_pool = 'avg' (mode 0) | 'max' (mode 1): nn.AvgPool3d / nn.MaxPool3d((R,1,1), stride (R,1,1))
+ * x3d_coarse.py:489-492 / :640-643.  x (BC,Tin,P) -> out (BC,floor(Tin/R),P); bwd writes all of gx (max: first maximal frame) ---- */
+int cfn_time_pool_fwd(const float* x, float* out, int mode, long BC, int Tin, int R, long P, void* stream);
+int cfn_time_pool_bwd(const float* g, const float* x, float* gx, int mode, long BC, int Tin, int R, long P, void* stream);
+
 /* ---- Interp1d.forward interp1d.py:8-147: x,y (B or 1 rows, N), xnew (B or 1 rows, Pq) -> ynew (B,Pq), ind int64
  * (searchsorted-left - 1, clamped to [0,N-2]).  *row flags: 1 = one row per batch entry, 0 = shared row.
  * bwd overwrites gx/gy/gq (any may be NULL) in gather form: every sum has a fixed order (reproducible). ---- */

@@ -419,10 +419,43 @@ def case_collate():
          vids=json.dumps(list(vids)), **{'feat_' + k: v for k, v in feat.items()}, **ins)
 
 
+def case_options():
+    """constructor options the reference scripts never set but the reference implements: temporal down-sampling
+    (t_downsample, x3d_fine.py:93,104), the parameter-free shortcut 'A' (:266-275, which only fits t_downsample=True), and
+    the fixed temporal poolings of the coarse stream t_pool = avg | max | stride | None (x3d_coarse.py:489-492, :640-660)."""
+    x = spec.rand_input(160, (1, 3, 16, 64, 64))
+    for tag, kw in (('tdown', dict(t_downsample=True)), ('tdown_A', dict(t_downsample=True, shortcut_type='A'))):
+        m = ref_fine.generate_model('M', n_classes=157, task='loc', base_bn_splits=1, dropout=0.0, **kw)
+        spec.fill_module_(m)
+        m.eval()
+        with torch.no_grad():
+            y = m([x, None])
+        m.train(True)
+        xt = spec.rand_input(161, (2, 3, 8, 64, 64))
+        yt = m([xt, None])
+        r = spec.rand_input(162, tuple(yt.shape))
+        (yt * r).sum().backward()
+        named = dict(m.named_parameters())
+        pick = ['fc2.weight', 'conv5.weight', 'layer4.6.conv2.weight', 'layer1.0.conv1.weight'] + ([] if 'A' in tag else ['layer2.0.downsample.0.weight'])
+        gn = {k: float(named[k].grad.double().norm()) for k in pick}
+        save('fine_' + tag, keys=keys_json(m), logits=y, train_logits=yt, grad_norms=json.dumps(gn),
+             **{('g_' + k.replace('.', '_')): thin(named[k].grad) for k in pick[:2]})
+    xc, feat, fm, meta, depth = coarse_inputs(170, 1, 16, 12)
+    for tp in ('avg', 'max', 'stride', None):
+        m = ref_coarse.generate_model('M', n_classes=400, feat_depth=depth, task='loc', dropout=0.0, base_bn_splits=1,
+                                      learnedMixing=True, isMixing=True, t_pool=tp)
+        m.replace_logits(157)
+        spec.fill_module_(m)
+        m.eval()
+        with torch.no_grad():
+            y = m([xc, feat, fm, 0, meta])
+        save('coarse_tpool_%s' % tp, keys=keys_json(m), logits=y)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     cases = [case_keys, case_interp1d, case_gridpool, case_gridunpool, case_gaussian, case_rewight, case_mixing,
-             case_subbn, case_bottleneck, case_loss_ap, case_fine, case_coarse, case_multicrop, case_collate]
+             case_subbn, case_bottleneck, case_loss_ap, case_fine, case_coarse, case_multicrop, case_collate, case_options]
     for c in cases:
         if only and c.__name__[5:] not in only:
             continue
