@@ -72,6 +72,10 @@ __device__ __forceinline__ float dw_rt(float v) { return v; }
 #endif
 
 enum { DW_FWD = 0, DW_DGRAD = 1, DW_WGRAD = 2 };
+#ifndef DW_BF16
+int dw_small_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
+                     int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);   // dwsmall.hip
+#endif
 
 struct DwArgs {
     const dwe_t* src;    // FWD/WGRAD: x raw (N,C,T,Hi,Wi)      DGRAD: gy (N,C,T,H,W)
@@ -1235,10 +1239,17 @@ extern "C" int DWN(cfn_dwconv3d_fwd)(const dwe_t* x, const double* A, const doub
     DwArgs a = {};
     a.src = x; a.A = A; a.B = B; a.act = act; a.w = w; a.dst = y; a.s1 = sum; a.s2 = sumsq;
     a.N = N; a.C = C; a.T = T; a.Hi = Hi; a.Wi = Wi;
+    hipStream_t st = (hipStream_t)stream;
+#ifndef DW_BF16
+    if (dw_small_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
+        // 14x14 / 7x7 stride 1: wave-per-channel kernel (dwsmall.hip)
+        CfnProfScope prof(CFN_K_DWCONV_FWD, st, (double)DW_ES * N * C * T * 2.0 * Hi * Wi + 4.0 * C * 27);
+        return dw_small_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, false);
+    }
+#endif
     DwPlan pl;
     int rc = dw_plan(a, stride, DW_FWD, pl);
     if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_DWCONV_FWD, st, (double)DW_ES * N * C * T * ((double)Hi * Wi + (double)a.Ho * a.Wo) + 4.0 * C * 27);
     return stride == 1 ? dw_launch<DW_FWD, 1>(a, pl, st) : dw_launch<DW_FWD, 2>(a, pl, st);
 }
