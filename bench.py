@@ -84,7 +84,8 @@ def cpu_baseline(frames_full, sample_frames=128, repeats=2, stream='fine'):
 
 # kernel families whose HIP-event times make up the roofline leg (cfn_prof_*): the metric's kernel set is the depthwise-conv
 # stack forward (fine stream, SURVEY 8d figure A) plus, for the coarse stream, the Grid Pool forward (figure B)
-ROOFLINE_FAMILIES = {'fine': ('dwconv_fwd',), 'coarse': ('dwconv_fwd', 'gridpool', 'dense_fwd')}
+ROOFLINE_FAMILIES = {'fine': ('dwconv_fwd',), 'coarse': ('dwconv_fwd', 'gridpool', 'dense_fwd'),
+                     'joint': ('dwconv_fwd', 'gridpool', 'dense_fwd')}
 
 
 def main():
@@ -92,10 +93,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--stream', choices=('fine', 'coarse'), default='fine',
+    ap.add_argument('--stream', choices=('fine', 'coarse', 'joint'), default='fine',
                     help='fine: x3d_fine X3D-M train step at T=256 (the headline metric); coarse: x3d_coarse fineFEAT-fusion '
-                         'train step on 64-frame clips + T\'=128 fine features (BASELINE configs[3] per-GPU shard)')
-    ap.add_argument('--frames', type=int, default=None, help='default 256 (fine) / 64 (coarse)')
+                         'train step on 64-frame clips + T\'=128 fine features (BASELINE configs[3] per-GPU shard); joint: both streams end '
+                         'to end, fine tower on 128 frames feeding the coarse stream on the centre 64 (BASELINE configs[4] per-GPU shard)')
+    ap.add_argument('--frames', type=int, default=None, help='default 256 (fine) / 64 (coarse) / 128 fine frames (joint)')
     ap.add_argument('--batch', type=int, default=8, help='clips per GPU per step')
     ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32',
                     help='storage type of activations / activation gradients (fine stream): f32 = the reference precision (the '
@@ -104,10 +106,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-frames', type=int, default=128)
     args = ap.parse_args()
-    coarse = args.stream == 'coarse'
+    coarse, joint = args.stream == 'coarse', args.stream == 'joint'
     assert not (coarse and args.dtype != 'f32'), 'the bf16 activation path covers the fine stream'
     if args.frames is None:
-        args.frames = 64 if coarse else 256
+        args.frames = 64 if coarse else (128 if joint else 256)
 
     from cfn_hip import dist as cdist
     import cfn_hip
@@ -120,7 +122,18 @@ def main():
     torch.manual_seed(0)
     B, T = args.batch, args.frames
     g = torch.Generator().manual_seed(1234 + rank)
-    if coarse:
+    if joint:
+        import train_joint as tj
+        fine_net, net = tj.build_models(dev, fine_act_dtype=args.dtype)
+        groups = tj.param_groups(fine_net, net, 0.02)
+        optimizer = optim.SGD(groups, lr=0.02, momentum=0.9, weight_decay=1e-5)
+        x = torch.randn(B, 3, T, 224, 224, generator=g).to(dev)
+        tl = (T // 2) * 10
+        labels = (torch.rand(B, 157, tl, generator=g) < 0.05).float().to(dev)
+        masks = torch.ones(B, tl, device=dev)
+        fine_net.train(True)
+        cdist.sync_module(fine_net)
+    elif coarse:
         net = tc.build_model(dev, pretrained=None)
         optimizer = optim.SGD(tc.param_groups(net, 0.02), lr=0.02, momentum=0.9, weight_decay=1e-5)
         x, labels, masks, feat, fm, meta, _, _ = next(iter(tc.SyntheticCoarse(B, 1, T, seed=1234 + rank)))
@@ -136,9 +149,11 @@ def main():
         masks = torch.ones(B, tl, device=dev)
     net.train(True)
     cdist.sync_module(net)            # one model on every rank, as under DataParallel
-    reducer = cdist.GradReducer(net.parameters())
+    reducer = cdist.GradReducer([p for gr in groups for p in gr['params']] if joint else net.parameters())
 
     def step():
+        if joint:
+            return tj.train_step(fine_net, net, reducer, optimizer, x, labels, masks)
         if coarse:
             return tc.train_step(net, reducer, optimizer, x, labels, masks, feat, fm, meta)
         return train_fine.train_step(net, reducer, optimizer, x, labels, masks)
@@ -197,7 +212,12 @@ def main():
                     traffic = round(doc['traffic_bytes_per_launch'] * B / doc['batch'])
                     traffic_note = 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), profiles/' + name
                 break
-        if coarse:
+        if joint:
+            metric = 'clips/sec (fwd+bwd+SGD) joint Coarse-Fine two-stream, fine T=%d + coarse T=%d, 224x224' % (T, T // 2)
+            workload = ('joint two-stream train step: x3d_fine tower (global_tower) on %dx3x%dx224x224 -> 5 feature maps -> x3d_coarse '
+                        '(Grid Pool + learned fusion) on the centre %d frames, one backward through both, random-init weights' % (B, T, T // 2))
+            kernel = 'dw3d / dwt5 <FWD> of both streams + Grid Pool forward'
+        elif coarse:
             metric = 'clips/sec (fwd+bwd+SGD) x3d_coarse fineFEAT fusion T=%dx224x224, T\'=128' % T
             workload = ('x3d_coarse X3D-M (Grid Pool + learned Multi-stage Fusion) train step, %dx3x%dx224x224 clips + fine features '
                         '(T\'=128, 7x7) per GPU, random-init weights' % (B, T))
@@ -224,8 +244,8 @@ def main():
                          'launches': launches, 'avg_launch_ms': round(ms / max(launches, 1), 4),
                          'algorithmic_bytes_per_launch': round(by / max(launches, 1))},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(T, args.cpu_sample_frames, stream=args.stream)
+        if world == 1 and not args.no_cpu_baseline and not joint:       # joint: the CPU legs of the two streams are reported by their own runs
+            out['cpu_baseline'] = cpu_baseline(T, args.cpu_sample_frames, stream=args.stream)   # joint: none (see below)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

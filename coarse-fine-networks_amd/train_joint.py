@@ -51,10 +51,13 @@ class SyntheticJoint(object):
             yield x, labels, torch.ones(self.bs, tl)
 
 
-def build_models(device, pretrained_fine=None, pretrained_coarse=None, dropout=0.5):
-    """(fine tower, coarse net).  The tower has no classifier of its own on this path (fc1 / fc2 get no gradient)."""
+def build_models(device, pretrained_fine=None, pretrained_coarse=None, dropout=0.5, fine_act_dtype=None):
+    """(fine tower, coarse net).  The tower has no classifier of its own on this path (fc1 / fc2 get no gradient).
+    fine_act_dtype='bf16': the Fine stream -- 2/3 of the joint step's bytes and flops -- stores its activations in bf16 and
+    runs its pointwise convs on bf16 MFMA (BASELINE configs[4] "fp16 MFMA pointwise"; CDNA4 bf16 = fp16 rate); its pooled
+    feature maps are fp32, so the Coarse stream and the fusion are unchanged."""
     fine = x3d_fine.generate_model(x3d_version='M', n_classes=NUM_CLASSES, n_input_channels=3, task='loc', dropout=dropout,
-                                   base_bn_splits=1, global_tower=True)
+                                   base_bn_splits=1, global_tower=True, act_dtype=fine_act_dtype)
     if pretrained_fine:
         state = fine.state_dict()
         state.update(torch.load(pretrained_fine, map_location='cpu')['model_state_dict'])
@@ -102,12 +105,12 @@ def train_step(fine, coarse, reducer, optimizer, clip, labels, masks, pre_step=N
 
 
 def run(init_lr=INIT_LR, warmup_steps=0, max_steps=None, batch_size=BS, fine_frames=128, coarse_frames=64, dataloader=None,
-        pretrained_fine=None, pretrained_coarse=None, save_model='models/joint_charades_', log=print):
+        pretrained_fine=None, pretrained_coarse=None, save_model='models/joint_charades_', log=print, fine_act_dtype=None):
     rank, world, dev = cdist.init_from_env()
     local_bs = max(batch_size // world, 1)
     if dataloader is None:
         dataloader = SyntheticJoint(local_bs, tc.CHARADES_TR_SIZE // batch_size, fine_frames, coarse_frames, seed=rank)
-    fine, coarse = build_models(dev, pretrained_fine, pretrained_coarse)
+    fine, coarse = build_models(dev, pretrained_fine, pretrained_coarse, fine_act_dtype=fine_act_dtype)
     cdist.sync_module(fine)
     cdist.sync_module(coarse)
     groups = param_groups(fine, coarse, init_lr)

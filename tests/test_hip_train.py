@@ -302,3 +302,31 @@ def test_bench_two_ranks_sharing_the_gpu(tmp_path):
     assert doc['n_gpus'] == 2 and doc['config']['dist']['world_size'] == 2 and doc['config']['parallelism'] == 'dp2'
     assert doc['value'] > 0 and all(v == v for v in doc['loss']['last_step_cls_loc'])
     assert 'cpu_baseline' not in doc          # N > 1: no CPU leg
+
+
+def test_joint_step_with_bf16_fine_tower():
+    """BASELINE configs[4] ("fp16 MFMA pointwise"): the Fine stream of the joint step in bf16 (bf16 MFMA pointwise convs), its
+    fp32 pooled features feeding the fp32 Coarse stream.  Logits against the all-fp32 joint forward at bf16 accuracy (eval
+    mode), and a train step that reaches the first layer of the tower."""
+    from oracle import spec
+    import train_joint
+    outs = {}
+    for dt in (None, 'bf16'):
+        fine, coarse = train_joint.build_models(DEV, dropout=0.0, fine_act_dtype=dt)
+        spec.fill_module_(fine)
+        spec.fill_module_(coarse)
+        fine.eval()
+        coarse.eval()
+        clip = spec.rand_input(9, (1, 3, 16, 224, 224)).to(DEV)
+        with torch.no_grad():
+            outs[dt], _ = train_joint.joint_forward(fine, coarse, clip)
+    err = float((outs['bf16'] - outs[None]).abs().max() / outs[None].abs().max())
+    print('joint logits, bf16 tower vs fp32: rel-max %.2e' % err)
+    assert err <= 2e-2
+    fine.train(True)
+    coarse.train(True)
+    coarse.rw6.dropout.p = 0.0
+    logits, _ = train_joint.joint_forward(fine, coarse, spec.rand_input(10, (2, 3, 16, 224, 224)).to(DEV))
+    logits.square().mean().backward()
+    g = fine.conv1_s.weight.grad
+    assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
