@@ -17,6 +17,7 @@ struct BnFoldArgs {
     float* run_mean; float* run_var;        // training: split_bn buffers (S*C) updated in place; eval: bn buffers (C)
     long* nbt;                              // num_batches_tracked (training) or null
     int training, N, C, S, Wd;
+    int stage;                              // SE matrices staged in LDS (0: they do not fit -- X3D-XL -- and are read through L2)
     double count, pool_count, eps, momentum;
     const float* w1; const float* b1; const float* w2; const float* b2;   // SE (Wd > 0): fc1 (Wd,C), fc2 (C,Wd)
     double* A; double* B;                     // (N,C) outputs (gated when SE)
@@ -38,12 +39,14 @@ __device__ __forceinline__ void bnf_stage_se(const float* w1, const float* w2, f
 
 __global__ __launch_bounds__(1024) void bn_fold_fwd_kernel(const BnFoldArgs a) {
     const int tid = threadIdx.x, nthr = blockDim.x, N = a.N, C = a.C, S = a.training ? a.S : 1, G = N / S, Wd = a.Wd;
-    extern __shared__ float sh[];      // w1s[Wd*C] | w2s[C*(Wd+1)] | pooled[NB*C] | h[NB*Wd]
-    float* w1s = sh;
-    float* w2s = w1s + (Wd > 0 ? Wd * C : 0);
-    float* sp = w2s + (Wd > 0 ? C * (Wd + 1) : 0);
+    extern __shared__ float sh[];      // [w1s[Wd*C] | w2s[C*(Wd+1)]] | pooled[NB*C] | h[NB*Wd]
+    const bool st = Wd > 0 && a.stage;
+    float* sp = sh + (st ? Wd * C + C * (Wd + 1) : 0);
     float* shh = sp + BNF_NB * C;
-    if (Wd > 0) bnf_stage_se(a.w1, a.w2, w1s, w2s, C, Wd);
+    const float* w1s = st ? sh : a.w1;
+    const float* w2s = st ? sh + Wd * C : a.w2;
+    const int w2p = st ? Wd + 1 : Wd;                  // row pitch of w2s
+    if (st) bnf_stage_se(a.w1, a.w2, sh, sh + Wd * C, C, Wd);
     // (1) statistics per (split group, channel)
     for (int e = tid; e < S * C; e += nthr) {
         const int g = e / C, c = e - g * C;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(1024) void bn_fold_fwd_kernel(const BnFoldArgs a) {
         for (int e = tid; e < nb * C; e += nthr) {               // gate[n][c] = sigmoid(b2[c] + w2[c,:] . h[n,:])
             const int nl = e / C, c = e - nl * C;
             float acc = a.b2[c];
-            for (int j = 0; j < Wd; ++j) acc = fmaf(w2s[c * (Wd + 1) + j], shh[nl * Wd + j], acc);
+            for (int j = 0; j < Wd; ++j) acc = fmaf(w2s[c * w2p + j], shh[nl * Wd + j], acc);
             const float gt = 1.0f / (1.0f + expf(-acc));
             const long o = (long)n0 * C + e;
             a.gate[o] = gt;
@@ -120,6 +123,7 @@ struct BnFoldBwdArgs {
     const float* A0; const float* B0; const float* gate; const float* hbuf; const float* pooled;
     const float* w1; const float* w2;
     int training, N, C, S, Wd;
+    int stage;                              // SE matrices staged in LDS (0: they do not fit -- X3D-XL -- and are read through L2)
     double count, pool_count;
     double* gs; double* gq;                 // (N,C) outputs (training) or null
     float* ggamma; float* gbeta;            // (C) outputs or null
@@ -132,13 +136,15 @@ __global__ __launch_bounds__(1024) void bn_fold_bwd_kernel(const BnFoldBwdArgs a
     extern __shared__ float sh[];      // w1s[Wd*C] | w2s[C*(Wd+1)] | z[NB*C] | pooled[NB*C] | gz1[NB*Wd] | h[NB*Wd]
     // (2') squeeze-excite adjoint -> gradients w.r.t. A0, B0, s (through pooled) and the SE parameters
     if (Wd > 0) {
-        float* w1s = sh;
-        float* w2s = w1s + Wd * C;
-        float* gz2 = w2s + C * (Wd + 1);
+        const bool st = a.stage != 0;
+        const float* w1s = st ? sh : a.w1;
+        const float* w2s = st ? sh + Wd * C : a.w2;
+        const int w2p = st ? Wd + 1 : Wd;
+        float* gz2 = sh + (st ? Wd * C + C * (Wd + 1) : 0);
         float* pl = gz2 + BNF_NB * C;
         float* gz1 = pl + BNF_NB * C;
         float* shh = gz1 + BNF_NB * Wd;
-        bnf_stage_se(a.w1, a.w2, w1s, w2s, C, Wd);
+        if (st) bnf_stage_se(a.w1, a.w2, sh, sh + Wd * C, C, Wd);
         const int wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
         for (int n0 = 0; n0 < N; n0 += BNF_NB) {
             const int nb = min(BNF_NB, N - n0);
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(1024) void bn_fold_bwd_kernel(const BnFoldBwdArgs a
             for (int p = wave; p < nb * Wd; p += nwaves) {       // gz1[n][j] = relu'(h) * gz2[n,:] . w2[:,j]
                 const int nl = p / Wd, j = p - nl * Wd;
                 float acc = 0.0f;
-                for (int c = lane; c < C; c += 64) acc = fmaf(gz2[nl * C + c], w2s[c * (Wd + 1) + j], acc);
+                for (int c = lane; c < C; c += 64) acc = fmaf(gz2[nl * C + c], w2s[c * w2p + j], acc);
                 acc = cfn_wave_sum(acc);
                 if (lane == 0) gz1[p] = shh[p] > 0.0f ? acc : 0.0f;
             }
@@ -232,12 +238,16 @@ extern "C" int cfn_bn_fold_fwd(const double* s, const double* q, const float* ga
                                float* gate, float* hbuf, float* pooled, void* stream) {
     CFN_REQUIRE(A && B && mean && rstd && run_mean && run_var, "cfn_bn_fold_fwd: null tensor");
     CFN_REQUIRE(!training || (s && q), "cfn_bn_fold_fwd: training needs sum / sumsq");
-    CFN_REQUIRE(N > 0 && C > 0 && S > 0 && N % S == 0, "cfn_bn_fold_fwd: batch %d not divisible by %d splits", N, S);
+    CFN_REQUIRE(N > 0 && C > 0 && S > 0, "cfn_bn_fold_fwd: bad sizes");
+    CFN_REQUIRE(!training || N % S == 0, "cfn_bn_fold_fwd: batch %d not divisible by %d splits", N, S);   // eval: no split groups
     CFN_REQUIRE(Wd <= 0 || (w1 && b1 && w2 && b2 && s && A0 && B0 && gate && hbuf && pooled), "cfn_bn_fold_fwd: SE needs its tensors");
-    BnFoldArgs a = {s, q, gamma, beta, run_mean, run_var, nbt, training, N, C, S, Wd, count, pool_count, eps, momentum,
+    const size_t lds_small = Wd > 0 ? BNF_NB * (size_t)(C + Wd) * sizeof(float) : 0;
+    const size_t lds_full = Wd > 0 ? lds_small + ((size_t)Wd * C + (size_t)C * (Wd + 1)) * sizeof(float) : 0;
+    const int stage = lds_full <= 150 * 1024;
+    const size_t lds = stage ? lds_full : lds_small;
+    BnFoldArgs a = {s, q, gamma, beta, run_mean, run_var, nbt, training, N, C, S, Wd, stage, count, pool_count, eps, momentum,
                     w1, b1, w2, b2, A, B, mean, rstd, A0, B0, gate, hbuf, pooled};
-    const size_t lds = Wd > 0 ? ((size_t)Wd * C + (size_t)C * (Wd + 1) + BNF_NB * (size_t)(C + Wd)) * sizeof(float) : 0;
-    CFN_REQUIRE(lds <= 150 * 1024, "cfn_bn_fold_fwd: SE tables (C=%d, width=%d) exceed LDS", C, Wd);
+    CFN_REQUIRE(lds <= 150 * 1024, "cfn_bn_fold_fwd: per-sample SE tables (C=%d, width=%d) exceed LDS", C, Wd);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)bn_fold_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3(1), dim3(Wd > 0 ? 1024 : 256), lds, (hipStream_t)stream, a);
     return cfn_check_launch("bn_fold_fwd");
@@ -252,10 +262,13 @@ extern "C" int cfn_bn_fold_bwd(const double* gA, const double* gB, const double*
     CFN_REQUIRE(Wd <= 0 || (s && A0 && B0 && gate && hbuf && pooled && w1 && w2 && gw1 && gb1 && gw2 && gb2 && tA && tB),
                 "cfn_bn_fold_bwd: SE needs its tensors");
     CFN_REQUIRE(!training || ((gs == nullptr) == (gq == nullptr)), "cfn_bn_fold_bwd: gs/gq mismatch");   // eval + SE: gs alone
-    BnFoldBwdArgs a = {gA, gB, s, gamma, mean, rstd, A0, B0, gate, hbuf, pooled, w1, w2, training, N, C, S, Wd, count,
+    const size_t lds_small = Wd > 0 ? 2 * BNF_NB * (size_t)(C + Wd) * sizeof(float) : 0;
+    const size_t lds_full = Wd > 0 ? lds_small + ((size_t)Wd * C + (size_t)C * (Wd + 1)) * sizeof(float) : 0;
+    const int stage = lds_full <= 150 * 1024;
+    const size_t lds = stage ? lds_full : lds_small;
+    BnFoldBwdArgs a = {gA, gB, s, gamma, mean, rstd, A0, B0, gate, hbuf, pooled, w1, w2, training, N, C, S, Wd, stage, count,
                        pool_count, gs, gq, ggamma, gbeta, gw1, gb1, gw2, gb2, tA, tB};
-    const size_t lds = Wd > 0 ? ((size_t)Wd * C + (size_t)C * (Wd + 1) + 2 * BNF_NB * (size_t)(C + Wd)) * sizeof(float) : 0;
-    CFN_REQUIRE(lds <= 150 * 1024, "cfn_bn_fold_bwd: SE tables (C=%d, width=%d) exceed LDS", C, Wd);
+    CFN_REQUIRE(lds <= 150 * 1024, "cfn_bn_fold_bwd: per-sample SE tables (C=%d, width=%d) exceed LDS", C, Wd);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)bn_fold_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3(1), dim3(Wd > 0 ? 1024 : 256), lds, (hipStream_t)stream, a);
     return cfn_check_launch("bn_fold_bwd");

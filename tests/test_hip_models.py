@@ -373,3 +373,33 @@ def test_coarse_run_to_run_reproducibility():
             worst, where = d, k
     print('coarse run-to-run: logits rel %.2e, worst gradient norm-rel %.2e (%s)' % (d_out, worst, where))
     assert d_out <= 1e-3 and worst <= 5e-2
+
+
+def test_x3d_xl_matches_oracle():
+    """X3D-XL (72/162/306/630 channels, 5/10/25/15 blocks, SE width 40 at 630 channels: the squeeze-excite matrices do not fit
+    in LDS and are read through L2) at odd plane sizes (160 -> 80, 40, 20, 10, 5): eval logits 1e-3, eval-mode gradients 2e-3"""
+    import x3d_fine
+    from oracle import spec, x3d_ref
+    m = x3d_fine.generate_model('XL', n_classes=157, task='loc', base_bn_splits=1, dropout=0.0)
+    spec.fill_module_(m)
+    m.to(DEV).eval()
+    x = spec.rand_input(41, (1, 3, 4, 160, 160))
+    y = m([x.to(DEV), None])
+    r = spec.rand_input(42, tuple(y.shape))
+    (y * r.to(DEV)).sum().backward()
+    sd = spec.procedural_fill(spec.fine_keys('XL', 157, 1))
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running' not in k:
+            v.requires_grad_(True)
+    yo = x3d_ref.x3d_fine_forward(sd, x, 'XL', training=False)
+    (yo * r).sum().backward()
+    assert maxdiff(y, yo) <= 1e-3
+    named = dict(m.named_parameters())
+    for k in ('conv1_t.weight', 'layer1.0.conv2.weight', 'layer2.4.fc1.weight', 'layer3.24.conv3.weight', 'layer4.14.conv2.weight',
+              'layer4.14.fc2.weight', 'conv5.weight', 'fc2.weight'):
+        a, b = named[k].grad.cpu().double().flatten(), sd[k].grad.double().flatten()
+        assert float((a - b).norm() / b.norm()) <= 2e-3, (k, float((a - b).norm() / b.norm()))
+    m.train(True)                       # batch statistics + SE training path at 630 channels
+    yt = m([spec.rand_input(43, (2, 3, 4, 160, 160)).to(DEV), None])
+    yto = x3d_ref.x3d_fine_forward(spec.procedural_fill(spec.fine_keys('XL', 157, 1)), spec.rand_input(43, (2, 3, 4, 160, 160)), 'XL', training=True)
+    assert maxdiff(yt, yto) <= 1e-3
