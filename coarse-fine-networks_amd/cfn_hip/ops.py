@@ -349,8 +349,31 @@ class _PwConv(Function):
 
 def pwconv(x, w, A=None, B=None, act=ACT_NONE, stride=1, stats=True, token=None, role=None, tail=None, tail_role=None):
     """returns (y, sum, sumsq); sum/sumsq are None when stats=False.  token / role ('main' | 'short'): see ShortcutToken;
-    tail / tail_role ('y' | 'res'): see TailLink"""
-    return _PwConv.apply(x, A, B, w, act, stride, stats, token, role, tail, tail_role)
+    tail / tail_role ('y' | 'res'): see TailLink.
+
+    The kernels address one sample's (channels x positions) block through a 32-bit buffer descriptor (2 GiB fp32, 1 GiB
+    bf16).  Whole-video validation exceeds that (x3d_coarse layer 1 on a 1000-frame chunk, train_coarse_fineFEAT.py:215-224:
+    54 x 1000 x 112 x 112 x 4 B = 2.7 GB): without autograd the conv then runs over frame ranges -- a 1x1x1 conv is
+    per-frame -- and the statistics add up.  With autograd the kernel's refusal stands."""
+    N, Cin, T, H, W = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    es = x.element_size()
+    lim = (1 << 31) if es == 4 else (1 << 30)
+    span = max(Cin * H * W, w.shape[0] * Ho * Wo, Cin * Ho * Wo) * es
+    needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, w, A, B))
+    if span * T < lim or needs_grad or T == 1:
+        return _PwConv.apply(x, A, B, w, act, stride, stats, token, role, tail, tail_role)
+    step = max((lim - 1) // span, 1)
+    if es == 2 and (Ho * Wo) % 2:
+        step -= step % 2                         # bf16 kernels need an even position count
+    y = torch.empty(N, w.shape[0], T, Ho, Wo, dtype=x.dtype, device=x.device)
+    s = q = None
+    for t0 in range(0, T, max(step, 1)):
+        yc, sc, qc = _PwConv.apply(x[:, :, t0:t0 + step].contiguous(), A, B, w, act, stride, stats, None, None)
+        y[:, :, t0:t0 + step] = yc
+        if stats:
+            s, q = (sc, qc) if s is None else (s + sc, q + qc)
+    return y, s, q
 
 
 def _sfx(t):

@@ -32,6 +32,17 @@ struct CfnProfScope {
 
 static inline int cfn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// grid.y is limited to 65535: kernels indexed by (n, c) = blockIdx.y + blockIdx.z * gridDim.y get an EXACT factorisation
+// gy * gz = N*C with gy, gz <= 65535, so no in-kernel range check is needed (a prime N*C > 65535 has none and is refused)
+static inline bool cfn_split_nc(long NC, unsigned& gy, unsigned& gz) {
+    gy = (unsigned)NC; gz = 1;
+    if (NC <= 65535) return NC > 0;
+    for (long d = 65535; d >= 1; --d)
+        if (NC % d == 0) { gy = (unsigned)d; gz = (unsigned)(NC / d); return gz <= 65535; }
+    return false;
+}
+static inline bool cfn_split_nc_ok(long NC) { unsigned a, b; return cfn_split_nc(NC, a, b); }
+
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------

@@ -803,7 +803,8 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
     // per workgroup so that the lanes stay busy (a 7x7 plane would fill 49 of 256 threads)
     const int cslot = PACKED ? threadIdx.x / a.PB : 0;
     const int p = PACKED ? threadIdx.x - cslot * a.PB : (threadIdx.x < a.PBLK ? pb * a.PBLK + threadIdx.x : Ho * Wo);
-    const int ncr = PACKED ? blockIdx.y * a.CPB + cslot : blockIdx.y;
+    const int by = blockIdx.y + blockIdx.z * gridDim.y;
+    const int ncr = PACKED ? by * a.CPB + cslot : by;
     const bool ok = (!PACKED || (cslot < a.CPB && ncr < a.NC)) && p < Ho * Wo;
     const int nc = (!PACKED || ncr < a.NC) ? ncr : a.NC - 1, c = nc % a.C;
     const int i = ok ? p / Wo : 0, j = ok ? p - i * Wo : 0;
@@ -952,7 +953,8 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_fast_kernel(const DwS2Args 
     const int chunk = blockIdx.x % a.nchunks, pb = blockIdx.x / a.nchunks;
     const int cslot = PACKED ? threadIdx.x / a.PB : 0;
     const int p = PACKED ? threadIdx.x - cslot * a.PB : (threadIdx.x < a.PBLK ? pb * a.PBLK + threadIdx.x : Ho * Wo);
-    const int nc0 = PACKED ? blockIdx.y * a.CPB : blockIdx.y;            // first (n,c) of this workgroup
+    const int by = blockIdx.y + blockIdx.z * gridDim.y;
+    const int nc0 = PACKED ? by * a.CPB : by;            // first (n,c) of this workgroup
     const int ncr = nc0 + cslot;
     const bool ok = (!PACKED || (cslot < a.CPB && ncr < a.NC)) && p < Ho * Wo;
     const int nc = (!PACKED || ncr < a.NC) ? ncr : a.NC - 1, c = nc % a.C;
@@ -1278,13 +1280,14 @@ extern "C" int DWN(cfn_dwconv3d_bwd_data)(const dwe_t* gy, const dwe_t* y, const
         // frames for 2 % of the work
         a.PBLK = (a.PB % a.pblocks == 0 && (a.PB / a.pblocks) % 4 == 0) ? a.PB / a.pblocks : 256;   // (uneven splits measured slower)
         const int ygrid = cfn_cdiv(a.NC, a.CPB);
-        CFN_REQUIRE(ygrid <= 65535, "cfn_dwconv3d_bwd_data: N*C exceeds grid.y");
+        unsigned gy_, gz_;
+        CFN_REQUIRE(cfn_split_nc(ygrid, gy_, gz_), "cfn_dwconv3d_bwd_data: N*C exceeds grid.y");
         int TT = 64;
         while (TT > 8 && (long)ygrid * a.pblocks * cfn_cdiv(T, TT) < 2048) TT >>= 1;
         a.TT = TT > T ? T : TT;
         a.nchunks = cfn_cdiv(T, a.TT);
         const bool fast = (Wi % 2 == 0) && A && a.y && a.gq && gA && (long)a.CPB * T * Hi * Wi * DW_ES < 0x7ffffff0L;
-        const dim3 grid(a.pblocks * a.nchunks, ygrid);
+        const dim3 grid(a.pblocks * a.nchunks, gy_, gz_);
         if (fast && a.CPB > 1) hipLaunchKernelGGL(dw3d_dgrad_s2_fast_kernel<true>, grid, dim3(256), 0, st, a);
         else if (fast) hipLaunchKernelGGL(dw3d_dgrad_s2_fast_kernel<false>, grid, dim3(256), 0, st, a);
         else if (a.CPB > 1) hipLaunchKernelGGL(dw3d_dgrad_s2_kernel<true>, grid, dim3(256), 0, st, a);

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void dwt5_kernel(const T5Args a) {
     constexpr bool SRC16 = BF && MODE == T5_DGRAD;      // element type of src / src2
     constexpr bool DST16 = BF && MODE == T5_FWD;        // element type of dst
     __shared__ float sh[20];
-    const long nc = blockIdx.y;
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;
     const int c = (int)(nc % a.C);
     const int chunk = blockIdx.x % a.nchunks, pc = blockIdx.x / a.nchunks;
     const long p = ((long)pc * 256 + threadIdx.x) * VEC;
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void dwt5_kernel(const T5Args a) {
 template <int MODE, bool BF = false>
 static int t5_launch(T5Args& a, int N, hipStream_t st) {
     const long NC = (long)N * a.C;
-    CFN_REQUIRE(NC <= 65535, "dwconv_t5: N*C = %ld exceeds grid.y", NC);
+    unsigned gy_, gz_;
+    CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "dwconv_t5: N*C = %ld exceeds grid.y", NC);
     const bool v4 = a.plane % 4 == 0;
     const int vec = v4 ? 4 : 1;
     a.pchunks = cfn_cdiv(a.plane, 256L * vec);
@@ -182,7 +183,7 @@ static int t5_launch(T5Args& a, int N, hipStream_t st) {
     if (TT > a.T) TT = a.T;
     a.TT = TT;
     a.nchunks = cfn_cdiv(a.T, TT);
-    dim3 grid((unsigned)(a.pchunks * a.nchunks), (unsigned)NC);
+    dim3 grid((unsigned)(a.pchunks * a.nchunks), gy_, gz_);
     if (v4) hipLaunchKernelGGL((dwt5_kernel<MODE, 4, BF>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((dwt5_kernel<MODE, 1, BF>), grid, dim3(256), 0, st, a);
     return cfn_check_launch("dwconv_t5");

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void bn_add_relu_fwd_kernel(const float* __res
                                                               const double* __restrict__ B, const float* __restrict__ res,
                                                               const double* __restrict__ Ar, const double* __restrict__ Br,
                                                               float* __restrict__ out, unsigned* __restrict__ mask, long vol) {
-    const long nc = blockIdx.y;
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;      // (y, z) = exact factorisation of N*C (cfn_split_nc)
     const float a = A[nc], b = B[nc] + (Br ? Br[nc] : 0.0f), ar = Ar ? Ar[nc] : 1.0f;
     const long base = nc * vol;
     long i = ((long)blockIdx.x * 256 * EW_ITEMS + threadIdx.x) * VEC;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void bn_add_relu_bwd_g_kernel(const float* __r
                                                                 float* __restrict__ g_out, double* __restrict__ gA,
                                                                 double* __restrict__ gB, double* __restrict__ gAr, long vol) {
     __shared__ float sh[12];
-    const long nc = blockIdx.y;
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;      // (y, z) = exact factorisation of N*C (cfn_split_nc)
     const long base = nc * vol;
     float acc[3] = {0.f, 0.f, 0.f};
     long i = ((long)blockIdx.x * 256 * EW_ITEMS + threadIdx.x) * VEC;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void bn_add_relu_bwd_kernel(const float* __res
                                                               double* __restrict__ gA, double* __restrict__ gB,
                                                               double* __restrict__ gAr, long vol) {
     __shared__ float sh[12];
-    const long nc = blockIdx.y;
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;      // (y, z) = exact factorisation of N*C (cfn_split_nc)
     const float a = A[nc], ar = Ar ? Ar[nc] : 1.0f;
     const long base = nc * vol;
     float acc[3] = {0.f, 0.f, 0.f};
@@ -167,7 +167,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void affine_act_fwd_kernel(const float* __restrict__ x, const double* __restrict__ A,
                                                              const double* __restrict__ B, int act, float* __restrict__ out,
                                                              long vol) {
-    const long nc = blockIdx.y;
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;      // (y, z) = exact factorisation of N*C (cfn_split_nc)
     const float a = A[nc], b = B[nc];
     const long base = nc * vol;
     long i = ((long)blockIdx.x * 256 * EW_ITEMS + threadIdx.x) * VEC;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __rest
                                                              float* __restrict__ gx, double* __restrict__ gA,
                                                              double* __restrict__ gB, long vol) {
     __shared__ float sh[8];
-    const long nc = blockIdx.y;
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;      // (y, z) = exact factorisation of N*C (cfn_split_nc)
     const float a = A[nc], b = B[nc];
     const long base = nc * vol;
     float acc[2] = {0.f, 0.f};
@@ -218,7 +218,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, double* __restrict__ sum,
                                                             double* __restrict__ sumsq, long vol) {
     __shared__ float sh[8];
-    const long nc = blockIdx.y;
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;      // (y, z) = exact factorisation of N*C (cfn_split_nc)
     const long base = nc * vol;
     float acc[2] = {0.f, 0.f};
     long i = ((long)blockIdx.x * 256 * EW_ITEMS + threadIdx.x) * VEC;
@@ -248,7 +248,7 @@ __device__ __forceinline__ int ap_end(int o, int O, int S) { return ((o + 1) * S
 __global__ __launch_bounds__(256) void pool_hw_fwd_kernel(const float* __restrict__ x, const double* __restrict__ A,
                                                           const double* __restrict__ B, int act, float* __restrict__ out,
                                                           int T, int H, int W, int OH, int OW) {
-    const long nc = blockIdx.y;
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;      // (y, z) = exact factorisation of N*C (cfn_split_nc)
     const long ovol = (long)T * OH * OW;
     const long o = (long)blockIdx.x * 256 + threadIdx.x;
     if (o >= ovol) return;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void pool_hw_bwd_kernel(const float* __restric
                                                           float* __restrict__ gx, double* __restrict__ gA,
                                                           double* __restrict__ gB, int T, int H, int W, int OH, int OW) {
     __shared__ float sh[8];
-    const long nc = blockIdx.y;
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;      // (y, z) = exact factorisation of N*C (cfn_split_nc)
     const long vol = (long)T * H * W;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     float acc[2] = {0.f, 0.f};
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void pool_hw_bwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void film_fwd_kernel(const float* __restrict__ x, const float* __restrict__ m,
                                                        const float* __restrict__ c, float* __restrict__ out, int T, int H,
                                                        int W, int f) {
-    const long nc = blockIdx.y;
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;      // (y, z) = exact factorisation of N*C (cfn_split_nc)
     const long vol = (long)T * H * W;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= vol) return;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void film_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ m, float* __restrict__ gx,
                                                        float* __restrict__ gm, float* __restrict__ gc, int T, int H, int W,
                                                        int f) {
-    const long nc = blockIdx.y;
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;      // (y, z) = exact factorisation of N*C (cfn_split_nc)
     const int Hs = H / f, Ws = W / f;
     const long svol = (long)T * Hs * Ws;
     const long s = (long)blockIdx.x * 256 + threadIdx.x;
@@ -338,13 +338,14 @@ __global__ __launch_bounds__(256) void film_bwd_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-static inline dim3 ew_grid(long vol, long NC, int vec) { return dim3(cfn_cdiv(vol, 256L * EW_ITEMS * vec), (unsigned)NC); }
+static inline dim3 ew_grid(long vol, long NC, int vec) { unsigned gy, gz; cfn_split_nc(NC, gy, gz); return dim3(cfn_cdiv(vol, 256L * EW_ITEMS * vec), gy, gz); }
+static inline dim3 nc_grid(long xblocks, long NC) { unsigned gy, gz; cfn_split_nc(NC, gy, gz); return dim3((unsigned)xblocks, gy, gz); }
 static inline bool ew_vec4(long vol, const void* p0, const void* p1 = nullptr, const void* p2 = nullptr,
                            const void* p3 = nullptr, const void* p4 = nullptr, const void* p5 = nullptr) {
     auto al = [](const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; };
     return vol % 4 == 0 && al(p0) && al(p1) && al(p2) && al(p3) && al(p4) && al(p5);
 }
-#define CFN_NC_CHECK(NC) CFN_REQUIRE((NC) > 0 && (NC) <= 65535, "N*C = %ld exceeds grid.y limit", (long)(NC))
+#define CFN_NC_CHECK(NC) CFN_REQUIRE((NC) > 0 && cfn_split_nc_ok(NC), "N*C = %ld has no grid factorisation", (long)(NC))
 
 // words of the ReLU bit mask cfn_bn_add_relu_fwd can emit for (NC, vol); 0 = no mask for this shape (vol % 4 != 0)
 extern "C" long cfn_bn_add_relu_mask_words(long NC, long vol) {
@@ -439,7 +440,7 @@ extern "C" int cfn_pool_hw_fwd(const float* x, const double* A, const double* B,
     CFN_NC_CHECK(NC);
     hipStream_t st = (hipStream_t)stream;
     const long ovol = (long)T * OH * OW;
-    hipLaunchKernelGGL(pool_hw_fwd_kernel, dim3(cfn_cdiv(ovol, 256), (unsigned)NC), dim3(256), 0, st, x, A, B, act, out, T, H, W, OH, OW);
+    hipLaunchKernelGGL(pool_hw_fwd_kernel, nc_grid(cfn_cdiv(ovol, 256), NC), dim3(256), 0, st, x, A, B, act, out, T, H, W, OH, OW);
     return cfn_check_launch("pool_hw_fwd");
 }
 
@@ -452,7 +453,7 @@ extern "C" int cfn_pool_hw_bwd(const float* gout, const float* x, const double* 
     CFN_NC_CHECK(NC);
     hipStream_t st = (hipStream_t)stream;
     const long vol = (long)T * H * W;
-    hipLaunchKernelGGL(pool_hw_bwd_kernel, dim3(cfn_cdiv(vol, 256), (unsigned)NC), dim3(256), 0, st, gout, x, A, B, act, gx,
+    hipLaunchKernelGGL(pool_hw_bwd_kernel, nc_grid(cfn_cdiv(vol, 256), NC), dim3(256), 0, st, gout, x, A, B, act, gx,
                        A ? gA : nullptr, A ? gB : nullptr, T, H, W, OH, OW);
     return cfn_check_launch("pool_hw_bwd");
 }
@@ -465,7 +466,7 @@ extern "C" int cfn_film_fwd(const float* x, const float* m, const float* c, floa
     hipStream_t st = (hipStream_t)stream;
     const long vol = (long)T * H * W;
     CfnProfScope prof(CFN_K_FUSION, st, 8.0 * NC * vol);
-    hipLaunchKernelGGL(film_fwd_kernel, dim3(cfn_cdiv(vol, 256), (unsigned)NC), dim3(256), 0, st, x, m, c, out, T, H, W, f);
+    hipLaunchKernelGGL(film_fwd_kernel, nc_grid(cfn_cdiv(vol, 256), NC), dim3(256), 0, st, x, m, c, out, T, H, W, f);
     return cfn_check_launch("film_fwd");
 }
 
@@ -477,6 +478,6 @@ extern "C" int cfn_film_bwd(const float* g, const float* x, const float* m, floa
     hipStream_t st = (hipStream_t)stream;
     const long svol = (long)T * (H / f) * (W / f);
     CfnProfScope prof(CFN_K_FUSION, st, 12.0 * NC * T * H * W);
-    hipLaunchKernelGGL(film_bwd_kernel, dim3(cfn_cdiv(svol, 256), (unsigned)NC), dim3(256), 0, st, g, x, m, gx, gm, gc, T, H, W, f);
+    hipLaunchKernelGGL(film_bwd_kernel, nc_grid(cfn_cdiv(svol, 256), NC), dim3(256), 0, st, g, x, m, gx, gm, gc, T, H, W, f);
     return cfn_check_launch("film_bwd");
 }

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void bn_add_relu_fwd_bf16_kernel(const uint16_
                                                                    const double* __restrict__ B, const uint16_t* __restrict__ res,
                                                                    const double* __restrict__ Ar, const double* __restrict__ Br,
                                                                    uint16_t* __restrict__ out, unsigned* __restrict__ mask, long vol) {
-    const long nc = blockIdx.y;
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;
     const float a = A[nc], b = B[nc] + (Br ? Br[nc] : 0.0f), ar = Ar ? Ar[nc] : 1.0f;
     const long base = nc * vol;
     unsigned mw = 0;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void bn_add_relu_bwd_g_bf16_kernel(const uint1
                                                                      uint16_t* __restrict__ g_out, double* __restrict__ gA,
                                                                      double* __restrict__ gB, double* __restrict__ gAr, long vol) {
     __shared__ float sh[12];
-    const long nc = blockIdx.y;
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;
     const long base = nc * vol;
     float acc[3] = {0.f, 0.f, 0.f};
     if (VEC) {
@@ -137,12 +137,13 @@ extern "C" int cfn_bn_add_relu_fwd_bf16(const uint16_t* y, const double* A, cons
                                         const double* Br, uint16_t* out, int* mask, long NC, long vol, void* stream) {
     CFN_REQUIRE(y && A && B && res && out, "cfn_bn_add_relu_fwd_bf16: null tensor");
     CFN_REQUIRE((Ar == nullptr) == (Br == nullptr), "cfn_bn_add_relu_fwd_bf16: Ar/Br mismatch");
-    CFN_REQUIRE(NC > 0 && NC <= 65535, "cfn_bn_add_relu_fwd_bf16: N*C = %ld exceeds grid.y", NC);
+    unsigned gy_, gz_;
+    CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "cfn_bn_add_relu_fwd_bf16: N*C = %ld exceeds grid.y", NC);
     const bool vec = sb_vec_ok(vol, y, res, out);
     CFN_REQUIRE(mask == nullptr || vec, "cfn_bn_add_relu_fwd_bf16: the bit mask needs the vector path (volume %% 8 == 0, 16-byte aligned)");
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_ELEMWISE, st, 6.0 * NC * vol);
-    const dim3 grid((unsigned)cfn_cdiv(vol, 256L * SB_ITEMS * 8), (unsigned)NC);
+    const dim3 grid((unsigned)cfn_cdiv(vol, 256L * SB_ITEMS * 8), gy_, gz_);
     if (vec) hipLaunchKernelGGL(bn_add_relu_fwd_bf16_kernel<true>, grid, dim3(256), 0, st, y, A, B, res, Ar, Br, out, (unsigned*)mask, vol);
     else hipLaunchKernelGGL(bn_add_relu_fwd_bf16_kernel<false>, grid, dim3(256), 0, st, y, A, B, res, Ar, Br, out, (unsigned*)nullptr, vol);
     return cfn_check_launch("bn_add_relu_fwd_bf16");
@@ -154,12 +155,13 @@ extern "C" int cfn_bn_add_relu_bwd_g_bf16(const uint16_t* gout, const uint16_t* 
     CFN_REQUIRE(gout && y && g && gA && gB, "cfn_bn_add_relu_bwd_g_bf16: null tensor");
     CFN_REQUIRE((out != nullptr) != (mask != nullptr), "cfn_bn_add_relu_bwd_g_bf16: give exactly one of out / mask");
     CFN_REQUIRE(gAr == nullptr || res != nullptr, "cfn_bn_add_relu_bwd_g_bf16: gAr needs res");
-    CFN_REQUIRE(NC > 0 && NC <= 65535, "cfn_bn_add_relu_bwd_g_bf16: N*C = %ld exceeds grid.y", NC);
+    unsigned gy_, gz_;
+    CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "cfn_bn_add_relu_bwd_g_bf16: N*C = %ld exceeds grid.y", NC);
     const bool vec = sb_vec_ok(vol, gout, y, g) && sb_vec_ok(vol, gout2, out, res);
     CFN_REQUIRE(mask == nullptr || vec, "cfn_bn_add_relu_bwd_g_bf16: the bit mask needs the vector path");
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_ELEMWISE, st, (6.0 + (gout2 ? 2.0 : 0.0) + (out ? 2.0 : 0.125) + (gAr ? 2.0 : 0.0)) * NC * vol);
-    const dim3 grid((unsigned)cfn_cdiv(vol, 256L * SB_ITEMS * 8), (unsigned)NC);
+    const dim3 grid((unsigned)cfn_cdiv(vol, 256L * SB_ITEMS * 8), gy_, gz_);
     if (vec) hipLaunchKernelGGL(bn_add_relu_bwd_g_bf16_kernel<true>, grid, dim3(256), 0, st, gout, gout2, out, (const unsigned*)mask, y, res, g, gA, gB, gAr, vol);
     else hipLaunchKernelGGL(bn_add_relu_bwd_g_bf16_kernel<false>, grid, dim3(256), 0, st, gout, gout2, out, (const unsigned*)nullptr, y, res, g, gA, gB, gAr, vol);
     return cfn_check_launch("bn_add_relu_bwd_g_bf16");
@@ -173,7 +175,7 @@ __device__ __forceinline__ int sb_ap_end(int o, int O, int S) { return ((o + 1) 
 __global__ __launch_bounds__(256) void pool_hw_fwd_bf16_kernel(const uint16_t* __restrict__ x, const double* __restrict__ A,
                                                                const double* __restrict__ B, int act, float* __restrict__ out, int T,
                                                                int H, int W, int OH, int OW) {
-    const long nc = blockIdx.y;
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;
     const long ovol = (long)T * OH * OW;
     const long o = (long)blockIdx.x * 256 + threadIdx.x;
     if (o >= ovol) return;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void pool_hw_bwd_bf16_kernel(const float* __re
                                                                uint16_t* __restrict__ gx, double* __restrict__ gA, double* __restrict__ gB,
                                                                int T, int H, int W, int OH, int OW) {
     __shared__ float sh[8];
-    const long nc = blockIdx.y;
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;
     const long vol = (long)T * H * W;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     float acc[2] = {0.f, 0.f};
@@ -225,10 +227,11 @@ extern "C" int cfn_pool_hw_fwd_bf16(const uint16_t* x, const double* A, const do
                                     int W, int OH, int OW, void* stream) {
     CFN_REQUIRE(x && out, "cfn_pool_hw_fwd_bf16: null tensor");
     CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pool_hw_fwd_bf16: A/B mismatch");
-    CFN_REQUIRE(NC > 0 && NC <= 65535, "cfn_pool_hw_fwd_bf16: N*C = %ld exceeds grid.y", NC);
+    unsigned gy_, gz_;
+    CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "cfn_pool_hw_fwd_bf16: N*C = %ld exceeds grid.y", NC);
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_ELEMWISE, st, 2.0 * NC * T * H * W);
-    hipLaunchKernelGGL(pool_hw_fwd_bf16_kernel, dim3((unsigned)cfn_cdiv((long)T * OH * OW, 256), (unsigned)NC), dim3(256), 0, st, x, A, B, act, out,
+    hipLaunchKernelGGL(pool_hw_fwd_bf16_kernel, dim3((unsigned)cfn_cdiv((long)T * OH * OW, 256), gy_, gz_), dim3(256), 0, st, x, A, B, act, out,
                        T, H, W, OH, OW);
     return cfn_check_launch("pool_hw_fwd_bf16");
 }
@@ -238,10 +241,11 @@ extern "C" int cfn_pool_hw_bwd_bf16(const float* gout, const uint16_t* x, const 
     CFN_REQUIRE(gout && x && gx, "cfn_pool_hw_bwd_bf16: null tensor");
     CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pool_hw_bwd_bf16: A/B mismatch");
     CFN_REQUIRE(A == nullptr || (gA && gB), "cfn_pool_hw_bwd_bf16: prologue needs gA, gB");
-    CFN_REQUIRE(NC > 0 && NC <= 65535, "cfn_pool_hw_bwd_bf16: N*C = %ld exceeds grid.y", NC);
+    unsigned gy_, gz_;
+    CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "cfn_pool_hw_bwd_bf16: N*C = %ld exceeds grid.y", NC);
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_ELEMWISE, st, 4.0 * NC * T * H * W);
-    hipLaunchKernelGGL(pool_hw_bwd_bf16_kernel, dim3((unsigned)cfn_cdiv((long)T * H * W, 256), (unsigned)NC), dim3(256), 0, st, gout, x, A, B, act, gx,
+    hipLaunchKernelGGL(pool_hw_bwd_bf16_kernel, dim3((unsigned)cfn_cdiv((long)T * H * W, 256), gy_, gz_), dim3(256), 0, st, gout, x, A, B, act, gx,
                        A ? gA : nullptr, A ? gB : nullptr, T, H, W, OH, OW);
     return cfn_check_launch("pool_hw_bwd_bf16");
 }

@@ -99,6 +99,36 @@ def test_pwconv_full_size(Cin, Cout, H):
     assert relerr(q, (y.double() ** 2).sum((2, 3, 4))) <= 1e-6
 
 
+
+def test_pwconv_sample_beyond_the_descriptor_range():
+    """whole-video validation (train_coarse_fineFEAT.py:215-224 feeds up to ~1000 frames at once): layer 1's conv1 output is
+    54 x 1000 x 112 x 112 x 4 B = 2.7 GB for ONE sample, beyond the kernels' 2 GiB buffer descriptor.  Without autograd the op
+    runs over frame ranges; with autograd it refuses loudly."""
+    Cin, Cout, Tn, H = 24, 54, 1000, 112
+    x = _rand(1, 1, Cin, Tn, H, H)
+    w = _rand(2, Cout, Cin, 1, 1, 1, scale=(2.0 / Cin) ** 0.5)
+    A = torch.rand(1, Cin, device=DEV) + 0.5
+    B = _rand(3, 1, Cin, scale=0.1)
+    with torch.no_grad():
+        y, s, q = ops().pwconv(x, w, A, B, 1, 1, True)
+        P = Tn * H * H
+        g = torch.Generator().manual_seed(0)
+        pos = torch.randint(0, P, (512,), generator=g)
+        pos[:4] = torch.tensor([0, P - 1, P // 2, 127])
+        a = torch.relu(x.view(Cin, P)[:, pos.to(DEV)].double() * A.double().view(Cin, 1) + B.double().view(Cin, 1))
+        ref = w.view(Cout, Cin).double() @ a
+        got = y.view(Cout, P)[:, pos.to(DEV)].double()
+        assert float((got - ref).abs().max() / ref.abs().max()) <= 2e-5
+        assert relerr(s, y.double().sum((2, 3, 4))) <= 1e-6
+        assert relerr(q, (y.double() ** 2).sum((2, 3, 4))) <= 1e-6
+        # the frame ranges agree with the one-launch result where one launch is possible
+        y_small = ops().pwconv(x[:, :, :300].contiguous(), w, A, B, 1, 1, False)[0]
+        assert relerr(y[:, :, :300], y_small) <= 1e-6
+    del y, got
+    with pytest.raises(RuntimeError, match='2 GiB'):
+        ops().pwconv(x, w.requires_grad_(True), A, B, 1, 1, True)
+
+
 def test_grid_pool_unpool_round_trip_full_size():
     """Grid Pool resampling + Grid Unpool at the in-model size (1,24,256,56,56), K = 65: frame indices bit-exact against
     the oracle, sorted and in range, gathered frames equal the 2-tap lerp of their sources, idempotent on a uniform CDF"""

@@ -621,3 +621,44 @@ def test_bitwise_reproducible(case):
     for r in runs[1:]:
         for a, b in zip(runs[0], r):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('op', ['affine_act', 'channel_stats', 'bn_add_relu', 'pool_hw', 'dwconv_t5'])
+def test_more_than_65535_channel_rows(op, dtype):
+    """batch x channels beyond grid.y's 65535 (batch 32 of X3D-M's 2048-wide head; big validation batches): the (n, c) index
+    is factorised over grid.y x grid.z.  Checked against the same op run on the two halves of the batch (each <= 65535 rows,
+    the path the CPU-parity tests above cover): forward and gradients identical."""
+    o = ops()
+    N, C, T, H, W = 70, 1000, 2, 4, 4                    # N*C = 70000 = 35000 x 2
+    dt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    if dtype == 'bf16' and op in ('affine_act', 'channel_stats'):
+        pytest.skip('fp32-only op')
+    x = rnd(1, N, C, T, H, W).to(DEV).to(dt)
+    A, B = (1 + 0.2 * rnd(2, N, C)).to(DEV), (0.2 * rnd(3, N, C)).to(DEV)
+    res = rnd(4, N, C, T, H, W).to(DEV).to(dt)
+    w5 = rnd(5, C, 1, 5, 1, 1).to(DEV)
+
+    def run(sl):
+        xs = x[sl].clone().requires_grad_(True)
+        As, Bs = A[sl].clone().requires_grad_(True), B[sl].clone().requires_grad_(True)
+        if op == 'affine_act':
+            out = (o.affine_act(xs, As, Bs, 2),)
+        elif op == 'channel_stats':
+            out = o.channel_stats(xs)
+        elif op == 'bn_add_relu':
+            out = (o.bn_add_relu(xs, As, Bs, res[sl]),)
+        elif op == 'pool_hw':
+            out = (o.pool_hw(xs, 1, 1, As, Bs, 1),)
+        else:
+            xin = xs.float() if dtype == 'bf16' else xs
+            out = o.dwconv_t5(xin, w5, stats=True, out_dtype=dt if dtype == 'bf16' else None)
+        sum((v.double() * (0.5 + i)).sum() for i, v in enumerate(out) if v is not None).backward()
+        grads = [xs.grad] + ([As.grad, Bs.grad] if As.grad is not None else [])
+        return [v.detach() for v in out if v is not None], grads
+
+    full_o, full_g = run(slice(0, N))
+    lo_o, lo_g = run(slice(0, N // 2))
+    hi_o, hi_g = run(slice(N // 2, N))
+    for f, a, b in zip(full_o + full_g, lo_o + lo_g, hi_o + hi_g):
+        assert torch.equal(f, torch.cat([a, b], 0))
