@@ -46,6 +46,24 @@ static inline bool cfn_split_nc_ok(long NC) { unsigned a, b; return cfn_split_nc
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
+// Wave-uniform values the compiler cannot prove uniform (a wave index threadIdx.x >> 6, a value merged out of a divergent
+// branch) put buffer descriptors / scalar offsets in VGPRs, and every buffer instruction built on them is wrapped in a
+// "waterfall" loop (readfirstlane + compare + saveexec + branch: ~10 extra instructions and a taken branch per access).
+// cfn_uni() states the uniformity; tools/waterfall_scan.py lists the kernels whose ISA still contains such loops.
+__device__ __forceinline__ int cfn_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned cfn_uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ long cfn_uni(long v) {
+    const unsigned lo = cfn_uni((unsigned)v), hi = cfn_uni((unsigned)((unsigned long)v >> 32));
+    return (long)(((unsigned long)hi << 32) | lo);
+}
+__device__ __forceinline__ float cfn_uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+template <class T> __device__ __forceinline__ T* cfn_uni(T* p) { return (T*)cfn_uni((long)p); }
+
+// raw buffer descriptor over `bytes` bytes at p (both stated wave uniform: see cfn_uni)
+template <class T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t cfn_rsrc(T* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)cfn_uni((long)p), 0, cfn_uni(bytes), 0x00020000);
+}
+
 // v_exp_f32 + v_rcp_f32 (1 ulp each): ~6 VALU slots instead of the ~16 of an IEEE division
 __device__ __forceinline__ float cfn_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 

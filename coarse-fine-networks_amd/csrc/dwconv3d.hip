@@ -206,15 +206,14 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
     constexpr int OOB = 0x7ffffff0;
     const long gi0 = ((long)n * C + c0) * T * plane_i, go0 = ((long)n * C + c0) * T * plane_o;
     const unsigned span_i = (unsigned)((long)ncg * T * plane_i * DW_ES), span_o = (unsigned)((long)ncg * T * plane_o * DW_ES);
-    __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<dwe_t*>(a.src + gi0), 0, span_i, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<dwe_t*>((MODE == DW_DGRAD && a.src2 ? a.src2 : a.src) + gi0), 0, span_i, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs1 = cfn_rsrc(const_cast<dwe_t*>(a.src + gi0), span_i);
+    __amdgpu_buffer_rsrc_t rs2 = cfn_rsrc(const_cast<dwe_t*>((MODE == DW_DGRAD && a.src2 ? a.src2 : a.src) + gi0), span_i);
     // per-thread operands / results at output resolution: FWD/DGRAD dst, DGRAD xin, WGRAD gy / yout
     const dwe_t* po1 = MODE == DW_WGRAD ? a.gy : (MODE == DW_DGRAD && a.xin ? a.xin : a.src);
     const dwe_t* po2 = MODE == DW_WGRAD && a.yout ? a.yout : po1;
-    __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<dwe_t*>(po1 + go0), 0, span_o, 0x00020000);
-    __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<dwe_t*>(po2 + go0), 0, span_o, 0x00020000);
-    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((MODE == DW_WGRAD ? const_cast<dwe_t*>(a.src) : a.dst) + (MODE == DW_WGRAD ? gi0 : go0), 0,
-                                                                   MODE == DW_WGRAD ? 0u : span_o, 0x00020000);
+    __amdgpu_buffer_rsrc_t ro1 = cfn_rsrc(const_cast<dwe_t*>(po1 + go0), span_o);
+    __amdgpu_buffer_rsrc_t ro2 = cfn_rsrc(const_cast<dwe_t*>(po2 + go0), span_o);
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc((MODE == DW_WGRAD ? const_cast<dwe_t*>(a.src) : a.dst) + (MODE == DW_WGRAD ? gi0 : go0), MODE == DW_WGRAD ? 0u : span_o);
     const int ovo = active ? (int)(((long)c_local * T * plane_o + (long)hrow0 * Wo + wo) * DW_ES) : OOB;   // this thread's first output
     int relb[MAXLD];
 #pragma unroll
@@ -425,7 +424,10 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
         }
 
         if (MODE != DW_WGRAD) {
-            const int vo = emit ? ovo : OOB, so = emit ? to * (int)plane_o * DW_ES : 0;
+            // the scalar offset depends on wave-uniform values only (a per-lane soffset makes hipcc wrap every store in a
+            // waterfall loop); the lane's own validity is in ovo
+            const bool emit_u = to >= t0 && to < t1;
+            const int vo = emit_u ? ovo : OOB, so = emit_u ? to * (int)plane_o * DW_ES : 0;
             const float em = emit ? 1.0f : 0.0f;
 #pragma unroll
             for (int i = 0; i < HS; ++i) {
@@ -967,13 +969,13 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_fast_kernel(const DwS2Args 
 #pragma unroll
     for (int k = 0; k < 27; ++k) w[k] = a.w[c * 27 + k];
     const float pa = a.A[nc], pb2 = a.B[nc];
-    const int po = Ho * Wo, pi = Hi * Wi;
+    const int po = cfn_uni(Ho * Wo), pi = cfn_uni(Hi * Wi);   // (hipcc merges Ho*Wo with the divergent definition of p)
     constexpr int OOB = 0x7ffffff0;
     const int nch = PACKED ? min(a.CPB, a.NC - nc0) : 1;
-    __amdgpu_buffer_rsrc_t rgy = __builtin_amdgcn_make_buffer_rsrc(const_cast<dwe_t*>(a.gy + (long)nc0 * T * po), 0, (unsigned)((long)nch * T * po * DW_ES), 0x00020000);
-    __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<dwe_t*>(a.y + (long)nc0 * T * po), 0, (unsigned)((long)nch * T * po * DW_ES), 0x00020000);
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<dwe_t*>(a.x + (long)nc0 * T * pi), 0, (unsigned)((long)nch * T * pi * DW_ES), 0x00020000);
-    __amdgpu_buffer_rsrc_t rgx = __builtin_amdgcn_make_buffer_rsrc(a.gx + (long)nc0 * T * pi, 0, (unsigned)((long)nch * T * pi * DW_ES), 0x00020000);
+    __amdgpu_buffer_rsrc_t rgy = cfn_rsrc(const_cast<dwe_t*>(a.gy + (long)nc0 * T * po), (unsigned)((long)nch * T * po * DW_ES));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(const_cast<dwe_t*>(a.y + (long)nc0 * T * po), (unsigned)((long)nch * T * po * DW_ES));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<dwe_t*>(a.x + (long)nc0 * T * pi), (unsigned)((long)nch * T * pi * DW_ES));
+    __amdgpu_buffer_rsrc_t rgx = cfn_rsrc(a.gx + (long)nc0 * T * pi, (unsigned)((long)nch * T * pi * DW_ES));
     const int gb = (cslot * T * po + i * Wo + j) * DW_ES;
     const int go[4] = {ok ? gb : OOB, ok && j1 ? gb + DW_ES : OOB, ok && i1 ? gb + Wo * DW_ES : OOB, ok && i1 && j1 ? gb + (Wo + 1) * DW_ES : OOB};
     const int xb = (cslot * T * pi + 2 * i * Wi + 2 * j) * DW_ES;

@@ -46,9 +46,10 @@ __global__ __launch_bounds__(256, 4) void dw3d_small_fwd_kernel(const DwSmallArg
     // come from L2
     const long widx = __builtin_amdgcn_readfirstlane((int)(L * 4 + wv));
     if (widx >= a.total_waves) return;                // whole waves only: no barrier anywhere below
-    const int chunk = (int)(widx % a.nchunks);
-    const long nc = widx / a.nchunks;
-    const int c = (int)(nc % a.C);
+    // (the 64-bit divisions are expanded into vector code: state the uniformity of their results as well)
+    const int chunk = cfn_uni((int)(widx % a.nchunks));
+    const long nc = cfn_uni((long)(widx / a.nchunks));
+    const int c = cfn_uni((int)(nc % a.C));
     const int T = a.T, t0 = chunk * a.TT, t1 = min(t0 + a.TT, T);
     float* img = smem + wv * 2 * IMG;
 
@@ -79,12 +80,12 @@ __global__ __launch_bounds__(256, 4) void dw3d_small_fwd_kernel(const DwSmallArg
     // offset: loads return 0, stores are dropped): with no vector-memory instruction under a branch the compiler counts
     // them and waits with vmcnt(N) for exactly the frame it needs, so the DEPTH prefetched frames really stay in flight
     // (with predicated loads it waits with vmcnt(0) and every frame costs a full HBM round trip).
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + nc * (long)T * P), 0, (unsigned)((long)T * P * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + nc * (long)T * P, 0, (unsigned)((long)T * P * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<float*>(a.x + nc * (long)T * P), (unsigned)((long)T * P * 4));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * P, (unsigned)((long)T * P * 4));
     const int ldo = ld_on ? e0 * 4 : OOB;
     auto fetch = [&](int f) -> f4 {
         const bool want = f >= 0 && f < T && f <= t1;
-        const int vo = want ? ldo : OOB, so = want ? f * P * 4 : 0;
+        const int vo = want ? ldo : OOB, so = cfn_uni(want ? f * P * 4 : 0);
         f4 v = {0.f, 0.f, 0.f, 0.f};
         if (LV == 4) v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, so, 0));
         else v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, so, 0));
@@ -109,9 +110,22 @@ __global__ __launch_bounds__(256, 4) void dw3d_small_fwd_kernel(const DwSmallArg
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
-    float acc[3][HS];
+    // Accumulators as explicit register PAIRS so that the taps run on v_pk_fma_f32 (two FMAs per issue slot; hipcc leaves
+    // this loop scalar): a01[i] = (out(f+1), out(f)) of row i share the input value and take the weight pair
+    // (w[kt=0][tap], w[kt=1][tap]); the kt=2 sums of two ADJACENT rows share the input rows in the middle and take the pair
+    // (w[2][kh][kw], w[2][kh-1][kw]).  108 -> 60 FMA instructions per 4-row strip and frame.
+    typedef float __attribute__((ext_vector_type(2))) p2;
+    constexpr int HP = (HS + 1) / 2;                  // row pairs
+    p2 a01[HS], a2[HP];
 #pragma unroll
-    for (int i = 0; i < HS; ++i) acc[0][i] = acc[1][i] = acc[2][i] = 0.0f;
+    for (int i = 0; i < HS; ++i) a01[i] = (p2){0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < HP; ++i) a2[i] = (p2){0.0f, 0.0f};
+    p2 w01[9], w2p[6];                                // wave uniform (SGPR pairs)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) w01[j] = (p2){wr[j], wr[9 + j]};
+#pragma unroll
+    for (int j = 0; j < 6; ++j) w2p[j] = (p2){wr[18 + 3 + j], wr[18 + j]};      // (kh = 1 + j/3, kh - 1) at kw = j % 3
     float st1 = 0.0f, st2 = 0.0f;
     const int yo = act_lane ? (row0 * PH + cc) * 4 : OOB;
 
@@ -128,30 +142,43 @@ __global__ __launch_bounds__(256, 4) void dw3d_small_fwd_kernel(const DwSmallArg
 #pragma unroll
             for (int r = 0; r < HS + 2; ++r) {
                 const float v0 = tp[r * PIT], v1 = tp[r * PIT + 1], v2 = tp[r * PIT + 2];
+                const p2 b0 = {v0, v0}, b1 = {v1, v1}, b2 = {v2, v2};
 #pragma unroll
                 for (int i = 0; i < HS; ++i) {
                     const int kh = r - i;
-                    if (kh >= 0 && kh < 3) {
+                    if (kh >= 0 && kh < 3)
+                        a01[i] = __builtin_elementwise_fma(w01[kh * 3 + 0], b0, __builtin_elementwise_fma(w01[kh * 3 + 1], b1, __builtin_elementwise_fma(w01[kh * 3 + 2], b2, a01[i])));
+                }
 #pragma unroll
-                        for (int kt = 0; kt < 3; ++kt)
-                            acc[kt][i] = fmaf(wr[kt * 9 + kh * 3 + 0], v0, fmaf(wr[kt * 9 + kh * 3 + 1], v1, fmaf(wr[kt * 9 + kh * 3 + 2], v2, acc[kt][i])));
+                for (int ip = 0; ip < HP; ++ip) {      // rows (2 ip, 2 ip + 1): kh = r - 2 ip for the first, kh - 1 for the second
+                    const int kh = r - 2 * ip;
+                    const bool has2 = 2 * ip + 1 < HS;
+                    if (kh == 0 || (kh == 1 && !has2) || (kh == 2 && !has2)) {
+                        a2[ip].x = fmaf(wr[18 + kh * 3 + 0], v0, fmaf(wr[18 + kh * 3 + 1], v1, fmaf(wr[18 + kh * 3 + 2], v2, a2[ip].x)));
+                    } else if (kh == 1 || kh == 2) {
+                        a2[ip] = __builtin_elementwise_fma(w2p[(kh - 1) * 3 + 0], b0, __builtin_elementwise_fma(w2p[(kh - 1) * 3 + 1], b1, __builtin_elementwise_fma(w2p[(kh - 1) * 3 + 2], b2, a2[ip])));
+                    } else if (kh == 3 && has2) {
+                        a2[ip].y = fmaf(wr[18 + 6 + 0], v0, fmaf(wr[18 + 6 + 1], v1, fmaf(wr[18 + 6 + 2], v2, a2[ip].y)));
                     }
                 }
             }
         }
         const int to = f - 1;
         const bool emit = to >= t0 && to < t1 && f <= f_last;
-        const int so = emit ? to * P * 4 : 0;
+        const int so = cfn_uni(emit ? to * P * 4 : 0);
 #pragma unroll
         for (int i = 0; i < HS; ++i) {
             const bool ok = emit && act_lane && row0 + i < PH;
-            const float v = ok ? acc[2][i] : 0.0f;
+            const float v = ok ? ((i & 1) ? a2[i >> 1].y : a2[i >> 1].x) : 0.0f;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, ok ? yo + i * PH * 4 : OOB, so, 0);
             st1 += v;
             st2 = fmaf(v, v, st2);
         }
 #pragma unroll
-        for (int i = 0; i < HS; ++i) { acc[2][i] = acc[1][i]; acc[1][i] = acc[0][i]; acc[0][i] = 0.0f; }
+        for (int i = 0; i < HS; ++i) {
+            if (i & 1) a2[i >> 1].y = a01[i].y; else a2[i >> 1].x = a01[i].y;
+            a01[i] = (p2){0.0f, a01[i].x};
+        }
     };
     constexpr int G = DEPTH;
     f4 cur[G], nxt[G];

@@ -8,6 +8,7 @@
 #include "cfn_common.h"
 
 typedef float __attribute__((ext_vector_type(4))) f4v;
+typedef unsigned __attribute__((ext_vector_type(4))) u4v_t5;
 enum { T5_FWD = 0, T5_DGRAD = 1, T5_WGRAD = 2 };
 
 // BF (bf16 activation path): the conv OUTPUT side (y, gy) is bf16, the input side (x, gx) stays fp32 -- the stem conv
@@ -170,6 +171,75 @@ __global__ __launch_bounds__(256) void dwt5_kernel(const T5Args a) {
     }
 }
 
+// Forward, float4 rows (plane % 4 == 0): the same march, but every global access of the frame loop is an UNCONDITIONAL
+// buffer load / store (an unwanted access gets an out-of-range offset).  With the loads under `if (t < T)` the compiler can
+// only wait with vmcnt(0), i.e. for the load it issued a moment ago as well: one HBM round trip per frame and 4.9 TB/s; with
+// exact vmcnt(N) waits the PF look-ahead loads really stay in flight (a one-float4-per-thread copy of the same tensor runs at
+// 6.35 TB/s on this box, tools/probe/stream_probe.hip).  env CFN_T5_STREAM=0 falls back to dwt5_kernel<T5_FWD>.
+template <bool BF>
+__global__ __launch_bounds__(256) void dwt5_fwd_stream_kernel(const T5Args a) {
+    typedef __bf16 __attribute__((ext_vector_type(4))) bf4;
+    typedef unsigned __attribute__((ext_vector_type(2))) u2v;
+    constexpr int PF = 3, OOB = 0x7ffffff0, OES = BF ? 2 : 4;
+    __shared__ float sh[8];
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;
+    const int c = (int)(nc % a.C);
+    const int chunk = blockIdx.x % a.nchunks, pc = blockIdx.x / a.nchunks;
+    const int p = (pc * 256 + (int)threadIdx.x) * 4;
+    const bool ok = p < a.plane;
+    const int T = a.T, t0 = chunk * a.TT, t1 = min(t0 + a.TT, T);
+    const int plane = (int)a.plane;
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(static_cast<const float*>(a.src) + nc * T * a.plane, (unsigned)((long)T * plane * 4));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(static_cast<char*>(a.dst) + nc * T * a.plane * OES, (unsigned)((long)T * plane * OES));
+    const int vx = ok ? p * 4 : OOB, vy = ok ? p * OES : OOB;
+    float wk[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) wk[k] = cfn_uni(a.w[c * 5 + k]);
+    auto ld = [&](int t) -> f4v {
+        const bool tv = t >= 0 && t < T && t <= t1 + 1;                   // wave uniform
+        return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rx, tv ? vx : OOB, tv ? t * plane * 4 : 0, 0));
+    };
+    // ring of RING = 5 + PF frame registers with STATIC slots (the loop is unrolled RING steps): slot (k % RING) holds frame
+    // t0 - 2 + k.  No register moves between steps, so the wait before step j is for the load issued PF steps earlier and the
+    // PF - 1 younger loads (and the stores) stay in flight.
+    constexpr int RING = 5 + PF;
+    f4v R[RING];
+#pragma unroll
+    for (int k = 0; k < RING - 1; ++k) R[k] = ld(t0 - 2 + k);             // frames t0-2 .. t0+1+PF (slots 0 .. RING-2)
+    float st1 = 0.f, st2 = 0.f;
+    for (int tb = t0; tb < t1; tb += RING) {
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+            const int t = tb + j;
+            const bool em = t < t1;                                        // wave uniform: steps beyond the chunk store nothing
+            R[(j + RING - 1) % RING] = ld(t + 2 + PF);                     // frame t-3's slot is free
+            f4v y = R[j % RING] * wk[0] + R[(j + 1) % RING] * wk[1] + R[(j + 2) % RING] * wk[2] + R[(j + 3) % RING] * wk[3] + R[(j + 4) % RING] * wk[4];
+            const int so = em ? t * plane * OES : 0;
+            if (BF) {                                                      // statistics over the rounded values the consumer reads
+                const bf4 yb = __builtin_convertvector(y, bf4);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, yb), ry, em ? vy : OOB, so, 0);
+                y = __builtin_convertvector(yb, f4v);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v_t5, y), ry, em ? vy : OOB, so, 0);
+            }
+            const float m = (em && ok) ? 1.0f : 0.0f;
+            const f4v ym = y * m;
+            st1 += ym.x + ym.y + ym.z + ym.w;
+            st2 += ym.x * y.x + ym.y * y.y + ym.z * y.z + ym.w * y.w;
+        }
+    }
+    if (a.s1) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        st1 = cfn_wave_sum(st1); st2 = cfn_wave_sum(st2);
+        if (lane == 0) { sh[wave] = st1; sh[4 + wave] = st2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&a.s1[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
+            atomicAdd(&a.s2[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
+        }
+    }
+}
+
 template <int MODE, bool BF = false>
 static int t5_launch(T5Args& a, int N, hipStream_t st) {
     const long NC = (long)N * a.C;
@@ -184,6 +254,11 @@ static int t5_launch(T5Args& a, int N, hipStream_t st) {
     a.TT = TT;
     a.nchunks = cfn_cdiv(a.T, TT);
     dim3 grid((unsigned)(a.pchunks * a.nchunks), gy_, gz_);
+    static const int stream_on = getenv("CFN_T5_STREAM") ? atoi(getenv("CFN_T5_STREAM")) : 1;
+    if (MODE == T5_FWD && v4 && stream_on && (long)a.T * a.plane * 4 < 0x7ffffff0L) {
+        hipLaunchKernelGGL((dwt5_fwd_stream_kernel<BF>), grid, dim3(256), 0, st, a);
+        return cfn_check_launch("dwconv_t5");
+    }
     if (v4) hipLaunchKernelGGL((dwt5_kernel<MODE, 4, BF>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((dwt5_kernel<MODE, 1, BF>), grid, dim3(256), 0, st, a);
     return cfn_check_launch("dwconv_t5");

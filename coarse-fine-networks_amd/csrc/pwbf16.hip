@@ -88,7 +88,7 @@ template <int MT, int MODE, bool STATS, int ACT, bool TWO>
 __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_kernel(const PwbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = 32 * MT;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kg = lane >> 5, j = lane & 31;
+    const int tid = threadIdx.x, wave = cfn_uni(tid >> 6), lane = tid & 63, kg = lane >> 5, j = lane & 31;
     const int K = a.K, M = a.M, Q = a.Q, Kp = a.Kp, rowb = a.rowb;
 
     unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
@@ -139,16 +139,14 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_kernel(const PwbArgs a) {
 
     constexpr bool two_src = MODE == PWB_DGRAD && TWO;
     const long src_n = (long)n * K * Q, dst_n = (long)n * M * Q;
-    __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.src + src_n), 0, (unsigned)((long)K * Q * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>((two_src ? a.src2 : a.src) + src_n), 0, (unsigned)((long)K * Q * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs1 = cfn_rsrc(const_cast<uint16_t*>(a.src + src_n), (unsigned)((long)K * Q * 2));
+    __amdgpu_buffer_rsrc_t rs2 = cfn_rsrc(const_cast<uint16_t*>((two_src ? a.src2 : a.src) + src_n), (unsigned)((long)K * Q * 2));
     // rows m0.. of the output sample block: rows >= M fall outside the range (stores dropped, loads return 0)
     const int mrows = max(min(BM, M - m0), 0);
-    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.dst + dst_n + (long)m0 * Q, 0, (unsigned)((long)mrows * Q * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>((MODE == PWB_DGRAD && a.ex ? a.ex : a.src) + (MODE == PWB_DGRAD && a.ex ? dst_n + (long)m0 * Q : 0)), 0,
-                                                                   (MODE == PWB_DGRAD && a.ex) ? (unsigned)((long)mrows * Q * 2) : 0u, 0x00020000);
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.dst + dst_n + (long)m0 * Q, (unsigned)((long)mrows * Q * 2));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<uint16_t*>((MODE == PWB_DGRAD && a.ex ? a.ex : a.src) + (MODE == PWB_DGRAD && a.ex ? dst_n + (long)m0 * Q : 0)), (MODE == PWB_DGRAD && a.ex) ? (unsigned)((long)mrows * Q * 2) : 0u);
     const long accP = (long)(Q / ((long)a.H * a.W)) * a.aHo * a.aWo;      // positions per (n, row) of the compact tensor
-    __amdgpu_buffer_rsrc_t rac = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>((MODE == PWB_DGRAD && a.acc ? a.acc + ((long)n * M + m0) * accP : a.src)), 0,
-                                                                    (MODE == PWB_DGRAD && a.acc) ? (unsigned)((long)mrows * accP * 2) : 0u, 0x00020000);
+    __amdgpu_buffer_rsrc_t rac = cfn_rsrc(const_cast<uint16_t*>((MODE == PWB_DGRAD && a.acc ? a.acc + ((long)n * M + m0) * accP : a.src)), (MODE == PWB_DGRAD && a.acc) ? (unsigned)((long)mrows * accP * 2) : 0u);
 
     float ssum[MT], qsum[MT];
 #pragma unroll
@@ -436,7 +434,7 @@ template <int MTW, int NTW, int ACT, bool HASY>
 __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_wgrad_kernel(const PwbWgArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* red = reinterpret_cast<float*>(smem);                           // [PWB_WAVES][MTW*NTW][64*16]  (one tile set per wave)
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kg = lane >> 5, r = lane & 31;
+    const int tid = threadIdx.x, wave = cfn_uni(tid >> 6), lane = tid & 63, kg = lane >> 5, r = lane & 31;
     const int M = a.M, K = a.K, Q = a.Q;
     unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
     const int strip = L % a.strips; L /= a.strips;
@@ -466,9 +464,9 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_wgrad_kernel(const PwbWgAr
         cpb[i] = (ok && a.pb) ? (float)a.pb[(long)n * K + k] : 0.0f;
         offk[i] = ok ? (k * Q + kg * 8) * 2 : PWB_OOB;
     }
-    __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.gy + (long)n * M * Q), 0, (unsigned)((long)M * Q * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>((has_y ? a.y : a.gy) + (long)n * M * Q), 0, (unsigned)((long)M * Q * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.x + (long)n * K * Q), 0, (unsigned)((long)K * Q * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(const_cast<uint16_t*>(a.gy + (long)n * M * Q), (unsigned)((long)M * Q * 2));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(const_cast<uint16_t*>((has_y ? a.y : a.gy) + (long)n * M * Q), (unsigned)((long)M * Q * 2));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<uint16_t*>(a.x + (long)n * K * Q), (unsigned)((long)K * Q * 2));
 
     f16v acc[MTW][NTW];
 #pragma unroll
@@ -487,7 +485,7 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_wgrad_kernel(const PwbWgAr
     auto issue = [&](int s, u4v (&g)[MTW], u4v (&yy)[MTW], u4v (&xx)[NTW]) {
         const int p0 = s << 4;
         const bool pv = s < s1 && p0 + kg * 8 < Q;
-        const int so = pv ? p0 * 2 : 0;
+        const int so = cfn_uni(s < s1 ? p0 * 2 : 0);                        // wave uniform; the lane's own validity is in the vector offset
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
             g[i] = __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rg, pv ? offm[i] : PWB_OOB, so, 0));

@@ -101,16 +101,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
     const long src_n = STEM ? (long)n * a.Cimg * a.Pin : (long)n * K * src_pitch;
     const long dst_n = (long)n * M * dst_pitch;
     const int row_bytes = src_pitch * 4;
-    __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src + src_n), 0,
-                                                                   STEM ? 0 : K * row_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((two_src ? a.src2 : a.src) + src_n), 0,
-                                                                   STEM ? 0 : K * row_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.dst + dst_n, 0, M * dst_pitch * 4, 0x00020000);
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((a.ex ? a.ex : a.src) + (a.ex ? dst_n : 0)), 0,
-                                                                   a.ex ? M * dst_pitch * 4 : 0, 0x00020000);
-    __amdgpu_buffer_rsrc_t racc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(MODE == PW_DGRAD && a.acc ? a.acc + (long)n * M * ((long)(a.Pin / (a.Hi * a.Wi)) * a.acc_Ho * a.acc_Wo) : a.src), 0,
-        MODE == PW_DGRAD && a.acc ? (unsigned)((long)M * (a.Pin / (a.Hi * a.Wi)) * a.acc_Ho * a.acc_Wo * 4) : 0u, 0x00020000);
+    __amdgpu_buffer_rsrc_t r1 = cfn_rsrc(const_cast<float*>(a.src + src_n), STEM ? 0 : K * row_bytes);
+    __amdgpu_buffer_rsrc_t r2 = cfn_rsrc(const_cast<float*>((two_src ? a.src2 : a.src) + src_n), STEM ? 0 : K * row_bytes);
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.dst + dst_n, M * dst_pitch * 4);
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<float*>((a.ex ? a.ex : a.src) + (a.ex ? dst_n : 0)), a.ex ? M * dst_pitch * 4 : 0);
+    __amdgpu_buffer_rsrc_t racc = cfn_rsrc(const_cast<float*>(MODE == PW_DGRAD && a.acc ? a.acc + (long)n * M * ((long)(a.Pin / (a.Hi * a.Wi)) * a.acc_Ho * a.acc_Wo) : a.src), MODE == PW_DGRAD && a.acc ? (unsigned)((long)M * (a.Pin / (a.Hi * a.Wi)) * a.acc_Ho * a.acc_Wo * 4) : 0u);
     float sacc[MT], qacc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) { sacc[i] = 0.0f; qacc[i] = 0.0f; }

@@ -104,11 +104,10 @@ __global__ __launch_bounds__(256, ACT < 0 ? 3 : 2) void pw_bwd_fused_kernel(cons
     // offset: loads return 0, stores are dropped): the compiler can then count them and wait with vmcnt(N) for the
     // prefetched rows only, instead of vmcnt(0), which would also wait for the previous stage's gx stores to retire.
     constexpr int OOB = 0x7ffffff0;
-    __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy + (long)n * M * Q), 0, (unsigned)((long)M * Q * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((a.y ? a.y : a.gy) + (long)n * M * Q), 0,
-                                                                   a.y ? (unsigned)((long)M * Q * 4) : 0u, 0x00020000);
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)n * K * Q), 0, (unsigned)((long)K * Q * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.gx + (long)n * K * Q, 0, (unsigned)((long)K * Q * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(const_cast<float*>(a.gy + (long)n * M * Q), (unsigned)((long)M * Q * 4));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(const_cast<float*>((a.y ? a.y : a.gy) + (long)n * M * Q), a.y ? (unsigned)((long)M * Q * 4) : 0u);
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<float*>(a.x + (long)n * K * Q), (unsigned)((long)K * Q * 4));
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + (long)n * K * Q, (unsigned)((long)K * Q * 4));
     pf4 pg[NG], py[NG], px[NX];
     int vog[NG], vox[NX];                                    // byte offsets of this thread's row segments (position 0)
 #pragma unroll
@@ -159,8 +158,7 @@ __global__ __launch_bounds__(256, ACT < 0 ? 3 : 2) void pw_bwd_fused_kernel(cons
     const int pbase = wave * (PF_PT / 4);
     const int hw = a.Hi * a.Wi;
     const int acc_pitch4 = a.T * a.acc_Ho * a.acc_Wo * 4;   // bytes per channel of the compact gradient
-    __amdgpu_buffer_rsrc_t racc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.acc ? a.acc + (long)n * K * (acc_pitch4 / 4) : a.gy), 0,
-                                                                     a.acc ? (unsigned)((long)K * acc_pitch4) : 0u, 0x00020000);
+    __amdgpu_buffer_rsrc_t racc = cfn_rsrc(const_cast<float*>(a.acc ? a.acc + (long)n * K * (acc_pitch4 / 4) : a.gy), a.acc ? (unsigned)((long)K * acc_pitch4) : 0u);
     for (int st = 0; st < nst; ++st) {
         const int q0 = qbeg + st * PF_PT;
         float* cur = img0 + (st & 1) * IMG;

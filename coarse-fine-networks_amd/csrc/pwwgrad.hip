@@ -98,11 +98,11 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
     }
     // buffer descriptors over one sample: rows >= M / K fall outside and read 0
     const int row_bytes = Q * 4;
-    __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy + (long)n * M * Q), 0, M * row_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((a.y ? a.y : a.gy) + (long)n * M * Q), 0, M * row_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(const_cast<float*>(a.gy + (long)n * M * Q), M * row_bytes);
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(const_cast<float*>((a.y ? a.y : a.gy) + (long)n * M * Q), M * row_bytes);
     const long xn = XMODE == 2 ? (long)n * a.Cimg * a.Pin : (long)n * K * a.Pin;
     const unsigned xspan = (unsigned)((XMODE == 2 ? (long)a.Cimg : (long)K) * a.Pin * 4);
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + xn), 0, xspan, 0x00020000);
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<float*>(a.x + xn), xspan);
     const bool has_y = a.y != nullptr;
 
     // the workgroup owns a contiguous run of 8-position groups; its waves take them interleaved (wave w: g0+w, g0+w+8,
