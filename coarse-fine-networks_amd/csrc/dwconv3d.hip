@@ -75,6 +75,8 @@ enum { DW_FWD = 0, DW_DGRAD = 1, DW_WGRAD = 2 };
 #ifndef DW_BF16
 int dw_small_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
                      int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);   // dwsmall.hip
+int dw_cp_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
+                  int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);      // dwcp.hip
 #endif
 
 struct DwArgs {
@@ -1245,6 +1247,11 @@ extern "C" int DWN(cfn_dwconv3d_fwd)(const dwe_t* x, const double* A, const doub
     a.N = N; a.C = C; a.T = T; a.Hi = Hi; a.Wi = Wi;
     hipStream_t st = (hipStream_t)stream;
 #ifndef DW_BF16
+    if (dw_cp_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
+        // 56x56 / 28x28 / 14x14 stride 1: column-pair wave kernel (dwcp.hip)
+        CfnProfScope prof(CFN_K_DWCONV_FWD, st, (double)DW_ES * N * C * T * 2.0 * Hi * Wi + 4.0 * C * 27);
+        return dw_cp_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, false);
+    }
     if (dw_small_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
         // 14x14 / 7x7 stride 1: wave-per-channel kernel (dwsmall.hip)
         CfnProfScope prof(CFN_K_DWCONV_FWD, st, (double)DW_ES * N * C * T * 2.0 * Hi * Wi + 4.0 * C * 27);
