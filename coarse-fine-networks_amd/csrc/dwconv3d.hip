@@ -77,6 +77,9 @@ int dw_small_fwd_try(const float* x, const double* A, const double* B, int act, 
                      int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);   // dwsmall.hip
 int dw_cp_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
                   int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);      // dwcp.hip
+int dw_cpb_try(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
+               const double* A, const double* B, int act, float* gx, double* gA, double* gB, double* gw,
+               int N, int C, int T, int H, int W, hipStream_t st, bool probe);                       // dwcpb.hip
 #endif
 
 struct DwArgs {
@@ -1248,8 +1251,9 @@ extern "C" int DWN(cfn_dwconv3d_fwd)(const dwe_t* x, const double* A, const doub
     hipStream_t st = (hipStream_t)stream;
 #ifndef DW_BF16
     if (dw_cp_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
-        // 56x56 / 28x28 / 14x14 stride 1: column-pair wave kernel (dwcp.hip)
-        CfnProfScope prof(CFN_K_DWCONV_FWD, st, (double)DW_ES * N * C * T * 2.0 * Hi * Wi + 4.0 * C * 27);
+        // output planes 56x56 / 28x28 / 14x14, stride 1 and 2: column-pair wave kernel (dwcp.hip)
+        const double po_ = stride == 1 ? (double)Hi * Wi : ((Hi - 1) / 2 + 1.0) * ((Wi - 1) / 2 + 1.0);
+        CfnProfScope prof(CFN_K_DWCONV_FWD, st, (double)DW_ES * N * C * T * ((double)Hi * Wi + po_) + 4.0 * C * 27);
         return dw_cp_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, false);
     }
     if (dw_small_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
@@ -1353,6 +1357,13 @@ extern "C" int DWN(cfn_dwconv3d_bwd_fused)(const dwe_t* gy, const dwe_t* y, cons
     CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_dwconv3d_bwd_fused: A/B mismatch");
     CFN_REQUIRE(A == nullptr || (gA != nullptr && gB != nullptr), "cfn_dwconv3d_bwd_fused: prologue needs gA, gB");
     CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv3d_bwd_fused: gsumsq needs y");
+#ifndef DW_BF16
+    if (dw_cpb_try(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, (hipStream_t)stream, true) == 0) {
+        // 56x56 / 28x28 / 14x14: column-pair wave kernel (dwcpb.hip)
+        CfnProfScope prof(CFN_K_DWCONV_BWD, (hipStream_t)stream, (double)DW_ES * N * C * T * (double)H * W * (y ? 4 : 3));
+        return dw_cpb_try(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, (hipStream_t)stream, false);
+    }
+#endif
     DwArgs a = {};
     a.N = N; a.C = C; a.T = T; a.Hi = H; a.Wi = W;
     DwPlan pl;

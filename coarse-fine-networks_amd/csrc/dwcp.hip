@@ -29,21 +29,22 @@ struct DwCpArgs {
     long total_waves;
 };
 
-template <int W, int HS, int RG, int D, int OCC>
+template <int W, int S, int HS, int RG, int D, int OCC>     // W: OUTPUT width (square planes), S: spatial stride
 __global__ __launch_bounds__(256, OCC) void dw3d_cp_fwd_kernel(const DwCpArgs a) {
     typedef float __attribute__((ext_vector_type(4))) f4;
     typedef float __attribute__((ext_vector_type(2))) p2;
     typedef unsigned __attribute__((ext_vector_type(2))) u2;
     typedef unsigned __attribute__((ext_vector_type(4))) u4;
-    constexpr int H = W, CP = W / 2;                  // column pairs per row
+    constexpr int H = W, CP = W / 2;                  // output plane, output column pairs per row
+    constexpr int WI = W * S, HI = H * S;             // input plane (even input sizes: stride 2 needs no bottom / right halo)
     constexpr int BR = RG * HS, NB = (H + BR - 1) / BR;   // output rows per band, bands per plane (the last may be ragged)
-    constexpr int IR = BR + 2;                        // image rows (band + halo)
-    constexpr int XO = 4, PIT = W + 8;                // plane column 0 sits at image column XO (16-byte aligned rows)
+    constexpr int IR = (BR - 1) * S + 3;              // image rows (the band's input rows + halo)
+    constexpr int XO = 4, PIT = WI + 8;               // input column 0 sits at image column XO (16-byte aligned rows)
     constexpr int IMG = IR * PIT;
-    constexpr int NLD = (IR * W / 4 + 63) / 64;       // float4 loads per lane and frame
-    constexpr int P = H * W, OOB = 0x7fff0000;     // + row offsets stays below 2^31
+    constexpr int NLD = (IR * WI / 4 + 63) / 64;      // float4 loads per lane and frame
+    constexpr int P = HI * WI, PO = H * W, OOB = 0x7fff0000;     // + row offsets stays below 2^31
     constexpr int U = D == 4 ? 12 : 6;                // steps per loop trip: multiple of 3, 2 and D
-    constexpr bool ROW4 = W % 4 == 0;                 // a float4 never straddles two rows
+    constexpr bool ROW4 = WI % 4 == 0;                // a float4 never straddles two rows
     static_assert(H % HS == 0 && CP * RG <= 64 && U % D == 0 && W % 2 == 0, "geometry");
     __shared__ __attribute__((aligned(16))) float smem[4 * 2 * IMG];
 
@@ -70,29 +71,29 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_fwd_kernel(const DwCpArgs a)
     for (int i = lane; i < 2 * IMG; i += 64) img[i] = 0.0f;       // halo (and everything else) zero; wave-private
 
     // loader: the band's valid input rows row_lo .. row_hi-1 are one contiguous run of the plane
-    const int row_lo = max(band * BR - 1, 0), row_hi = min(band * BR + BR + 1, H);
-    const int nel = (row_hi - row_lo) * W;
+    const int row_lo = max(band * BR * S - 1, 0), row_hi = min(band * BR * S - 1 + IR, HI);
+    const int nel = (row_hi - row_lo) * WI;
     int ldo[NLD], lo0[NLD], lo1[ROW4 ? 1 : NLD];
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int e0 = (k * 64 + lane) * 4;
         const bool on = e0 < nel;
-        const int r0 = row_lo + e0 / W - (band * BR - 1), c0 = e0 % W;
-        ldo[k] = on ? (row_lo * W + e0) * 4 : OOB;
+        const int r0 = row_lo + e0 / WI - (band * BR * S - 1), c0 = e0 % WI;
+        ldo[k] = on ? (row_lo * WI + e0) * 4 : OOB;
         lo0[k] = on ? r0 * PIT + XO + c0 : 0;
         if (!ROW4) {
-            const int r2 = row_lo + (e0 + 2) / W - (band * BR - 1), c2 = (e0 + 2) % W;
+            const int r2 = row_lo + (e0 + 2) / WI - (band * BR * S - 1), c2 = (e0 + 2) % WI;
             lo1[k] = on ? r2 * PIT + XO + c2 : 0;
         }
     }
     // compute lane: row group g, column pair cp
     const int g = lane / CP, cp = lane - g * CP;
     const bool act_lane = g < RG && band * BR + g * HS < H;        // H % HS == 0: a row group is valid as a whole
-    const float* tb = img + (act_lane ? (g * HS) * PIT + (XO - 1) + 2 * cp : 0);
+    const float* tb = img + (act_lane ? (g * HS * S) * PIT + (XO - 1) + 2 * S * cp : 0);
     const int yo = act_lane ? ((band * BR + g * HS) * W + 2 * cp) * 4 : OOB;
 
     __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * P, (unsigned)((long)T * P * 4));
-    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * P, (unsigned)((long)T * P * 4));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * PO, (unsigned)((long)T * PO * 4));
 
     auto fetch = [&](int f, f4 (&dst)[NLD]) {        // unconditional: an unwanted frame reads nothing (zeros)
         const bool want = f >= 0 && f < T && f <= t1;
@@ -154,21 +155,23 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_fwd_kernel(const DwCpArgs a)
             const float* tp = tb + par * IMG;
             // input rows one ahead of their use in two static register sets; the scheduling barriers keep hipcc from hoisting
             // all HS + 2 rows' reads (and the operand pairs built from them) to the top of the step, which spills
-            float qv[2][4];
+            constexpr int NQ = S + 3, NR = (HS - 1) * S + 3;               // dwords per lane and input row; input rows per lane
+            float qv[2][NQ];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) qv[0][e] = tp[e];
+            for (int e = 0; e < NQ; ++e) qv[0][e] = tp[e];
 #pragma unroll
-            for (int r = 0; r < HS + 2; ++r) {
-                if (r + 1 < HS + 2) {
+            for (int r = 0; r < NR; ++r) {
+                if (r + 1 < NR) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) qv[(r + 1) & 1][e] = tp[(r + 1) * PIT + e];
+                    for (int e = 0; e < NQ; ++e) qv[(r + 1) & 1][e] = tp[(r + 1) * PIT + e];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const float* q = qv[r & 1];
-                const p2 v0 = {q[0], q[1]}, v1 = {q[1], q[2]}, v2 = {q[2], q[3]};
+                // tap kw of the output pair (c, c+1) reads input columns (S c + kw - 1, S (c+1) + kw - 1)
+                const p2 v0 = {q[0], q[S]}, v1 = {q[1], q[1 + S]}, v2 = {q[2], q[2 + S]};
 #pragma unroll
                 for (int i = 0; i < HS; ++i) {
-                    const int kh = r - i;
+                    const int kh = r - i * S;
                     if (kh >= 0 && kh < 3) {
 #pragma unroll
                         for (int kt = 0; kt < 3; ++kt) {
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_fwd_kernel(const DwCpArgs a)
             const int se = (j + 2) % 3;
             const int to = f - 1;
             const bool emit = to >= t0 && to < t1;                         // wave uniform
-            const int so = cfn_uni(emit ? to * P * 4 : 0);
+            const int so = cfn_uni(emit ? to * PO * 4 : 0);
             const float mf = emit ? lane_m : 0.0f;
             const int vo = emit ? yo : OOB;                                // + i * W * 4 below: the instruction's immediate offset
 #pragma unroll
@@ -211,20 +214,29 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_fwd_kernel(const DwCpArgs a)
 // otherwise the launch status
 int dw_cp_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
                   int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe) {
-    static const int enabled = getenv("CFN_DW_CP") ? atoi(getenv("CFN_DW_CP")) : 7;      // bit mask of the planes served: 1 = 56x56, 2 = 28x28, 4 = 14x14
+    // bit mask of the shapes served: stride 1: 1 = 56x56, 2 = 28x28, 4 = 14x14; stride 2: 8 = 112->56, 16 = 56->28, 32 = 28->14
+    static const int enabled = getenv("CFN_DW_CP") ? atoi(getenv("CFN_DW_CP")) : 63;
     static const int tt_env = getenv("CFN_DW_CP_TT") ? atoi(getenv("CFN_DW_CP_TT")) : 0;
-    if (!enabled || stride != 1 || Hi != Wi || (Hi != 56 && Hi != 28 && Hi != 14)) return -1;
-    if (!(enabled & (Hi == 56 ? 1 : Hi == 28 ? 2 : 4))) return -1;
+    if (Hi != Wi || (stride != 1 && stride != 2)) return -1;
+    const int Ho = stride == 1 ? Hi : Hi / 2;
+    if ((stride == 2 && (Hi & 1)) || (Ho != 56 && Ho != 28 && Ho != 14)) return -1;
+    const int bit = (Ho == 56 ? 1 : Ho == 28 ? 2 : 4) << (stride == 2 ? 3 : 0);
+    if (!(enabled & bit)) return -1;
     if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && A != nullptr) return -1;      // branch-free prologue: none / ReLU (every X3D conv2)
-    if ((long)T * Hi * Wi * 4 >= 0x7ffffff0L) return -1;
+    if ((long)T * Hi * Wi * 4 >= 0x7fff0000L) return -1;
     if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0) return -1;
     if (probe) return 0;
     DwCpArgs a = {x, A, B, w, y, sum, sumsq, N, C, T, act, 0, 0, 0};
-    const int NB = Hi == 56 ? 14 : Hi == 28 ? 7 : 1;                                 // row bands per plane (see the launches below)
+    // lanes = column pairs x row groups (few rows per lane = few accumulators = many resident waves, which is what these
+    // kernels need: measured on 56x56, 8 clips x T=256: 7 rows per lane, 168 VGPRs, 3 waves per SIMD: 3.5 TB/s; 2 rows, 93
+    // VGPRs, 5 waves: 5.1 TB/s; capped at 80 / 64 VGPRs the spills cost 1.6x / 3x)
+    //   stride 1: 56x56: 28 x 2 lanes x 2 rows (14 bands of 4 rows); 28x28: 14 x 4 x 1 (7 bands); 14x14: 7 x 7 x 2 (the plane)
+    //   stride 2: ->56: 28 x 2 x 2 (14 bands); ->28: 14 x 4 x 1 (7 bands); ->14: 7 x 7 x 1 (2 bands)
+    const int NB = Ho == 56 ? 14 : Ho == 28 ? 7 : (stride == 2 ? 2 : 1);
     // t-chunks: >= ~6 rounds of the chip's resident waves (16 per CU) so that the tail of the last round stays small; the
     // chunk length + 2 halo frames is a multiple of the unrolled trip (6 or 12 steps) where T allows it
     const long units = (long)N * C * NB;
-    const int U = Hi == 14 ? 12 : 6;
+    const int U = (Ho == 14 && stride == 1) ? 12 : 6;
     long nch = (6L * 256 * 16 + units - 1) / units;
     if (nch < 1) nch = 1;
     int TT = (int)((T + nch - 1) / nch);
@@ -236,12 +248,12 @@ int dw_cp_fwd_try(const float* x, const double* A, const double* B, int act, con
     a.nchunks = (T + TT - 1) / TT;
     a.total_waves = units * a.nchunks;
     const unsigned blocks = (unsigned)((a.total_waves + 3) / 4);
-    // lanes = column pairs x row groups: 56x56: 28 x 2 lanes, 2 rows each (14 bands of 4 rows); 28x28: 14 x 4 lanes, 1 row each
-    // (7 bands of 4 rows); 14x14: 7 x 7 lanes, 2 rows each (the plane).  Few rows per lane = few accumulators = many resident
-    // waves, which is what these kernels need (measured, 8 clips x T=256: 56x56 with 7 rows per lane, 168 VGPRs, 3 waves per
-    // SIMD: 3.5 TB/s; 2 rows, 93 VGPRs, 5 waves: 5.1 TB/s; capped at 80 / 64 VGPRs the spills cost 1.6x / 3x)
-    if (Hi == 56) hipLaunchKernelGGL((dw3d_cp_fwd_kernel<56, 2, 2, 2, 4>), dim3(blocks), dim3(256), 0, st, a);
-    else if (Hi == 28) hipLaunchKernelGGL((dw3d_cp_fwd_kernel<28, 1, 4, 2, 4>), dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((dw3d_cp_fwd_kernel<14, 2, 7, 4, 4>), dim3(blocks), dim3(256), 0, st, a);
+#define CFN_CP_GO(...) hipLaunchKernelGGL((dw3d_cp_fwd_kernel<__VA_ARGS__>), dim3(blocks), dim3(256), 0, st, a)
+    if (stride == 1) {
+        if (Ho == 56) CFN_CP_GO(56, 1, 2, 2, 2, 4); else if (Ho == 28) CFN_CP_GO(28, 1, 1, 4, 2, 4); else CFN_CP_GO(14, 1, 2, 7, 4, 4);
+    } else {
+        if (Ho == 56) CFN_CP_GO(56, 2, 2, 2, 2, 4); else if (Ho == 28) CFN_CP_GO(28, 2, 1, 4, 2, 4); else CFN_CP_GO(14, 2, 1, 7, 2, 4);
+    }
+#undef CFN_CP_GO
     return cfn_check_launch("dwconv3d column-pair forward");
 }
