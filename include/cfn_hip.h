@@ -56,6 +56,11 @@ int cfn_dwconv3d_bwd_weight(const float* gy, const float* y, const double* gsum,
 int cfn_dwconv3d_bwd_fused(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
                            const float* x, const double* A, const double* B, int act, float* gx, double* gA, double* gB,
                            double* gw, int N, int C, int T, int H, int W, void* stream);
+/* the same for the STRIDE-2 conv (H, W: input size; x is read once instead of twice).  Returns -1 without launching when the
+ * geometry is not handled (handled: 112 -> 56, 56 -> 28, 28 -> 14 with a none / ReLU prologue): call the two kernels. */
+int cfn_dwconv3d_bwd_fused_s2(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
+                              const float* x, const double* A, const double* B, int act, float* gx, double* gA, double* gB,
+                              double* gw, int N, int C, int T, int H, int W, void* stream);
 
 /* ---- depthwise 5x1x1, pad (2,0,0): conv1_t x3d_fine.py:216-222 / x3d_coarse.py:502-508 ; plane = H*W ---- */
 int cfn_dwconv_t5_fwd(const float* x, const float* w, float* y, double* sum, double* sumsq, int N, int C, int T,

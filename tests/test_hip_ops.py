@@ -76,6 +76,8 @@ DW_CASES = [
     (1, 4, 4, 28, 28, 2, 0, False),
     (1, 3, 37, 56, 56, 1, 1, True),      # several t-chunks
     (1, 2, 3, 112, 112, 2, 1, True),
+    (2, 5, 7, 56, 56, 2, 1, True),       # fused stride-2 backward, several bands, ReLU prologue
+    (1, 3, 20, 28, 28, 2, 1, True),
     (1, 3, 4, 40, 40, 1, 1, True),       # X3D-S sizes (HS=4 path)
     (1, 2, 3, 80, 80, 2, 1, True),
     (1, 3, 3, 10, 10, 1, 2, True),       # HS=1 path
