@@ -132,7 +132,9 @@ def bench_dw(T, bwd, NB=1):
             d = devtime(f)
             md, mw = d.get('dwconv_bwd', 0.0), d.get('dwconv_wgrad', 0.0)
             if mw == 0.0:      # fused data + weight gradient: one kernel, 4 tensor passes
-                print('%-28s dgrad+wgrad fused %7.3f ms %7.1f GB/s (4 passes)' % ('', md, 16.0 * NB * c * T * H * H / 1e6 / md))
+                # bytes: x read + gx written at input resolution, gy + y read at output resolution
+                print('%-28s dgrad+wgrad fused %7.3f ms %7.1f GB/s (x, gx, gy, y once each)' %
+                      ('', md, 4.0 * NB * c * T * (2 * H * H + 2 * Ho * Ho) / 1e6 / md))
             else:
                 print('%-28s dgrad %7.3f ms %7.1f GB/s | wgrad %7.3f ms %7.1f GB/s' %
                       ('', md, 4.0 * NB * c * T * (2 * H * H + 2 * Ho * Ho) / 1e6 / md, mw, 4.0 * NB * c * T * (H * H + 2 * Ho * Ho) / 1e6 / mw))

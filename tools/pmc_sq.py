@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc SQ counter passes (counter_collection.csv files) per kernel variant:
 
-    python tools/pmc_sq.py <out.json> <pass1_counter_collection.csv> [<pass2...>] [--filter dw3d_kernel<0]
+    python tools/pmc_sq.py <out.json> <pass1_counter_collection.csv> [<pass2...>] [--filter dw3d_,dwt5_]
 
 Per kernel (first launch of each (kernel, grid) dropped as warm-up): mean of every counter per launch, plus derived
 fractions of SQ_WAVE_CYCLES: issue-active (ACTIVE_INST_ANY), VALU-active, parked (WAIT_ANY: s_waitcnt / barrier),
@@ -16,7 +16,7 @@ def main():
     it = iter(sys.argv[2:])
     for a in it:
         if a == '--filter':
-            flt = next(it)
+            flt = next(it).split(',')
         else:
             files.append(a)
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -25,7 +25,7 @@ def main():
         rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Dispatch_Id']))
         for r in rows:
             name = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')
-            if flt and flt not in name:
+            if flt and not any(x in name for x in flt):
                 continue
             key = (name, r['Grid_Size'])
             tag = (key, r['Counter_Name'])
@@ -33,9 +33,13 @@ def main():
                 seen.add(tag)
                 continue
             acc['%s grid %s' % key][r['Counter_Name']].append(float(r['Counter_Value']))
+            if r['Counter_Name'] == 'SQ_WAVE_CYCLES' and 'Start_Timestamp' in r:
+                acc['%s grid %s' % key]['_ns'].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
     res = {}
     for k, cs in acc.items():
         m = {c: sum(v) / len(v) for c, v in cs.items()}
+        ns = m.pop('_ns', None)
+        cs = {c: v for c, v in cs.items() if c != '_ns'}
         wc = m.get('SQ_WAVE_CYCLES')
         d = {'launches': max(len(v) for v in cs.values()), 'counters': {c: round(v, 1) for c, v in m.items()}}
         if wc:
@@ -46,6 +50,12 @@ def main():
                     d['frac_of_wave_cycles_' + lab] = round(m[c] / wc, 4)
         if 'SQ_INSTS_VALU' in m and 'SQ_WAVES' in m and m['SQ_WAVES']:
             d['valu_insts_per_wave'] = round(m['SQ_INSTS_VALU'] / m['SQ_WAVES'], 1)
+        if ns and wc:      # per-SIMD view at an ASSUMED 2.1 GHz (1024 SIMDs; SQ cycle counters are in quad-cycles)
+            simd_cycles = 1024.0 * ns * 2.1
+            d['avg_us'] = round(ns / 1e3, 1)
+            d['per_simd_at_2.1GHz'] = {'valu_busy': round(4 * m.get('SQ_ACTIVE_INST_VALU', 0) / simd_cycles, 3),
+                                       'inst_issue_busy': round(4 * m.get('SQ_ACTIVE_INST_ANY', 0) / simd_cycles, 3),
+                                       'resident_waves': round(4 * wc / simd_cycles, 2)}
         res[k] = d
     json.dump({'source': 'rocprofv3 --kernel-trace --pmc <SQ counters> (separate passes) -- python tools/dwfwd_only.py', 'kernels': res},
               open(out, 'w'), indent=1)

@@ -2,13 +2,24 @@
 # Regenerate the measurements kept under profiles/ (run on the GPU box through gpurun; writes into gpurun_out/refresh).
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/refresh
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+FILT="^RCCL\|^HIP\|^ROCm\|^Host\|^Lib\|amdgpu.ids"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python $R/bench.py > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_bf16 -- python $R/bench.py --dtype bf16 > $O/bench_bf16.json 2>> $O/bench.err
+python $R/bench.py --stream coarse > $O/bench_coarse.json 2>> $O/bench.err
+python $R/bench.py --stream joint > $O/bench_joint.json 2>> $O/bench.err
+python $R/bench.py --stream joint --dtype bf16 > $O/bench_joint_bf16tower.json 2>> $O/bench.err
+# HBM traffic of the depthwise forward family: separate --pmc passes, kernel trace only
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/tools/dwfwd_only.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/tools/dwfwd_only.py > /dev/null 2>&1
-python $R/tools/microbench.py pw --bwd --batch 8 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Lib\|amdgpu.ids" > $O/microbench_b8.txt
-python $R/tools/microbench.py dw --bwd --batch 8 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Lib\|amdgpu.ids" >> $O/microbench_b8.txt
-python $R/tools/coarse_step.py 16 > $O/coarse_step.txt 2>&1
-find $O -name "*kernel_trace.csv" -size +20M -delete
+# SQ counters of the same workload (two passes)
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq1 -- python $R/tools/dwfwd_only.py > /dev/null 2> $O/pmc_sq1.err
+rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM --output-format csv -d $O/pmc_sq2 -- python $R/tools/dwfwd_only.py > /dev/null 2> $O/pmc_sq2.err
+python $R/tools/microbench.py pw --bwd --batch 8 2>&1 | grep -v "$FILT" > $O/microbench_b8.txt
+python $R/tools/microbench.py dw --bwd --batch 8 2>&1 | grep -v "$FILT" >> $O/microbench_b8.txt
+python $R/tools/microbench_bf16.py 2>&1 | grep -v "$FILT" > $O/microbench_bf16_b8.txt
+$R/tools/probe/stream_probe > $O/stream_probe.txt 2>&1
+$R/tools/probe/mfma_rate_probe > $O/mfma_rate_probe.txt 2>&1
+find $O -name "*kernel_trace.csv" -size +4M -delete
 ls -la $O $O/*
