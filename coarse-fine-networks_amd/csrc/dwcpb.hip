@@ -36,18 +36,19 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_kernel(const DwCpbArgs a
     typedef float __attribute__((ext_vector_type(4))) f4;
     typedef float __attribute__((ext_vector_type(2))) p2;
     typedef unsigned __attribute__((ext_vector_type(2))) u2;
-    constexpr int H = W, CP = W / 2;
+    constexpr int H = W, CP = (W + 1) / 2;            // column pairs per row (odd width: the last pair has one column)
+    constexpr int LV = W % 2 == 0 ? 4 : 1;            // elements per loader lane (odd width: frames are not 16-byte aligned)
     constexpr int BR = RG * HS, NB = (H + BR - 1) / BR;   // output rows per band, bands per plane (the last may be ragged)
     constexpr int IR = BR + 2;                        // image rows (band + halo)
     constexpr int XO = 4, PIT = W + 8;                // plane column 0 sits at image column XO (16-byte aligned rows)
     constexpr int IMG = IR * PIT;
-    constexpr int NLD = (IR * W / 4 + 63) / 64;       // float4 loads per lane, frame and tensor
+    constexpr int NLD = (IR * W / LV + 63) / 64;      // loads per lane, frame and tensor
     constexpr int P = H * W, OOB = 0x7fff0000;
     constexpr int U = 2;                              // steps per loop trip: LDS image parity and the register ring are static;
                                                       // the accumulator sets are rotated with moves (24 of ~350 instructions per step:
                                                       // renaming them needs a 6-step trip, which hipcc allocates at 168 VGPRs + spills)
     constexpr bool ROW4 = W % 4 == 0;                 // a float4 never straddles two rows
-    static_assert(H % HS == 0 && CP * RG <= 64 && U % D == 0 && W % 2 == 0, "geometry");
+    static_assert(H % HS == 0 && CP * RG <= 64 && U % D == 0, "geometry");
     constexpr int WSZ = 6 * IMG + 8;                   // per wave: six images + a dump slot for the loader lanes without an element
     __shared__ __attribute__((aligned(16))) float smem[4 * WSZ];
 
@@ -80,15 +81,15 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_kernel(const DwCpbArgs a
     // loader: the band's valid input rows row_lo .. row_hi-1 are one contiguous run of the plane (same for gy, y, x)
     const int row_lo = max(band * BR - 1, 0), row_hi = min(band * BR + BR + 1, H);
     const int nel = (row_hi - row_lo) * W;
-    int ldo[NLD], lo0[NLD], lo1[ROW4 ? 1 : NLD];
+    int ldo[NLD], lo0[NLD], lo1[(ROW4 || LV == 1) ? 1 : NLD];
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-        const int e0 = (k * 64 + lane) * 4;
+        const int e0 = (k * 64 + lane) * LV;
         const bool on = e0 < nel;
         const int r0 = row_lo + e0 / W - (band * BR - 1), c0 = e0 % W;
         ldo[k] = on ? (row_lo * W + e0) * 4 : OOB;
         lo0[k] = on ? r0 * PIT + XO + c0 : -1;
-        if (!ROW4) {
+        if (!ROW4 && LV == 4) {
             const int r2 = row_lo + (e0 + 2) / W - (band * BR - 1), c2 = (e0 + 2) % W;
             lo1[k] = on ? r2 * PIT + XO + c2 : -1;
         }
@@ -108,13 +109,18 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_kernel(const DwCpbArgs a
         const bool want = f >= 0 && f < T && f <= t1;
         const int so = cfn_uni(want ? f * P * 4 : 0);
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) dst[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, want ? ldo[k] : OOB, so, 0));
+        for (int k = 0; k < NLD; ++k) {
+            if (LV == 4) dst[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, want ? ldo[k] : OOB, so, 0));
+            else dst[k] = (f4){__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, want ? ldo[k] : OOB, so, 0)), 0.0f, 0.0f, 0.0f};
+        }
     };
     // branch-free staging: a loader lane without an element writes into the wave's dump slot (no exec-mask branches in the
     // frame loop: straight-line code schedules and allocates far better)
     float* dump = imG + 6 * IMG;
     auto put = [&](float* im, int k, f4 v) {
-        if (ROW4) {
+        if (LV == 1) {
+            *(lo0[k] >= 0 ? im + lo0[k] : dump) = v.x;
+        } else if (ROW4) {
             *reinterpret_cast<f4*>(lo0[k] >= 0 ? im + lo0[k] : dump) = v;
         } else {
             *reinterpret_cast<p2*>(lo0[k] >= 0 ? im + lo0[k] : dump) = (p2){v.x, v.y};
@@ -158,6 +164,8 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_kernel(const DwCpbArgs a
     for (int j = 0; j < 27; ++j) dwa[j] = 0.0f;
     p2 s1p = {0.0f, 0.0f}, s2p = {0.0f, 0.0f};
     const float lane_m = act_lane ? 1.0f : 0.0f;
+    const bool col2 = 2 * cp + 1 < W;                              // the pair's second column exists (odd width: not in the last pair)
+    const p2 lane_m2 = {lane_m, col2 ? lane_m : 0.0f};
 
     // steps f = t0-1 .. t1+1.  Step j of a trip: G(f) is in imG[j & 1], A / X(f-1) in im?[(j+1) & 1]; ring slot (j+1) % D of the
     // gy / y rings holds frame f+1, slot j % D of the x ring frame f; each slot is refilled right after it was staged.
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_kernel(const DwCpbArgs a
             const int to = f - 1;
             const bool emit = to >= t0 && to < t1;                         // wave uniform
             const int so = cfn_uni(emit ? to * P * 4 : 0);
-            const float mf = emit ? lane_m : 0.0f;
+            const p2 mf = emit ? lane_m2 : (p2){0.0f, 0.0f};
             const int vo = emit ? yo : OOB;
             const float* tx = imX + pq * IMG + tofs;
 #pragma unroll
@@ -260,7 +268,15 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_kernel(const DwCpbArgs a
                     s2p += dm;
                     v = dz * pa;
                 }
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rd, vo + i * W * 4, so, 0);
+                if (LV == 4) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rd, vo + i * W * 4, so, 0);
+                } else {                                                   // odd width: rows are only 4-byte aligned
+                    float v0 = v.x, v1 = v.y;
+                    asm volatile("" : "+v"(v0), "+v"(v1));                 // (hipcc 7.2 otherwise stores v.x twice: it reuses v.y's register
+                                                                           //  for the second address before the store has read it)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rd, vo + i * W * 4, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rd, col2 ? vo + i * W * 4 + 4 : OOB, so, 0);
+                }
             }
 #pragma unroll
             for (int i = 0; i < HS; ++i) {                                 // rotate: frame f+1 becomes frame f of the next step
@@ -303,18 +319,18 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_kernel(const DwCpbArgs a
 int dw_cpb_try(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
                const double* A, const double* B, int act, float* gx, double* gA, double* gB, double* gw,
                int N, int C, int T, int H, int W, hipStream_t st, bool probe) {
-    // bit mask of the planes served: 1 = 56x56, 2 = 28x28, 4 = 14x14
-    static const int enabled = getenv("CFN_DW_CPB") ? atoi(getenv("CFN_DW_CPB")) : 7;
+    // bit mask of the planes served: 1 = 56x56, 2 = 28x28, 4 = 14x14, 8 = 7x7
+    static const int enabled = getenv("CFN_DW_CPB") ? atoi(getenv("CFN_DW_CPB")) : 15;
     static const int tt_env = getenv("CFN_DW_CPB_TT") ? atoi(getenv("CFN_DW_CPB_TT")) : 0;
-    if (H != W || (H != 56 && H != 28 && H != 14)) return -1;
-    if (!(enabled & (H == 56 ? 1 : H == 28 ? 2 : 4))) return -1;
+    if (H != W || (H != 56 && H != 28 && H != 14 && H != 7)) return -1;
+    if (!(enabled & (H == 56 ? 1 : H == 28 ? 2 : H == 14 ? 4 : 8))) return -1;
     if (A != nullptr && act != CFN_ACT_NONE && act != CFN_ACT_RELU) return -1;      // act' from the sign of a: none / ReLU (every X3D conv2)
     if ((long)T * H * W * 4 >= 0x7fff0000L) return -1;
-    if ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)(y ? y : gy)) & 15) != 0) return -1;
+    if (H != 7 && (((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)(y ? y : gy)) & 15) != 0) return -1;
     if (probe) return 0;
     const bool hasy = y != nullptr && gq != nullptr;
     DwCpbArgs a = {gy, hasy ? y : nullptr, gs, hasy ? gq : nullptr, w, x, A, B, gx, A ? gA : nullptr, A ? gB : nullptr, gw, N, C, T, act, 0, 0, 0};
-    const int NB = H == 56 ? 14 : H == 28 ? 7 : 1;
+    const int NB = H == 56 ? 14 : H == 28 ? 7 : 1;                                    // 14x14 and 7x7: the plane is one band
     // t-chunks: >= ~6 rounds of the chip's resident waves (16 per CU)
     // t-chunks of ~52 frames: a wave's fixed cost (LDS clear, pipeline fill, the 27-value reduction) is worth ~4 frame steps
     // (measured, 8 clips x T=256, 56x56: chunks of 9 / 21 / 33 / 63 frames: 4.5 / 2.3 / 1.7 / 1.3 ms); more chunks only while
@@ -334,7 +350,8 @@ int dw_cpb_try(const float* gy, const float* y, const double* gs, const double* 
                              else hipLaunchKernelGGL((dw3d_cp_bwd_kernel<__VA_ARGS__, false>), dim3(blocks), dim3(256), 0, st, a); } while (0)
     if (H == 56) CFN_CPB_GO(56, 2, 2, 1, 3);
     else if (H == 28) CFN_CPB_GO(28, 1, 4, 1, 3);
-    else CFN_CPB_GO(14, 2, 7, 2, 3);
+    else if (H == 14) CFN_CPB_GO(14, 2, 7, 2, 3);
+    else CFN_CPB_GO(7, 1, 7, 2, 3);                                                  // 4 column pairs x 7 rows = 28 lanes
 #undef CFN_CPB_GO
     return cfn_check_launch("dwconv3d column-pair fused backward");
 }
