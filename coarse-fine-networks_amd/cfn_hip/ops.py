@@ -424,9 +424,9 @@ class _DwConv3d(Function):
         sfx = _sfx(x)
         fused = want_x and want_w and stride == 1 and call_try('cfn_dwconv3d_bwd_fused' + sfx, gy, y, gs, gq, w2, x, A, B, act,
                                                              gx, a64, b64, g64, N, C, T, H, W)
-        # stride 2 (first block of a stage): x read once instead of twice (fp32 tensors; declines other geometries)
-        if not fused and want_x and want_w and stride == 2 and sfx == '':
-            fused = call_try('cfn_dwconv3d_bwd_fused_s2', gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, g64, N, C, T, H, W)
+        # stride 2 (first block of a stage): x read once instead of twice (declines other geometries)
+        if not fused and want_x and want_w and stride == 2:
+            fused = call_try('cfn_dwconv3d_bwd_fused_s2' + sfx, gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, g64, N, C, T, H, W)
         if not fused:
             if want_x:
                 call('cfn_dwconv3d_bwd_data' + sfx, gy, y, gs, gq, w2, x, A, B, act, gx, a64, b64, N, C, T, H, W, stride)

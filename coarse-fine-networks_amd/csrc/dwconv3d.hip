@@ -75,12 +75,13 @@ enum { DW_FWD = 0, DW_DGRAD = 1, DW_WGRAD = 2 };
 #ifndef DW_BF16
 int dw_small_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
                      int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);   // dwsmall.hip
-int dw_cp_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
-                  int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);      // dwcp.hip
-int dw_cpb_try(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
-               const double* A, const double* B, int act, float* gx, double* gA, double* gB, double* gw,
-               int N, int C, int T, int H, int W, hipStream_t st, bool probe);                       // dwcpb.hip
 #endif
+// column-pair wave kernels (dwcp.hip, dwcpb.hip; compiled for both element types like this file: cp_io.h)
+int DWN(dw_cp_fwd_try)(const dwe_t* x, const double* A, const double* B, int act, const float* w, dwe_t* y, double* sum, double* sumsq,
+                       int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);
+int DWN(dw_cpb_try)(const dwe_t* gy, const dwe_t* y, const double* gs, const double* gq, const float* w, const dwe_t* x,
+                    const double* A, const double* B, int act, dwe_t* gx, double* gA, double* gB, double* gw,
+                    int N, int C, int T, int H, int W, hipStream_t st, bool probe);
 
 struct DwArgs {
     const dwe_t* src;    // FWD/WGRAD: x raw (N,C,T,Hi,Wi)      DGRAD: gy (N,C,T,H,W)
@@ -1249,13 +1250,13 @@ extern "C" int DWN(cfn_dwconv3d_fwd)(const dwe_t* x, const double* A, const doub
     a.src = x; a.A = A; a.B = B; a.act = act; a.w = w; a.dst = y; a.s1 = sum; a.s2 = sumsq;
     a.N = N; a.C = C; a.T = T; a.Hi = Hi; a.Wi = Wi;
     hipStream_t st = (hipStream_t)stream;
-#ifndef DW_BF16
-    if (dw_cp_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
+    if (DWN(dw_cp_fwd_try)(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
         // output planes 56x56 / 28x28 / 14x14, stride 1 and 2: column-pair wave kernel (dwcp.hip)
         const double po_ = stride == 1 ? (double)Hi * Wi : ((Hi - 1) / 2 + 1.0) * ((Wi - 1) / 2 + 1.0);
         CfnProfScope prof(CFN_K_DWCONV_FWD, st, (double)DW_ES * N * C * T * ((double)Hi * Wi + po_) + 4.0 * C * 27);
-        return dw_cp_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, false);
+        return DWN(dw_cp_fwd_try)(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, false);
     }
+#ifndef DW_BF16
     if (dw_small_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
         // 14x14 / 7x7 stride 1: wave-per-channel kernel (dwsmall.hip)
         CfnProfScope prof(CFN_K_DWCONV_FWD, st, (double)DW_ES * N * C * T * 2.0 * Hi * Wi + 4.0 * C * 27);
@@ -1357,13 +1358,11 @@ extern "C" int DWN(cfn_dwconv3d_bwd_fused)(const dwe_t* gy, const dwe_t* y, cons
     CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_dwconv3d_bwd_fused: A/B mismatch");
     CFN_REQUIRE(A == nullptr || (gA != nullptr && gB != nullptr), "cfn_dwconv3d_bwd_fused: prologue needs gA, gB");
     CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv3d_bwd_fused: gsumsq needs y");
-#ifndef DW_BF16
-    if (dw_cpb_try(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, (hipStream_t)stream, true) == 0) {
+    if (DWN(dw_cpb_try)(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, (hipStream_t)stream, true) == 0) {
         // 56x56 / 28x28 / 14x14: column-pair wave kernel (dwcpb.hip)
         CfnProfScope prof(CFN_K_DWCONV_BWD, (hipStream_t)stream, (double)DW_ES * N * C * T * (double)H * W * (y ? 4 : 3));
-        return dw_cpb_try(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, (hipStream_t)stream, false);
+        return DWN(dw_cpb_try)(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, (hipStream_t)stream, false);
     }
-#endif
     DwArgs a = {};
     a.N = N; a.C = C; a.T = T; a.Hi = H; a.Wi = W;
     DwPlan pl;

@@ -19,12 +19,15 @@
 // (unconditional buffer loads: exact vmcnt waits), staged through a wave-private LDS image with a zero halo.  The four waves
 // of a workgroup are the bands of one (n, c, t-chunk) (56x56) or neighbouring t-chunks of one channel: halo rows / frames
 // come out of L2.  Shapes / activations outside this list use the band kernel (dw_cp_fwd_try returns -1).
-#include "cfn_common.h"
+#include "cp_io.h"
 #include <stdint.h>
 #include <stdlib.h>
 
+#ifdef DW_BF16
+#define DwCpArgs DwCpArgsBf16
+#endif
 struct DwCpArgs {
-    const float* x; const double* A; const double* B; const float* w; float* y; double* s1; double* s2;
+    const cpe_t* x; const double* A; const double* B; const float* w; cpe_t* y; double* s1; double* s2;
     int N, C, T, act, TT, nchunks;
     long total_waves;
 };
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_fwd_kernel(const DwCpArgs a)
         const int e0 = (k * 64 + lane) * 4;
         const bool on = e0 < nel;
         const int r0 = row_lo + e0 / WI - (band * BR * S - 1), c0 = e0 % WI;
-        ldo[k] = on ? (row_lo * WI + e0) * 4 : OOB;
+        ldo[k] = on ? (row_lo * WI + e0) * CP_ES : OOB;
         lo0[k] = on ? r0 * PIT + XO + c0 : 0;
         if (!ROW4) {
             const int r2 = row_lo + (e0 + 2) / WI - (band * BR * S - 1), c2 = (e0 + 2) % WI;
@@ -90,16 +93,16 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_fwd_kernel(const DwCpArgs a)
     const int g = lane / CP, cp = lane - g * CP;
     const bool act_lane = g < RG && band * BR + g * HS < H;        // H % HS == 0: a row group is valid as a whole
     const float* tb = img + (act_lane ? (g * HS * S) * PIT + (XO - 1) + 2 * S * cp : 0);
-    const int yo = act_lane ? ((band * BR + g * HS) * W + 2 * cp) * 4 : OOB;
+    const int yo = act_lane ? ((band * BR + g * HS) * W + 2 * cp) * CP_ES : OOB;
 
-    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * P, (unsigned)((long)T * P * 4));
-    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * PO, (unsigned)((long)T * PO * 4));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * PO, (unsigned)((long)T * PO * CP_ES));
 
     auto fetch = [&](int f, f4 (&dst)[NLD]) {        // unconditional: an unwanted frame reads nothing (zeros)
         const bool want = f >= 0 && f < T && f <= t1;
-        const int so = cfn_uni(want ? f * P * 4 : 0);
+        const int so = cfn_uni(want ? f * P * CP_ES : 0);
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) dst[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, want ? ldo[k] : OOB, so, 0));
+        for (int k = 0; k < NLD; ++k) dst[k] = cp_ld4(rx, want ? ldo[k] : OOB, so);
     };
     auto stage = [&](int f, const f4 (&src)[NLD], float* im) {   // frames outside the clip are zero AFTER the prologue
         const float m = (f >= 0 && f < T) ? 1.0f : 0.0f;
@@ -188,13 +191,13 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_fwd_kernel(const DwCpArgs a)
             const int se = (j + 2) % 3;
             const int to = f - 1;
             const bool emit = to >= t0 && to < t1;                         // wave uniform
-            const int so = cfn_uni(emit ? to * PO * 4 : 0);
+            const int so = cfn_uni(emit ? to * PO * CP_ES : 0);
             const float mf = emit ? lane_m : 0.0f;
             const int vo = emit ? yo : OOB;                                // + i * W * 4 below: the instruction's immediate offset
 #pragma unroll
             for (int i = 0; i < HS; ++i) {
-                const p2 y = acc[se][i];
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, y), ry, vo + i * W * 4, so, 0);
+                const p2 y = cp_rt2(acc[se][i]);                            // (bf16: statistics over the stored values)
+                cp_st2(y, ry, vo + i * W * CP_ES, so);
                 const p2 ym = y * mf;
                 s1p += ym;
                 s2p = __builtin_elementwise_fma(ym, y, s2p);
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_fwd_kernel(const DwCpArgs a)
 
 // returns -1 when the shape is not handled (caller goes on to the other kernels); probe: 0 = handled, nothing launched;
 // otherwise the launch status
-int dw_cp_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
+int CPN(dw_cp_fwd_try)(const cpe_t* x, const double* A, const double* B, int act, const float* w, cpe_t* y, double* sum, double* sumsq,
                   int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe) {
     // bit mask of the shapes served: stride 1: 1 = 56x56, 2 = 28x28, 4 = 14x14; stride 2: 8 = 112->56, 16 = 56->28, 32 = 28->14
     static const int enabled = getenv("CFN_DW_CP") ? atoi(getenv("CFN_DW_CP")) : 63;
@@ -223,8 +226,8 @@ int dw_cp_fwd_try(const float* x, const double* A, const double* B, int act, con
     const int bit = (Ho == 56 ? 1 : Ho == 28 ? 2 : 4) << (stride == 2 ? 3 : 0);
     if (!(enabled & bit)) return -1;
     if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && A != nullptr) return -1;      // branch-free prologue: none / ReLU (every X3D conv2)
-    if ((long)T * Hi * Wi * 4 >= 0x7fff0000L) return -1;
-    if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0) return -1;
+    if ((long)T * Hi * Wi * CP_ES >= 0x7fff0000L) return -1;
+    if ((((uintptr_t)x | (uintptr_t)y) & (4 * CP_ES - 1)) != 0) return -1;
     if (probe) return 0;
     DwCpArgs a = {x, A, B, w, y, sum, sumsq, N, C, T, act, 0, 0, 0};
     // lanes = column pairs x row groups (few rows per lane = few accumulators = many resident waves, which is what these

@@ -20,13 +20,16 @@
 // hipcc-flags: -fno-slp-vectorize
 // (the SLP vectoriser re-pairs the scalar weight-gradient FMAs into v_pk_fma_f32 with ~300 pair-building moves per trip and
 // pushes the kernel into spills; measured with and without)
-#include "cfn_common.h"
+#include "cp_io.h"
 #include <stdint.h>
 #include <stdlib.h>
 
+#ifdef DW_BF16
+#define DwCpbArgs DwCpbArgsBf16
+#endif
 struct DwCpbArgs {
-    const float* gy; const float* y; const double* gs; const double* gq; const float* w; const float* x;
-    const double* A; const double* B; float* gx; double* gA; double* gB; double* gw;
+    const cpe_t* gy; const cpe_t* y; const double* gs; const double* gq; const float* w; const cpe_t* x;
+    const double* A; const double* B; cpe_t* gx; double* gA; double* gB; double* gw;
     int N, C, T, act, TT, nchunks;
     long total_waves;
 };
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_kernel(const DwCpbArgs a
         const int e0 = (k * 64 + lane) * LV;
         const bool on = e0 < nel;
         const int r0 = row_lo + e0 / W - (band * BR - 1), c0 = e0 % W;
-        ldo[k] = on ? (row_lo * W + e0) * 4 : OOB;
+        ldo[k] = on ? (row_lo * W + e0) * CP_ES : OOB;
         lo0[k] = on ? r0 * PIT + XO + c0 : -1;
         if (!ROW4 && LV == 4) {
             const int r2 = row_lo + (e0 + 2) / W - (band * BR - 1), c2 = (e0 + 2) % W;
@@ -98,20 +101,20 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_kernel(const DwCpbArgs a
     const int g = lane / CP, cp = lane - g * CP;
     const bool act_lane = g < RG && band * BR + g * HS < H;        // H % HS == 0: a row group is valid as a whole
     const int tofs = act_lane ? (g * HS) * PIT + (XO - 1) + 2 * cp : 0;
-    const int yo = act_lane ? ((band * BR + g * HS) * W + 2 * cp) * 4 : OOB;
+    const int yo = act_lane ? ((band * BR + g * HS) * W + 2 * cp) * CP_ES : OOB;
 
-    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(a.gy + nc * (long)T * P, (unsigned)((long)T * P * 4));
-    __amdgpu_buffer_rsrc_t ry = cfn_rsrc((HASY ? a.y : a.gy) + nc * (long)T * P, (unsigned)((long)T * P * 4));
-    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * P, (unsigned)((long)T * P * 4));
-    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + nc * (long)T * P, (unsigned)((long)T * P * 4));
+    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(a.gy + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc((HASY ? a.y : a.gy) + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
 
     auto fetch1 = [&](__amdgpu_buffer_rsrc_t r, int f, f4 (&dst)[NLD]) {     // unconditional: an unwanted frame reads zeros
         const bool want = f >= 0 && f < T && f <= t1;
-        const int so = cfn_uni(want ? f * P * 4 : 0);
+        const int so = cfn_uni(want ? f * P * CP_ES : 0);
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
-            if (LV == 4) dst[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, want ? ldo[k] : OOB, so, 0));
-            else dst[k] = (f4){__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, want ? ldo[k] : OOB, so, 0)), 0.0f, 0.0f, 0.0f};
+            if (LV == 4) dst[k] = cp_ld4(r, want ? ldo[k] : OOB, so);
+            else dst[k] = (f4){cp_ld1(r, want ? ldo[k] : OOB, so), 0.0f, 0.0f, 0.0f};
         }
     };
     // branch-free staging: a loader lane without an element writes into the wave's dump slot (no exec-mask branches in the
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_kernel(const DwCpbArgs a
             const int se = 2;
             const int to = f - 1;
             const bool emit = to >= t0 && to < t1;                         // wave uniform
-            const int so = cfn_uni(emit ? to * P * 4 : 0);
+            const int so = cfn_uni(emit ? to * P * CP_ES : 0);
             const p2 mf = emit ? lane_m2 : (p2){0.0f, 0.0f};
             const int vo = emit ? yo : OOB;
             const float* tx = imX + pq * IMG + tofs;
@@ -269,13 +272,13 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_kernel(const DwCpbArgs a
                     v = dz * pa;
                 }
                 if (LV == 4) {
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rd, vo + i * W * 4, so, 0);
+                    cp_st2(v, rd, vo + i * W * CP_ES, so);
                 } else {                                                   // odd width: rows are only 4-byte aligned
                     float v0 = v.x, v1 = v.y;
                     asm volatile("" : "+v"(v0), "+v"(v1));                 // (hipcc 7.2 otherwise stores v.x twice: it reuses v.y's register
                                                                            //  for the second address before the store has read it)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rd, vo + i * W * 4, so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rd, col2 ? vo + i * W * 4 + 4 : OOB, so, 0);
+                    cp_st1(v0, rd, vo + i * W * CP_ES, so);
+                    cp_st1(v1, rd, col2 ? vo + i * W * CP_ES + CP_ES : OOB, so);
                 }
             }
 #pragma unroll
@@ -316,8 +319,8 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_kernel(const DwCpbArgs a
 }
 
 // returns -1 when the shape is not handled (caller goes on to the band kernels); otherwise the launch status
-int dw_cpb_try(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
-               const double* A, const double* B, int act, float* gx, double* gA, double* gB, double* gw,
+int CPN(dw_cpb_try)(const cpe_t* gy, const cpe_t* y, const double* gs, const double* gq, const float* w, const cpe_t* x,
+               const double* A, const double* B, int act, cpe_t* gx, double* gA, double* gB, double* gw,
                int N, int C, int T, int H, int W, hipStream_t st, bool probe) {
     // bit mask of the planes served: 1 = 56x56, 2 = 28x28, 4 = 14x14, 8 = 7x7
     static const int enabled = getenv("CFN_DW_CPB") ? atoi(getenv("CFN_DW_CPB")) : 15;
@@ -325,8 +328,8 @@ int dw_cpb_try(const float* gy, const float* y, const double* gs, const double* 
     if (H != W || (H != 56 && H != 28 && H != 14 && H != 7)) return -1;
     if (!(enabled & (H == 56 ? 1 : H == 28 ? 2 : H == 14 ? 4 : 8))) return -1;
     if (A != nullptr && act != CFN_ACT_NONE && act != CFN_ACT_RELU) return -1;      // act' from the sign of a: none / ReLU (every X3D conv2)
-    if ((long)T * H * W * 4 >= 0x7fff0000L) return -1;
-    if (H != 7 && (((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)(y ? y : gy)) & 15) != 0) return -1;
+    if ((long)T * H * W * CP_ES >= 0x7fff0000L) return -1;
+    if (H != 7 && (((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)(y ? y : gy)) & (4 * CP_ES - 1)) != 0) return -1;
     if (probe) return 0;
     const bool hasy = y != nullptr && gq != nullptr;
     DwCpbArgs a = {gy, hasy ? y : nullptr, gs, hasy ? gq : nullptr, w, x, A, B, gx, A ? gA : nullptr, A ? gB : nullptr, gw, N, C, T, act, 0, 0, 0};

@@ -20,13 +20,16 @@
 // a(f-1)[2o+kh-1][2j+kw-1] (the forward is y(t) = sum w[kt] a(t+kt-1)).  Even input sizes only (no bottom / right input halo);
 // prologue activations other than none / ReLU and other planes keep the two band kernels (dw_cpb2_try returns -1).
 // hipcc-flags: -fno-slp-vectorize
-#include "cfn_common.h"
+#include "cp_io.h"
 #include <stdint.h>
 #include <stdlib.h>
 
+#ifdef DW_BF16
+#define DwCpb2Args DwCpb2ArgsBf16
+#endif
 struct DwCpb2Args {
-    const float* gy; const float* y; const double* gs; const double* gq; const float* w; const float* x;
-    const double* A; const double* B; float* gx; double* gA; double* gB; double* gw;
+    const cpe_t* gy; const cpe_t* y; const double* gs; const double* gq; const float* w; const cpe_t* x;
+    const double* A; const double* B; cpe_t* gx; double* gA; double* gB; double* gw;
     int N, C, T, act, TT, nchunks;
     long total_waves;
 };
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_s2_kernel(const DwCpb2Ar
     for (int k = 0; k < NLG; ++k) {
         const int e0 = eb + (k * 64 + lane) * 4;
         const bool on = e0 < gr_hi * WO;
-        ldg[k] = on ? e0 * 4 : OOB;
+        ldg[k] = on ? e0 * CP_ES : OOB;
         const int r0 = e0 / WO - gr_lo, r2 = (e0 + 2) / WO - gr_lo;
         lg0[k] = (on && e0 >= gr_lo * WO) ? r0 * GP + e0 % WO : -1;
         if (!GROW4) lg1[k] = (on && e0 + 2 < gr_hi * WO) ? r2 * GP + (e0 + 2) % WO : -1;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_s2_kernel(const DwCpb2Ar
     for (int k = 0; k < NLA; ++k) {
         const int e0 = (k * 64 + lane) * 4;                                // WI % 4 == 0: a float4 stays in its row
         const bool on = e0 < nela;
-        lda[k] = on ? (ar_lo * WI + e0) * 4 : OOB;
+        lda[k] = on ? (ar_lo * WI + e0) * CP_ES : OOB;
         la0[k] = on ? (ar_lo + e0 / WI - (2 * band * BR - 1)) * PIT + XO + e0 % WI : -1;
     }
     // compute lane: output row o = band*BR + g, output columns 2cp, 2cp+1; input block rows 2o, 2o+1, columns 4cp .. 4cp+3
@@ -104,24 +107,24 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_s2_kernel(const DwCpb2Ar
     const bool act_lane = g < RG && band * BR + g < HO;
     const int gofs = act_lane ? g * GP + 2 * cp : 0;                       // G image: g'[o][2cp]
     const int aofs = act_lane ? (2 * g) * PIT + (XO - 1) + 4 * cp : XO - 1;   // A / X image: row 2o-1, column 4cp-1 (idle lanes: aligned too)
-    const int xo = act_lane ? ((2 * (band * BR + g)) * WI + 4 * cp) * 4 : OOB;   // gx: row 2o, column 4cp
+    const int xo = act_lane ? ((2 * (band * BR + g)) * WI + 4 * cp) * CP_ES : OOB;   // gx: row 2o, column 4cp
 
-    __amdgpu_buffer_rsrc_t rgy = cfn_rsrc(a.gy + nc * (long)T * PO, (unsigned)((long)T * PO * 4));
-    __amdgpu_buffer_rsrc_t ryy = cfn_rsrc((HASY ? a.y : a.gy) + nc * (long)T * PO, (unsigned)((long)T * PO * 4));
-    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * PI, (unsigned)((long)T * PI * 4));
-    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + nc * (long)T * PI, (unsigned)((long)T * PI * 4));
+    __amdgpu_buffer_rsrc_t rgy = cfn_rsrc(a.gy + nc * (long)T * PO, (unsigned)((long)T * PO * CP_ES));
+    __amdgpu_buffer_rsrc_t ryy = cfn_rsrc((HASY ? a.y : a.gy) + nc * (long)T * PO, (unsigned)((long)T * PO * CP_ES));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * PI, (unsigned)((long)T * PI * CP_ES));
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + nc * (long)T * PI, (unsigned)((long)T * PI * CP_ES));
 
     auto fetchG = [&](__amdgpu_buffer_rsrc_t r, int f, f4 (&dst)[NLG]) {     // unconditional: an unwanted frame reads zeros
         const bool want = f >= 0 && f < T && f <= t1;
-        const int so = cfn_uni(want ? f * PO * 4 : 0);
+        const int so = cfn_uni(want ? f * PO * CP_ES : 0);
 #pragma unroll
-        for (int k = 0; k < NLG; ++k) dst[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, want ? ldg[k] : OOB, so, 0));
+        for (int k = 0; k < NLG; ++k) dst[k] = cp_ld4(r, want ? ldg[k] : OOB, so);
     };
     auto fetchX = [&](int f, f4 (&dst)[NLA]) {
         const bool want = f >= 0 && f < T && f <= t1;
-        const int so = cfn_uni(want ? f * PI * 4 : 0);
+        const int so = cfn_uni(want ? f * PI * CP_ES : 0);
 #pragma unroll
-        for (int k = 0; k < NLA; ++k) dst[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, want ? lda[k] : OOB, so, 0));
+        for (int k = 0; k < NLA; ++k) dst[k] = cp_ld4(rx, want ? lda[k] : OOB, so);
     };
     // branch-free staging: a loader lane without an element writes into the wave's dump slot
     auto stageG = [&](int f, const f4 (&sg)[NLG], const f4 (&sy)[NLG], float* im) {   // g' = gy + gs + 2 y gq, zero outside
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_s2_kernel(const DwCpb2Ar
             // ---- emit gx(f-1): complete in set 2 ----------------------------------------------------------------------------
             const int to = f - 1;
             const bool emit = to >= t0 && to < t1;                         // wave uniform
-            const int so = cfn_uni(emit ? to * PI * 4 : 0);
+            const int so = cfn_uni(emit ? to * PI * CP_ES : 0);
             const float mf = emit ? lane_m : 0.0f;
             const int vo = emit ? xo : OOB;
             const float* tx = imX + pq * IMGA + aofs;
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_s2_kernel(const DwCpb2Ar
                         v[e] = dz * pa;
                     }
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rd, vo + rr * WI * 4, so, 0);
+                cp_st4(v, rd, vo + rr * WI * CP_ES, so);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {                                  // rotate: frame f+1 becomes frame f of the next step
@@ -299,8 +302,8 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_s2_kernel(const DwCpb2Ar
 }
 
 // returns -1 when the shape is not handled (caller uses the two band kernels); otherwise the launch status.  H, W: input size.
-int dw_cpb2_try(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
-                const double* A, const double* B, int act, float* gx, double* gA, double* gB, double* gw,
+int CPN(dw_cpb2_try)(const cpe_t* gy, const cpe_t* y, const double* gs, const double* gq, const float* w, const cpe_t* x,
+                const double* A, const double* B, int act, cpe_t* gx, double* gA, double* gB, double* gw,
                 int N, int C, int T, int H, int W, hipStream_t st) {
     // bit mask of the shapes served: 1 = 112->56, 2 = 56->28, 4 = 28->14
     static const int enabled = getenv("CFN_DW_CPB2") ? atoi(getenv("CFN_DW_CPB2")) : 7;
@@ -308,8 +311,8 @@ int dw_cpb2_try(const float* gy, const float* y, const double* gs, const double*
     if (H != W || (H != 112 && H != 56 && H != 28)) return -1;
     if (!(enabled & (H == 112 ? 1 : H == 56 ? 2 : 4))) return -1;
     if (A != nullptr && act != CFN_ACT_NONE && act != CFN_ACT_RELU) return -1;      // act' from the sign of a: none / ReLU (every X3D conv2)
-    if ((long)T * H * W * 4 >= 0x7fff0000L) return -1;
-    if ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)(y ? y : gy)) & 15) != 0) return -1;
+    if ((long)T * H * W * CP_ES >= 0x7fff0000L) return -1;
+    if ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)(y ? y : gy)) & (4 * CP_ES - 1)) != 0) return -1;
     const bool hasy = y != nullptr && gq != nullptr;
     DwCpb2Args a = {gy, hasy ? y : nullptr, gs, hasy ? gq : nullptr, w, x, A, B, gx, A ? gA : nullptr, A ? gB : nullptr, gw, N, C, T, act, 0, 0, 0};
     const int NB = H == 112 ? 28 : H == 56 ? 7 : 2;
@@ -336,8 +339,8 @@ int dw_cpb2_try(const float* gy, const float* y, const double* gs, const double*
 }
 
 // C ABI (include/cfn_hip.h): data AND weight gradient of the stride-2 conv in one pass; -1 = not handled, call the two kernels
-extern "C" int cfn_dwconv3d_bwd_fused_s2(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
-                                         const float* x, const double* A, const double* B, int act, float* gx, double* gA, double* gB,
+extern "C" int CPN(cfn_dwconv3d_bwd_fused_s2)(const cpe_t* gy, const cpe_t* y, const double* gsum, const double* gsumsq, const float* w,
+                                         const cpe_t* x, const double* A, const double* B, int act, cpe_t* gx, double* gA, double* gB,
                                          double* gw, int N, int C, int T, int H, int W, void* stream) {
     CFN_REQUIRE(gy && w && x && gx && gw, "cfn_dwconv3d_bwd_fused_s2: null tensor");
     CFN_REQUIRE(N > 0 && C > 0 && T > 0 && H > 0 && W > 0, "cfn_dwconv3d_bwd_fused_s2: bad shape");
@@ -347,6 +350,6 @@ extern "C" int cfn_dwconv3d_bwd_fused_s2(const float* gy, const float* y, const 
     if (H != W || (H != 112 && H != 56 && H != 28)) return -1;
     hipStream_t st = (hipStream_t)stream;
     const double po = (double)(H / 2) * (W / 2);
-    CfnProfScope prof(CFN_K_DWCONV_BWD, st, 4.0 * N * C * T * (2.0 * H * W + po * (y ? 2 : 1)));
-    return dw_cpb2_try(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, st);
+    CfnProfScope prof(CFN_K_DWCONV_BWD, st, (double)CP_ES * N * C * T * (2.0 * H * W + po * (y ? 2 : 1)));
+    return CPN(dw_cpb2_try)(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, st);
 }

@@ -271,6 +271,10 @@ int cfn_dwconv3d_bwd_fused_bf16(const unsigned short* gy, const unsigned short* 
                                 const float* w, const unsigned short* x, const double* A, const double* B, int act,
                                 unsigned short* gx, double* gA, double* gB, double* gw, int N, int C, int T, int H, int W,
                                 void* stream);
+int cfn_dwconv3d_bwd_fused_s2_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                                   const float* w, const unsigned short* x, const double* A, const double* B, int act,
+                                   unsigned short* gx, double* gA, double* gB, double* gw, int N, int C, int T, int H, int W,
+                                   void* stream);
 
 /* conv1_t depthwise 5x1x1 x3d_fine.py:216-222: x / gx fp32, y / gy bf16 */
 int cfn_dwconv_t5_fwd_bf16(const float* x, const float* w, unsigned short* y, double* sum, double* sumsq, int N, int C, int T,

@@ -101,6 +101,8 @@ DW_CASES = [
     # N, C, T, H, W, stride, act
     (2, 54, 5, 16, 16, 1, 1), (1, 24, 4, 28, 28, 1, 1), (2, 54, 4, 16, 16, 2, 1), (1, 216, 6, 14, 14, 1, 1), (1, 432, 6, 7, 7, 1, 1),
     (1, 432, 4, 14, 14, 2, 1), (1, 54, 6, 56, 56, 1, 1), (1, 9, 3, 10, 6, 1, 2),
+    # stride 2 on the planes of the wave kernels (dwcp / dwcpb2: 112->56, 56->28, 28->14), several bands and t-steps
+    (1, 4, 5, 112, 112, 2, 1), (2, 6, 7, 56, 56, 2, 1), (1, 8, 9, 28, 28, 2, 1),
 ]
 
 
