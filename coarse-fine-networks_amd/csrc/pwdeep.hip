@@ -139,8 +139,12 @@ __global__ __launch_bounds__(64 * PWD_WAVES) void pw_deep_kernel(const PwArgs a)
         auto bload = [&](int k0, float (&d)[NU], float (&d2)[NU]) {   // rows k0 + 2j + half
 #pragma unroll
             for (int j = 0; j < NU; ++j) {
-                d[j] = pw_bload(r1, voff, (k0 + 2 * j) * row_bytes);
-                if (MODE == PW_DGRAD) d2[j] = two_src ? pw_bload(r2, voff, (k0 + 2 * j) * row_bytes) : 0.0f;
+                // a row base at or beyond K would push the scalar offset past the descriptor's range (which wraps instead of
+                // failing the check): such rows are switched off through the vector offset and read 0
+                const bool live = k0 + 2 * j < K;                          // wave uniform
+                const int vo = live ? voff : 0x7fffffff, so = live ? (k0 + 2 * j) * row_bytes : 0;
+                d[j] = pw_bload(r1, vo, so);
+                if (MODE == PW_DGRAD) d2[j] = two_src ? pw_bload(r2, vo, so) : 0.0f;
             }
         };
         f16v acc[MT];
@@ -154,7 +158,6 @@ __global__ __launch_bounds__(64 * PWD_WAVES) void pw_deep_kernel(const PwArgs a)
         //   B operand: two register sets ping-pong over units of 8 channels; a set is reloaded right after it is
         //              consumed and is not touched again for a whole unit (28+ MFMAs), no copies, no early waits;
         //   A operand: the MT weights of k-pair j+1 are read from LDS before the MT MFMAs of k-pair j issue.
-        float ra[NU], ra2[NU], rb[NU], rb2[NU];
         float a0[MT], a1[MT];
         auto lda = [&](float (&ar)[MT], int kl) {
             const float* p = As + kl * BM + col;
@@ -195,19 +198,23 @@ __global__ __launch_bounds__(64 * PWD_WAVES) void pw_deep_kernel(const PwArgs a)
             __builtin_amdgcn_sched_barrier(0);
             mm(a1, v3);
         };
-        bload(0, ra, ra2);
-        bload(PW_UNIT, rb, rb2);
+        // B operand ring of NS register sets with static slots: the loads of unit u + NS are issued right after unit u was
+        // consumed, so they have NS - 1 units of MFMA work (x 2 waves per SIMD) to land.  With the two-set ping-pong of
+        // round 1 that was ONE unit = MT x 256 MFMA cycles, less than the loaded HBM latency for MT <= 3 (layers 3-4: 56 % of
+        // the MFMA peak); unconditional loads (past the end reads 0: bounds check), units past the end are skipped.
+        constexpr int NS = 4;
+        float rs[NS][NU], rs2[NS][NU];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) bload(s * PW_UNIT, rs[s], rs2[s]);
         lda(a0, half);
-        int u = 0;
-        for (; u + 2 * PW_UNIT <= Kpad; u += 2 * PW_UNIT) {
-            unit(ra, ra2, u);
-            bload(u + 2 * PW_UNIT, ra, ra2);                  // past the end reads 0 (bounds check)
-            __builtin_amdgcn_sched_barrier(0);
-            unit(rb, rb2, u + PW_UNIT);
-            bload(u + 3 * PW_UNIT, rb, rb2);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < Kpad; u += NS * PW_UNIT) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (u + s * PW_UNIT < Kpad) unit(rs[s], rs2[s], u + s * PW_UNIT);          // wave uniform, no vector memory inside
+                bload(u + (s + NS) * PW_UNIT, rs[s], rs2[s]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (u < Kpad) unit(ra, ra2, u);                       // odd number of units
 
         // ---- epilogue (same scheme as pw_gemm_kernel) -------------------------------------------
         const float vm = valid ? 1.0f : 0.0f;
