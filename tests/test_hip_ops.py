@@ -95,6 +95,39 @@ def test_dwconv3d(N, C, T, H, W, stride, act, pro):
                lambda a, w_: F.conv3d(a, w_, stride=(1, stride, stride), padding=1, groups=C), x, w, A, B, act)
 
 
+WAVE_CASES = [
+    # N, C, T, H, stride, act, prologue  -- the planes of the column-pair wave kernels (dwcp / dwcpb / dwcpb2)
+    (2, 3, 1, 56, 1, 1, True), (1, 2, 2, 56, 1, 0, False), (1, 3, 61, 28, 1, 1, True), (2, 2, 7, 14, 1, 0, True),
+    (1, 5, 4, 7, 1, 1, True), (1, 3, 3, 7, 1, 0, False),
+    (1, 2, 1, 112, 2, 1, True), (2, 3, 5, 56, 2, 0, False), (1, 4, 58, 28, 2, 1, True),
+]
+
+
+@pytest.mark.parametrize('N,C,T,H,stride,act,pro', WAVE_CASES)
+@pytest.mark.parametrize('stats', [True, False])
+def test_dwconv3d_wave_kernels(N, C, T, H, stride, act, pro, stats):
+    """T = 1 / 2 / one frame more than a t-chunk, batch > 1, no prologue, and -- stats=False -- the backward WITHOUT the
+    statistics gradients (gs, gq null: the kernels' HASY = false instantiation, which the model path never takes)"""
+    x, w = rnd(1, N, C, T, H, H), rnd(2, C, 1, 3, 3, 3, scale=0.3)
+    A = (1 + 0.2 * rnd(3, N, C)) if pro else None
+    B = 0.3 * rnd(4, N, C) if pro else None
+    ref = lambda a, w_: F.conv3d(a, w_, stride=(1, stride, stride), padding=1, groups=C)
+    if stats:
+        check_conv(lambda x_, w_, A_, B_: ops().dwconv3d(x_, w_, A_, B_, act, stride, True), ref, x, w, A, B, act)
+        return
+    leaves_c = [v.clone().requires_grad_(True) if v is not None else None for v in (x, w, A, B)]
+    leaves_g = [v.clone().to(DEV).requires_grad_(True) if v is not None else None for v in (x, w, A, B)]
+    yc = ref(prologue_ref(leaves_c[0], leaves_c[2], leaves_c[3], act), leaves_c[1])
+    yg, sg, qg = ops().dwconv3d(*leaves_g, act, stride, False)
+    assert sg is None and qg is None and relerr(yg, yc) <= 2e-5
+    r = rnd(7, *yc.shape)
+    (yc * r).sum().backward()
+    (yg * r.to(DEV)).sum().backward()
+    for nm, c, g in zip(('x', 'w', 'A', 'B'), leaves_c, leaves_g):
+        if c is not None:
+            assert relerr(g.grad, c.grad) <= 2e-4, (nm, relerr(g.grad, c.grad))
+
+
 PW_CASES = [
     # N, Cin, Cout, T, H, W, stride, act, pro
     (2, 24, 54, 3, 8, 8, 1, 0, False),
