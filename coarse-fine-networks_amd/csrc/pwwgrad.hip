@@ -235,7 +235,10 @@ static int wd_launch(WdArgs& a, hipStream_t st) {
     const long groups = (long)a.N * a.mgroups * a.kgroups;
     // ~one workgroup per CU (measured: more, shorter strips lose); the single-tile variant is load bound and small:
     // four workgroups per CU
-    long strips = (WD_T == 1 ? 1024 : 256) / groups;
+    // (re-measured with the round-2 kernels, 8 clips: 2x2 / 2x3 tiles everywhere lose 3-12 % against the shapes chosen below;
+    //  two workgroups per CU gain 5-6 % for the 2x4 / 4x2 groups of layer 2 and nothing elsewhere)
+    static const int wg_env = getenv("CFN_PWD_WGS") ? atoi(getenv("CFN_PWD_WGS")) : 0;
+    long strips = (wg_env > 0 ? wg_env : (WD_T == 1 ? 1024 : (WD_T == 8 ? 512 : 256))) / groups;
     if (strips < 1) strips = 1;
     const long g8 = cfn_cdiv(a.Q, 8);
     if (strips > cfn_cdiv(g8, WD_WAVES * 4)) strips = cfn_cdiv(g8, WD_WAVES * 4);   // >= 4 position groups per wave
