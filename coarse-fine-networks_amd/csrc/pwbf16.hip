@@ -569,7 +569,8 @@ extern "C" int cfn_pwconv_bwd_weight_bf16(const uint16_t* gy, const uint16_t* y,
     a.kblocks = cfn_cdiv(Cin, 32 * NTW);
     const long groups = (long)N * a.mblocks * a.kblocks;
     const int nsteps = (int)((Q + 15) / 16);
-    long strips = (1024 + groups - 1) / groups;
+    static const int wgs_env = getenv("CFN_PWB_WG_WGS") ? atoi(getenv("CFN_PWB_WG_WGS")) : 0;
+    long strips = ((wgs_env > 0 ? wgs_env : 1024) + groups - 1) / groups;
     const long maxs = cfn_cdiv(nsteps, PWB_WAVES * 4);
     if (strips > maxs) strips = maxs;
     if (strips < 1) strips = 1;

@@ -103,6 +103,8 @@ DW_CASES = [
     (1, 432, 4, 14, 14, 2, 1), (1, 54, 6, 56, 56, 1, 1), (1, 9, 3, 10, 6, 1, 2),
     # stride 2 on the planes of the wave kernels (dwcp / dwcpb2: 112->56, 56->28, 28->14), several bands and t-steps
     (1, 4, 5, 112, 112, 2, 1), (2, 6, 7, 56, 56, 2, 1), (1, 8, 9, 28, 28, 2, 1),
+    # edge cases of the wave kernels: T = 1 / 2, batch > 1, a t-chunk boundary, no activation
+    (2, 3, 1, 56, 56, 1, 1), (1, 5, 2, 28, 28, 1, 0), (2, 4, 1, 112, 112, 2, 1), (1, 3, 58, 14, 14, 1, 1), (2, 5, 3, 7, 7, 1, 1),
 ]
 
 
