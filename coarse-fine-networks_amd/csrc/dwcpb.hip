@@ -351,10 +351,12 @@ int CPN(dw_cpb_try)(const cpe_t* gy, const cpe_t* y, const double* gs, const dou
     const unsigned blocks = (unsigned)((a.total_waves + 3) / 4);
 #define CFN_CPB_GO(...) do { if (hasy) hipLaunchKernelGGL((dw3d_cp_bwd_kernel<__VA_ARGS__, true>), dim3(blocks), dim3(256), 0, st, a); \
                              else hipLaunchKernelGGL((dw3d_cp_bwd_kernel<__VA_ARGS__, false>), dim3(blocks), dim3(256), 0, st, a); } while (0)
+    // (one row per lane fits 128 VGPRs = 4 waves per SIMD on 28x28 and 7x7: 0.67 -> 0.62 and 0.34 -> 0.31 ms; on 56x56 and
+    //  14x14 a one-row variant at 4 waves measured 10-15 % SLOWER than two rows at 3 waves: more halo rows and LDS reads per output)
     if (H == 56) CFN_CPB_GO(56, 2, 2, 1, 3);
-    else if (H == 28) CFN_CPB_GO(28, 1, 4, 1, 3);
+    else if (H == 28) CFN_CPB_GO(28, 1, 4, 1, 4);
     else if (H == 14) CFN_CPB_GO(14, 2, 7, 2, 3);
-    else CFN_CPB_GO(7, 1, 7, 2, 3);                                                  // 4 column pairs x 7 rows = 28 lanes
+    else CFN_CPB_GO(7, 1, 7, 2, 4);                                                  // 4 column pairs x 7 rows = 28 lanes
 #undef CFN_CPB_GO
     return cfn_check_launch("dwconv3d column-pair fused backward");
 }
