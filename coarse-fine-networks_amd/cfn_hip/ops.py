@@ -470,12 +470,19 @@ class _DwConvT5(Function):
         gy = torch.zeros_like(y) if gy is None else gy.contiguous()
         gs, gq = _opt(gs), _opt(gq)
         gx = gw = None
-        if ctx.needs_input_grad[0]:
+        want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if want_x:
             gx = torch.empty_like(x)
-            call('cfn_dwconv_t5_bwd_data' + _sfx(y), gy, y, gs, gq, w2, gx, N, C, T, H * W)
-        if ctx.needs_input_grad[1]:
+        if want_w:
             g64, fin = _gw_buffers(ctx.wparam, C, 5, x.device)
-            call('cfn_dwconv_t5_bwd_weight' + _sfx(y), gy, y, gs, gq, x, g64, N, C, T, H * W)
+        # both gradients in one march over gy, y, x (declines planes that are not whole float4s)
+        fused = want_x and want_w and call_try('cfn_dwconv_t5_bwd_fused' + _sfx(y), gy, y, gs, gq, w2, x, gx, g64, N, C, T, H * W)
+        if not fused:
+            if want_x:
+                call('cfn_dwconv_t5_bwd_data' + _sfx(y), gy, y, gs, gq, w2, gx, N, C, T, H * W)
+            if want_w:
+                call('cfn_dwconv_t5_bwd_weight' + _sfx(y), gy, y, gs, gq, x, g64, N, C, T, H * W)
+        if want_w:
             gw = fin()
         return gx, gw, None, None
 

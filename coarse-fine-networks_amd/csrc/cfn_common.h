@@ -64,6 +64,15 @@ template <class T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t cfn_rsrc(T*
     return __builtin_amdgcn_make_buffer_rsrc((void*)cfn_uni((long)p), 0, cfn_uni(bytes), 0x00020000);
 }
 
+// 16-byte buffer store.  Measured on gfx950 with hipcc 7.2 (csrc/dwt5.hip, fused backward): a VALU instruction that overwrites the
+// data registers RIGHT behind a 16-byte buffer store with a register soffset can reach the register file before the store has read
+// them -- lanes 12-15 / 28-31 of the second dword carried the NEXT frame's value.  LLVM's hazard recognizer inserts wait states
+// for this pair only when soffset is not a register.  The asm keeps the data registers alive for two more wait states.
+__device__ __forceinline__ void cfn_bst128(unsigned __attribute__((ext_vector_type(4))) data, __amdgpu_buffer_rsrc_t r, int vo, int so) {
+    __builtin_amdgcn_raw_buffer_store_b128(data, r, vo, so, 0);
+    asm volatile("s_nop 1" : "+v"(data));
+}
+
 // v_exp_f32 + v_rcp_f32 (1 ulp each): ~6 VALU slots instead of the ~16 of an IEEE division
 __device__ __forceinline__ float cfn_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 

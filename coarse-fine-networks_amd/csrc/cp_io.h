@@ -39,6 +39,6 @@ __device__ __forceinline__ cp_f4 cp_ld4(__amdgpu_buffer_rsrc_t r, int vo, int so
 __device__ __forceinline__ float cp_ld1(__amdgpu_buffer_rsrc_t r, int vo, int so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0)); }
 __device__ __forceinline__ void cp_st1(float v, __amdgpu_buffer_rsrc_t r, int vo, int so) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, so, 0); }
 __device__ __forceinline__ void cp_st2(cp_f2 v, __amdgpu_buffer_rsrc_t r, int vo, int so) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cp_u2, v), r, vo, so, 0); }
-__device__ __forceinline__ void cp_st4(cp_f4 v, __amdgpu_buffer_rsrc_t r, int vo, int so) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cp_u4, v), r, vo, so, 0); }
+__device__ __forceinline__ void cp_st4(cp_f4 v, __amdgpu_buffer_rsrc_t r, int vo, int so) { cfn_bst128(__builtin_bit_cast(cp_u4, v), r, vo, so); }
 __device__ __forceinline__ cp_f2 cp_rt2(cp_f2 v) { return v; }
 #endif

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void dwt5_fwd_stream_kernel(const T5Args a) {
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, yb), ry, em ? vy : OOB, so, 0);
                 y = __builtin_convertvector(yb, f4v);
             } else {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v_t5, y), ry, em ? vy : OOB, so, 0);
+                cfn_bst128(__builtin_bit_cast(u4v_t5, y), ry, em ? vy : OOB, so);
             }
             const float m = (em && ok) ? 1.0f : 0.0f;
             const f4v ym = y * m;
@@ -238,6 +238,123 @@ __global__ __launch_bounds__(256) void dwt5_fwd_stream_kernel(const T5Args a) {
             atomicAdd(&a.s2[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
         }
     }
+}
+
+// Backward, float4 rows: data gradient AND weight gradient in one march (gy, y, x read once, gx written once: 4 tensor
+// passes instead of the 6 of dwt5_kernel<T5_DGRAD> + <T5_WGRAD>), same streaming scheme as dwt5_fwd_stream_kernel: static
+// register rings, unconditional buffer accesses.  Ring slot (k % RING) holds frame t0 - 2 + k of g' = gy + gs + 2 y gq and of
+// x; a frame's raw gy / y land PF steps before it enters the 5-frame window and are combined in place at that step.
+//   gx(t)  = sum_k g'(t - 2 + k) w[4 - k]          gw[k] += sum_t g'(t) x(t - 2 + k)
+template <bool BF, bool HASY>
+__global__ __launch_bounds__(256) void dwt5_bwd_fused_kernel(const T5Args a) {
+    typedef unsigned __attribute__((ext_vector_type(2))) u2v;
+    constexpr int PF = 3, RING = 5 + PF, OOB = 0x7ffffff0, GES = BF ? 2 : 4;
+    __shared__ float sh[20];
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;
+    const int c = (int)(nc % a.C);
+    const int chunk = blockIdx.x % a.nchunks, pc = blockIdx.x / a.nchunks;
+    const int p = (pc * 256 + (int)threadIdx.x) * 4;
+    const bool ok = p < a.plane;
+    const int T = a.T, t0 = chunk * a.TT, t1 = min(t0 + a.TT, T);
+    const int plane = (int)a.plane;
+    // a.src = gy, a.src2 = y (output side: fp32 | bf16), a.yout = x (fp32), a.dst = gx (fp32), a.s1 = gw
+    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(static_cast<const char*>(a.src) + nc * T * a.plane * GES, (unsigned)((long)T * plane * GES));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(static_cast<const char*>(HASY ? a.src2 : a.src) + nc * T * a.plane * GES, (unsigned)((long)T * plane * GES));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(static_cast<const float*>(a.yout) + nc * T * a.plane, (unsigned)((long)T * plane * 4));
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(static_cast<float*>(a.dst) + nc * T * a.plane, (unsigned)((long)T * plane * 4));
+    const int vg = ok ? p * GES : OOB, vx = ok ? p * 4 : OOB;
+    float wk[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) wk[k] = cfn_uni(a.w[c * 5 + 4 - k]);        // flipped taps
+    const float gsv = cfn_uni(a.gs ? (float)a.gs[nc] : 0.0f);
+    const float gqv = cfn_uni((HASY && a.gq) ? 2.0f * (float)a.gq[nc] : 0.0f);
+    auto wanted = [&](int t) { return t >= 0 && t < T && t <= t1 + 1; };     // wave uniform
+    auto ldg = [&](__amdgpu_buffer_rsrc_t r, int t) -> f4v {
+        const bool tv = wanted(t);
+        const int vo = tv ? vg : OOB, so = tv ? t * plane * GES : 0;
+        if (BF) {
+            const u2v u = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0));
+            return (f4v){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                         __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+        }
+        return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0));
+    };
+    auto ldx = [&](int t) -> f4v {
+        const bool tv = wanted(t);
+        return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rx, tv ? vx : OOB, tv ? t * plane * 4 : 0, 0));
+    };
+    auto fin = [&](f4v g, f4v y, int t) -> f4v {                            // g' of frame t (zero outside the clip)
+        const float m = (t >= 0 && t < T && ok) ? 1.0f : 0.0f;
+        f4v v = g + gsv;
+        if (HASY) v += y * gqv;
+        return v * m;
+    };
+    f4v RG[RING], RY[RING], RX[RING];
+#pragma unroll
+    for (int k = 0; k < RING - 1; ++k) {                                   // frames t0-2 .. t0+1+PF (slots 0 .. RING-2)
+        RG[k] = ldg(rg, t0 - 2 + k);
+        if (HASY) RY[k] = ldg(ry, t0 - 2 + k);
+        RX[k] = ldx(t0 - 2 + k);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) RG[k] = fin(RG[k], HASY ? RY[k] : RG[k], t0 - 2 + k);   // frames t0-2 .. t0+1 enter the window now
+    f4v acc[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc[k] = (f4v){0.f, 0.f, 0.f, 0.f};
+    for (int tb = t0; tb < t1; tb += RING) {
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+            const int t = tb + j;
+            const bool em = t < t1;                                        // wave uniform: steps beyond the chunk contribute nothing
+            const int sn = (j + RING - 1) % RING;                          // frame t-3's slot is free: frame t + 2 + PF
+            RG[sn] = ldg(rg, t + 2 + PF);
+            if (HASY) RY[sn] = ldg(ry, t + 2 + PF);
+            RX[sn] = ldx(t + 2 + PF);
+            const int s4 = (j + 4) % RING;                                 // frame t+2 enters the window
+            RG[s4] = fin(RG[s4], HASY ? RY[s4] : RG[s4], t + 2);
+            const f4v gx = RG[j % RING] * wk[0] + RG[(j + 1) % RING] * wk[1] + RG[(j + 2) % RING] * wk[2] + RG[(j + 3) % RING] * wk[3] +
+                           RG[(j + 4) % RING] * wk[4];
+            cfn_bst128(__builtin_bit_cast(u4v_t5, gx), rd, em ? vx : OOB, em ? t * plane * 4 : 0);
+            const f4v gc = RG[(j + 2) % RING] * (em ? 1.0f : 0.0f);        // g'(t)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc[k] += gc * RX[(j + k) % RING];
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float v = cfn_wave_sum(acc[k].x + acc[k].y + acc[k].z + acc[k].w);
+        if (lane == 0) sh[k * 4 + wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5)
+        atomicAdd(&a.s1[c * 5 + threadIdx.x], (double)(sh[threadIdx.x * 4] + sh[threadIdx.x * 4 + 1] + sh[threadIdx.x * 4 + 2] + sh[threadIdx.x * 4 + 3]));
+}
+
+// -1 = not handled (the plane is not a whole number of float4s): the caller runs the two separate kernels
+template <bool BF>
+static int t5_bwd_fused(const void* gy, const void* y, const double* gs, const double* gq, const float* w, const float* x, float* gx,
+                        double* gw, int N, int C, int T, long plane, hipStream_t st) {
+    static const int on = getenv("CFN_T5_FUSED") ? atoi(getenv("CFN_T5_FUSED")) : 1;
+    if (!on || plane % 4 != 0 || (long)T * plane * 4 >= 0x7ffffff0L) return -1;
+    if ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)(y ? y : gy)) & 15) != 0) return -1;
+    const bool hasy = y != nullptr && gq != nullptr;
+    T5Args a = {};
+    a.src = gy; a.src2 = hasy ? y : nullptr; a.gs = gs; a.gq = hasy ? gq : nullptr; a.w = w; a.yout = x; a.dst = gx; a.s1 = gw;
+    a.C = C; a.T = T; a.plane = plane;
+    const long NC = (long)N * C;
+    unsigned gy_, gz_;
+    CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "dwconv_t5: N*C = %ld exceeds grid.y", NC);
+    a.pchunks = cfn_cdiv(plane, 1024L);
+    int TT = 64;
+    while (TT > 16 && NC * a.pchunks * cfn_cdiv(T, TT) < 2048) TT >>= 1;
+    if (TT > T) TT = T;
+    a.TT = TT;
+    a.nchunks = cfn_cdiv(T, TT);
+    dim3 grid((unsigned)(a.pchunks * a.nchunks), gy_, gz_);
+    if (hasy) hipLaunchKernelGGL((dwt5_bwd_fused_kernel<BF, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dwt5_bwd_fused_kernel<BF, false>), grid, dim3(256), 0, st, a);
+    return cfn_check_launch("dwconv_t5 fused backward");
 }
 
 template <int MODE, bool BF = false>
@@ -331,4 +448,24 @@ extern "C" int cfn_dwconv_t5_bwd_weight_bf16(const unsigned short* gy, const uns
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_DWCONV_BWD, st, N * (double)C * T * plane * (a.yout ? 8.0 : 6.0));
     return t5_launch<T5_WGRAD, true>(a, N, st);
+}
+
+// data AND weight gradient in one pass (gy, y, x read once); -1 = not handled, call the two entry points above
+extern "C" int cfn_dwconv_t5_bwd_fused(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
+                                       const float* x, float* gx, double* gw, int N, int C, int T, long plane, void* stream) {
+    CFN_REQUIRE(gy && w && x && gx && gw, "cfn_dwconv_t5_bwd_fused: null tensor");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv_t5_bwd_fused: gsumsq needs y");
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DWCONV_BWD, st, 4.0 * N * C * T * plane * (gsumsq ? 4 : 3));
+    return t5_bwd_fused<false>(gy, gsumsq ? y : nullptr, gsum, gsumsq, w, x, gx, gw, N, C, T, plane, st);
+}
+
+extern "C" int cfn_dwconv_t5_bwd_fused_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                                            const float* w, const float* x, float* gx, double* gw, int N, int C, int T, long plane,
+                                            void* stream) {
+    CFN_REQUIRE(gy && w && x && gx && gw, "cfn_dwconv_t5_bwd_fused_bf16: null tensor");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv_t5_bwd_fused_bf16: gsumsq needs y");
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DWCONV_BWD, st, N * (double)C * T * plane * (gsumsq ? 12.0 : 10.0));
+    return t5_bwd_fused<true>(gy, gsumsq ? y : nullptr, gsum, gsumsq, w, x, gx, gw, N, C, T, plane, st);
 }

@@ -69,6 +69,10 @@ int cfn_dwconv_t5_bwd_data(const float* gy, const float* y, const double* gsum, 
                            float* gx, int N, int C, int T, long plane, void* stream);
 int cfn_dwconv_t5_bwd_weight(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* x,
                              double* gw, int N, int C, int T, long plane, void* stream);
+/* data AND weight gradient of conv1_t in one pass over gy, y, x (4 tensor passes instead of 6).  Returns -1 without launching
+ * when the plane is not a whole number of float4s: call the two entry points above. */
+int cfn_dwconv_t5_bwd_fused(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w,
+                            const float* x, float* gx, double* gw, int N, int C, int T, long plane, void* stream);
 
 /* ---- pointwise 1x1x1, spatial stride s in {1,2}: conv1x1x1 x3d_fine.py:100-105 (conv1 :115, conv3 :119,
  * shortcut :284-287), conv5 :245-250, fc1 :256; fp32 MFMA (v_mfma_f32_32x32x2_f32).  w is (Cout,Cin).
@@ -283,6 +287,9 @@ int cfn_dwconv_t5_bwd_data_bf16(const unsigned short* gy, const unsigned short* 
                                 const float* w, float* gx, int N, int C, int T, long plane, void* stream);
 int cfn_dwconv_t5_bwd_weight_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
                                   const float* x, double* gw, int N, int C, int T, long plane, void* stream);
+int cfn_dwconv_t5_bwd_fused_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                                 const float* w, const float* x, float* gx, double* gw, int N, int C, int T, long plane,
+                                 void* stream);
 
 /* block tail x3d_fine.py:167-173 (cfn_bn_add_relu_fwd / _bwd_g) and spatial pooling :255,:345-366 (bf16 in, fp32 pooled) */
 long cfn_bn_add_relu_mask_words_bf16(long NC, long vol);
