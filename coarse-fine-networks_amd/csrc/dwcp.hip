@@ -244,7 +244,7 @@ int CPN(dw_cp_fwd_try)(const cpe_t* x, const double* A, const double* B, int act
     if (nch < 1) nch = 1;
     int TT = (int)((T + nch - 1) / nch);
     TT = ((TT + 2 + U - 1) / U) * U - 2;                                            // TT + 2 = k * U
-    if (TT < U - 2) TT = U - 2;
+    if (TT < 16) TT = 16;                                                           // (measured at T = 16, 8 clips: chunks of 4 frames cost 15-40 % against one chunk of 16)
     if (tt_env > 0) TT = tt_env;
     if (TT > T) TT = T;
     a.TT = TT;
