@@ -1,5 +1,6 @@
-// Depthwise 3x3x3 forward, stride 1, on the even square planes of X3D at 224x224 input (56x56, 28x28, 14x14: conv2 of
-// layers 1-3; x3d_fine.py:89-97,171-201) -- COLUMN-PAIR kernel: one WAVE per (sample, channel, t-chunk, row band), no
+// Depthwise 3x3x3 forward, stride 1 and 2, onto the even square output planes of X3D at 224x224 input (56x56, 28x28, 14x14:
+// conv2 of layers 1-3 and the first block of layers 1-3; x3d_fine.py:89-97,171-201), fp32 or bf16 tensors (cp_io.h) --
+// COLUMN-PAIR kernel: one WAVE per (sample, channel, t-chunk, row band), no
 // workgroup barrier.
 //
 // Why: the band kernel of dwconv3d.hip gives a lane 7 vertically adjacent outputs of ONE column: 21 accumulators, operand
@@ -7,11 +8,11 @@
 // frame; the wave-per-channel kernel of dwsmall.hip showed on 14x14 / 7x7 that independent waves and occupancy are what these
 // kernels respond to.  Here a lane owns TWO ADJACENT COLUMNS x HS (1-2) rows:
 //   * the two outputs of a row share every tap's weight, so each tap is ONE v_pk_fma_f32 on a natural register pair (inputs
-//     (c+kw-1, c+kw) straight out of LDS, the wave-uniform weight an SGPR operand): 27 packed FMAs per output pair and no
+//     (c+kw-1, c+kw) -- stride 2: (2c+kw-1, 2c+kw+1) -- straight out of LDS, the wave-uniform weight an SGPR operand): 27 packed FMAs per output pair and no
 //     pair-building moves (issue rates measured with tools/probe/mfma_rate_probe.hip at 4 waves per SIMD: v_fma_f32 2.9,
 //     v_pk_fma_f32 4.9 cycles per wave instruction; v_mfma_f32_4x4x1 at 9.8 cycles for 192 useful FMAs is no faster than
 //     the vector ALU -- an outer-product MFMA formulation of this conv was built and measured 1.3-1.7x SLOWER);
-//   * an input row is 4 LDS dwords per lane for its 2 x 3 taps;
+//   * an input row is 4 (stride 2: 5) LDS dwords per lane for its 2 x 3 taps;
 //   * the three rolling accumulator sets (temporal taps) are renamed instead of moved: the frame loop is unrolled U = 6 (12)
 //     steps, a multiple of 3 (accumulator roles), 2 (LDS image parity) and D (register ring of prefetched frames);
 //   * results leave as one 8-byte store per row; 93-97 VGPRs, 5 waves per SIMD, no barrier.
