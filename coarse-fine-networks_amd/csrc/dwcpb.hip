@@ -1,21 +1,22 @@
 // Fused backward of the stride-1 depthwise 3x3x3 conv (data gradient AND weight gradient in one pass over gy, y, x) on the
-// even square planes 56x56 / 28x28 / 14x14 (conv2 of X3D layers 1-3, x3d_fine.py:89-97,171-201) -- column-pair wave kernel,
-// the backward counterpart of dwcp.hip.
+// square planes 56x56 / 28x28 / 14x14 / 7x7 (conv2 of X3D layers 1-4, x3d_fine.py:89-97,171-201), fp32 or bf16 tensors
+// (cp_io.h) -- column-pair wave kernel, the backward counterpart of dwcp.hip.
 //
 // Why: run separately the two gradients move 7 tensor passes (dgrad: gy, y, x -> gx; wgrad: gy, y, x), fused 5.  The band
 // kernel dw3d_bwd_fused_kernel (dwconv3d.hip) does fuse them, but with 7 / 4 output rows per lane it needs 211 / 163 VGPRs
 // (2-3 waves per SIMD, one workgroup barrier per frame) and runs at 2.5-2.9 TB/s; it spills on 14x14, which therefore used the
 // two separate kernels (profiles/r02_microbench_b8.txt).  dwcp.hip showed what these kernels respond to: independent waves,
-// few rows per lane, 4-5 waves per SIMD.  Same skeleton here: one WAVE per (sample, channel, t-chunk, row band), a lane owns
+// few rows per lane, as many waves per SIMD as the registers allow (here 3-4).  Same skeleton here: one WAVE per (sample, channel, t-chunk, row band), a lane owns
 // two adjacent columns x HS (1-2) rows, three wave-private LDS images per frame parity, no workgroup barrier:
 //   G image  g'(f)   = gy + gs + 2 y gq     window -> data gradient (flipped taps, packed FMAs), centre -> weight gradient
 //   A image  a(f-1)  = act(A x + B)         window -> weight gradient; centre > 0 = act' of the ReLU prologue
 //   X image  x(f-1)                         centre -> the prologue-coefficient gradients (gA += dz x, gB += dz)
 // At step f:  gx accumulators += flipped taps * G-window(f);  gw[kt] += g'(f-kt)[centre] * A-window(f-1) with the three g'
-// centres rolling in (renamed) registers; output frame f-1 is finished with the act' epilogue.  The forward is
+// centres and the three gx accumulator sets rotating in registers; output frame f-1 is finished with the act' epilogue.  The forward is
 // y(t) = sum_kt w[kt] a(t+kt-1), so gw[kt] = sum_t g'(t) a(t+kt-1): with the A frame fa = f-1, t = f - kt.
 // The 27 weight-gradient sums of a lane are scalar (54 registers as pairs would cost a wave per SIMD); they are reduced over
 // the wave at the end and added with fp64 atomics like everywhere else.
+// 7x7 (odd width): dword loads, the last column pair has one column, 28 of 64 lanes busy.
 // Prologue activations other than none / ReLU and other planes keep the band kernels (dw_cpb_try returns -1).
 // hipcc-flags: -fno-slp-vectorize
 // (the SLP vectoriser re-pairs the scalar weight-gradient FMAs into v_pk_fma_f32 with ~300 pair-building moves per trip and
