@@ -8,7 +8,7 @@
 // two separate kernels (profiles/r02_microbench_b8.txt).  dwcp.hip showed what these kernels respond to: independent waves,
 // few rows per lane, as many waves per SIMD as the registers allow (here 3-4).  Same skeleton here: one WAVE per (sample, channel, t-chunk, row band), a lane owns
 // two adjacent columns x HS (1-2) rows, three wave-private LDS images per frame parity, no workgroup barrier:
-//   G image  g'(f)   = gy + gs + 2 y gq     window -> data gradient (flipped taps, packed FMAs), centre -> weight gradient
+//   G image  g'(f)   = gy + gs + 2 y gq     window -> data gradient (flipped taps), centre -> weight gradient
 //   A image  a(f-1)  = act(A x + B)         window -> weight gradient; centre > 0 = act' of the ReLU prologue
 //   X image  x(f-1)                         centre -> the prologue-coefficient gradients (gA += dz x, gB += dz)
 // At step f:  gx accumulators += flipped taps * G-window(f);  gw[kt] += g'(f-kt)[centre] * A-window(f-1) with the three g'
