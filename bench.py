@@ -3,6 +3,7 @@
 Bx3x256x224x224 clips (B = 8 clips per GPU by default), one process per GPU, gradients all-reduced over RCCL.
 
     python bench.py --gpus 1 --steps 8 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          # N > 1 outside torchrun: re-launches itself as N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -10,8 +11,9 @@ Rank 0 prints ONE JSON line.  ``value`` = clips all ranks processed / max-over-r
 timed steps (inputs already resident in HBM).  ``roofline`` is measured live: HIP events bracket every
 launch of the depthwise-conv forward kernels (the headline kernel family) on the stream they
 run on; achieved = algorithmic bytes (N_in + N_out elements x 4 B + weights, per launch) / device time.
-``cpu_baseline`` times the CPU oracle (plain torch fp32, all host cores) on a bounded sample of the same
-workload (rank 0, N=1 only).
+``cpu_baseline`` times the CPU oracle (plain torch fp32; 16 threads by default -- torch's CPU conv kernels stop scaling far
+below the GPU box's 256 logical CPUs; CFN_CPU_THREADS overrides, `cores` in the JSON is what was used) on a bounded sample
+of the same workload (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -88,6 +90,21 @@ ROOFLINE_FAMILIES = {'fine': ('dwconv_fwd',), 'coarse': ('dwconv_fwd', 'gridpool
                      'joint': ('dwconv_fwd', 'gridpool', 'dense_fwd')}
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` outside torchrun: one rank per GPU under torch.distributed.run (as train_fine._spawn)"""
+    import socket
+    import subprocess
+    port = os.environ.get('MASTER_PORT')
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -106,6 +123,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-frames', type=int, default=128)
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(_self_launch(args.gpus))
     coarse, joint = args.stream == 'coarse', args.stream == 'joint'
     assert not (coarse and args.dtype != 'f32'), 'the bf16 activation path covers the fine stream'
     if args.frames is None:
@@ -116,6 +135,7 @@ def main():
     import train_fine
     import train_coarse_fineFEAT as tc
     rank, world, dev = cdist.init_from_env()
+    assert world == args.gpus, '--gpus %d but WORLD_SIZE is %d: launch one rank per GPU (or let bench.py do it)' % (args.gpus, world)
     assert torch.cuda.is_available(), 'bench.py measures the HIP path; it needs a GPU'
     cfn_hip.load()
 

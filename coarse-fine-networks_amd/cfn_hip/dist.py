@@ -42,10 +42,8 @@ def init_from_env(backend=None):
 
 
 class _BucketHook(object):
-    """post-accumulate hook of GradReducer.  The marker tells cfn_hip.ops that this hook flushes the lazily cast weight
-    gradients before it reads them (ops._lazy_ok); any other post-accumulate hook disables the lazy cast for its
-    parameter."""
-    _cfn_flushes_grad_casts = True
+    """post-accumulate hook of GradReducer: counts a bucket's gradients in and launches its all-reduce when the last one
+    exists.  It flushes the lazily cast weight gradients before it reads them (ops.flush_grad_casts)."""
 
     def __init__(self, reducer):
         self.reducer = reducer
@@ -55,7 +53,14 @@ class _BucketHook(object):
 
 
 class GradReducer(object):
-    """Bucketed, backward-overlapped gradient averaging for a replica's parameters."""
+    """Bucketed, backward-overlapped gradient averaging for a replica's parameters.
+
+    Collectives are matched across ranks by issue order, so buckets are launched strictly in bucket order.
+    Every bucket owns ONE static flat buffer (gradients + one "somebody had a gradient" flag per parameter), allocated at the
+    first use and reused every step: no allocation inside backward.  Every step issues exactly one all-reduce per bucket, in
+    bucket order, on every rank -- a bucket whose parameters got no gradient on this rank (data-dependent branches: the rw6
+    dropout path, multi-crop) is sent zero-filled by finish(), so the ranks can never disagree on the number of collectives.
+    A parameter without a local gradient receives the averaged one iff some rank had one (its flag came back non-zero)."""
 
     def __init__(self, params, bucket_bytes=4 << 20, group=None, force=False):
         """force=True registers the bucket hooks even for a single rank (the collective is then an identity): used by the
@@ -64,9 +69,12 @@ class GradReducer(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = bool(force) and dist.is_initialized()
         self.params = [p for p in params if p.requires_grad]
-        self.buckets = []            # list of lists of params, in reverse registration order
+        self.buckets = []            # list of lists of params, in reverse registration order; one dtype / device per bucket
         cur, size = [], 0
         for p in reversed(self.params):   # backward produces gradients roughly in reverse order
+            if cur and (p.dtype != cur[0].dtype or p.device != cur[0].device):
+                self.buckets.append(cur)
+                cur, size = [], 0
             cur.append(p)
             size += p.numel() * p.element_size()
             if size >= bucket_bytes:
@@ -78,10 +86,20 @@ class GradReducer(object):
         for bi, b in enumerate(self.buckets):
             for p in b:
                 self._bucket_of[p] = bi
+        nb = len(self.buckets)
         self._pending = [len(b) for b in self.buckets]
+        self._next = 0               # buckets [0, _next) have been launched this step
+        self._flat = [None] * nb     # static flat buffer per bucket: [gradients ..., one flag per parameter]
+        self._views = [None] * nb
         self._inflight = []
         self._stream = None
         self._hooks = []
+        # the lazily cast weight gradients (ops._GradCast) are handed out only for parameters whose every reader flushes
+        # first: this reducer does (see _launch), so it opts its own parameters in.  Parameters nobody opted in -- a model
+        # wrapped in torch DDP / FSDP, whose reducer hooks sit on the AccumulateGrad node where they cannot be seen -- get an
+        # immediate cast.
+        from . import ops
+        ops.allow_lazy_grad_cast(self.params)
         if self.world > 1 or self.force:
             hook = _BucketHook(self)
             for p in self.params:
@@ -94,47 +112,73 @@ class GradReducer(object):
             self._stream = torch.cuda.Stream(device=dev)
         return self._stream
 
+    def _buffers(self, bi):
+        if self._flat[bi] is None:
+            b = self.buckets[bi]
+            flat = torch.zeros(sum(p.numel() for p in b) + len(b), dtype=b[0].dtype, device=b[0].device)
+            views, off = [], 0
+            for p in b:
+                views.append(flat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+            self._flat[bi], self._views[bi] = flat, views
+        return self._flat[bi], self._views[bi]
+
     def _on_grad(self, p):
         bi = self._bucket_of[p]
         self._pending[bi] -= 1
-        if self._pending[bi] == 0:
-            self._launch(bi)
+        # collectives are matched across ranks by issue order: buckets are launched strictly in bucket order, a complete
+        # bucket behind an incomplete one waits (for that one, or for finish())
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch(self._next)
 
     def _launch(self, bi):
-        ps = [p for p in self.buckets[bi] if p.grad is not None]
-        if not ps:
-            return
+        b = self.buckets[bi]
+        flat, views = self._buffers(bi)
         from . import ops
         ops.flush_grad_casts()   # weight gradients are cast fp64 -> fp32 lazily; make this bucket's valid
-        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        have = [i for i, p in enumerate(b) if p.grad is not None]
+        if len(have) == len(b):
+            flat[-len(b):].fill_(1.0)
+        else:                    # gradient-less parameters travel as zeros with a zero flag
+            flat.zero_()
+            if have:
+                flat[-len(b):].copy_(torch.tensor([1.0 if b[i].grad is not None else 0.0 for i in range(len(b))], dtype=flat.dtype),
+                                     non_blocking=True)
+        if have:
+            torch._foreach_copy_([views[i] for i in have], [b[i].grad for i in have])
         flat.div_(self.world)
         st = self._comm_stream(flat.device)
         if st is not None:
             st.wait_stream(torch.cuda.current_stream(flat.device))
             with torch.cuda.stream(st):
                 work = dist.all_reduce(flat, group=self.group, async_op=True)
-            flat.record_stream(st)
         else:
             work = dist.all_reduce(flat, group=self.group, async_op=True)
-        self._inflight.append((work, flat, ps))
+        assert bi == self._next
+        self._next = bi + 1
+        self._inflight.append((work, bi))
 
     def finish(self):
-        """Call after backward(): waits for the collectives and writes the averaged gradients back."""
+        """Call after backward(): launches the buckets backward did not complete (so that every rank issues one collective
+        per bucket, always), waits for the collectives and writes the averaged gradients back."""
         if self.world == 1 and not self.force:
             return
-        for bi, left in enumerate(self._pending):   # buckets whose params got no gradient this step
-            if left != 0 and left != len(self.buckets[bi]):
-                self._launch(bi)
-        for work, flat, ps in self._inflight:
+        while self._next < len(self.buckets):
+            self._launch(self._next)
+        for work, bi in self._inflight:
             work.wait()
-            views, off = [], 0
-            for p in ps:
-                n = p.numel()
-                views.append(flat[off:off + n].view_as(p.grad))
-                off += n
-            torch._foreach_copy_([p.grad for p in ps], views)     # one multi-tensor launch per bucket, not one per parameter
+            b, flat, views = self.buckets[bi], self._flat[bi], self._views[bi]
+            have = [i for i, p in enumerate(b) if p.grad is not None]
+            if have:    # one multi-tensor launch per bucket, not one per parameter
+                torch._foreach_copy_([b[i].grad for i in have], [views[i] for i in have])
+            if len(have) != len(b):
+                flags = flat[-len(b):].tolist()          # rare path (a host sync): who, anywhere, had a gradient
+                for i, p in enumerate(b):
+                    if p.grad is None and flags[i] > 0:
+                        p.grad = views[i].clone()
         self._inflight = []
         self._pending = [len(b) for b in self.buckets]
+        self._next = 0
 
 
 def global_mask_count(masks, group=None, local=False):

@@ -16,8 +16,8 @@ Rules the captured callable has to respect (checked where possible):
   * gradients live in the graph's memory pool: never `zero_grad(set_to_none=True)` between replays from outside (the
     captured step may do it internally: backward then re-creates them at the same addresses at capture time);
   * the learning rate is baked into the optimizer kernels: a changed `lr` (scheduler, warm-up) triggers a re-capture;
-  * multi-GPU: collectives are NOT captured.  With world_size > 1 pass `reducer=`: the captured part ends after backward,
-    the bucketed all-reduce runs eagerly on the static gradient buffers, and the optimizer step is a second graph.
+  * multi-GPU: collectives are NOT captured, and GradReducer's hooks would launch RCCL on a side stream inside the capture:
+    with torch.distributed initialised at world_size > 1 a GraphedStep refuses to capture (RuntimeError) -- run eager.
 """
 import torch
 
@@ -96,6 +96,9 @@ class GraphedStep(object):
         if entry is not None and entry[3] != _lr_signature(self.optimizer):
             entry = None                       # learning rate changed: the optimizer kernels hold the old value
         if entry is None:
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                raise RuntimeError('GraphedStep: collectives are not captured; with world_size > 1 run the step eagerly')
             entry = self._capture(args)
             self._graphs[sig] = entry
             # the capture itself executed nothing: fall through to a replay so that this call performs one real step

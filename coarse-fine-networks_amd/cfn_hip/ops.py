@@ -145,15 +145,35 @@ def flush_grad_casts():
     _tls.gradcast.flush()
 
 
+def allow_lazy_grad_cast(params):
+    """Opt parameters in to the lazily cast weight gradients (_GradCast): their gradient may be handed to autograd as a view
+    that is filled at the end of the backward pass.  ONLY for parameters whose every reader inside the pass calls
+    flush_grad_casts() first -- cfn_hip.dist.GradReducer does and opts its parameters in.  Anything else (torch DDP / FSDP
+    reducers and other hooks on the AccumulateGrad node, which cannot be detected from here) keeps the default: an immediate
+    cast, one small kernel per weight gradient."""
+    for p in params:
+        p._cfn_lazy_grad_ok = True
+
+
 def _lazy_ok(w):
     if not LAZY_GRAD_CAST or w is None or not w.is_leaf or w.grad is not None or torch.is_grad_enabled():
         return False
+    if not getattr(w, '_cfn_lazy_grad_ok', False):
+        return False      # not opted in (allow_lazy_grad_cast): somebody unseen (DDP / FSDP node hooks) might read it early
     if w._backward_hooks:
         return False
     hooks = getattr(w, '_post_accumulate_grad_hooks', None)
-    if hooks and not all(getattr(h, '_cfn_flushes_grad_casts', False) for h in hooks.values()):
-        return False      # somebody else (DDP, FSDP, optimizer-in-backward) would read the gradient before the flush
+    if hooks:
+        from .dist import _BucketHook
+        if not all(isinstance(h, _BucketHook) for h in hooks.values()):
+            return False  # a foreign post-accumulate hook (optimizer-in-backward ...) would read the gradient before the flush
     return True
+
+
+def _lazy_ok_probe(w):
+    """_lazy_ok as the backward pass would see it (grad mode off); for tests"""
+    with torch.no_grad():
+        return _lazy_ok(w)
 
 
 def _gw_buffers(w, rows, cols, dev):
@@ -359,20 +379,34 @@ def pwconv(x, w, A=None, B=None, act=ACT_NONE, stride=1, stats=True, token=None,
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     es = x.element_size()
     lim = (1 << 31) if es == 4 else (1 << 30)
-    span = max(Cin * H * W, w.shape[0] * Ho * Wo, Cin * Ho * Wo) * es
+    span = max(Cin * H * W, w.shape[0] * H * W, w.shape[0] * Ho * Wo, Cin * Ho * Wo) * es     # pw_plan range-checks M * Pin too
     needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, w, A, B))
     if span * T < lim or needs_grad or T == 1:
         return _PwConv.apply(x, A, B, w, act, stride, stats, token, role, tail, tail_role)
     step = max((lim - 1) // span, 1)
-    if es == 2 and (Ho * Wo) % 2:
-        step -= step % 2                         # bf16 kernels need an even position count
+    odd_plane = es == 2 and (Ho * Wo) % 2 == 1       # bf16 kernels need an even position count: even frame counts then
+    if odd_plane:
+        step = max(step & ~1, 2)
     y = torch.empty(N, w.shape[0], T, Ho, Wo, dtype=x.dtype, device=x.device)
     s = q = None
-    for t0 in range(0, T, max(step, 1)):
-        yc, sc, qc = _PwConv.apply(x[:, :, t0:t0 + step].contiguous(), A, B, w, act, stride, stats, None, None)
-        y[:, :, t0:t0 + step] = yc
+    t0 = 0
+    while t0 < T:
+        t1 = min(t0 + step, T)
+        if odd_plane and (t1 - t0) % 2 and t1 - t0 > 1:
+            t1 -= 1                               # keep the chunk even; a single odd frame is left for the end
+        pad = odd_plane and (t1 - t0) % 2 == 1     # T itself odd: the last frame travels with a zero frame (zero prologue too)
+        xc = x[:, :, t0:t1].contiguous()
+        if pad:
+            xc = torch.cat([xc, torch.zeros_like(xc)], 2)
+        yc, sc, qc = _PwConv.apply(xc, A, B, w, act, stride, False if pad else stats, None, None)
+        if pad:
+            yc = yc[:, :, :1]
+            if stats:
+                sc, qc = yc.double().sum((2, 3, 4)), (yc.double() ** 2).sum((2, 3, 4))
+        y[:, :, t0:t1] = yc
         if stats:
             s, q = (sc, qc) if s is None else (s + sc, q + qc)
+        t0 = t1
     return y, s, q
 
 

@@ -48,6 +48,12 @@ __device__ __forceinline__ float pw_bload(__amdgpu_buffer_rsrc_t r, int voff, in
 // otherwise the launch status.  mode: PW_FWD / PW_DGRAD; stats: epilogue statistics / act' epilogue present.
 int pwd_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st);
 
+// pwsplit.hip / pwsplitw.hip: the same contractions with split-bf16 arithmetic (fp32 tensors, operands split into 2-3 bf16
+// terms on load, 3 or 6 bf16 MFMAs per k-block); tried first, -1 = shape not handled or the split is switched off
+int pws_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st);
+int pws_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const double* gsc, const float* x,
+                         const double* pa, const double* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st);
+
 // pwwgrad.hip: direct-operand weight gradient for M, K >= 48 (stride 1); -1 = shape not handled.
 // gsc: per-(n,m) scale of gy (null = 1)
 int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const double* gsc, const float* x,

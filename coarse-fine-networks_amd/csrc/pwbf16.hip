@@ -321,9 +321,11 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_kernel(const PwbArgs a) {
 // rows per weight slab: 128 forward, 64 backward (two staged tensors and the act' epilogue need the registers)
 static int pwb_plan(PwbArgs& a, int& MT, unsigned& blocks, size_t& lds, int max_rows) {
     if (a.Q % 2) return cfn_fail(CFN_ERR_UNSUPPORTED, "bf16 pointwise conv: T*H*W = %d must be even (position pairs share a dword)", a.Q);
-    if ((long)a.Kp * a.Q * 2 >= 0x3ffffff0L || (long)max_rows * a.Q * 2 >= 0x3ffffff0L)
-        return cfn_fail(CFN_ERR_UNSUPPORTED, "bf16 pointwise conv: a sample's (channels x positions) block exceeds the 1 GiB buffer range");
     a.Kp = (a.K + 31) / 32 * 32;
+    // every descriptor spans one sample's (rows x positions) block: the contraction side (K rows, padded k-blocks address up
+    // to Kp), the output / epilogue side (M rows)
+    if ((long)a.Kp * a.Q * 2 >= 0x3ffffff0L || (long)a.M * a.Q * 2 >= 0x3ffffff0L)
+        return cfn_fail(CFN_ERR_UNSUPPORTED, "bf16 pointwise conv: a sample's (channels x positions) block exceeds the 1 GiB buffer range");
     a.mslabs = (a.M + max_rows - 1) / max_rows;
     const int per = (a.M + a.mslabs - 1) / a.mslabs;
     MT = (per + 31) / 32;

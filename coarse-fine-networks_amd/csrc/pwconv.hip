@@ -598,6 +598,7 @@ extern "C" int cfn_pwconv_fwd(const float* x, const double* A, const double* B, 
     CFN_REQUIRE((long)T * Hi * Wi < (1L << 31), "cfn_pwconv_fwd: per-sample volume too large");
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_FWD, st, 4.0 * N * ((double)Cin * a.Q + (double)Cout * a.Q) + 4.0 * Cin * Cout);
+    { const int rc = pws_try_launch(a, PW_FWD, sum != nullptr, st); if (rc >= 0) return rc; }
     { const int rc = pwd_try_launch(a, PW_FWD, sum != nullptr, st); if (rc >= 0) return rc; }
     int MT; unsigned blocks; size_t lds;
     { int rc = pw_plan(a, MT, blocks, lds); if (rc) return rc; }
@@ -625,6 +626,7 @@ extern "C" int cfn_pwconv_bwd_data_acc(const float* gy, const float* y, const do
     if (acc) { a.acc = acc; a.acc_s = acc_stride; a.acc_Ho = (Hi - 1) / acc_stride + 1; a.acc_Wo = (Wi - 1) / acc_stride + 1; }
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_BWD, st, 4.0 * N * ((double)Cout * a.Q * (a.src2 ? 2 : 1) + (double)Cin * a.Q * (A ? 2 : 1)));
+    { const int rc = pws_try_launch(a, PW_DGRAD, A != nullptr, st); if (rc >= 0) return rc; }
     { const int rc = pwd_try_launch(a, PW_DGRAD, A != nullptr, st); if (rc >= 0) return rc; }
     int MT; unsigned blocks; size_t lds;
     { int rc = pw_plan(a, MT, blocks, lds); if (rc) return rc; }
@@ -696,6 +698,10 @@ extern "C" int cfn_pwconv_bwd_weight(const float* gy, const float* y, const doub
     wg_plan(a, MTW, NTW);
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_WGRAD, st, 4.0 * N * ((double)Cout * a.Q * (a.y ? 2 : 1) + (double)Cin * a.Q));
+    if (stride == 1) {
+        const int rc = pws_wgrad_try_launch(gy, a.y, gsum, gsumsq, gscale, x, A, B, act, gw, N, Cout, Cin, a.Q, st);
+        if (rc >= 0) return rc;
+    }
     {
         const int rc = stride == 1 ? pwd_wgrad_try_launch(gy, a.y, gsum, gsumsq, gscale, x, A, B, act, gw, N, Cout, Cin, a.Q, st)
                                    : pwd_wgrad_try_strided(gy, a.y, gsum, gsumsq, gscale, x, A, B, act, gw, N, Cout, Cin, T, Hi, Wi, stride, st);

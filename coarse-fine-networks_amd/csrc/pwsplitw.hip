@@ -1,0 +1,258 @@
+// Weight gradient of the pointwise contractions on FP32 tensors with SPLIT-BF16 arithmetic (see pwsplit.hip for the
+// split; x3d_fine.py:100-105 conv1 / conv3 of layers 2-4):
+//     gW[m][k] += sum_q G'[m][q] * a[k][q],   G' = gsc*gy + gs + 2 y gq,   a = act(A x + B).
+// The contraction runs over POSITIONS, contiguous in both operands, and their order inside an MFMA k-block is free as long
+// as both operands agree: lane (r = l & 31, kg = l >> 5) streams along ONE channel row and takes, of every 16-position
+// step, the two aligned float4s at p0 + 4 kg and p0 + 8 + 4 kg (8 of the step's 16 positions = its 8 consecutive k of
+// v_mfma_f32_32x32x16_bf16), straight from HBM into VGPRs (no LDS transpose, no barrier in the main loop), applies the
+// prologue with per-lane coefficients, splits into NS bf16 terms and feeds 3 (NS = 2) or 6 (NS = 3) MFMAs per tile pair.
+// A wave owns TM x TN tiles of 32x32 outputs over its own steps; the 8 waves of a workgroup take the steps of a strip
+// interleaved (the pieces of every 128-byte line are consumed by neighbouring waves at about the same time) and are
+// combined through LDS into one fp64 atomic per element per workgroup.
+#include "pw_common.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+#define PWSW_WAVES 8
+#define PWSW_OOB 0x7ffffff0
+
+__device__ __forceinline__ float pwsw_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float pwsw_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ unsigned pwsw_pack(float lo, float hi) {
+    const bf16x2 b = __builtin_convertvector((f2v){lo, hi}, bf16x2);
+    return __builtin_bit_cast(unsigned, b);
+}
+template <int NS>
+__device__ __forceinline__ void pwsw_split(float v0, float v1, unsigned (&p)[NS]) {
+    p[0] = pwsw_pack(v0, v1);
+#pragma unroll
+    for (int s = 1; s < NS; ++s) {
+        v0 -= pwsw_lo(p[s - 1]);
+        v1 -= pwsw_hi(p[s - 1]);
+        p[s] = pwsw_pack(v0, v1);
+    }
+}
+template <int NS, class F>
+__device__ __forceinline__ void pwsw_terms(F&& f) {
+    if (NS == 3) { f(2, 0); f(0, 2); f(1, 1); }
+    if (NS >= 2) { f(1, 0); f(0, 1); }
+    f(0, 0);
+}
+
+struct WsArgs {
+    const float* gy; const float* y; const double* gs; const double* gq; const double* gsc;
+    const float* x; const double* pa; const double* pb;
+    double* gw;
+    int N, M, K, Q, act;
+    int mgroups, kgroups, nstrips, mt32, kt32;
+};
+
+// balanced split of `tiles` into `groups` runs: run g covers [first, first + count)
+__device__ __forceinline__ void pwsw_run(int tiles, int groups, int g, int& first, int& count) {
+    const int base = tiles / groups, rem = tiles - base * groups;
+    first = g * base + min(g, rem);
+    count = base + (g < rem ? 1 : 0);
+}
+
+template <int TM, int TN, int ACT, bool HASY, int NS>
+__global__ __launch_bounds__(64 * PWSW_WAVES) void pws_wgrad_kernel(const WsArgs a) {
+    __shared__ float cw[PWSW_WAVES][32 * 33];
+    const int tid = threadIdx.x, wave = cfn_uni(tid >> 6), lane = tid & 63, kg = lane >> 5, row = lane & 31;
+    unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    // tile groups vary fastest: workgroups that stream the same positions (and re-read the same operand rows) are
+    // neighbours on one XCD and find each other's lines in its L2
+    const int kgi = L % a.kgroups; L /= a.kgroups;
+    const int mgi = L % a.mgroups; L /= a.mgroups;
+    const int strip = L % a.nstrips;
+    const int n = L / a.nstrips;
+    const int M = a.M, K = a.K, Q = a.Q;
+    int mt0, mtn, kt0, ktn;
+    pwsw_run(a.mt32, a.mgroups, mgi, mt0, mtn);   // <= TM row tiles
+    pwsw_run(a.kt32, a.kgroups, kgi, kt0, ktn);   // <= TN column tiles
+    const int m0 = mt0 * 32, k0 = kt0 * 32;
+
+    // per-lane prologue coefficients (lane <-> channel row of each tile)
+    float cs[TM], cq[TM], cz[TM], ca[TN], cb[TN];
+    int om[TM], ok_[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + i * 32 + row;
+        const bool ok = i < mtn && m < M;
+        cs[i] = (ok && a.gs) ? (float)a.gs[(long)n * M + m] : 0.0f;
+        cq[i] = (ok && HASY && a.gq) ? 2.0f * (float)a.gq[(long)n * M + m] : 0.0f;
+        cz[i] = (ok && a.gsc) ? (float)a.gsc[(long)n * M + m] : 1.0f;
+        om[i] = ok ? m * Q * 4 : PWSW_OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int k = k0 + i * 32 + row;
+        const bool ok = i < ktn && k < K;
+        ca[i] = (ok && a.pa) ? (float)a.pa[(long)n * K + k] : 1.0f;
+        cb[i] = (ok && a.pb) ? (float)a.pb[(long)n * K + k] : 0.0f;
+        ok_[i] = ok ? k * Q * 4 : PWSW_OOB;
+    }
+    const int row_bytes = Q * 4;
+    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(const_cast<float*>(a.gy + (long)n * M * Q), (unsigned)((long)M * row_bytes));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(const_cast<float*>((HASY ? a.y : a.gy) + (long)n * M * Q), (unsigned)((long)M * row_bytes));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<float*>(a.x + (long)n * K * Q), (unsigned)((long)K * row_bytes));
+
+    // steps of 16 positions; the workgroup owns a contiguous run of steps, its waves take them interleaved
+    const int nst = (Q + 15) >> 4;
+    const int per = (nst + a.nstrips - 1) / a.nstrips;
+    const int sbeg = strip * per + wave, send = min(strip * per + per, nst);
+    f16v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) acc[i][jn] = (f16v)0.0f;
+
+    auto ld4 = [&](__amdgpu_buffer_rsrc_t r, int voff) -> f4v {
+        return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+    };
+    f4v rG[TM][2], rY[TM][2], rX[TN][2];
+    // unconditional loads: a float4 beyond the row end (Q % 4 == 0: all inside or all outside) or of a dead row goes to an
+    // out-of-range offset and reads 0
+    auto load = [&](int s) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int q = s * 16 + 8 * e + 4 * kg;
+            const bool inq = q < Q;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int vm = inq && om[i] != PWSW_OOB ? om[i] + q * 4 : PWSW_OOB;
+                rG[i][e] = ld4(rg, vm);
+                if (HASY) rY[i][e] = ld4(ry, vm);
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) rX[i][e] = ld4(rx, inq && ok_[i] != PWSW_OOB ? ok_[i] + q * 4 : PWSW_OOB);
+        }
+    };
+    if (sbeg < send) load(sbeg);
+    for (int s = sbeg; s < send; s += PWSW_WAVES) {
+        u4v Aop[TM][NS], Bop[TN][NS];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float vm = (s * 16 + 8 * e + 4 * kg < Q) ? 1.0f : 0.0f;     // masks the constant term beyond the row end
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float c0 = cs[i] * vm;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float g0 = fmaf(rG[i][e][2 * h], cz[i], c0), g1 = fmaf(rG[i][e][2 * h + 1], cz[i], c0);
+                    if (HASY) { g0 = fmaf(rY[i][e][2 * h], cq[i], g0); g1 = fmaf(rY[i][e][2 * h + 1], cq[i], g1); }
+                    unsigned p[NS];
+                    pwsw_split<NS>(g0, g1, p);
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp) Aop[i][sp][2 * e + h] = p[sp];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float x0 = cfn_act<ACT>(fmaf(rX[i][e][2 * h], ca[i], cb[i])), x1 = cfn_act<ACT>(fmaf(rX[i][e][2 * h + 1], ca[i], cb[i]));
+                    unsigned p[NS];
+                    pwsw_split<NS>(x0, x1, p);
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp) Bop[i][sp][2 * e + h] = p[sp];
+                }
+            }
+        }
+        if (s + PWSW_WAVES < send) load(s + PWSW_WAVES);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+                if (i < mtn && jn < ktn)
+                    pwsw_terms<NS>([&](int sa, int sb) {
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Aop[i][sa]), __builtin_bit_cast(bf16x8, Bop[jn][sb]), acc[i][jn], 0, 0, 0);
+                    });
+    }
+
+    // ---- combine the 8 waves tile by tile through LDS, one fp64 atomic per element per workgroup ----------
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            if (i < mtn && jn < ktn) {                           // workgroup uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cw[wave][((r & 3) + 8 * (r >> 2) + 4 * kg) * 33 + row] = acc[i][jn][r];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int el = tid + e * 64 * PWSW_WAVES;    // 1024 elements of the tile
+                    const int ml = el >> 5, kl = el & 31;
+                    float v = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < PWSW_WAVES; ++w) v += cw[w][ml * 33 + kl];
+                    const int m = m0 + i * 32 + ml, k = k0 + jn * 32 + kl;
+                    if (m < M && k < K) atomicAdd(&a.gw[(long)m * K + k], (double)v);
+                }
+                __syncthreads();
+            }
+        }
+}
+
+template <int TM, int TN, int NS>
+static int pwsw_launch(WsArgs& a, hipStream_t st) {
+    a.mt32 = cfn_cdiv(a.M, 32); a.kt32 = cfn_cdiv(a.K, 32);
+    a.mgroups = cfn_cdiv(a.mt32, TM); a.kgroups = cfn_cdiv(a.kt32, TN);
+    const long groups = (long)a.N * a.mgroups * a.kgroups;
+    static const int wg_env = getenv("CFN_PWSW_WGS") ? atoi(getenv("CFN_PWSW_WGS")) : 0;
+    long strips = (wg_env > 0 ? wg_env : 512) / groups;
+    if (strips < 1) strips = 1;
+    const long nst = cfn_cdiv(a.Q, 16);
+    if (strips > cfn_cdiv(nst, PWSW_WAVES * 4)) strips = cfn_cdiv(nst, PWSW_WAVES * 4);   // >= 4 steps per wave
+    a.nstrips = (int)strips;
+    const unsigned blocks = (unsigned)(groups * strips);
+#define PWSW_GO(AV)                                                                                                        \
+    do {                                                                                                                   \
+        if (a.y) hipLaunchKernelGGL((pws_wgrad_kernel<TM, TN, AV, true, NS>), dim3(blocks), dim3(64 * PWSW_WAVES), 0, st, a); \
+        else hipLaunchKernelGGL((pws_wgrad_kernel<TM, TN, AV, false, NS>), dim3(blocks), dim3(64 * PWSW_WAVES), 0, st, a);    \
+    } while (0)
+    switch (a.act) {
+        case CFN_ACT_RELU: PWSW_GO(CFN_ACT_RELU); break;
+        case CFN_ACT_SWISH: PWSW_GO(CFN_ACT_SWISH); break;
+        default: PWSW_GO(CFN_ACT_NONE); break;
+    }
+#undef PWSW_GO
+    return cfn_check_launch("pwconv_bwd_weight(split bf16)");
+}
+
+extern "C" int cfn_pw_split_terms(int terms);
+
+// contiguous pointwise conv (stride 1), M, K >= 48; -1 = not handled (caller falls through to the fp32-MFMA kernels)
+int pws_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const double* gsc, const float* x,
+                         const double* pa, const double* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st) {
+    const int terms = cfn_pw_split_terms(-1);
+    if (terms == 0 || M < 48 || K < 48 || Q % 4 != 0) return -1;
+    if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && act != CFN_ACT_SWISH) return -1;
+    if (((uintptr_t)gy | (uintptr_t)(y ? y : gy) | (uintptr_t)x) & 15) return -1;
+    if ((long)M * Q * 4 >= (1L << 31) - 64 || (long)K * Q * 4 >= (1L << 31) - 64) return -1;
+    WsArgs a = {gy, gq ? y : nullptr, gs, gq, gsc, x, pa, pb, gw, N, M, K, Q, act};
+    // tile group per wave: the candidate with the least operand traffic  kgroups * M rows (x2 with y) + mgroups * K rows
+    const int mt = cfn_cdiv(M, 32), kt = cfn_cdiv(K, 32);
+    static const int tm_env = getenv("CFN_PWSW_TM") ? atoi(getenv("CFN_PWSW_TM")) : 0;
+    static const int tn_env = getenv("CFN_PWSW_TN") ? atoi(getenv("CFN_PWSW_TN")) : 0;
+    const int cand[3][2] = {{2, 2}, {2, 3}, {3, 2}};
+    int best = 0; long best_cost = -1;
+    for (int c = 0; c < (a.y ? 2 : 3); ++c) {       // 3 row tiles with two row-side tensors (gy, y) spill
+        const long cost = (long)cfn_cdiv(kt, cand[c][1]) * M * (a.y ? 2 : 1) + (long)cfn_cdiv(mt, cand[c][0]) * K;
+        if (best_cost < 0 || cost < best_cost) { best = c; best_cost = cost; }
+    }
+    int TM = cand[best][0], TN = cand[best][1];
+    if (tm_env && tn_env) { TM = tm_env; TN = tn_env; }
+    if (terms == 3) {
+        if (TM == 2 && TN == 2) return pwsw_launch<2, 2, 2>(a, st);
+        if (TM == 2 && TN == 3) return pwsw_launch<2, 3, 2>(a, st);
+        return pwsw_launch<3, 2, 2>(a, st);
+    }
+    if (TM == 2 && TN == 2) return pwsw_launch<2, 2, 3>(a, st);
+    if (TM == 2 && TN == 3) return pwsw_launch<2, 3, 3>(a, st);
+    return pwsw_launch<3, 2, 3>(a, st);
+}

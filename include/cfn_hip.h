@@ -95,6 +95,12 @@ int cfn_pwconv_bwd_weight(const float* gy, const float* y, const double* gsum, c
                           const double* A, const double* B, int act, double* gw, int N, int Cin, int Cout, int T, int Hi,
                           int Wi, int stride, const double* gscale, void* stream);
 
+/* Arithmetic of the fp32 pointwise contractions with >= 48 channels on both sides (layers 2-4; conv1x1x1 x3d_fine.py:100-105):
+ * 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 3 / 6 = split-bf16: fp32 tensors, each operand split into 2 / 3 bf16 terms on load,
+ * 3 / 6 v_mfma_f32_32x32x16_bf16 per k-block with fp32 accumulation (relative error of a product <= 3*2^-18 / 3*2^-27).
+ * Default 6 (env CFN_PW_SPLIT).  -1 only queries.  Returns the previous setting.  Host-side, no stream. */
+int cfn_pw_split_terms(int terms);
+
 /* Data AND weight gradient of a stride-1 pointwise conv with few channels in ONE pass (Cin, Cout <= 64 and not both > 32:
  * X3D layer 1, where the backward is HBM bound): gy, y, x leave HBM once for both products.  Same arguments and results
  * as cfn_pwconv_bwd_data_acc (stride 1) + cfn_pwconv_bwd_weight; x is always required.  Returns -1 WITHOUT launching

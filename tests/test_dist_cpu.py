@@ -195,3 +195,45 @@ def test_finish_reduces_buckets_with_gradientless_parameters():
         assert unused_grad is None
         for g in res:                                       # mean over ranks of 2 * (rank + 1) = 3
             assert torch.allclose(g, torch.full((3, 4), 3.0))
+
+
+def _worker_asymmetric(rank, port, out):
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD), LOCAL_RANK=str(rank))
+    from cfn_hip import dist as cdist
+    cdist.init_from_env(backend='gloo')
+    torch.manual_seed(0)
+    a, b, c = nn.Linear(4, 3), nn.Linear(4, 3), nn.Linear(4, 3)
+    params = list(a.parameters()) + list(b.parameters()) + list(c.parameters())
+    reducer = cdist.GradReducer(params, bucket_bytes=1)               # one parameter per bucket: 6 buckets
+    assert len(reducer.buckets) == 6
+    x = torch.full((2, 4), float(rank + 1))
+    res = []
+    for step in range(3):
+        for p in params:
+            p.grad = None
+        # data-dependent branch (rw6's dropout path, multi-crop): `b` is used by rank 1 only, `c` by nobody
+        y = a(x).sum() + (b(x).sum() if rank == 1 else 0.0)
+        y.backward()
+        reducer.finish()                                              # must not hang: same collectives on both ranks
+        res.append((a.weight.grad.clone(), None if b.weight.grad is None else b.weight.grad.clone(), c.weight.grad))
+    flat_ids = [id(f) for f in reducer._flat]
+    out[rank] = (res, len(set(flat_ids)) == 6 and all(f is not None for f in reducer._flat))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_that_saw_different_gradients_issue_the_same_collectives():
+    """a bucket in which THIS rank saw no gradient at all used to be skipped; if another rank saw one
+    the ranks issued different numbers of all-reduces (a hang).  Now every bucket is reduced every step (zero-filled where
+    nothing arrived) and a parameter without a local gradient gets the average iff somebody had one."""
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker_asymmetric, args=(port, out), nprocs=WORLD, join=True)
+    for rank in range(WORLD):
+        res, static = out[rank]
+        assert static                                                  # one static flat buffer per bucket, reused
+        for ga, gb, gc in res:
+            assert torch.allclose(ga, torch.full((3, 4), 3.0))         # mean of 2 * (rank + 1)
+            assert gb is not None and torch.allclose(gb, torch.full((3, 4), 2.0))   # rank 1's 2 * 2, averaged with rank 0's zero
+            assert gc is None                                          # nobody had one: stays None, as in the reference

@@ -26,8 +26,16 @@ class _Scale(torch.autograd.Function):
         return gy * ctx.wparam, fin(), None
 
 
+def _param(vals, lazy=True):
+    w = torch.nn.Parameter(torch.tensor(vals))
+    if lazy:
+        ops.allow_lazy_grad_cast([w])      # what GradReducer does for its parameters
+    return w
+
+
 def test_lazy_view_is_filled_at_end_of_backward():
-    w = torch.nn.Parameter(torch.tensor([1.0, 2.0, 3.0]))
+    w = _param([1.0, 2.0, 3.0])
+    assert ops._lazy_ok_probe(w)
     x = torch.tensor([2.0, 2.0, 2.0], requires_grad=True)
     _Scale.apply(x, w, False).sum().backward()
     assert torch.equal(w.grad, torch.tensor([2.0, 2.0, 2.0]))
@@ -35,7 +43,7 @@ def test_lazy_view_is_filled_at_end_of_backward():
 
 def test_weight_used_twice_in_one_graph_sums_both_terms():
     """autograd adds the two gradients mid-pass: the second use must not get an unfilled view"""
-    w = torch.nn.Parameter(torch.tensor([1.0, 2.0, 3.0]))
+    w = _param([1.0, 2.0, 3.0])
     x1 = torch.tensor([2.0, 2.0, 2.0], requires_grad=True)
     x2 = torch.tensor([5.0, 6.0, 7.0], requires_grad=True)
     (_Scale.apply(x1, w, False).sum() + _Scale.apply(x2, w, False).sum()).backward()
@@ -43,7 +51,7 @@ def test_weight_used_twice_in_one_graph_sums_both_terms():
 
 
 def test_foreign_post_accumulate_hook_sees_a_valid_gradient():
-    w = torch.nn.Parameter(torch.tensor([1.0, 2.0, 3.0]))
+    w = _param([1.0, 2.0, 3.0])
     seen = []
     w.register_post_accumulate_grad_hook(lambda p: seen.append(p.grad.clone()))
     x = torch.tensor([2.0, 3.0, 4.0], requires_grad=True)
@@ -52,7 +60,7 @@ def test_foreign_post_accumulate_hook_sees_a_valid_gradient():
 
 
 def test_failed_backward_does_not_poison_the_next_pass():
-    w = torch.nn.Parameter(torch.tensor([1.0, 2.0, 3.0]))
+    w = _param([1.0, 2.0, 3.0])
     x = torch.tensor([2.0, 2.0, 2.0], requires_grad=True)
     with pytest.raises(RuntimeError):
         _Scale.apply(x, w, True).sum().backward()
@@ -64,9 +72,32 @@ def test_failed_backward_does_not_poison_the_next_pass():
 def test_eager_cast_switch():
     ops.LAZY_GRAD_CAST = False
     try:
-        w = torch.nn.Parameter(torch.tensor([1.0, 2.0]))
+        w = _param([1.0, 2.0])
         x = torch.tensor([3.0, 4.0], requires_grad=True)
         _Scale.apply(x, w, False).sum().backward()
         assert torch.equal(w.grad, torch.tensor([3.0, 4.0]))
     finally:
         ops.LAZY_GRAD_CAST = True
+
+
+def test_parameter_that_nobody_opted_in_gets_an_immediate_cast():
+    """hooks on the AccumulateGrad NODE (torch DDP's reducer, grad_accumulator.register_hook users) are
+    invisible in the parameter's hook dicts, so the lazy cast is opt-in: without allow_lazy_grad_cast such a hook reads a
+    filled gradient."""
+    w = _param([1.0, 2.0, 3.0], lazy=False)
+    assert not ops._lazy_ok_probe(w)
+    x = torch.tensor([2.0, 3.0, 4.0], requires_grad=True)
+    y = _Scale.apply(x, w, False)
+    acc = y.grad_fn.next_functions[1][0]          # w's AccumulateGrad node, as DDP's Reducer finds it
+    assert type(acc).__name__ == 'AccumulateGrad'
+    seen = []
+    acc.register_hook(lambda *_: seen.append(w.grad.clone()))
+    y.sum().backward()
+    assert torch.equal(seen[0], torch.tensor([2.0, 3.0, 4.0]))
+
+
+def test_grad_reducer_opts_its_parameters_in():
+    from cfn_hip import dist as cdist
+    w = _param([1.0, 2.0, 3.0], lazy=False)
+    cdist.GradReducer([w])
+    assert ops._lazy_ok_probe(w)

@@ -1,0 +1,152 @@
+"""GPU parity of the split-bf16 pointwise kernels (csrc/pwsplit.hip, pwsplitw.hip; conv1x1x1 of the reference,
+x3d_fine.py:100-105): fp32 tensors, operands split into 2 / 3 bf16 terms, 3 / 6 bf16 MFMAs per k-block.
+
+Checked against fp32 torch on the CPU (same tolerances as the fp32-MFMA kernels: forward 3e-5, gradients 3e-4 of the
+largest reference value), against an fp64 reference (the 6-term product must be as accurate as the fp32-MFMA kernel,
+the 3-term product within 2e-5), and -- through the C ABI -- against the fp32-MFMA kernels on the same device buffers
+for everything the backward entry points take (statistics gradients, tail scale, compact shortcut gradient)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import relerr
+from test_hip_ops import DEV, check_conv, ops, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def split():
+    import cfn_hip
+    prev = cfn_hip.query('cfn_pw_split_terms', -1)
+
+    def set_terms(t):
+        cfn_hip.query('cfn_pw_split_terms', t)
+    yield set_terms
+    cfn_hip.query('cfn_pw_split_terms', prev)
+
+
+def test_split_terms_setting():
+    import cfn_hip
+    prev = cfn_hip.query('cfn_pw_split_terms', -1)
+    assert prev in (0, 3, 6)
+    assert cfn_hip.query('cfn_pw_split_terms', 3) == prev
+    assert cfn_hip.query('cfn_pw_split_terms', -1) == 3
+    assert cfn_hip.query('cfn_pw_split_terms', 5) == -2 and cfn_hip.query('cfn_pw_split_terms', -1) == 3
+    cfn_hip.query('cfn_pw_split_terms', prev)
+
+
+# shapes inside the split kernels' range (Cin >= 48, Cout > 32 [weight gradient: both >= 48], even position count)
+SPLIT_CASES = [
+    # N, Cin, Cout, T, H, W, act, pro
+    (2, 48, 108, 2, 6, 6, 1, True),        # 1 slab of 4 row tiles (ragged: 108 rows)
+    (1, 108, 48, 3, 6, 5, 2, True),        # K not a multiple of 16 / 32, 90 positions (ragged last tile)
+    (1, 96, 216, 2, 7, 8, 1, True),        # 2 slabs forward
+    (1, 216, 96, 2, 14, 14, 2, True),      # X3D layer-3 conv3, several position tiles per wave
+    (1, 192, 432, 3, 4, 4, 0, False),      # 4 slabs, no prologue
+    (1, 432, 192, 2, 4, 3, 2, True),       # deep K: slabs limited by LDS
+    (2, 50, 70, 1, 5, 6, 2, True),         # nothing aligned: K % 16 = 2, M % 32 = 6, 30 positions
+    (1, 64, 33, 2, 2, 2, 0, True),         # M = 33: two row tiles, one of a single row (forward / data gradient only)
+    (1, 432, 2048, 4, 1, 1, 0, False),     # fc1-like: 4 positions
+]
+
+
+@pytest.mark.parametrize('terms', [3, 6])
+@pytest.mark.parametrize('N,Cin,Cout,T,H,W,act,pro', SPLIT_CASES)
+def test_pwconv_split(split, terms, N, Cin, Cout, T, H, W, act, pro):
+    split(terms)
+    x, w = rnd(1, N, Cin, T, H, W), rnd(2, Cout, Cin, 1, 1, 1, scale=(2.0 / Cin) ** 0.5)
+    A = (1 + 0.2 * rnd(3, N, Cin)) if pro else None
+    B = 0.3 * rnd(4, N, Cin) if pro else None
+    check_conv(lambda x_, w_, A_, B_: ops().pwconv(x_, w_, A_, B_, act, 1, True),
+               lambda a, w_: F.conv3d(a, w_), x, w, A, B, act, tol_f=3e-5, tol_g=3e-4)
+
+
+def _ref64(x, w, A, B, act):
+    """fp64 forward / backward of act(A x + B) -> 1x1x1 conv with a random cotangent; returns (y, gx, gw)"""
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    shp = (x.shape[0], -1, 1, 1, 1)
+    z = xd * A.double().view(shp) + B.double().view(shp)
+    a = F.relu(z) if act == 1 else (z * torch.sigmoid(z) if act == 2 else z)
+    y = F.conv3d(a, wd)
+    r = rnd(7, *y.shape).double()
+    gx, gw = torch.autograd.grad((y * r).sum(), (xd, wd))
+    return y, gx, gw, r
+
+
+@pytest.mark.parametrize('cfg', [(1, 96, 216, 4, 14, 14, 1), (1, 216, 96, 4, 14, 14, 2), (1, 432, 192, 6, 7, 7, 2)])
+def test_split_accuracy_vs_fp64(split, cfg):
+    """errors against an fp64 reference, fp32-MFMA kernel next to the 3- and 6-term split: 6 terms is an fp32 product
+    (dropped terms 3*2^-27), 3 terms drops 3*2^-18 per product"""
+    N, Cin, Cout, T, H, W, act = cfg
+    x, w = rnd(1, N, Cin, T, H, W), rnd(2, Cout, Cin, 1, 1, 1, scale=(2.0 / Cin) ** 0.5)
+    A, B = 1 + 0.2 * rnd(3, N, Cin), 0.3 * rnd(4, N, Cin)
+    y64, gx64, gw64, r = _ref64(x, w, A, B, act)
+    err = {}
+    for terms in (0, 3, 6):
+        split(terms)
+        xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        y, _, _ = ops().pwconv(xg, wg, A.to(DEV), B.to(DEV), act, 1, True)
+        gx, gw = torch.autograd.grad((y * r.float().to(DEV)).sum(), (xg, wg))
+        err[terms] = (relerr(y, y64), relerr(gx, gx64), relerr(gw, gw64))
+    print('split accuracy vs fp64 (y, gx, gw):', cfg, {k: ['%.2e' % e for e in v] for k, v in err.items()})
+    for i in range(3):
+        assert err[6][i] <= 2.0 * err[0][i] + 2e-7, (i, err)
+        assert err[3][i] <= 2e-5, (i, err)
+
+
+@pytest.mark.parametrize('terms', [3, 6])
+@pytest.mark.parametrize('act', [None, 0, 1, 2])
+@pytest.mark.parametrize('cfg', [(2, 48, 108, 3, 8, 8, 0), (1, 108, 48, 2, 12, 12, 2), (1, 96, 216, 2, 7, 7, 2), (1, 216, 96, 3, 6, 6, 0),
+                                 (1, 60, 50, 2, 6, 5, 2), (1, 192, 432, 2, 4, 4, 0)])
+def test_split_backward_matches_fp32_mfma(split, cfg, act, terms):
+    """cfn_pwconv_bwd_data_acc / cfn_pwconv_bwd_weight with the split switched on against the fp32-MFMA kernels on the same
+    buffers: with / without prologue (act None = no A, B), statistics gradients, the tail scale `gscale`, the compact
+    shortcut gradient `acc` on its stride lattice (odd width: both positions of a pair can be on it)."""
+    import cfn_hip
+    N, Cin, Cout, T, H, W, acc_s = cfg
+    f64 = lambda seed, *shape, scale=1.0: (rnd(seed, *shape) * scale).double().to(DEV)
+    gy, y, x = rnd(1, N, Cout, T, H, W).to(DEV), rnd(2, N, Cout, T, H, W).to(DEV), rnd(3, N, Cin, T, H, W).to(DEV)
+    w = (0.3 * rnd(4, Cout, Cin)).to(DEV)
+    gs, gq, gsc = f64(5, N, Cout, scale=0.05), f64(6, N, Cout, scale=0.01), 1.0 + f64(7, N, Cout, scale=0.3)
+    A = B = None
+    if act is not None:
+        A, B = 1.0 + f64(8, N, Cin, scale=0.2), f64(9, N, Cin, scale=0.2)
+    acc = None
+    if acc_s:
+        acc = rnd(10, N, Cin, T, (H - 1) // acc_s + 1, (W - 1) // acc_s + 1).to(DEV)
+
+    def run(t):
+        split(t)
+        gx = torch.empty_like(x)
+        gA = gB = None
+        if A is not None:
+            gA, gB = (torch.zeros(N, Cin, dtype=torch.float64, device=DEV) for _ in range(2))
+        gw = torch.zeros(Cout, Cin, dtype=torch.float64, device=DEV)
+        a_ = 0 if act is None else act
+        cfn_hip.call('cfn_pwconv_bwd_data_acc', gy, y, gs, gq, w, x, A, B, a_, gx, gA, gB, N, Cin, Cout, T, H, W, 1, acc,
+                     acc_s or 1, gsc)
+        cfn_hip.call('cfn_pwconv_bwd_weight', gy, y, gs, gq, x, A, B, a_, gw, N, Cin, Cout, T, H, W, 1, gsc)
+        return gx, gA, gB, gw
+
+    ref, got = run(0), run(terms)
+    for name, r, g in zip(('gx', 'gA', 'gB', 'gw'), ref, got):
+        if r is not None:
+            assert relerr(g, r) <= (2e-5 if terms == 3 else 3e-6), (name, relerr(g, r))
+
+
+@pytest.mark.parametrize('terms', [3, 6])
+def test_split_bitwise_reproducible(split, terms):
+    split(terms)
+    o = ops()
+    x, w = rnd(1, 2, 96, 4, 14, 14).to(DEV), (0.2 * rnd(2, 216, 96, 1, 1, 1)).to(DEV)
+    A, B = (1 + 0.2 * rnd(3, 2, 96)).to(DEV), (0.1 * rnd(4, 2, 96)).to(DEV)
+    runs = []
+    for _ in range(3):
+        leaves = [v.clone().requires_grad_(True) for v in (x, w, A, B)]
+        y, s, q = o.pwconv(*leaves, 2, 1, True)
+        ((y * y).sum() + s.sum() + 0.1 * q.sum()).backward()
+        runs.append([y.detach(), s.detach(), q.detach()] + [v.grad for v in leaves])
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert torch.equal(a, b)

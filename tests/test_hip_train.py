@@ -281,11 +281,13 @@ def test_graphed_step_equals_eager_step(stream):
     assert moved == 0.0         # SGD at lr 0 leaves every parameter where it was: the re-captured graph holds the new rate
 
 
-def test_bench_two_ranks_sharing_the_gpu(tmp_path):
+@pytest.mark.parametrize('launcher', ['torchrun', 'self'])
+def test_bench_two_ranks_sharing_the_gpu(tmp_path, launcher):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), with the two
     ranks sharing the box's single GPU over gloo (RCCL needs a device per rank): parameter sync from rank 0, the bucketed
     all-reduce queued behind backward on a side stream, the global loss normaliser, max-over-ranks timing and the one JSON
-    line are all exercised with the real kernels.  Small clips keep it short."""
+    line are all exercised with the real kernels.  Small clips keep it short.  launcher = 'self': plain `python bench.py
+    --gpus 2` (no torchrun), which must re-launch itself as two ranks."""
     import json
     import subprocess
     import sys
@@ -294,6 +296,8 @@ def test_bench_two_ranks_sharing_the_gpu(tmp_path):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29541', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--frames', '16',
            '--batch', '2']
+    if launcher == 'self':
+        cmd = [sys.executable] + cmd[cmd.index(os.path.join(ROOT, 'bench.py')):]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
