@@ -254,6 +254,12 @@ def main():
             'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
+            'dtype_note': ('fp32 tensors everywhere; pointwise contractions with >= 48 channels run as split-bf16 (each fp32 operand = 3 bf16 '
+                           'terms, 6 bf16 MFMAs per k-block, fp32 accumulation: an fp32-accurate product), all other arithmetic fp32'
+                           if args.dtype == 'f32' else
+                           'bf16 activations / activation gradients, fp32 weights, statistics and accumulation'
+                           + ('; bf16 stands in for BASELINE configs[4]\'s "fp16 MFMA pointwise" (same MFMA rate on gfx950, no loss-scaling '
+                              'needed: the engine has no fp16 path)' if joint else '')),
             'config': {'workload': workload, 'clips_per_gpu': B, 'frames': T, 'parallelism': 'dp%d' % world,
                        'launch': 'hipGraph replay' if args.graph else 'eager', 'dist': cdist.describe()},
             'loss': {'first_step_cls_loc': [round(v, 6) for v in loss_first], 'last_step_cls_loc': [round(v, 6) for v in loss_last]},

@@ -18,6 +18,7 @@
 // of 16-byte slots: conflict-free ds_read_b128).  Rows beyond the slab = more slabs side by side (re-reads hit the XCD's L2).
 #include "pw_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -26,6 +27,7 @@ typedef unsigned u2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 #define PWS_WAVES 8
+#define PWS_NSET 3
 #define PWS_OOB 0x40000000     // beyond every range used here (< 2^30 bytes per sample block); OOB + row offsets stay positive
 
 // NOTE: __builtin_bit_cast(float, v.y) on an ELEMENT of an ext-vector lvalue reads element 0 (hipcc 7.2 front end: the element
@@ -56,38 +58,16 @@ __device__ __forceinline__ void pws_terms(F&& f) {
     f(0, 0);
 }
 
-// transpose-reduce over the 32 column lanes (as pwbf16.hip): a lane starts with 16 row values of its column; the lane ends
-// up with the 32-lane sum of row (lane & 31) >> 1 of the 16-row set
-__device__ __forceinline__ float pws_fold16(float lo_row, float hi_row, int lane) {
-    const bool b4 = lane & 16;
-    const float send = b4 ? lo_row : hi_row, keep = b4 ? hi_row : lo_row;
-    return keep + __shfl_xor(send, 16, 64);
-}
-__device__ __forceinline__ float pws_rowsum(const float (&a)[8], int lane) {
-    float b[4], c[2];
-    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float send = b3 ? a[i] : a[i + 4], keep = b3 ? a[i + 4] : a[i];
-        b[i] = keep + __shfl_xor(send, 8, 64);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float send = b2 ? b[i] : b[i + 2], keep = b2 ? b[i + 2] : b[i];
-        c[i] = keep + __shfl_xor(send, 4, 64);
-    }
-    const float send = b1 ? c[0] : c[1], keep = b1 ? c[1] : c[0];
-    float d = keep + __shfl_xor(send, 2, 64);
-    d += __shfl_xor(d, 1, 64);
-    return d;
-}
-
-// PwArgs fields re-used by the plan: Kpad = K padded to 32, mtiles = row slabs, nstrips = workgroups per (n, slab),
-// kres = LDS bytes per weight row of ONE split image
-template <int MT, int MODE, bool STATS, int ACT, bool TWO, int NS>
+// PwArgs fields re-used by the plan: Kpad = K padded to 48 (3 k-blocks), mtiles = row slabs, nstrips = workgroups per (n, slab),
+// kres = LDS bytes per weight row of ONE split image.
+// NP = positions per lane: 2 (64-position wave tiles, 8-byte accesses) or 1 (32-position tiles, 4-byte accesses: half the
+// accumulators per row tile, so a slab of up to 7 row tiles = 224 rows fits the registers and a 216-row layer needs ONE slab --
+// a second slab re-reads every activation, and re-reads cost the vector-memory path as much as HBM reads do).
+template <int MT, int NP, int MODE, bool STATS, int ACT, bool TWO, int NS>
 __global__ __launch_bounds__(64 * PWS_WAVES) void pws_kernel(const PwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = 32 * MT;
+    constexpr int TP = 32 * NP;                                             // positions per wave tile
     const int tid = threadIdx.x, wave = cfn_uni(tid >> 6), lane = tid & 63, kg = lane >> 5, j = lane & 31;
     const int K = a.K, M = a.M, Q = a.Q, Kp = a.Kpad, rowb = a.kres;
 
@@ -101,7 +81,7 @@ __global__ __launch_bounds__(64 * PWS_WAVES) void pws_kernel(const PwArgs a) {
     const size_t img = (size_t)BM * rowb;
     float4* sP = reinterpret_cast<float4*>(Ws + NS * img);                 // [Kp] prologue coefficients
     float2* sE = reinterpret_cast<float2*>(sP + Kp);                       // [BM] epilogue coefficients (DGRAD)
-    float* red = reinterpret_cast<float*>(sE + BM);                        // [PWS_WAVES][BM][2]
+    float* red = reinterpret_cast<float*>(sE + BM);                        // [PWS_WAVES][16][33] transpose scratch, then [PWS_WAVES][BM][2]
 
     for (int k = tid; k < Kp; k += 64 * PWS_WAVES) {
         float4 c = {1.0f, 0.0f, 1.0f, 0.0f};
@@ -150,173 +130,237 @@ __global__ __launch_bounds__(64 * PWS_WAVES) void pws_kernel(const PwArgs a) {
     __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.dst + dst_n + (long)m0 * Q, (unsigned)((long)mrows * Q * 4));
     const bool has_ex = MODE == PW_DGRAD && a.ex && a.ea;
     __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<float*>(has_ex ? a.ex + dst_n + (long)m0 * Q : a.src), has_ex ? (unsigned)((long)mrows * Q * 4) : 0u);
-    const bool has_acc = MODE == PW_DGRAD && a.acc;
-    const long accP = has_acc ? (long)(Q / ((long)a.Hi * a.Wi)) * a.acc_Ho * a.acc_Wo : 0;   // positions per (n, row) of the compact tensor
-    __amdgpu_buffer_rsrc_t rac = cfn_rsrc(const_cast<float*>(has_acc ? a.acc + ((long)n * M + m0) * accP : a.src), has_acc ? (unsigned)((long)mrows * accP * 4) : 0u);
-
     float ssum[MT], qsum[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) ssum[mt] = qsum[mt] = 0.0f;
 
-    const int ntiles = (Q + 63) >> 6, nkb = Kp >> 4;
-    const int lane_voff = kg * 8 * Q * 4 + j * 8;                           // this lane's (channel group, position pair) offset
+    const int ntiles = (Q + TP - 1) / TP, nkb = Kp >> 4;
+    const int lane_voff = kg * 8 * Q * 4 + j * 4 * NP;                      // this lane's (channel group, position [pair]) offset
     const unsigned char* wrow = Ws + (size_t)j * rowb + kg * 16;             // A operand: row j (+32*mt), k = kb*16 + kg*8 ..
 
-    for (int tile = wg * PWS_WAVES + wave; tile < ntiles; tile += a.nstrips * PWS_WAVES) {
-        const int q0 = tile << 6;
-        const bool cv = q0 + 2 * j < Q;                                      // Q is even: a pair is valid or not as a whole
-        f16v acc[MT][2];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f16v)0.0f; acc[mt][1] = (f16v)0.0f; }
-
-        // offsets into the compact lattice tensor for the two positions of the pair (OOB = not on the lattice): with an even
-        // width only the even position can be on it
-        int ao = PWS_OOB, ao2 = PWS_OOB;
-        const bool odd_w = has_acc && (a.Wi & 1);
-        if (has_acc && cv) {
-            auto lat = [&](int q) {
-                const int w_ = q % a.Wi, h_ = (q / a.Wi) % a.Hi, t_ = q / (a.Wi * a.Hi);
-                return ((h_ % a.acc_s) == 0 && (w_ % a.acc_s) == 0) ? ((t_ * a.acc_Ho + h_ / a.acc_s) * a.acc_Wo + w_ / a.acc_s) * 4 : PWS_OOB;
-            };
-            ao = lat(q0 + 2 * j);
-            if (odd_w) ao2 = lat(q0 + 2 * j + 1);
+    // element p (< NP) of a loaded / stored position group
+    auto ldp = [&](__amdgpu_buffer_rsrc_t r, int vo, int so, float (&out)[NP]) {
+        if constexpr (NP == 2) {
+            const u2v d = __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0);
+            out[0] = pws_f(d.x); out[1] = pws_f(d.y);
+        } else {
+            out[0] = pws_f(__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0));
         }
-        // Row addressing of the epilogue: the lane part (column pair, kg's 4-row offset) sits in the vector offset, the
+    };
+
+    // Operand ring of PWS_NSET = 3 load sets with STATIC slots (k-block kb of a tile lives in slot kb % 3; Kp is a multiple of 48 so
+    // every tile starts at slot 0) and an issue cursor that runs TWO k-blocks ahead of the arithmetic and straight on into the
+    // wave's next tile: with one set ahead (round-3 first version) a CU had 16-32 KB in flight -- by Little's law 2-4 TB/s at the
+    // loaded HBM latency -- and the pipeline drained at every tile end.  Unconditional loads (exact vmcnt waits).  The hardware
+    // checks  voffset >= num_records - soffset: the scalar part must never exceed the range (it would wrap), so a k-block that
+    // starts beyond K (or a tile beyond the last) is switched off through the lane offset; channels >= K inside a live block fall
+    // out of range by themselves and read as 0.
+    float ld[PWS_NSET][8][NP], ld2[PWS_NSET][8][NP];
+    const int tstep = a.nstrips * PWS_WAVES;
+    int itile = wg * PWS_WAVES + wave, ikb = 0;                             // issue cursor (wave uniform)
+    auto issue_next = [&](float (&d)[8][NP], float (&d2)[8][NP]) {
+        const bool tlive = itile < ntiles;
+        const int vo = tlive ? lane_voff : PWS_OOB;
+        const int base = tlive ? itile * TP * 4 : 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // the row part of the address is SCALAR (s_cselect / s_mul: no VALU).  A row at or beyond K must not enter the scalar
+            // offset (see above): it is replaced by row 0 -- the lanes then read finite activations of rows 0 / 8, which meet
+            // the zero-padded weight columns k >= K
+            const int row = ikb * 16 + i;
+            const int so = row < K ? row * Q * 4 + base : base;
+            ldp(rs1, vo, so, d[i]);
+            if (two_src) ldp(rs2, vo, so, d2[i]);
+        }
+        if (++ikb == nkb) { ikb = 0; itile += tstep; }
+    };
+    issue_next(ld[0], ld2[0]);
+    issue_next(ld[1], ld2[1]);
+
+    for (int tile = wg * PWS_WAVES + wave; tile < ntiles; tile += tstep) {
+        const int q0 = tile * TP;
+        const bool cv = q0 + NP * j < Q;                                     // NP == 2: Q is even, a pair is valid or not as a whole
+        f16v acc[MT][NP];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) acc[mt][p] = (f16v)0.0f;
+
+        // Row addressing of the epilogue: the lane part (column, kg's 4-row offset) sits in the vector offset, the
         // wave-uniform row base in the scalar offset; a row base beyond the slab's valid rows would push the scalar offset
         // past the range (which wraps instead of failing the check), so such rows are switched off through the vector offset.
-        const int cvk = cv ? (q0 + 2 * j) * 4 + 4 * kg * Q * 4 : PWS_OOB;
+        const int cvk = cv ? (q0 + NP * j) * 4 + 4 * kg * Q * 4 : PWS_OOB;
         auto rowbase = [&](int mt, int r) { return mt * 32 + (r & 3) + 8 * (r >> 2); };
-        u2v ld[2][8], ld2[2][8];
-        // unconditional loads (exact vmcnt waits).  The hardware checks  voffset >= num_records - soffset: the scalar part
-        // must never exceed the range (it would wrap), so a k-block that starts beyond K is switched off through the lane
-        // offset; channels >= K inside a live block fall out of range by themselves and read as 0
-        auto issue = [&](int kb, u2v (&d)[8], u2v (&d2)[8]) {
-            const bool live = kb * 16 < K;
-            const int so = live ? (kb * 16 * Q + q0) * 4 : 0;
-            const int vo = live ? lane_voff : PWS_OOB;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                d[i] = __builtin_amdgcn_raw_buffer_load_b64(rs1, vo + i * Q * 4, so, 0);
-                if (two_src) d2[i] = __builtin_amdgcn_raw_buffer_load_b64(rs2, vo + i * Q * 4, so, 0);
-            }
-        };
-        auto compute = [&](int kb, const u2v (&d)[8], const u2v (&d2)[8]) {
-            float ve[8], vo[8];
+        auto compute = [&](int kb, const float (&d)[8][NP], const float (&d2)[8][NP]) {
+            float v[NP][8];
             const float4* cp = sP + kb * 16 + kg * 8;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float4 c = cp[i];
-                float e = pws_f(d[i].x), o = pws_f(d[i].y);
-                if (MODE == PW_FWD) {
-                    e = cfn_act<ACT>(fmaf(e, c.x, c.y));
-                    o = cfn_act<ACT>(fmaf(o, c.x, c.y));
-                } else {
-                    e = fmaf(e, c.z, c.x);
-                    o = fmaf(o, c.z, c.x);
-                    if (two_src) { e = fmaf(pws_f(d2[i].x), c.y, e); o = fmaf(pws_f(d2[i].y), c.y, o); }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    float e = d[i][p];
+                    if (MODE == PW_FWD) {
+                        e = cfn_act<ACT>(fmaf(e, c.x, c.y));
+                    } else {
+                        e = fmaf(e, c.z, c.x);
+                        if (two_src) e = fmaf(d2[i][p], c.y, e);
+                    }
+                    v[p][i] = e;
                 }
-                ve[i] = e; vo[i] = o;
             }
-            u4v pe[NS], po[NS];
+            u4v pb[NP][NS];
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                unsigned se[NS], so_[NS];
-                pws_split<NS>(ve[2 * h], ve[2 * h + 1], se);
-                pws_split<NS>(vo[2 * h], vo[2 * h + 1], so_);
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
-                for (int s = 0; s < NS; ++s) { pe[s][h] = se[s]; po[s][h] = so_[s]; }
-            }
+                for (int h = 0; h < 4; ++h) {
+                    unsigned sp[NS];
+                    pws_split<NS>(v[p][2 * h], v[p][2 * h + 1], sp);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) pb[p][s][h] = sp[s];
+                }
+            // All MT row tiles, branch free (a ragged last slab multiplies its zero-padded weight rows: a block-uniform skip per
+            // tile put every tile's MFMAs in a basic block of their own, each opening with its ds_read + s_waitcnt lgkmcnt).
+            // The A operand of tile mt+1 is read from LDS before the MFMAs of tile mt issue (two static register sets); the
+            // 3 / 6 MFMAs of a term set chain on one accumulator (srcC = vDst of the predecessor: forwarded, no wait states).
+            bf16x8 A[2][NS];
+            auto lda = [&](bf16x8 (&dst)[NS], int mt) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) dst[s] = *reinterpret_cast<const bf16x8*>(wrow + s * img + (size_t)mt * 32 * rowb + kb * 32);
+            };
+            lda(A[0], 0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                if (m0 + mt * 32 < M) {                                      // block-uniform: a ragged last slab skips its empty tiles
-                    bf16x8 A[NS];
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) A[s] = *reinterpret_cast<const bf16x8*>(wrow + s * img + (size_t)mt * 32 * rowb + kb * 32);
+                if (mt + 1 < MT) lda(A[(mt + 1) & 1], mt + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #define PWS_MM(SA, SB)                                                                                                     \
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA], __builtin_bit_cast(bf16x8, pe[SB]), acc[mt][0], 0, 0, 0); \
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA], __builtin_bit_cast(bf16x8, po[SB]), acc[mt][1], 0, 0, 0)
-                    if constexpr (NS == 3) { PWS_MM(2, 0); PWS_MM(0, 2); PWS_MM(1, 1); }
-                    PWS_MM(1, 0); PWS_MM(0, 1); PWS_MM(0, 0);
+                _Pragma("unroll") for (int p = 0; p < NP; ++p)                                                             \
+                    acc[mt][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt & 1][SA], __builtin_bit_cast(bf16x8, pb[p][SB]), acc[mt][p], 0, 0, 0)
+                if constexpr (NS == 3) { PWS_MM(2, 0); PWS_MM(0, 2); PWS_MM(1, 1); }
+                PWS_MM(1, 0); PWS_MM(0, 1); PWS_MM(0, 0);
 #undef PWS_MM
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
-        issue(0, ld[0], ld2[0]);
-        for (int kb = 0; kb < nkb; kb += 2) {                               // Kp is a multiple of 32: nkb is even
-            issue(kb + 1, ld[1], ld2[1]);
+        for (int kb = 0; kb < nkb; kb += PWS_NSET) {                        // Kp is a multiple of 48: nkb is a multiple of 3
+            issue_next(ld[2], ld2[2]);
             compute(kb, ld[0], ld2[0]);
-            issue(kb + 2, ld[0], ld2[0]);                                    // kb + 2 == nkb: out of range -> zeros, never used
+            issue_next(ld[0], ld2[0]);
             compute(kb + 1, ld[1], ld2[1]);
+            issue_next(ld[1], ld2[1]);
+            compute(kb + 2, ld[2], ld2[2]);
         }
 
-        // ---- epilogue: C layout of the 32x32 tile: column = lane & 31 (position pair j), row = (r & 3) + 8 (r >> 2) + 4 kg
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (m0 + mt * 32 >= M) continue;
+        // ---- epilogue: C layout of the 32x32 tile: column = lane & 31 (position [pair] j), row = (r & 3) + 8 (r >> 2) + 4 kg
+        // FULL (wave uniform): all 32 rows of the tile exist and all 32 NP columns lie inside the row -- no per-row / per-column
+        // selects on the store offsets and the statistics operands (38 v_cndmask per row tile otherwise)
+        auto epilogue = [&](auto full_tag, int mt) {
+            constexpr bool FULL = decltype(full_tag)::value;
             // DGRAD epilogue operands (forward input x of the output rows, for act'): the 16 row loads of this 32-row tile go
             // out as ONE batch (next to their consumers they would cost one HBM round trip each)
-            u2v xq[16];
+            float xq[16][NP];
             if (MODE == PW_DGRAD && STATS) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const bool live = rowbase(mt, r) < mrows;
-                    xq[r] = __builtin_amdgcn_raw_buffer_load_b64(rx, live ? cvk : PWS_OOB, live ? rowbase(mt, r) * Q * 4 : 0, 0);
+                    const bool live = FULL || rowbase(mt, r) < mrows;
+                    ldp(rx, live ? cvk : PWS_OOB, live ? rowbase(mt, r) * Q * 4 : 0, xq[r]);
                 }
             }
-            if (has_acc) {      // compact gradient of the strided second consumer, added on its lattice
-                float ap[16];
+            // Stores, and the per-row reductions (statistics forward; sum dz*x, sum dz backward) through a wave-private LDS
+            // transpose, 16 rows at a time: 8 ds_write + 8 ds_read + ~16 VALU per half tile and quantity, where the shuffle
+            // butterfly of pwbf16.hip costs ~100 VALU (the epilogue was half of this kernel's VALU instructions, and VALU, not the
+            // matrix pipe, is what the 6-term product is short of).  Registers r = 8 hf + i hold tile rows 16 hf + (i & 3) +
+            // 8 (i >> 2) + 4 kg; lane l then sums row l >> 2 over the 8 columns 8 (l & 3) .. +7 (conflict-free both ways at a
+            // 33-float pitch), the quad adds its four partial sums and lane l keeps the total of row 16 (l & 1) + (l >> 2).
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    ap[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rac, ao + (rowbase(mt, r) + 4 * kg) * (int)accP * 4, 0, 0));
+            for (int hf = 0; hf < 2; ++hf) {
+                float t1[8], t2[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][0][r] += ap[r];
-                if (odd_w) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        ap[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rac, ao2 + (rowbase(mt, r) + 4 * kg) * (int)accP * 4, 0, 0));
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mt][1][r] += ap[r];
-                }
-            }
-            float f1[8], f2[8];
-#pragma unroll
-            for (int rp = 0; rp < 8; ++rp) {
-                float t1[2], t2[2];
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int r = rp + 8 * hh;
+                for (int i = 0; i < 8; ++i) {
+                    const int r = 8 * hf + i;
                     const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                    float e = acc[mt][0][r], o = acc[mt][1][r];
-                    t1[hh] = t2[hh] = 0.0f;
-                    const bool live = rowbase(mt, r) < mrows;
-                    if (MODE == PW_FWD) {
-                        if (STATS) {
-                            const float em = cv ? e : 0.0f, om = cv ? o : 0.0f;
-                            t1[hh] = em + om; t2[hh] = fmaf(em, em, om * om);
+                    float o[NP];
+                    t1[i] = t2[i] = 0.0f;
+                    const bool live = FULL || rowbase(mt, r) < mrows;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        float e = acc[mt][p][r];
+                        if (MODE == PW_FWD) {
+                            if (STATS) {
+                                const float em = (FULL || cv) ? e : 0.0f;
+                                t1[i] += em;
+                                if (NP == 2) t2[i] = fmaf(em, em, t2[i]);
+                            }
+                        } else if (STATS) {                                  // act' epilogue + prologue-coefficient gradients
+                            const float2 c = sE[row];
+                            const float xe = xq[r][p];
+                            const float de = (FULL || cv) ? e * cfn_act_grad<ACT>(fmaf(xe, c.x, c.y)) : 0.0f;
+                            t1[i] = fmaf(de, xe, t1[i]); t2[i] += de;
+                            e = de * c.x;
                         }
-                    } else if (STATS) {                                      // act' epilogue + prologue-coefficient gradients
-                        const float2 c = sE[row];
-                        const float xe = pws_f(xq[r].x), xo = pws_f(xq[r].y);
-                        const float de = cv ? e * cfn_act_grad<ACT>(fmaf(xe, c.x, c.y)) : 0.0f;
-                        const float dn = cv ? o * cfn_act_grad<ACT>(fmaf(xo, c.x, c.y)) : 0.0f;
-                        t1[hh] = fmaf(de, xe, dn * xo); t2[hh] = de + dn;
-                        e = de * c.x; o = dn * c.x;
+                        o[p] = e;
                     }
-                    const u2v st = {__builtin_bit_cast(unsigned, e), __builtin_bit_cast(unsigned, o)};
-                    __builtin_amdgcn_raw_buffer_store_b64(st, rd, live ? cvk : PWS_OOB, live ? rowbase(mt, r) * Q * 4 : 0, 0);
+                    if constexpr (NP == 2) {
+                        const u2v st = {__builtin_bit_cast(unsigned, o[0]), __builtin_bit_cast(unsigned, o[NP - 1])};
+                        __builtin_amdgcn_raw_buffer_store_b64(st, rd, live ? cvk : PWS_OOB, live ? rowbase(mt, r) * Q * 4 : 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[0]), rd, live ? cvk : PWS_OOB, live ? rowbase(mt, r) * Q * 4 : 0, 0);
+                    }
                 }
-                if (STATS) { f1[rp] = pws_fold16(t1[0], t1[1], lane); f2[rp] = pws_fold16(t2[0], t2[1], lane); }
+                if (STATS) {
+                    float* scr = red + wave * (16 * 33);
+                    auto keep = [&](float sm) {                              // the row's four partial sums: quad permutes;
+                        sm += __shfl_xor(sm, 1, 64);                         // lane l keeps row 16 (l & 1) + (l >> 2)
+                        sm += __shfl_xor(sm, 2, 64);
+                        return (lane & 1) == hf ? sm : 0.0f;
+                    };
+                    if constexpr (MODE == PW_FWD && NP == 1) {               // one pass: the reader forms sum and sum of squares
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) scr[((i & 3) + 8 * (i >> 2) + 4 * kg) * 33 + j] = t1[i];
+                        asm volatile("" ::: "memory");
+                        float sm = 0.0f, sq = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const float v = scr[(lane >> 2) * 33 + (lane & 3) * 8 + c];
+                            sm += v; sq = fmaf(v, v, sq);
+                        }
+                        ssum[mt] += keep(sm); qsum[mt] += keep(sq);
+                        asm volatile("" ::: "memory");
+                    } else {
+#pragma unroll
+                        for (int pass = 0; pass < 2; ++pass) {
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) scr[((i & 3) + 8 * (i >> 2) + 4 * kg) * 33 + j] = pass == 0 ? t1[i] : t2[i];
+                            asm volatile("" ::: "memory");
+                            float sm = 0.0f;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) sm += scr[(lane >> 2) * 33 + (lane & 3) * 8 + c];
+                            if (pass == 0) ssum[mt] += keep(sm); else qsum[mt] += keep(sm);
+                            asm volatile("" ::: "memory");
+                        }
+                    }
+                }
             }
-            if (STATS) { ssum[mt] += pws_rowsum(f1, lane); qsum[mt] += pws_rowsum(f2, lane); }
+        };
+        const bool colfull = q0 + TP <= Q;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (m0 + mt * 32 >= M) continue;
+            if (colfull && mrows - mt * 32 >= 32) epilogue(std::true_type{}, mt);
+            else epilogue(std::false_type{}, mt);
         }
     }
 
     if (STATS && a.s1) {
-        // lane (j, kg) holds row (j >> 1) of the 16-row set, i.e. tile row (r & 3) + 8 (r >> 2) + 4 kg with r = j >> 1
-        if ((j & 1) == 0) {
+        // lane l holds the sums of row 16 (l & 1) + (l >> 2) of every row tile (lanes with l & 2 hold copies); `red` doubles as
+        // the transpose scratch of the other waves, hence the barrier before it is re-used for the cross-wave combine
+        __syncthreads();
+        if ((lane & 2) == 0) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int r = j >> 1, row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const int row = mt * 32 + 16 * (lane & 1) + (lane >> 2);
                 red[(wave * BM + row) * 2] = ssum[mt];
                 red[(wave * BM + row) * 2 + 1] = qsum[mt];
             }
@@ -354,46 +398,53 @@ extern "C" int cfn_pw_split_terms(int terms) {
 }
 
 static size_t pws_lds(int BM, int Kp, int rowb, int NS) {
-    return (size_t)NS * BM * rowb + (size_t)Kp * 16 + (size_t)BM * 8 + (size_t)PWS_WAVES * BM * 2 * 4;
+    const size_t red = (size_t)PWS_WAVES * 4 * (BM * 2 > 16 * 33 ? BM * 2 : 16 * 33);
+    return (size_t)NS * BM * rowb + (size_t)Kp * 16 + (size_t)BM * 8 + red;
 }
 
 template <int MODE, bool STATS, int ACT, bool TWO, int NS>
-static int pws_go_mt(const PwArgs& a, int MT, unsigned blocks, size_t lds, hipStream_t st) {
-#define PWS_GO(MTV)                                                                                                        \
+static int pws_go_mt(const PwArgs& a, int MT, int NP, unsigned blocks, size_t lds, hipStream_t st) {
+#define PWS_GO(MTV, NPV)                                                                                                   \
     do {                                                                                                                   \
-        auto k = pws_kernel<MTV, MODE, STATS, ACT, TWO, NS>;                                                               \
+        auto k = pws_kernel<MTV, NPV, MODE, STATS, ACT, TWO, NS>;                                                          \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * PWS_WAVES), lds, st, a);                                             \
     } while (0)
-    if constexpr (MODE == PW_DGRAD && TWO) {
-        if (MT == 1) PWS_GO(1); else PWS_GO(2);
+    if (NP == 1) {      // 32-position tiles: the many-row slabs
+        if constexpr (MODE == PW_DGRAD && TWO) {
+            switch (MT) { case 3: PWS_GO(3, 1); break; case 4: PWS_GO(4, 1); break; case 5: PWS_GO(5, 1); break; default: PWS_GO(6, 1); break; }
+        } else {
+            switch (MT) { case 3: PWS_GO(3, 1); break; case 4: PWS_GO(4, 1); break; case 5: PWS_GO(5, 1); break; case 6: PWS_GO(6, 1); break; default: PWS_GO(7, 1); break; }
+        }
+    } else if constexpr (MODE == PW_DGRAD && TWO) {
+        if (MT == 1) PWS_GO(1, 2); else PWS_GO(2, 2);
     } else if constexpr (MODE == PW_DGRAD) {
-        switch (MT) { case 1: PWS_GO(1); break; case 2: PWS_GO(2); break; default: PWS_GO(3); break; }
+        switch (MT) { case 1: PWS_GO(1, 2); break; case 2: PWS_GO(2, 2); break; default: PWS_GO(3, 2); break; }
     } else {
-        switch (MT) { case 1: PWS_GO(1); break; case 2: PWS_GO(2); break; case 3: PWS_GO(3); break; default: PWS_GO(4); break; }
+        switch (MT) { case 1: PWS_GO(1, 2); break; case 2: PWS_GO(2, 2); break; default: PWS_GO(3, 2); break; }
     }
 #undef PWS_GO
     return cfn_check_launch("pwconv(split bf16)");
 }
 
 template <int MODE, bool STATS, bool TWO, int NS>
-static int pws_go_act(const PwArgs& a, int MT, unsigned blocks, size_t lds, hipStream_t st) {
+static int pws_go_act(const PwArgs& a, int MT, int NP, unsigned blocks, size_t lds, hipStream_t st) {
     if constexpr (MODE == PW_DGRAD && !STATS) {
-        return pws_go_mt<MODE, STATS, CFN_ACT_NONE, TWO, NS>(a, MT, blocks, lds, st);
+        return pws_go_mt<MODE, STATS, CFN_ACT_NONE, TWO, NS>(a, MT, NP, blocks, lds, st);
     } else {
         switch (a.act) {
-            case CFN_ACT_RELU: return pws_go_mt<MODE, STATS, CFN_ACT_RELU, TWO, NS>(a, MT, blocks, lds, st);
-            case CFN_ACT_SWISH: return pws_go_mt<MODE, STATS, CFN_ACT_SWISH, TWO, NS>(a, MT, blocks, lds, st);
-            default: return pws_go_mt<MODE, STATS, CFN_ACT_NONE, TWO, NS>(a, MT, blocks, lds, st);
+            case CFN_ACT_RELU: return pws_go_mt<MODE, STATS, CFN_ACT_RELU, TWO, NS>(a, MT, NP, blocks, lds, st);
+            case CFN_ACT_SWISH: return pws_go_mt<MODE, STATS, CFN_ACT_SWISH, TWO, NS>(a, MT, NP, blocks, lds, st);
+            default: return pws_go_mt<MODE, STATS, CFN_ACT_NONE, TWO, NS>(a, MT, NP, blocks, lds, st);
         }
     }
 }
 
 template <int NS>
-static int pws_go(const PwArgs& a, int mode, bool stats, int MT, unsigned blocks, size_t lds, hipStream_t st) {
-    if (mode == PW_FWD) return stats ? pws_go_act<PW_FWD, true, false, NS>(a, MT, blocks, lds, st) : pws_go_act<PW_FWD, false, false, NS>(a, MT, blocks, lds, st);
-    if (a.src2) return stats ? pws_go_act<PW_DGRAD, true, true, NS>(a, MT, blocks, lds, st) : pws_go_act<PW_DGRAD, false, true, NS>(a, MT, blocks, lds, st);
-    return stats ? pws_go_act<PW_DGRAD, true, false, NS>(a, MT, blocks, lds, st) : pws_go_act<PW_DGRAD, false, false, NS>(a, MT, blocks, lds, st);
+static int pws_go(const PwArgs& a, int mode, bool stats, int MT, int NP, unsigned blocks, size_t lds, hipStream_t st) {
+    if (mode == PW_FWD) return stats ? pws_go_act<PW_FWD, true, false, NS>(a, MT, NP, blocks, lds, st) : pws_go_act<PW_FWD, false, false, NS>(a, MT, NP, blocks, lds, st);
+    if (a.src2) return stats ? pws_go_act<PW_DGRAD, true, true, NS>(a, MT, NP, blocks, lds, st) : pws_go_act<PW_DGRAD, false, true, NS>(a, MT, NP, blocks, lds, st);
+    return stats ? pws_go_act<PW_DGRAD, true, false, NS>(a, MT, NP, blocks, lds, st) : pws_go_act<PW_DGRAD, false, false, NS>(a, MT, NP, blocks, lds, st);
 }
 
 // returns -1 when the shape is not handled (caller falls through to the fp32-MFMA kernels), otherwise the launch status.
@@ -401,28 +452,46 @@ static int pws_go(const PwArgs& a, int mode, bool stats, int MT, unsigned blocks
 int pws_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
     const int terms = pws_terms_now();
     if (terms == 0) return -1;
-    if (a.stem || a.stride != 1 || a.K < 48 || a.M <= 32 || (a.Q & 1)) return -1;
+    // the compact shortcut gradient `acc` (first block of a stage: 3 calls per step) stays on the fp32-MFMA kernel: its lattice
+    // loads cost the many-row variants 90+ registers
+    if (a.stem || a.stride != 1 || a.K < 48 || a.M <= 32 || (a.Q & 1) || a.acc) return -1;
     if (a.act != CFN_ACT_NONE && a.act != CFN_ACT_RELU && a.act != CFN_ACT_SWISH) return -1;
+    // The split costs VALU work per CONTRACTION-side element (prologue + 9 instructions per pair for three terms) and saves matrix
+    // time per product: measured (8 clips, T = 256, profiles/r03_microbench_b8.txt) it wins up to K = 108 (layer 2 both convs,
+    // layer 3 conv1 forward 0.18 vs 0.21 ms, conv3 data gradient 0.24 vs 0.33 ms) and loses from K = 216 on (layer 3 conv3
+    // forward 0.22-0.26 vs 0.20 ms): those stay on the fp32-MFMA kernel
+    static const int maxk_env = getenv("CFN_PWS_MAXK") ? atoi(getenv("CFN_PWS_MAXK")) : 128;
+    if (a.K > maxk_env) return -1;
     if ((long)a.K * a.Q * 4 >= 0x3ffffff0L || (long)a.M * a.Q * 4 >= 0x3ffffff0L) return -1;
     if (((uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)(a.src2 ? a.src2 : a.src) | (uintptr_t)(a.ex ? a.ex : a.src)) & 7) return -1;
     const int NS = terms == 3 ? 2 : 3;
     PwArgs b = a;
-    b.Kpad = (a.K + 31) / 32 * 32;
+    b.Kpad = (a.K + 47) / 48 * 48;
     b.kres = b.Kpad * 2 + 16;
     if (((b.kres / 16) & 1) == 0) b.kres += 16;                          // odd number of 16-byte slots per row
     if (mode == PW_DGRAD && !stats) b.act = CFN_ACT_NONE;
-    // rows per slab: registers allow 128 forward (8 accumulator tiles), 96 backward, 64 backward with two staged tensors
-    // (96 spills: measured 80-188 bytes per lane); the NS weight images of a slab must fit LDS
-    int mt_max = mode == PW_FWD ? 4 : (a.src2 ? 2 : 3);
-    while (mt_max > 0 && pws_lds(32 * mt_max, b.Kpad, b.kres, NS) > 160 * 1024) --mt_max;
-    if (mt_max < 1) return -1;
+    // rows per slab, limited by registers (accumulators + the 3-set operand ring; measured with -Rpass-analysis: the next size
+    // spills 50-230 bytes per lane).  64-position tiles (NP = 2): 96 rows forward, 96 / 64 backward (one / two staged tensors).
+    // 32-position tiles (NP = 1): 224 rows, 192 backward with two staged tensors.  The NS weight images of a slab must fit
+    // LDS.  Fewer slabs win (every extra slab re-reads the activations), then the wider tile.
+    auto fit = [&](int mt) { while (mt > 0 && pws_lds(32 * mt, b.Kpad, b.kres, NS) > 160 * 1024) --mt; return mt; };
+    const int mt2 = fit(mode == PW_FWD ? 3 : (a.src2 ? 2 : 3)), mt1 = fit(mode == PW_DGRAD && a.src2 ? 6 : 7);
+    if (mt2 < 1) return -1;
+    static const int np_env = getenv("CFN_PWS_NP") ? atoi(getenv("CFN_PWS_NP")) : 0;
+    int NP = 2, mt_max = mt2;
+    if (mt1 >= 3 && (cfn_cdiv(a.M, 32 * mt1) < cfn_cdiv(a.M, 32 * mt2) || np_env == 1) && np_env != 2) { NP = 1; mt_max = mt1; }
     int slabs = cfn_cdiv(a.M, 32 * mt_max);
     const int per = cfn_cdiv(a.M, slabs);
-    const int MT = cfn_cdiv(per, 32);
+    int MT = cfn_cdiv(per, 32);
+    if (NP == 1 && MT < 3) MT = 3;
     slabs = cfn_cdiv(a.M, 32 * MT);
+    // three or more slabs (X3D layer 4: the weight images of 432 x 192 do not fit LDS in fewer) re-read every activation that
+    // often: measured slower than the fp32-MFMA kernel with its 4-byte weight image (0.19-0.31 vs 0.20-0.24 ms) -- declined
+    static const int slab_env = getenv("CFN_PWS_MAXSLABS") ? atoi(getenv("CFN_PWS_MAXSLABS")) : 2;
+    if (slabs > slab_env) return -1;
     b.mtiles = slabs;
     const size_t lds = pws_lds(32 * MT, b.Kpad, b.kres, NS);
-    const int ntiles = cfn_cdiv(a.Q, 64);
+    const int ntiles = cfn_cdiv(a.Q, 32 * NP);
     const long groups = (long)a.N * slabs;
     static const int wg_env = getenv("CFN_PWS_WGS") ? atoi(getenv("CFN_PWS_WGS")) : 0;
     long wgs = cfn_cdiv(wg_env > 0 ? wg_env : 256, groups);              // one 8-wave workgroup per CU (up to 256 VGPRs)
@@ -431,5 +500,5 @@ int pws_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
     if (wgs < 1) wgs = 1;
     b.nstrips = (int)wgs;
     const unsigned blocks = (unsigned)(groups * wgs);
-    return NS == 2 ? pws_go<2>(b, mode, stats, MT, blocks, lds, st) : pws_go<3>(b, mode, stats, MT, blocks, lds, st);
+    return NS == 2 ? pws_go<2>(b, mode, stats, MT, NP, blocks, lds, st) : pws_go<3>(b, mode, stats, MT, NP, blocks, lds, st);
 }

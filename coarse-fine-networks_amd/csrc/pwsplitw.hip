@@ -224,6 +224,262 @@ static int pwsw_launch(WsArgs& a, hipStream_t st) {
     return cfn_check_launch("pwconv_bwd_weight(split bf16)");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-staged variant (the one in use).  The direct kernel above reads 32-byte pieces of 32 different rows per load
+// instruction; measured with the matrix pipe out of the way it moves 1.4-3.2 TB/s -- exactly what the fp32-MFMA kernel of the
+// same access pattern reached, i.e. that pattern, not the MFMA rate, was the limit.  Here a workgroup (8 waves) owns a whole
+// (row group x column group) block of gW and a strip of positions, and streams the strip in half-stages of 32 positions:
+//   * every thread loads whole-line pieces (8 lanes x 16 B = one 128-byte line of a row; 8 rows per wave instruction) of gy, y
+//     and x into one of TWO register sets, unconditionally (exact vmcnt waits; the other set stays in flight);
+//   * G' = gsc gy + gs + 2 y gq and a = act(A x + B) are formed ONCE per element, split into NS bf16 terms and written to one
+//     of TWO LDS buffers as [row][32 positions] bf16 images (80-byte pitch: 5 slots, odd => conflict-free ds_read_b128);
+//   * one barrier per half-stage (two buffers: the writes of half-stage h+2 are separated from the reads of h by the barrier of
+//     h+1); then the loads of half-stage h+2 are issued and every wave runs the MFMAs of ITS tiles (up to TPW 32x32 tiles, dealt
+//     in row-major runs), reading both operands of a k-block as 16 contiguous bytes per lane;
+//   * no cross-wave reduction: a wave owns its tiles for the whole strip and adds them to gW with one fp64 atomic per element.
+// ---------------------------------------------------------------------------------------------------------------------
+#define PWSS_P 32
+#define PWSS_PITCH 80
+#define PWSS_THREADS 512
+
+struct WssArgs {
+    const float* gy; const float* y; const double* gs; const double* gq; const double* gsc;
+    const float* x; const double* pa; const double* pb;
+    double* gw;
+    int N, M, K, Q, act;
+    int mgroups, kgroups, nstrips, mt32, kt32;
+    int mtg, ktg, per;      // row / column tiles per group (LDS images are 32*mtg / 32*ktg rows), positions per strip (multiple of 32)
+};
+
+template <int SM, int TPW, int ACT, bool HASY, int NS>
+__global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const WssArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = cfn_uni(tid >> 6), lane = tid & 63, kg = lane >> 5, r = lane & 31;
+    unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    // tile groups vary fastest: workgroups that stream the same positions are neighbours on one XCD (shared rows hit its L2)
+    const int kgi = L % a.kgroups; L /= a.kgroups;
+    const int mgi = L % a.mgroups; L /= a.mgroups;
+    const int strip = L % a.nstrips;
+    const int n = L / a.nstrips;
+    const int M = a.M, K = a.K, Q = a.Q;
+    int mt0, mtn, kt0, ktn;
+    pwsw_run(a.mt32, a.mgroups, mgi, mt0, mtn);
+    pwsw_run(a.kt32, a.kgroups, kgi, kt0, ktn);
+    const int m0 = mt0 * 32, k0 = kt0 * 32;
+    const int GR = 32 * a.mtg, XR = 32 * a.ktg;                 // LDS image rows (padded: rows beyond the group / M / K hold zeros)
+    const int gimg = GR * PWSS_PITCH, ximg = XR * PWSS_PITCH;
+    const int bufb = NS * (gimg + ximg);
+    unsigned char* buf0 = smem;                                 // [2][ G: NS x GR x 80 | X: NS x XR x 80 ]
+    float4* cG = reinterpret_cast<float4*>(smem + 2 * bufb);    // [GR] (gs, 2 gq, gsc, -)
+    float2* cX = reinterpret_cast<float2*>(cG + GR);            // [XR] (A, B)
+    for (int i = tid; i < GR; i += PWSS_THREADS) {
+        const int m = m0 + i;
+        const bool ok = i < mtn * 32 && m < M;
+        float4 c;
+        c.x = (ok && a.gs) ? (float)a.gs[(long)n * M + m] : 0.0f;
+        c.y = (ok && HASY && a.gq) ? 2.0f * (float)a.gq[(long)n * M + m] : 0.0f;
+        c.z = (ok && a.gsc) ? (float)a.gsc[(long)n * M + m] : 1.0f;
+        c.w = 0.0f;
+        cG[i] = c;
+    }
+    for (int i = tid; i < XR; i += PWSS_THREADS) {
+        const int k = k0 + i;
+        const bool ok = i < ktn * 32 && k < K;
+        cX[i] = float2{(ok && a.pa) ? (float)a.pa[(long)n * K + k] : 1.0f, (ok && a.pb) ? (float)a.pb[(long)n * K + k] : 0.0f};
+    }
+    __syncthreads();
+
+    // this thread's slots: slot q = tid + 512 i -> (row q >> 3, float4 q & 7 of the 32-position half-stage)
+    int offG[SM], offX[SM], ldsG[SM], ldsX[SM];
+    const int c4 = tid & 7;
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+        const int row = (tid + PWSS_THREADS * i) >> 3;
+        const bool okm = row < mtn * 32 && m0 + row < M, okk = row < ktn * 32 && k0 + row < K;
+        offG[i] = okm ? ((m0 + row) * Q + c4 * 4) * 4 : PWSW_OOB;
+        offX[i] = okk ? ((k0 + row) * Q + c4 * 4) * 4 : PWSW_OOB;
+        ldsG[i] = row < GR ? row * PWSS_PITCH + c4 * 8 : -1;        // -1: beyond the image, nothing to write
+        ldsX[i] = row < XR ? row * PWSS_PITCH + c4 * 8 : -1;
+    }
+    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(const_cast<float*>(a.gy + (long)n * M * Q), (unsigned)((long)M * Q * 4));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(const_cast<float*>((HASY ? a.y : a.gy) + (long)n * M * Q), (unsigned)((long)M * Q * 4));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<float*>(a.x + (long)n * K * Q), (unsigned)((long)K * Q * 4));
+
+    const int pbeg = strip * a.per, pend = min(pbeg + a.per, Q);
+    const int nh = pend > pbeg ? (pend - pbeg + PWSS_P - 1) / PWSS_P : 0;
+
+    // this wave's tiles: a row-major run of TPW tiles of the group's mtn x ktn
+    int aoff[TPW], boff[TPW];
+    bool live[TPW];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int t = wave * TPW + tt;
+        live[tt] = t < mtn * ktn;                                 // wave uniform
+        const int ti = live[tt] ? t / ktn : 0, tj = live[tt] ? t - ti * ktn : 0;
+        aoff[tt] = (ti * 32 + r) * PWSS_PITCH + kg * 16;
+        boff[tt] = NS * gimg + (tj * 32 + r) * PWSS_PITCH + kg * 16;
+    }
+    f16v acc[TPW];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) acc[tt] = (f16v)0.0f;
+
+    f4v rG[2][SM], rY[2][SM], rX[2][SM];
+    auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, int vo, int so) -> f4v {
+        return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
+    };
+    auto issue = [&](int h, f4v (&g)[SM], f4v (&yy)[SM], f4v (&xx)[SM]) {
+        const int p0 = pbeg + h * PWSS_P;
+        const bool hv = h < nh;                                   // uniform; beyond the strip: nothing is fetched
+        const bool pv = hv && p0 + c4 * 4 < pend;                 // Q % 4 == 0 and per % 32 == 0: a float4 is all inside or all outside
+        const int so = hv ? p0 * 4 : 0;
+#pragma unroll
+        for (int i = 0; i < SM; ++i) {
+            g[i] = ld4(rg, pv ? offG[i] : PWSW_OOB, so);
+            if (HASY) yy[i] = ld4(ry, pv ? offG[i] : PWSW_OOB, so);
+            xx[i] = ld4(rx, pv ? offX[i] : PWSW_OOB, so);
+        }
+    };
+    auto convert = [&](int h, unsigned char* buf, const f4v (&g)[SM], const f4v (&yy)[SM], const f4v (&xx)[SM]) {
+        const float vm = (h < nh && pbeg + h * PWSS_P + c4 * 4 < pend) ? 1.0f : 0.0f;   // masks the constant term beyond the strip
+#pragma unroll
+        for (int i = 0; i < SM; ++i) {
+            if (ldsG[i] >= 0) {
+                const float4 c = cG[(tid + PWSS_THREADS * i) >> 3];
+                const float c0 = c.x * vm;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaf(g[i][e], c.z, c0);
+                    if (HASY) v[e] = fmaf(yy[i][e], c.y, v[e]);
+                }
+                unsigned p0[NS], p1[NS];
+                pwsw_split<NS>(v[0], v[1], p0);
+                pwsw_split<NS>(v[2], v[3], p1);
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp)
+                    *reinterpret_cast<uint2*>(buf + sp * gimg + ldsG[i]) = uint2{p0[sp], p1[sp]};
+            }
+            if (ldsX[i] >= 0) {
+                const float2 c = cX[(tid + PWSS_THREADS * i) >> 3];
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = cfn_act<ACT>(fmaf(xx[i][e], c.x, c.y));
+                unsigned p0[NS], p1[NS];
+                pwsw_split<NS>(v[0], v[1], p0);
+                pwsw_split<NS>(v[2], v[3], p1);
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp)
+                    *reinterpret_cast<uint2*>(buf + NS * gimg + sp * ximg + ldsX[i]) = uint2{p0[sp], p1[sp]};
+            }
+        }
+    };
+    auto mfma = [&](const unsigned char* buf) {
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            if (live[tt]) {
+#pragma unroll
+                for (int kb = 0; kb < PWSS_P / 16; ++kb) {
+                    bf16x8 A[NS], B[NS];
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp) {
+                        A[sp] = *reinterpret_cast<const bf16x8*>(buf + sp * gimg + aoff[tt] + kb * 32);
+                        B[sp] = *reinterpret_cast<const bf16x8*>(buf + sp * ximg + boff[tt] + kb * 32);
+                    }
+#define PWSS_MM(SA, SB) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA], B[SB], acc[tt], 0, 0, 0)
+                    if constexpr (NS == 3) { PWSS_MM(2, 0); PWSS_MM(0, 2); PWSS_MM(1, 1); }
+                    PWSS_MM(1, 0); PWSS_MM(0, 1); PWSS_MM(0, 0);
+#undef PWSS_MM
+                }
+            }
+        }
+    };
+
+    unsigned char* buf1 = buf0 + bufb;
+    issue(0, rG[0], rY[0], rX[0]);
+    issue(1, rG[1], rY[1], rX[1]);
+    for (int h = 0; h < nh; h += 2) {
+        convert(h, buf0, rG[0], rY[0], rX[0]);
+        __syncthreads();
+        issue(h + 2, rG[0], rY[0], rX[0]);
+        mfma(buf0);
+        convert(h + 1, buf1, rG[1], rY[1], rX[1]);                // h + 1 == nh: zeros (masked loads, masked constant term)
+        __syncthreads();
+        issue(h + 3, rG[1], rY[1], rX[1]);
+        mfma(buf1);
+    }
+
+    // tile element e of lane (r, kg): row (e & 3) + 8 (e >> 2) + 4 kg, column r
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        if (live[tt]) {
+            const int t = wave * TPW + tt, ti = t / ktn, tj = t - ti * ktn;
+            const int k = k0 + tj * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+                if (m < M && k < K) atomicAdd(&a.gw[(long)m * K + k], (double)acc[tt][e]);
+            }
+        }
+    }
+}
+
+static size_t pwss_lds(int mtg, int ktg, int NS) {
+    return (size_t)2 * NS * 32 * (mtg + ktg) * PWSS_PITCH + (size_t)32 * mtg * 16 + (size_t)32 * ktg * 8;
+}
+
+template <int SM, int TPW, int NS>
+static int pwss_launch(const WssArgs& a, unsigned blocks, size_t lds, hipStream_t st) {
+#define PWSS_GO(AV, HY)                                                                                                    \
+    do {                                                                                                                   \
+        auto k = pws_wgrad_staged_kernel<SM, TPW, AV, HY, NS>;                                                             \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(PWSS_THREADS), lds, st, a);                                               \
+    } while (0)
+#define PWSS_ACT(HY)                                                                                                       \
+    do {                                                                                                                   \
+        if (a.act == CFN_ACT_RELU) PWSS_GO(CFN_ACT_RELU, HY);                                                              \
+        else if (a.act == CFN_ACT_SWISH) PWSS_GO(CFN_ACT_SWISH, HY);                                                       \
+        else PWSS_GO(CFN_ACT_NONE, HY);                                                                                    \
+    } while (0)
+    if (a.y) PWSS_ACT(true); else PWSS_ACT(false);
+#undef PWSS_ACT
+#undef PWSS_GO
+    return cfn_check_launch("pwconv_bwd_weight(split bf16, staged)");
+}
+
+// -1 = shape not handled
+static int pwss_try(const float* gy, const float* y, const double* gs, const double* gq, const double* gsc, const float* x,
+                    const double* pa, const double* pb, int act, double* gw, int N, int M, int K, int Q, int terms, hipStream_t st) {
+    const int NS = terms == 3 ? 2 : 3;
+    WssArgs a = {gy, gq ? y : nullptr, gs, gq, gsc, x, pa, pb, gw, N, M, K, Q, act};
+    a.mt32 = cfn_cdiv(M, 32); a.kt32 = cfn_cdiv(K, 32);
+    // tile groups: least operand traffic  kgroups * M rows (x2 with y) + mgroups * K rows  under the limits of one workgroup:
+    // <= 8 tiles (256 rows) per side, <= 48 tiles, both double-buffered LDS images within 160 KiB
+    long best = -1;
+    for (int mg = 1; mg <= a.mt32; ++mg)
+        for (int kg = 1; kg <= a.kt32; ++kg) {
+            const int mtg = cfn_cdiv(a.mt32, mg), ktg = cfn_cdiv(a.kt32, kg);
+            if (mtg > 8 || ktg > 8 || mtg * ktg > 48 || pwss_lds(mtg, ktg, NS) > 160 * 1024) continue;
+            const long cost = ((long)kg * M * (a.y ? 2 : 1) + (long)mg * K) * 64 + mg * kg;
+            if (best < 0 || cost < best) { best = cost; a.mgroups = mg; a.kgroups = kg; a.mtg = mtg; a.ktg = ktg; }
+        }
+    if (best < 0) return -1;
+    const long groups = (long)N * a.mgroups * a.kgroups;
+    static const int wg_env = getenv("CFN_PWSS_WGS") ? atoi(getenv("CFN_PWSS_WGS")) : 0;
+    long strips = (wg_env > 0 ? wg_env : 256) / groups;          // one 8-wave workgroup per CU
+    if (strips < 1) strips = 1;
+    const long maxs = cfn_cdiv(Q, 4 * PWSS_P);                    // >= 4 half-stages per strip
+    if (strips > maxs) strips = maxs;
+    a.per = cfn_cdiv(cfn_cdiv(Q, strips), PWSS_P) * PWSS_P;
+    a.nstrips = cfn_cdiv(Q, a.per);
+    const unsigned blocks = (unsigned)(groups * a.nstrips);
+    const size_t lds = pwss_lds(a.mtg, a.ktg, NS);
+    const int tiles = a.mtg * a.ktg;
+    if (a.mtg <= 4 && a.ktg <= 4) return NS == 2 ? pwss_launch<2, 2, 2>(a, blocks, lds, st) : pwss_launch<2, 2, 3>(a, blocks, lds, st);
+    if (tiles <= 24) return NS == 2 ? pwss_launch<4, 3, 2>(a, blocks, lds, st) : pwss_launch<4, 3, 3>(a, blocks, lds, st);
+    return NS == 2 ? pwss_launch<4, 6, 2>(a, blocks, lds, st) : pwss_launch<4, 6, 3>(a, blocks, lds, st);
+}
+
 extern "C" int cfn_pw_split_terms(int terms);
 
 // contiguous pointwise conv (stride 1), M, K >= 48; -1 = not handled (caller falls through to the fp32-MFMA kernels)
@@ -234,6 +490,11 @@ int pws_wgrad_try_launch(const float* gy, const float* y, const double* gs, cons
     if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && act != CFN_ACT_SWISH) return -1;
     if (((uintptr_t)gy | (uintptr_t)(y ? y : gy) | (uintptr_t)x) & 15) return -1;
     if ((long)M * Q * 4 >= (1L << 31) - 64 || (long)K * Q * 4 >= (1L << 31) - 64) return -1;
+    static const int direct_env = getenv("CFN_PWSW_DIRECT") ? atoi(getenv("CFN_PWSW_DIRECT")) : 0;
+    if (!direct_env) {
+        const int rc = pwss_try(gy, y, gs, gq, gsc, x, pa, pb, act, gw, N, M, K, Q, terms, st);
+        if (rc >= 0) return rc;
+    }
     WsArgs a = {gy, gq ? y : nullptr, gs, gq, gsc, x, pa, pb, gw, N, M, K, Q, act};
     // tile group per wave: the candidate with the least operand traffic  kgroups * M rows (x2 with y) + mgroups * K rows
     const int mt = cfn_cdiv(M, 32), kt = cfn_cdiv(K, 32);

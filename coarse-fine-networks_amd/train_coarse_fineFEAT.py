@@ -143,7 +143,7 @@ def localize_rows(probs, labels, valid_t, names, dur):
 def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, train_split=None,
         batch_size=BS * BS_UPSCALE, frames=80 * 4, dataloaders=None, max_steps=None,
         save_model='models/coarse_fineFEAT_charades_', pretrained='models/x3d_multigrid_kinetics_fb_pretrained.pt',
-        csv_path='localize_corr_v1.csv', log=print):
+        csv_path='localize_corr_v1.csv', log=print, phase_hook=None):
     rank, world, dev = cdist.init_from_env()
     gamma_tau = 5
     clip_frames = frames * 2 // (gamma_tau * 2)
@@ -233,7 +233,9 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
                     write_file.close()
                     write_file = writer = None
                 val_apm.reset()
-                lr_sched.step()
+                lr_sched.step()            # once per val phase, as the reference (not per epoch, not per step)
+            if phase_hook is not None:         # test / logging hook: end of a phase (not in the reference's signature)
+                phase_hook(phase, epochs, optimizer)
     return net
 
 

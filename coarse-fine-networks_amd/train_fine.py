@@ -140,7 +140,7 @@ def _ap_rows(probs, labels, valid_t):
 
 def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, train_split=None,
         batch_size=BS * BS_UPSCALE, frames=80 * 4, dataloaders=None, max_steps=None, save_model='models/fine_charades_',
-        pretrained='models/x3d_multigrid_kinetics_fb_pretrained.pt', log=print):
+        pretrained='models/x3d_multigrid_kinetics_fb_pretrained.pt', log=print, phase_hook=None):
     rank, world, dev = cdist.init_from_env()
     gamma_tau = {'S': 6, 'M': 5, 'XL': 5}[X3D_VERSION]
     crop = {'S': 160, 'M': 224, 'XL': 312}[X3D_VERSION]
@@ -221,7 +221,9 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
                     log(' Epoch:{} val Loc Loss: {:.4f} Cls Loss: {:.4f} mAP: {:.4f}'.format(
                         epochs, g_loc / max(g_it, 1), g_cls / max(g_it, 1), _mean_ap(val_apm)))
                 val_apm.reset()
-                lr_sched.step()
+                lr_sched.step()            # once per val phase, as the reference (not per epoch, not per step)
+            if phase_hook is not None:         # test / logging hook: end of a phase (not in the reference's signature)
+                phase_hook(phase, epochs, optimizer)
     return net
 
 

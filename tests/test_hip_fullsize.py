@@ -323,3 +323,52 @@ def test_x3d_fine_train_mode_t256_vs_oracle():
         cos, ratio = float(torch.dot(a, b) / (a.norm() * b.norm())), float(a.norm() / b.norm())
         print('T=256 train-mode gradient %s: cosine %.4f norm ratio %.3f' % (k, cos, ratio))
         assert cos >= 0.97 and 0.9 <= ratio <= 1.1, (k, cos, ratio)
+
+
+def test_cfg3_literal_grid_pool_unpool_on_3x256x224x224():
+    """BASELINE configs[2] as written: GridPoolLayer(4, 3) on a 1 x 3 x 256 x 224 x 224 clip -> GridUnpool([y, cdf, False]) ->
+    (1, 3, 260, 224, 224), through the MODULES (3-channel saliency convs on 50,176-element planes, CDF, resampler, Interp1d
+    inversion, time_resize to 260 frames).  Saliency logits and CDF against the CPU oracle run on the same weights; frame
+    indices bit-exact against oracle/index_ref.c from the CDF the module produced; sampled frames against the 2-tap lerp
+    of their source frames; the unpooled clip against the oracle's grid_sample + trilinear resize on a channel slice."""
+    import ctypes
+    import numpy as np
+    import __graft_entry__ as ge
+    import x3d_coarse
+    from oracle import spec, x3d_ref as R
+    gp = x3d_coarse.GridPoolLayer(4, 3)
+    spec.fill_module_(gp)
+    gp = gp.to(DEV).eval()
+    x = _rand(11, 1, 3, T, 224, 224)
+    with torch.no_grad():
+        y, cdf = gp(x)
+        out, inv, ind = x3d_coarse.GridUnpool([y, cdf, False], return_aux=True)
+    K = T // 4 + 1
+    assert y.shape == (1, 3, K, 224, 224) and cdf.shape == (1, K) and out.shape == (1, 3, 4 * K, 224, 224) and 4 * K == 260
+    # saliency + CDF vs the oracle on the CPU (same procedural weights)
+    sd = {'p.' + k: v.detach().cpu() for k, v in gp.state_dict().items()}
+    g_ref = R.grid_pool_saliency(x.cpu(), sd, 'p', training=False)
+    cdf_ref = R.grid_cdf(g_ref)
+    assert maxdiff(cdf, cdf_ref) <= 2e-6
+    # indices: bit-exact against the plain-C oracle from the CDF the module itself produced
+    lib = ctypes.CDLL(ge.build_oracle())
+    c = np.ascontiguousarray(cdf.cpu().numpy(), dtype=np.float32)
+    i0c, w1c = np.empty(c.size, np.int32), np.empty(c.size, np.float32)
+    lib.cfn_ref_grid_time_index(c.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(c.size), ctypes.c_int(T),
+                                i0c.ctypes.data_as(ctypes.c_void_p), w1c.ctypes.data_as(ctypes.c_void_p))
+    i0g, w1g = ops().grid_time_index(cdf, T)
+    assert np.array_equal(i0g.cpu().numpy().reshape(-1), i0c) and np.array_equal(w1g.cpu().numpy().reshape(-1), w1c)
+    assert bool((np.diff(i0c) >= 0).all()) and i0c.min() >= 0 and i0c.max() <= T - 1
+    # pooled frames = 2-tap lerp of their source frames
+    for k in (0, 1, K // 3, K // 2, K - 2, K - 1):
+        a0 = int(i0c[k]); a1 = min(a0 + 1, T - 1)
+        ref = x[0, :, a0] * (1.0 - float(w1c[k])) + (x[0, :, a1] * float(w1c[k]) if a0 + 1 <= T - 1 else 0.0)
+        assert maxdiff(y[0, :, k], ref) <= 2e-5, k
+    # Interp1d inversion: indices bit-exact, values to fp32 rounding (oracle on the module's CDF)
+    o_ref, inv_ref, ind_ref = R.grid_unpool(y[:, :1, :, :8, :8].cpu().contiguous(), cdf.cpu(), False)
+    assert torch.equal(ind.cpu().view(ind_ref.shape), ind_ref) and maxdiff(inv, inv_ref) <= 1e-6
+    # Grid Unpool is per pixel along t: a spatial crop of the unpooled clip equals the oracle run on that crop, except
+    # that the reference's trilinear resize keeps h, w (identity in space)
+    assert maxdiff(out[:, :1, :, :8, :8], o_ref) <= 2e-5
+    # in range: every unpooled frame is a convex combination of pooled frames
+    assert float(out.max()) <= float(y.max()) + 1e-5 and float(out.min()) >= float(y.min()) - 1e-5

@@ -334,3 +334,34 @@ def test_joint_step_with_bf16_fine_tower():
     logits.square().mean().backward()
     g = fine.conv1_s.weight.grad
     assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+
+
+def test_forward_video_chunks_long_videos_like_the_reference():
+    """train_coarse_fineFEAT.py:215-224: a video longer than 1005 frames is evaluated in 1000-frame chunks, `meta[:, 0]`
+    (the clip's start inside the fine features) advanced by 1000 per chunk, logits concatenated in time.  A 1100-frame
+    synthetic video at a reduced crop: forward_video == the two chunks run by hand, and differs from an (incorrect)
+    evaluation that forgets to advance meta."""
+    import train_coarse_fineFEAT as tc
+    from oracle import spec
+    net = tc.build_model(DEV, pretrained=None, dropout=0.0)
+    spec.fill_module_(net)
+    net.eval()
+    g = torch.Generator().manual_seed(5)
+    Tv, Tf = 1100, 160
+    x = torch.randn(1, 3, Tv, 64, 64, generator=g).to(DEV)
+    feat = {k: torch.relu(torch.randn(1, c, Tf, 7, 7, generator=g)).to(DEV) for k, c in tc.FEAT_DEPTH.items()}
+    fm = torch.ones(1, Tf, device=DEV)
+    meta = torch.tensor([[10, Tv, 1500, 1]], dtype=torch.int64, device=DEV)
+    with torch.no_grad():
+        got = tc.forward_video(net, x, feat, fm, 0, meta)
+        a = net([x[:, :, :1000].contiguous(), feat, fm, 0, meta])
+        m2 = meta.clone(); m2[:, 0] += 1000
+        b = net([x[:, :, 1000:].contiguous(), feat, fm, 0, m2])
+        b_wrong = net([x[:, :, 1000:].contiguous(), feat, fm, 0, meta])
+        short = tc.forward_video(net, x[:, :, :1004].contiguous(), feat, fm, 0, meta)      # < 1005 frames: one piece
+        whole = net([x[:, :, :1004].contiguous(), feat, fm, 0, meta])
+    want = torch.cat([a, b], dim=2)
+    assert got.shape == want.shape and torch.equal(got, want)
+    assert int(meta[0, 0]) == 10                                   # the caller's meta is not modified
+    assert not torch.equal(b, b_wrong)                             # the start offset matters
+    assert torch.equal(short, whole)

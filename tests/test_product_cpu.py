@@ -66,3 +66,87 @@ def test_coarse_collate_equals_reference_mt_collate_fn():
         assert torch.equal(feat[k], t(z['feat_' + k])), k
     assert fmask.shape[1] == 128 and float(fmask[0].sum()) == 100.0       # capped at 128, sample 0 is 100 frames long
     assert list(vids) == json.loads(str(z['vids']))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# checkpoint compatibility and learning-rate schedule of the two entry points
+# ---------------------------------------------------------------------------------------------------------------------------
+def _reference_checkpoint(tmp_path, which):
+    """a checkpoint file laid out like models/x3d_multigrid_kinetics_fb_pretrained.pt: the reference's own key set and shapes
+    for the 400-class Kinetics X3D-M (tests/golden/state_keys.npz, captured from the reference's state_dict), values filled
+    procedurally by key name"""
+    import os
+    from conftest import GOLDEN
+    from oracle import spec
+    z = np.load(os.path.join(GOLDEN, 'state_keys.npz'))
+    shapes = {k: tuple(s) for k, s in json.loads(str(z[which]))}
+    # the Kinetics checkpoint holds the plain X3D trunk with a 400-way head: fc2 is (400, 2048); the coarse-only modules
+    # (rw*, mix*, pool_1) are not in it
+    shapes = {k: ((400,) + s[1:] if k.startswith('fc2.') else s) for k, s in shapes.items()
+              if not any(p in k for p in ('rw', 'mix', 'pool_1'))}
+    sd = spec.procedural_fill(shapes)
+    path = str(tmp_path / 'kinetics_like.pt')
+    torch.save({'model_state_dict': sd}, path)
+    return path, sd
+
+
+@pytest.mark.parametrize('which', ['fine', 'coarse'])
+def test_reference_format_checkpoint_loads_through_build_model(tmp_path, which):
+    """train_fine.py:104-110 / train_coarse_fineFEAT.py:112-118: state.update(ckpt['model_state_dict']) on a 400-class model,
+    then replace_logits(157): every trunk tensor comes from the checkpoint, fc2 is re-drawn at (157, 2048), the modules the
+    checkpoint does not know keep their initial values"""
+    import train_fine
+    import train_coarse_fineFEAT as tc
+    path, sd = _reference_checkpoint(tmp_path, which)
+    build = train_fine.build_model if which == 'fine' else tc.build_model
+    net = build(torch.device('cpu'), pretrained=path)
+    mine = net.state_dict()
+    assert tuple(mine['fc2.weight'].shape) == (157, 2048) and tuple(mine['fc2.bias'].shape) == (157,)
+    checked = 0
+    for k, v in sd.items():
+        if k.startswith('fc2.'):
+            continue
+        assert k in mine and torch.equal(mine[k], v), k
+        checked += 1
+    assert checked >= 800
+    if which == 'coarse':
+        assert any('rw' in k for k in mine) and any('mix' in k for k in mine)
+    # the run() checkpoints (every 1000 steps) hold net.state_dict(): a fresh model loads them strictly (resume path,
+    # train_fine.py:112-114)
+    again = build(torch.device('cpu'), pretrained=None)
+    again.load_state_dict({k: v.clone() for k, v in mine.items()})
+    for k, v in again.state_dict().items():
+        assert torch.equal(v, mine[k]), k
+    with pytest.raises(FileNotFoundError):
+        build(torch.device('cpu'), pretrained=str(tmp_path / 'missing.pt'))
+
+
+@pytest.mark.parametrize('which', ['fine', 'coarse'])
+def test_learning_rate_steps_once_per_val_phase(which):
+    """train_fine.py:131,256 -- MultiStepLR([15, 20, 25]) stepped after every VAL phase (4 train epochs per val phase);
+    train_coarse_fineFEAT.py:147,296 -- MultiStepLR([15, 25, 35]), 2 train epochs per val phase, the rw / mix group at 10x.
+    Empty loaders: the phase / epoch / scheduler bookkeeping of run() without a single forward."""
+    import train_fine
+    import train_coarse_fineFEAT as tc
+    mod, milestones, per_val = (train_fine, [15, 20, 25], 4) if which == 'fine' else (tc, [15, 25, 35], 2)
+    seen = []
+
+    def hook(phase, epochs, opt):
+        seen.append((phase, epochs, [g['lr'] for g in opt.param_groups]))
+
+    kw = dict(csv_path=None) if which == 'coarse' else {}
+    mod.run(init_lr=0.02, max_epochs=per_val * 40, dataloaders={'train': [], 'val': []}, pretrained=None, log=lambda *_: None,
+            phase_hook=hook, **kw)
+    vals = [s for s in seen if s[0] == 'val']
+    assert len(vals) == 40 and [s[1] for s in vals] == [per_val * (i + 1) for i in range(40)]     # epochs count TRAIN phases
+    ref_opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.02)
+    ref_sched = torch.optim.lr_scheduler.MultiStepLR(ref_opt, milestones)
+    for k, (_, _, lrs) in enumerate(vals):
+        ref_sched.step()                                     # k + 1 val phases so far
+        want = ref_opt.param_groups[0]['lr']
+        assert abs(lrs[0] - want) <= 1e-12, (k, lrs, want)
+        if which == 'coarse':
+            assert len(lrs) == 2 and abs(lrs[1] - 10 * want) <= 1e-12      # the 10x group keeps its ratio through the decays
+    trains = [s for s in seen if s[0] == 'train']
+    assert len(trains) == per_val * 40 and abs(trains[0][2][0] - 0.02) <= 1e-12
+    assert abs(vals[14][2][0] - 0.002) <= 1e-12 and abs(vals[13][2][0] - 0.02) <= 1e-12     # first decay after the 15th val phase

@@ -48,6 +48,10 @@ def main():
                            ('active_inst_vmem', 'SQ_ACTIVE_INST_VMEM'), ('wait_inst_lds', 'SQ_WAIT_INST_LDS')):
                 if c in m:
                     d['frac_of_wave_cycles_' + lab] = round(m[c] / wc, 4)
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in m and 'SQ_BUSY_CYCLES' in m and m['SQ_BUSY_CYCLES']:
+            # MFMA-busy cycles (per SIMD, summed) over the cycles the SQs were busy: SQ_BUSY_CYCLES counts per SE-level SQ, so the
+            # ratio is reported next to the per-SIMD figure derived from the wall time below
+            d['mfma_busy_over_sq_busy'] = round(m['SQ_VALU_MFMA_BUSY_CYCLES'] / m['SQ_BUSY_CYCLES'], 4)
         if 'SQ_INSTS_VALU' in m and 'SQ_WAVES' in m and m['SQ_WAVES']:
             d['valu_insts_per_wave'] = round(m['SQ_INSTS_VALU'] / m['SQ_WAVES'], 1)
         if ns and wc:      # per-SIMD view at an ASSUMED 2.1 GHz (1024 SIMDs; SQ cycle counters are in quad-cycles)
@@ -56,8 +60,10 @@ def main():
             d['per_simd_at_2.1GHz'] = {'valu_busy': round(4 * m.get('SQ_ACTIVE_INST_VALU', 0) / simd_cycles, 3),
                                        'inst_issue_busy': round(4 * m.get('SQ_ACTIVE_INST_ANY', 0) / simd_cycles, 3),
                                        'resident_waves': round(4 * wc / simd_cycles, 2)}
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' in m:      # counts cycles, not quad-cycles (MI355X_MICROARCH.md)
+                d['per_simd_at_2.1GHz']['mfma_busy'] = round(m['SQ_VALU_MFMA_BUSY_CYCLES'] / simd_cycles, 3)
         res[k] = d
-    json.dump({'source': 'rocprofv3 --kernel-trace --pmc <SQ counters> (separate passes) -- python tools/dwfwd_only.py', 'kernels': res},
+    json.dump({'source': 'rocprofv3 --kernel-trace --pmc <SQ counters> (separate passes) -- python tools/dwfwd_only.py | tools/pw_only.py', 'kernels': res},
               open(out, 'w'), indent=1)
     for k, d in res.items():
         print(k, {x: y for x, y in d.items() if x.startswith('frac') or x.startswith('valu')})
