@@ -339,8 +339,9 @@ def test_joint_step_with_bf16_fine_tower():
 def test_forward_video_chunks_long_videos_like_the_reference():
     """train_coarse_fineFEAT.py:215-224: a video longer than 1005 frames is evaluated in 1000-frame chunks, `meta[:, 0]`
     (the clip's start inside the fine features) advanced by 1000 per chunk, logits concatenated in time.  A 1100-frame
-    synthetic video at a reduced crop: forward_video == the two chunks run by hand, and differs from an (incorrect)
-    evaluation that forgets to advance meta."""
+    synthetic video (224 x 224: the fusion layers tile the 7 x 7 fine features by whole factors): forward_video == the two
+    chunks run by hand, and differs from an (incorrect) evaluation that forgets to advance meta.  The 1000-frame chunk also
+    takes layer 1 through the frame-range path of ops.pwconv (54 x 1000 x 112 x 112 x 4 B exceeds the 2 GiB descriptor)."""
     import train_coarse_fineFEAT as tc
     from oracle import spec
     net = tc.build_model(DEV, pretrained=None, dropout=0.0)
@@ -348,7 +349,7 @@ def test_forward_video_chunks_long_videos_like_the_reference():
     net.eval()
     g = torch.Generator().manual_seed(5)
     Tv, Tf = 1100, 160
-    x = torch.randn(1, 3, Tv, 64, 64, generator=g).to(DEV)
+    x = torch.randn(1, 3, Tv, 224, 224, generator=torch.Generator(device=DEV).manual_seed(6), device=DEV)
     feat = {k: torch.relu(torch.randn(1, c, Tf, 7, 7, generator=g)).to(DEV) for k, c in tc.FEAT_DEPTH.items()}
     fm = torch.ones(1, Tf, device=DEV)
     meta = torch.tensor([[10, Tv, 1500, 1]], dtype=torch.int64, device=DEV)
