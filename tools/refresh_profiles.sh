@@ -16,10 +16,17 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write --
 # SQ counters of the same workload (two passes)
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq1 -- python $R/tools/dwfwd_only.py > /dev/null 2> $O/pmc_sq1.err
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM --output-format csv -d $O/pmc_sq2 -- python $R/tools/dwfwd_only.py > /dev/null 2> $O/pmc_sq2.err
+# MFMA-busy / VALU / LDS counters of the pointwise kernels of layers 2-4: fp32 MFMA, 6-term split bf16, bf16 activations
+for v in "0 f32 fp32mfma" "6 f32 split6" "6 bf16 bf16"; do set -- $v
+  CFN_PW_SPLIT=$1 DT=$2 CFN_PWS_MAXK=100000 CFN_PWS_MAXSLABS=100 REPS=2 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_pw1_$3 -- python $R/tools/pw_only.py > /dev/null 2> $O/pmc_pw1_$3.err
+  CFN_PW_SPLIT=$1 DT=$2 CFN_PWS_MAXK=100000 CFN_PWS_MAXSLABS=100 REPS=2 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $O/pmc_pw2_$3 -- python $R/tools/pw_only.py > /dev/null 2> $O/pmc_pw2_$3.err
+done
+python $R/bench.py --stream coarse --frames 256 --no-cpu-baseline > $O/bench_coarse_t256.json 2>> $O/bench.err
 python $R/tools/microbench.py pw --bwd --batch 8 2>&1 | grep -v "$FILT" > $O/microbench_b8.txt
 python $R/tools/microbench.py dw --bwd --batch 8 2>&1 | grep -v "$FILT" >> $O/microbench_b8.txt
 python $R/tools/microbench_bf16.py 2>&1 | grep -v "$FILT" > $O/microbench_bf16_b8.txt
 $R/tools/probe/stream_probe > $O/stream_probe.txt 2>&1
 $R/tools/probe/mfma_rate_probe > $O/mfma_rate_probe.txt 2>&1
 find $O -name "*kernel_trace.csv" -size +4M -delete
+find $O -name "*agent_info.csv" -delete
 ls -la $O $O/*
