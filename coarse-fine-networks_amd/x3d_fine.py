@@ -16,11 +16,19 @@ produced and consumed by the hand-written gfx950 kernels of ``cfn_hip`` (C ABI: 
 The (N,C)-sized statistics algebra (mean/var, running stats, SE FCs) is ordinary torch on tiny
 tensors and is differentiated by autograd; reference semantics cited inline.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from cfn_hip import ops, ACT_NONE, ACT_RELU, ACT_SWISH
+
+# CFN_USE_TORCH_OPS=1 (or x3d_fine.USE_TORCH_OPS = True): Bottleneck runs through the registered dispatcher operators
+# torch.ops.cfn.* (cfn_hip/torchlib.py) with plain semantics -- the same kernels, visible to torch.compile / torch.export as opaque
+# nodes; the cross-operator fusions of the default path (shortcut tokens, tail links, deferred prologues between blocks, batched
+# gradient casts) are not expressible in functional operator signatures and are off in this mode.
+USE_TORCH_OPS = os.environ.get('CFN_USE_TORCH_OPS', '0') == '1'
 
 
 class Deferred(object):
@@ -93,6 +101,22 @@ class SubBatchNorm3d(nn.Module):
         gamma, beta = (self.weight, self.bias) if self.affine else (None, None)
         return ops.bn_fold(s, q, gamma, beta, bufs, self.training, n, self.num_features, self.num_splits, count, self.eps,
                            self.momentum, se=se, pool_count=count)
+
+    def fold_op(self, s, q, count, n, se=None):
+        """`fold` through the functional dispatcher operator torch.ops.cfn.bn_fold: the operator returns the updated running
+        statistics, which are copied into the buffers here"""
+        tr = self.training
+        bn = self.split_bn if tr else self.bn
+        gamma, beta = (self.weight, self.bias) if self.affine else (None, None)
+        w1, b1, w2, b2 = se if se is not None else (None, None, None, None)
+        out = torch.ops.cfn.bn_fold(s, q, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked, tr, n,
+                                    self.num_features, self.num_splits, float(count), self.eps, self.momentum, w1, b1, w2, b2, float(count))
+        if tr:
+            with torch.no_grad():
+                bn.running_mean.copy_(out[9])
+                bn.running_var.copy_(out[10])
+                bn.num_batches_tracked.copy_(out[11])
+        return out[0], out[1]
 
     def forward(self, x):
         n = x.shape[0]
@@ -172,7 +196,34 @@ class Bottleneck(nn.Module):
             width_out += divisor
         return int(width_out)
 
+    def _forward_torch_ops(self, x):
+        """the block on torch.ops.cfn.* (plain tensors in and out; x3d_fine.py:146-175)"""
+        import cfn_hip.torchlib  # noqa: F401  (registers the operators)
+        T = torch.ops.cfn
+        if isinstance(x, tuple):
+            x = x[0]
+        if isinstance(x, Deferred):
+            x = x.materialize()
+        if self.t_stride != 1 or (self.downsample is not None and not isinstance(self.downsample, nn.Sequential)):
+            raise NotImplementedError('CFN_USE_TORCH_OPS: t_downsample / shortcut type A run on the default path only')
+        n = x.shape[0]
+        has_se = self.index % 2 == 0
+        y1, s1, q1 = T.pwconv(x, self.conv1.weight, None, None, ACT_NONE, 1)
+        A1, B1 = self.bn1.fold_op(s1, q1, _count(y1), n)
+        y2, s2, q2 = T.dwconv3d(y1, self.conv2.weight, A1, B1, ACT_RELU, self.stride)
+        se = (self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias) if has_se else None
+        A2, B2 = self.bn2.fold_op(s2, q2, _count(y2), n, se=se)
+        y3, s3, q3 = T.pwconv(y2, self.conv3.weight, A2, B2, ACT_SWISH, 1)
+        A3, B3 = self.bn3.fold_op(s3, q3, _count(y3), n)
+        if self.downsample is not None:
+            yd, sd, qd = T.pwconv(x, self.downsample[0].weight, None, None, ACT_NONE, self.stride)
+            Ad, Bd = self.downsample[1].fold_op(sd, qd, _count(yd), n)
+            return T.bn_add_relu(y3, A3, B3, yd, Ad, Bd)
+        return T.bn_add_relu(y3, A3, B3, x)
+
     def forward(self, x):
+        if USE_TORCH_OPS:
+            return self._forward_torch_ops(x)
         # a (x_for_conv1, x_for_residual) pair: the previous block handed out its output twice (see split_out below)
         x, x_res = x if isinstance(x, tuple) else (x, x)
         xr, xa, xb, xact = _unpack(x)

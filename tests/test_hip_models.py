@@ -43,9 +43,12 @@ def test_subbn_module(S):
 
 @pytest.mark.parametrize('tag,index,stride,cin,planes', [('even_s1', 0, 1, 24, (54, 24)), ('odd_s1', 1, 1, 24, (54, 24)),
                                                          ('even_s2', 0, 2, 24, (54, 48)), ('odd_s2', 1, 2, 48, (108, 48))])
-def test_bottleneck_vs_reference(tag, index, stride, cin, planes):
+@pytest.mark.parametrize('torch_ops', [False, True])
+def test_bottleneck_vs_reference(tag, index, stride, cin, planes, torch_ops, monkeypatch):
+    """torch_ops=True: the same block through the registered dispatcher operators torch.ops.cfn.* (x3d_fine.USE_TORCH_OPS)"""
     import x3d_fine
     from oracle import spec
+    monkeypatch.setattr(x3d_fine, 'USE_TORCH_OPS', torch_ops)
     z = load_golden('bottleneck_' + tag)
     ds = None
     if stride != 1 or cin != planes[1]:

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import relerr
+from conftest import relerr, maxdiff
 
 DEV = 'cuda'
 
@@ -91,3 +91,155 @@ def test_opcheck():
     cdf = torch.linspace(0, 1, 5).view(1, 5).to(DEV).requires_grad_(True)
     torch.library.opcheck(torch.ops.cfn.time_sample.default, (xs, cdf),
                           test_utils=('test_schema', 'test_faketensor', 'test_autograd_registration'))
+
+
+def test_full_operator_set_is_registered():
+    """the op set behind the module API, each with a schema and a fake implementation (CPU: meta tensors only)"""
+    import cfn_hip.torchlib as tl
+    assert set(tl.OPERATORS) >= {'dwconv3d', 'pwconv', 'time_sample', 'dwconv_t5', 'stem_conv', 'conv3d_dense', 'bn_fold',
+                                 'bn_add_relu', 'affine_act', 'pool_hw', 'interp1d', 'grid_cdf', 'gauss_align', 'fusion_gather',
+                                 'film', 'time_resize'}
+    for name in tl.OPERATORS:
+        assert hasattr(torch.ops.cfn, name) and hasattr(torch.ops.cfn, name + '_backward'), name
+    m = lambda *s, dt=torch.float32: torch.empty(*s, device='meta', dtype=dt)
+    assert torch.ops.cfn.stem_conv(m(2, 3, 4, 32, 32), m(24, 3, 1, 3, 3)).shape == (2, 24, 4, 16, 16)
+    y, s, q = torch.ops.cfn.conv3d_dense(m(1, 3, 8, 16, 16), m(3, 3, 3, 3, 3), [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    assert y.shape == (1, 3, 4, 8, 8) and s.dtype == torch.float64
+    out = torch.ops.cfn.bn_fold(m(2, 6, dt=torch.float64), m(2, 6, dt=torch.float64), m(6), m(6), m(6), m(6), m((), dt=torch.int64),
+                                True, 2, 6, 1, 64.0, 1e-5, 0.1)
+    assert len(out) == 12 and out[0].shape == (2, 6) and out[0].dtype == torch.float64 and out[9].shape == (6,)
+    assert torch.ops.cfn.time_resize(m(1, 5, 7, 3), 21, True).shape == (1, 5, 21, 3)
+    assert torch.ops.cfn.grid_cdf(m(2, 16)).shape == (2, 17)
+    assert torch.ops.cfn.gauss_align(m(2, 4, dt=torch.int64), m(2, 12), None, 1.0, 4.0, 1, 5).shape == (2, 12, 5)
+    z, den = torch.ops.cfn.fusion_gather(m(2, 8, 12, 49), m(2, 12, 49), None, m(2, 12, 5), m(2, 12))
+    assert z.shape == (2, 8, 5, 49) and den.shape == (2, 5, 49)
+
+
+def _cases():
+    """(operator, args, kwargs) samples for opcheck / comparison with cfn_hip.ops"""
+    g = torch.Generator().manual_seed(0)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    N, C = 2, 6
+    coef = lambda: ((1 + 0.2 * torch.randn(N, C, generator=g)).to(DEV), (0.2 * torch.randn(N, C, generator=g)).to(DEV))
+    A, B = coef()
+    Ar, Br = coef()
+    cdf = torch.sort(torch.rand(2, 9, generator=g), dim=1)[0].to(DEV)
+    s = torch.randn(N, C, generator=g).double().to(DEV) * 10
+    q = (s * s / 64 + torch.rand(N, C, generator=g).double().to(DEV) * 64)
+    bufs = lambda: (torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV))
+    se = (r(8, C, 1, 1, 1, sc=0.3), r(8, sc=0.1), r(C, 8, 1, 1, 1, sc=0.3), r(C, sc=0.1))
+    meta = torch.tensor([[2, 8, 12, 1], [0, 8, 10, 1]], dtype=torch.int64, device=DEV)
+    mask = torch.ones(2, 12, device=DEV)
+    return [
+        ('dwconv_t5', (r(N, C, 7, 6, 6), r(C, 1, 5, 1, 1, sc=0.4)), {}),
+        ('stem_conv', (r(N, 3, 3, 16, 16), r(24, 3, 1, 3, 3, sc=0.3)), {}),
+        ('conv3d_dense', (r(1, 3, 8, 16, 16), r(3, 3, 3, 3, 3, sc=0.3), [3, 3, 3], [2, 2, 2], [1, 1, 1]), {}),
+        ('conv3d_dense', (r(N, C, 4, 8, 8), r(1, C, 1, 3, 3, sc=0.3), [1, 3, 3], [1, 2, 2], [0, 1, 1], A, B, 1), {}),
+        ('bn_fold', (s, q, r(C), r(C), *bufs(), True, N, C, 1, 64.0, 1e-5, 0.1), {}),
+        ('bn_fold', (s, q, r(C), r(C), *bufs(), True, N, C, 1, 64.0, 1e-5, 0.1, *se, 64.0), {}),
+        ('bn_fold', (s, None, r(C), r(C), *bufs(), False, N, C, 1, 64.0, 1e-5, 0.1, *se, 64.0), {}),
+        ('bn_add_relu', (r(N, C, 3, 8, 8), A, B, r(N, C, 3, 8, 8)), {}),
+        ('bn_add_relu', (r(N, C, 3, 8, 8), A, B, r(N, C, 3, 8, 8), Ar, Br), {}),
+        ('affine_act', (r(N, C, 3, 8, 8), A, B, 2), {}),
+        ('pool_hw', (r(N, C, 3, 14, 14), 7, 7, A, B, 1), {}),
+        ('pool_hw', (r(N, C, 3, 14, 14), 1, 1), {}),
+        ('interp1d', (cdf, torch.linspace(0, 1, 9).view(1, 9).repeat(2, 1).to(DEV), torch.rand(2, 9, generator=g).to(DEV)), {}),
+        ('grid_cdf', (r(2, 16), r(1, sc=0.1)), {}),
+        ('gauss_align', (meta, mask, cdf[:, :5].contiguous(), 1.0, 4.0, 1, 5), {}),
+        ('fusion_gather', (torch.relu(r(2, 8, 12, 49)), r(2, 12, 49), r(1, sc=0.1), torch.softmax(r(2, 12, 5), 1), mask, 1), {}),
+        ('film', (r(N, C, 3, 14, 14), r(N, C, 3, 7, 7), r(N, C, 3, 7, 7), 2), {}),
+        ('time_resize', (r(2, 5, 7, 3), 21, True), {}),
+        ('time_resize', (r(2, 5, 7), 30, False), {}),
+    ]
+
+
+@pytest.mark.gpu
+def test_opcheck_every_operator():
+    """torch.library.opcheck: schema (no undeclared mutation / aliasing), fake implementation vs real outputs, autograd
+    registration -- for every registered operator, on the sample arguments above (floating-point inputs require grad)"""
+    import cfn_hip.torchlib  # noqa: F401
+    for name, args, kw in _cases():
+        args = tuple(a.clone().requires_grad_(True) if torch.is_tensor(a) and a.is_floating_point() and a.dim() > 0 and name != 'bn_fold'
+                     else a for a in args)
+        if name == 'bn_fold':      # running statistics / counters are plain buffers
+            args = tuple(a.clone().requires_grad_(True) if (torch.is_tensor(a) and a.is_floating_point() and i not in (4, 5)) else a
+                         for i, a in enumerate(args))
+        torch.library.opcheck(getattr(torch.ops.cfn, name).default, args, kw,
+                              test_utils=('test_schema', 'test_autograd_registration', 'test_faketensor'))
+
+
+@pytest.mark.gpu
+def test_operators_equal_the_ops_functions():
+    """values and gradients of torch.ops.cfn.* == cfn_hip.ops.* (same kernels): bitwise for the tensors, to fp32 rounding for
+    gradients that the plain path casts at the end of the pass"""
+    import cfn_hip.torchlib  # noqa: F401
+    from cfn_hip import ops
+    pairs = {
+        'dwconv_t5': lambda x, w: ops.dwconv_t5(x, w, True),
+        'stem_conv': ops.stem_conv,
+        'conv3d_dense': lambda x, w, k, s, p, A=None, B=None, act=0: ops.conv3d_dense(x, w, tuple(k), tuple(s), tuple(p), A, B, act, True),
+        'bn_add_relu': ops.bn_add_relu, 'affine_act': ops.affine_act,
+        'pool_hw': lambda x, OH, OW, A=None, B=None, act=0: ops.pool_hw(x, OH, OW, A, B, act),
+        'interp1d': ops.interp1d, 'grid_cdf': ops.grid_cdf, 'gauss_align': ops.gauss_align,
+        'fusion_gather': ops.fusion_gather, 'film': ops.film, 'time_resize': ops.time_resize,
+    }
+    for name, args, kw in _cases():
+        if name not in pairs:
+            continue
+        def leaves():
+            return [a.clone().requires_grad_(True) if torch.is_tensor(a) and a.is_floating_point() else a for a in args]
+        la, lb = leaves(), leaves()
+        oa = getattr(torch.ops.cfn, name)(*la)
+        ob = pairs[name](*lb)
+        oa = oa if isinstance(oa, (tuple, list)) else (oa,)
+        ob = ob if isinstance(ob, (tuple, list)) else (ob,)
+        loss_a = loss_b = 0.0
+        for k, (ta, tb) in enumerate(zip(oa, ob)):
+            if tb is None:
+                continue
+            assert torch.equal(ta, tb), (name, k)
+            if ta.is_floating_point() and ta.requires_grad:
+                wgt = torch.randn(ta.shape, generator=torch.Generator().manual_seed(k)).to(DEV).to(ta.dtype)
+                loss_a = loss_a + (ta * wgt).sum()
+                loss_b = loss_b + (tb * wgt).sum()
+        loss_a.backward()
+        loss_b.backward()
+        for k, (xa, xb) in enumerate(zip(la, lb)):
+            if torch.is_tensor(xa) and xa.requires_grad and xb.grad is not None:
+                assert xa.grad is not None, (name, k)
+                assert relerr(xa.grad, xb.grad) <= 1e-6, (name, k, relerr(xa.grad, xb.grad))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('train', [False, True])
+def test_bottleneck_on_torch_ops_compiles_without_graph_breaks(train, monkeypatch):
+    """torch.compile(fullgraph=True) of one Bottleneck forward on torch.ops.cfn.*: dynamo traces the block into ONE graph (the
+    operators are opaque nodes with fake implementations; `aot_eager` = dynamo + functionalisation + the real kernels, no
+    Triton involved); the compiled block equals the eager one, and the default ctypes path"""
+    import x3d_fine
+    from oracle import spec
+    torch._dynamo.reset()
+    m = x3d_fine.Bottleneck(24, (54, 24), 1, None, index=0, base_bn_splits=1)
+    spec.fill_module_(m)
+    m = m.to(DEV).train(train)
+    x = F.relu(spec.rand_input(3, (2, 24, 4, 8, 8))).to(DEV)
+    monkeypatch.setattr(x3d_fine, 'USE_TORCH_OPS', False)
+    with torch.no_grad():
+        y_default = m(x)
+    monkeypatch.setattr(x3d_fine, 'USE_TORCH_OPS', True)
+    rm0 = m.bn2.split_bn.running_mean.clone()
+    with torch.no_grad():
+        y_eager = m(x)
+    cm = torch.compile(m, fullgraph=True, backend='aot_eager')
+    with torch.no_grad():
+        y_comp = cm(x)
+    assert torch.equal(y_eager, y_comp)
+    assert maxdiff(y_eager, y_default) <= 1e-6
+    if train:
+        assert not torch.equal(m.bn2.split_bn.running_mean, rm0)      # the running statistics did move (three times)
+    # and with autograd through the compiled graph
+    xg = x.clone().requires_grad_(True)
+    cm(xg).square().sum().backward()
+    xe = x.clone().requires_grad_(True)
+    m(xe).square().sum().backward()
+    assert relerr(xg.grad, xe.grad) <= 1e-5
