@@ -236,7 +236,11 @@ int CPN(dw_cp_fwd_try)(const cpe_t* x, const double* A, const double* B, int act
     // VGPRs, 5 waves: 5.1 TB/s; capped at 80 / 64 VGPRs the spills cost 1.6x / 3x)
     //   stride 1: 56x56: 28 x 2 lanes x 2 rows (14 bands of 4 rows); 28x28: 14 x 4 x 1 (7 bands); 14x14: 7 x 7 x 2 (the plane)
     //   stride 2: ->56: 28 x 2 x 2 (14 bands); ->28: 14 x 4 x 1 (7 bands); ->14: 7 x 7 x 1 (2 bands)
-    const int NB = Ho == 56 ? 14 : Ho == 28 ? 7 : (stride == 2 ? 2 : 1);
+    // CFN_DW_CP_TALL=1: stride-1 56x56 / 28x28 with 8-row bands (10 input rows per 8 output rows instead of 6 per 4: the halo rows
+    // are re-read by the neighbouring band, and re-reads cost the vector-memory path as much as first reads)
+    static const int tall = getenv("CFN_DW_CP_TALL") ? atoi(getenv("CFN_DW_CP_TALL")) : 0;
+    const bool tall56 = (tall & 1) && stride == 1 && Ho == 56, tall28 = (tall & 2) && stride == 1 && Ho == 28;
+    const int NB = tall56 ? 7 : tall28 ? 4 : Ho == 56 ? 14 : Ho == 28 ? 7 : (stride == 2 ? 2 : 1);
     // t-chunks: >= ~6 rounds of the chip's resident waves (16 per CU) so that the tail of the last round stays small; the
     // chunk length + 2 halo frames is a multiple of the unrolled trip (6 or 12 steps) where T allows it
     const long units = (long)N * C * NB;
@@ -254,7 +258,8 @@ int CPN(dw_cp_fwd_try)(const cpe_t* x, const double* A, const double* B, int act
     const unsigned blocks = (unsigned)((a.total_waves + 3) / 4);
 #define CFN_CP_GO(...) hipLaunchKernelGGL((dw3d_cp_fwd_kernel<__VA_ARGS__>), dim3(blocks), dim3(256), 0, st, a)
     if (stride == 1) {
-        if (Ho == 56) CFN_CP_GO(56, 1, 2, 2, 2, 4); else if (Ho == 28) CFN_CP_GO(28, 1, 1, 4, 2, 4); else CFN_CP_GO(14, 1, 2, 7, 4, 4);
+        if (tall56) CFN_CP_GO(56, 1, 4, 2, 2, 3); else if (tall28) CFN_CP_GO(28, 1, 2, 4, 2, 4);
+        else if (Ho == 56) CFN_CP_GO(56, 1, 2, 2, 2, 4); else if (Ho == 28) CFN_CP_GO(28, 1, 1, 4, 2, 4); else CFN_CP_GO(14, 1, 2, 7, 4, 4);
     } else {
         if (Ho == 56) CFN_CP_GO(56, 2, 2, 2, 2, 4); else if (Ho == 28) CFN_CP_GO(28, 2, 1, 4, 2, 4); else CFN_CP_GO(14, 2, 1, 7, 2, 4);
     }
