@@ -224,7 +224,7 @@ def main():
         # passes, gfx950 correction applied) is measured offline -- bench.py cannot run under the counter tool -- and
         # committed in profiles/; quoted only for the configuration it was measured on
         traffic = traffic_note = None
-        for name in ('r02_pmc_dwfwd.json', 'r01_pmc_dwfwd.json'):
+        for name in ('r03_pmc_dwfwd.json', 'r02_pmc_dwfwd.json', 'r01_pmc_dwfwd.json'):
             pmc = os.path.join(ROOT, 'profiles', name)
             if not coarse and args.dtype == 'f32' and os.path.exists(pmc):
                 doc = json.load(open(pmc))
