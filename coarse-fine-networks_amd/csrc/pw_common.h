@@ -54,6 +54,10 @@ int pws_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st);
 int pws_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const double* gsc, const float* x,
                          const double* pa, const double* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st);
 
+// the LDS-staged weight gradient of pwsplitw.hip on bf16 tensors (one bf16 term per operand); -1 = not handled
+int pwss_wgrad_try_bf16(const uint16_t* gy, const uint16_t* y, const double* gs, const double* gq, const double* gsc, const uint16_t* x,
+                        const double* pa, const double* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st);
+
 // pwwgrad.hip: direct-operand weight gradient for M, K >= 48 (stride 1); -1 = shape not handled.
 // gsc: per-(n,m) scale of gy (null = 1)
 int pwd_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const double* gsc, const float* x,

@@ -14,7 +14,7 @@
 // an odd number of 16-byte slots: conflict-free ds_read_b128 of the A operand); position tiles are dealt round robin.
 // Per-(n, row) reductions (BN statistics forward; sum dz*x, sum dz backward) use a transpose-reduce butterfly over the
 // 32 column lanes (16 shuffles per 16 rows) and accumulate in registers across tiles: one fp64 atomic per row per block.
-#include "cfn_common.h"
+#include "pw_common.h"
 #include <stdint.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -580,6 +580,11 @@ extern "C" int cfn_pwconv_bwd_weight_bf16(const uint16_t* gy, const uint16_t* y,
     const size_t lds = (size_t)PWB_WAVES * MTW * NTW * 1024 * 4;
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_WGRAD, st, 2.0 * N * ((double)Cout * Q * (a.y ? 2 : 1) + (double)Cin * Q));
+    {   // LDS-staged kernel (pwsplitw.hip): whole-line loads, operands formed once per element
+        const int rc = pwss_wgrad_try_bf16(gy, gsumsq ? y : nullptr, gsum, gsumsq, gscale, x, A, B, A ? act : CFN_ACT_NONE, gw, N, Cout, Cin, (int)Q,
+                                           st);
+        if (rc >= 0) return rc;
+    }
     const dim3 grid((unsigned)(groups * strips));
 #define PWB_WG_GO(MV, NV, AV)                                                                                              \
     do {                                                                                                                   \

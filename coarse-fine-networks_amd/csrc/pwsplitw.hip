@@ -242,16 +242,18 @@ static int pwsw_launch(WsArgs& a, hipStream_t st) {
 #define PWSS_PITCH 80
 #define PWSS_THREADS 512
 
-struct WssArgs {
-    const float* gy; const float* y; const double* gs; const double* gq; const double* gsc;
-    const float* x; const double* pa; const double* pb;
+struct WssArgs {      // gy, y, x: fp32 (ES = 4) or bf16 (ES = 2) tensors
+    const void* gy; const void* y; const double* gs; const double* gq; const double* gsc;
+    const void* x; const double* pa; const double* pb;
     double* gw;
     int N, M, K, Q, act;
     int mgroups, kgroups, nstrips, mt32, kt32;
     int mtg, ktg, per;      // row / column tiles per group (LDS images are 32*mtg / 32*ktg rows), positions per strip (multiple of 32)
 };
 
-template <int SM, int TPW, int ACT, bool HASY, int NS>
+// ES = 2: bf16 tensors (the bf16 activation path, section 4b of DESIGN.md): the same staging with 8-byte loads of 4 positions and
+// ONE bf16 term per operand (NS = 1: the operands are bf16 already; G' and the prologue are formed in fp32 and rounded once)
+template <int SM, int TPW, int ACT, bool HASY, int NS, int ES>
 __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const WssArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = cfn_uni(tid >> 6), lane = tid & 63, kg = lane >> 5, r = lane & 31;
@@ -296,14 +298,15 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
     for (int i = 0; i < SM; ++i) {
         const int row = (tid + PWSS_THREADS * i) >> 3;
         const bool okm = row < mtn * 32 && m0 + row < M, okk = row < ktn * 32 && k0 + row < K;
-        offG[i] = okm ? ((m0 + row) * Q + c4 * 4) * 4 : PWSW_OOB;
-        offX[i] = okk ? ((k0 + row) * Q + c4 * 4) * 4 : PWSW_OOB;
+        offG[i] = okm ? ((m0 + row) * Q + c4 * 4) * ES : PWSW_OOB;
+        offX[i] = okk ? ((k0 + row) * Q + c4 * 4) * ES : PWSW_OOB;
         ldsG[i] = row < GR ? row * PWSS_PITCH + c4 * 8 : -1;        // -1: beyond the image, nothing to write
         ldsX[i] = row < XR ? row * PWSS_PITCH + c4 * 8 : -1;
     }
-    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(const_cast<float*>(a.gy + (long)n * M * Q), (unsigned)((long)M * Q * 4));
-    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(const_cast<float*>((HASY ? a.y : a.gy) + (long)n * M * Q), (unsigned)((long)M * Q * 4));
-    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<float*>(a.x + (long)n * K * Q), (unsigned)((long)K * Q * 4));
+    auto base = [&](const void* p, long rows) { return (char*)const_cast<void*>(p) + (long)n * rows * Q * ES; };
+    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(base(a.gy, M), (unsigned)((long)M * Q * ES));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(base(HASY ? a.y : a.gy, M), (unsigned)((long)M * Q * ES));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(base(a.x, K), (unsigned)((long)K * Q * ES));
 
     const int pbeg = strip * a.per, pend = min(pbeg + a.per, Q);
     const int nh = pend > pbeg ? (pend - pbeg + PWSS_P - 1) / PWSS_P : 0;
@@ -325,13 +328,20 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
 
     f4v rG[2][SM], rY[2][SM], rX[2][SM];
     auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, int vo, int so) -> f4v {
-        return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
+        if constexpr (ES == 4) {
+            return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
+        } else {
+            typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
+            const u2v_ d = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
+            const unsigned d0 = d.x, d1 = d.y;
+            return (f4v){pwsw_lo(d0), pwsw_hi(d0), pwsw_lo(d1), pwsw_hi(d1)};
+        }
     };
     auto issue = [&](int h, f4v (&g)[SM], f4v (&yy)[SM], f4v (&xx)[SM]) {
         const int p0 = pbeg + h * PWSS_P;
         const bool hv = h < nh;                                   // uniform; beyond the strip: nothing is fetched
         const bool pv = hv && p0 + c4 * 4 < pend;                 // Q % 4 == 0 and per % 32 == 0: a float4 is all inside or all outside
-        const int so = hv ? p0 * 4 : 0;
+        const int so = hv ? p0 * ES : 0;
 #pragma unroll
         for (int i = 0; i < SM; ++i) {
             g[i] = ld4(rg, pv ? offG[i] : PWSW_OOB, so);
@@ -387,7 +397,8 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
                     }
 #define PWSS_MM(SA, SB) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA], B[SB], acc[tt], 0, 0, 0)
                     if constexpr (NS == 3) { PWSS_MM(2, 0); PWSS_MM(0, 2); PWSS_MM(1, 1); }
-                    PWSS_MM(1, 0); PWSS_MM(0, 1); PWSS_MM(0, 0);
+                    if constexpr (NS >= 2) { PWSS_MM(1, 0); PWSS_MM(0, 1); }
+                    PWSS_MM(0, 0);
 #undef PWSS_MM
                 }
             }
@@ -427,11 +438,11 @@ static size_t pwss_lds(int mtg, int ktg, int NS) {
     return (size_t)2 * NS * 32 * (mtg + ktg) * PWSS_PITCH + (size_t)32 * mtg * 16 + (size_t)32 * ktg * 8;
 }
 
-template <int SM, int TPW, int NS>
+template <int SM, int TPW, int NS, int ES = 4>
 static int pwss_launch(const WssArgs& a, unsigned blocks, size_t lds, hipStream_t st) {
 #define PWSS_GO(AV, HY)                                                                                                    \
     do {                                                                                                                   \
-        auto k = pws_wgrad_staged_kernel<SM, TPW, AV, HY, NS>;                                                             \
+        auto k = pws_wgrad_staged_kernel<SM, TPW, AV, HY, NS, ES>;                                                             \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(k, dim3(blocks), dim3(PWSS_THREADS), lds, st, a);                                               \
     } while (0)
@@ -448,9 +459,10 @@ static int pwss_launch(const WssArgs& a, unsigned blocks, size_t lds, hipStream_
 }
 
 // -1 = shape not handled
-static int pwss_try(const float* gy, const float* y, const double* gs, const double* gq, const double* gsc, const float* x,
+// terms: 3 / 6 (fp32 tensors, split), 1 (bf16 tensors)
+static int pwss_try(const void* gy, const void* y, const double* gs, const double* gq, const double* gsc, const void* x,
                     const double* pa, const double* pb, int act, double* gw, int N, int M, int K, int Q, int terms, hipStream_t st) {
-    const int NS = terms == 3 ? 2 : 3;
+    const int NS = terms == 1 ? 1 : (terms == 3 ? 2 : 3);
     WssArgs a = {gy, gq ? y : nullptr, gs, gq, gsc, x, pa, pb, gw, N, M, K, Q, act};
     a.mt32 = cfn_cdiv(M, 32); a.kt32 = cfn_cdiv(K, 32);
     // tile groups: least operand traffic  kgroups * M rows (x2 with y) + mgroups * K rows  under the limits of one workgroup:
@@ -475,6 +487,11 @@ static int pwss_try(const float* gy, const float* y, const double* gs, const dou
     const unsigned blocks = (unsigned)(groups * a.nstrips);
     const size_t lds = pwss_lds(a.mtg, a.ktg, NS);
     const int tiles = a.mtg * a.ktg;
+    if (NS == 1) {
+        if (a.mtg <= 4 && a.ktg <= 4) return pwss_launch<2, 2, 1, 2>(a, blocks, lds, st);
+        if (tiles <= 24) return pwss_launch<4, 3, 1, 2>(a, blocks, lds, st);
+        return pwss_launch<4, 6, 1, 2>(a, blocks, lds, st);
+    }
     if (a.mtg <= 4 && a.ktg <= 4) return NS == 2 ? pwss_launch<2, 2, 2>(a, blocks, lds, st) : pwss_launch<2, 2, 3>(a, blocks, lds, st);
     if (tiles <= 24) return NS == 2 ? pwss_launch<4, 3, 2>(a, blocks, lds, st) : pwss_launch<4, 3, 3>(a, blocks, lds, st);
     return NS == 2 ? pwss_launch<4, 6, 2>(a, blocks, lds, st) : pwss_launch<4, 6, 3>(a, blocks, lds, st);
@@ -516,4 +533,16 @@ int pws_wgrad_try_launch(const float* gy, const float* y, const double* gs, cons
     if (TM == 2 && TN == 2) return pwsw_launch<2, 2, 3>(a, st);
     if (TM == 2 && TN == 3) return pwsw_launch<2, 3, 3>(a, st);
     return pwsw_launch<3, 2, 3>(a, st);
+}
+
+// bf16 tensors (cfn_pwconv_bwd_weight_bf16), M, K >= 48; -1 = not handled (the caller keeps its direct-operand kernel)
+int pwss_wgrad_try_bf16(const uint16_t* gy, const uint16_t* y, const double* gs, const double* gq, const double* gsc, const uint16_t* x,
+                        const double* pa, const double* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st) {
+    static const int off = getenv("CFN_PWB_WG_DIRECT") ? atoi(getenv("CFN_PWB_WG_DIRECT")) : 0;
+    // few rows (layer 1: 54 + 24): a 32-position half-stage moves ~5 KB per barrier -- measured 0.60 vs 0.34-0.50 ms: declined
+    if (off || Q % 4 != 0 || M < 48 || K < 48) return -1;
+    if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && act != CFN_ACT_SWISH) return -1;
+    if (((uintptr_t)gy | (uintptr_t)(y ? y : gy) | (uintptr_t)x) & 7) return -1;
+    if ((long)M * Q * 2 >= (1L << 31) - 64 || (long)K * Q * 2 >= (1L << 31) - 64) return -1;
+    return pwss_try(gy, y, gs, gq, gsc, x, pa, pb, act, gw, N, M, K, Q, 1, st);
 }
