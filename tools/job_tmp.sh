@@ -1,4 +1,6 @@
-O=gpurun_out/r3l; mkdir -p $O
-python -m pytest tests/test_hip_bf16.py -q 2>&1 | tail -5 > $O/bf16_tests.txt; tail -4 $O/bf16_tests.txt
-for d in 1 0; do echo "DIRECT=$d"; CFN_PWB_WG_DIRECT=$d python tools/microbench_bf16.py 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Lib"; done > $O/mb_bf16.txt; cat $O/mb_bf16.txt
-for d in 1 0; do CFN_PWB_WG_DIRECT=$d python bench.py --dtype bf16 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bf16 step direct=$d', d['value'], d['ms_per_step'])"; done
+R=$PWD; O=$R/gpurun_out/r3m; rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/coarse -- python $R/bench.py --stream coarse --no-cpu-baseline > $O/bench_coarse.json 2> $O/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/coarse256 -- python $R/bench.py --stream coarse --frames 256 --no-cpu-baseline > $O/bench_coarse_t256.json 2>> $O/err.txt
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
+ls $O/coarse/runc
