@@ -99,25 +99,43 @@ __global__ __launch_bounds__(64 * PWS_WAVES) void pws_kernel(const PwArgs a) {
         const bool ok = (m0 + m) < M && MODE == PW_DGRAD && a.ea;
         sE[m] = ok ? float2{(float)a.ea[(long)n * M + m0 + m], (float)a.eb[(long)n * M + m0 + m]} : float2{1.0f, 0.0f};
     }
-    // weight images: Ws[s][m][k] = term s of W[m0+m][k] (FWD, w is (M,K)) or of W[k][m0+m] (DGRAD, w is (K,M)); zero padded
-    for (int e = tid; e < BM * (Kp / 2); e += 64 * PWS_WAVES) {
-        int m, k2;
-        if (MODE == PW_FWD) { m = e / (Kp / 2); k2 = (e - m * (Kp / 2)) * 2; }     // consecutive threads along k (w rows)
-        else { k2 = (e / BM) * 2; m = e - (e / BM) * BM; }                          // consecutive threads along m (w rows)
-        float v0 = 0.0f, v1 = 0.0f;
-        if (m0 + m < M) {
-            if (MODE == PW_FWD) {
-                if (k2 < K) v0 = a.w[(long)(m0 + m) * a.Cin + k2];
-                if (k2 + 1 < K) v1 = a.w[(long)(m0 + m) * a.Cin + k2 + 1];
-            } else {
-                if (k2 < K) v0 = a.w[(long)k2 * a.Cin + m0 + m];
-                if (k2 + 1 < K) v1 = a.w[(long)(k2 + 1) * a.Cin + m0 + m];
+    // weight images: Ws[s][m][k] = term s of W[m0+m][k] (FWD, w is (M,K)) or of W[k][m0+m] (DGRAD, w is (K,M)); zero padded.
+    // Batches of 8 pairs per thread: all 16 loads in flight, then the splits and LDS writes (a dependent load -> store loop costs one
+    // L2 round trip per iteration: 20-50 iterations at the start of EVERY workgroup)
+    {
+        constexpr int UB = 8, NT = 64 * PWS_WAVES;
+        const int total = BM * (Kp / 2);
+        for (int e0 = tid; e0 < total; e0 += NT * UB) {
+            float v0[UB], v1[UB];
+            int off[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int e = e0 + u * NT;
+                int m, k2;
+                if (MODE == PW_FWD) { m = e / (Kp / 2); k2 = (e - m * (Kp / 2)) * 2; }     // consecutive threads along k (w rows)
+                else { k2 = (e / BM) * 2; m = e - (e / BM) * BM; }                          // consecutive threads along m (w rows)
+                v0[u] = v1[u] = 0.0f;
+                off[u] = e < total ? m * rowb + k2 * 2 : -1;
+                if (e < total && m0 + m < M) {
+                    if (MODE == PW_FWD) {
+                        if (k2 < K) v0[u] = a.w[(long)(m0 + m) * a.Cin + k2];
+                        if (k2 + 1 < K) v1[u] = a.w[(long)(m0 + m) * a.Cin + k2 + 1];
+                    } else {
+                        if (k2 < K) v0[u] = a.w[(long)k2 * a.Cin + m0 + m];
+                        if (k2 + 1 < K) v1[u] = a.w[(long)(k2 + 1) * a.Cin + m0 + m];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (off[u] >= 0) {
+                    unsigned p[NS];
+                    pws_split<NS>(v0[u], v1[u], p);
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp) *reinterpret_cast<unsigned*>(Ws + sp * img + off[u]) = p[sp];
+                }
             }
         }
-        unsigned p[NS];
-        pws_split<NS>(v0, v1, p);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) *reinterpret_cast<unsigned*>(Ws + s * img + (size_t)m * rowb + k2 * 2) = p[s];
     }
     __syncthreads();
 
