@@ -119,7 +119,7 @@ def main():
     ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32',
                     help='storage type of activations / activation gradients (fine stream): f32 = the reference precision (the '
                          'headline), bf16 = BASELINE configs[1] (bf16 MFMA pointwise, fp32 accumulation and statistics)')
-    ap.add_argument('--graph', action='store_true', help='replay the whole step from one captured hipGraph (single GPU)')
+    ap.add_argument('--graph', action='store_true', help='replay the step from captured hipGraphs (one graph on a single GPU; with --gpus > 1: forward+backward graph, eager all-reduce, optimizer graph)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-frames', type=int, default=128)
     args = ap.parse_args()
@@ -178,8 +178,16 @@ def main():
             return tc.train_step(net, reducer, optimizer, x, labels, masks, feat, fm, meta)
         return train_fine.train_step(net, reducer, optimizer, x, labels, masks)
 
-    if args.graph:
-        assert world == 1, '--graph captures the whole step incl. the optimizer: single GPU only (see cfn_hip/graph.py)'
+    if args.graph and world > 1:
+        # two hipGraphs around the eager bucketed all-reduce (cfn_hip/graph.py GraphedDPStep): fine stream only
+        assert not (coarse or joint), '--graph with --gpus > 1 covers the fine stream'
+        from cfn_hip.graph import GraphedDPStep
+        graphed = GraphedDPStep(lambda x_, l_, m_, tot: train_fine.forward_backward(net, x_, l_, m_, mask_total=tot)[:2], reducer, optimizer,
+                                pre=lambda x_, l_, m_: (cdist.global_mask_count(m_),))
+
+        def step():
+            return tuple(v.clone() for v in graphed(x, labels, masks))
+    elif args.graph:
         from cfn_hip.graph import GraphedStep
         eager_step = step
         graphed = GraphedStep(lambda: eager_step()[:2], optimizer=optimizer)

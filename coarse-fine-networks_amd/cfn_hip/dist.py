@@ -94,6 +94,7 @@ class GradReducer(object):
         self._inflight = []
         self._stream = None
         self._hooks = []
+        self.suspended = False       # True while a backward is being CAPTURED (cfn_hip.graph.GraphedDPStep): no collective may enter the graph
         # the lazily cast weight gradients (ops._GradCast) are handed out only for parameters whose every reader flushes
         # first: this reducer does (see _launch), so it opts its own parameters in.  Parameters nobody opted in -- a model
         # wrapped in torch DDP / FSDP, whose reducer hooks sit on the AccumulateGrad node where they cannot be seen -- get an
@@ -124,6 +125,8 @@ class GradReducer(object):
         return self._flat[bi], self._views[bi]
 
     def _on_grad(self, p):
+        if self.suspended:
+            return
         bi = self._bucket_of[p]
         self._pending[bi] -= 1
         # collectives are matched across ranks by issue order: buckets are launched strictly in bucket order, a complete
@@ -162,6 +165,8 @@ class GradReducer(object):
         """Call after backward(): launches the buckets backward did not complete (so that every rank issues one collective
         per bucket, always), waits for the collectives and writes the averaged gradients back."""
         if self.world == 1 and not self.force:
+            return
+        if self.suspended:           # captured backward: the reduction runs eagerly after the replay (finish() is called again there)
             return
         while self._next < len(self.buckets):
             self._launch(self._next)

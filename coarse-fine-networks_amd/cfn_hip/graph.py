@@ -17,7 +17,9 @@ Rules the captured callable has to respect (checked where possible):
     captured step may do it internally: backward then re-creates them at the same addresses at capture time);
   * the learning rate is baked into the optimizer kernels: a changed `lr` (scheduler, warm-up) triggers a re-capture;
   * multi-GPU: collectives are NOT captured, and GradReducer's hooks would launch RCCL on a side stream inside the capture:
-    with torch.distributed initialised at world_size > 1 a GraphedStep refuses to capture (RuntimeError) -- run eager.
+    with torch.distributed initialised at world_size > 1 a GraphedStep refuses to capture (RuntimeError).  Use GraphedDPStep:
+    graph A = forward + loss + backward (reducer suspended), then the bucketed all-reduce EAGERLY on the reducer's static flat
+    buffers, then graph B = optimizer step.
 """
 import torch
 
@@ -106,4 +108,68 @@ class GraphedStep(object):
         for dst, src in zip(static_in, args):
             self._copy(dst, src)
         graph.replay()
+        return static_out
+
+
+class GraphedDPStep(GraphedStep):
+    """Data-parallel step as two hipGraphs around an eager gradient all-reduce (world_size >= 1):
+
+        step = GraphedDPStep(lambda x, l, m, tot: train_fine.forward_backward(net, x, l, m, mask_total=tot), reducer, optimizer,
+                             pre=lambda x, l, m: (cdist.global_mask_count(m),))
+        cls, loc, probs = step(x, labels, masks)
+
+    `fwd_bwd(*args, *pre(*args))` must do forward + loss + backward and NOTHING collective (`pre` runs eagerly before it every step:
+    the global loss normaliser); the reducer's hooks are suspended while it is captured; after every replay `reducer.finish()`
+    packs / all-reduces / unpacks on its static flat buffers (gradients live at fixed addresses in the graph's pool) and a second
+    graph replays `optimizer.step()`.  Gradients are never set to None between replays."""
+
+    def __init__(self, fwd_bwd, reducer, optimizer, pre=None, eager_first=1, pool=None):
+        super(GraphedDPStep, self).__init__(fwd_bwd, optimizer=optimizer, eager_first=eager_first, pool=pool)
+        self.reducer, self.pre = reducer, pre
+        self._opt_graphs = {}
+
+    def _params(self):
+        return [p for g in self.optimizer.param_groups for p in g['params']]
+
+    def __call__(self, *args):
+        extra = tuple(self.pre(*args)) if self.pre is not None else ()
+        full = tuple(args) + extra
+        if self.calls < self.eager_first:          # ordinary eager step(s): momentum buffers come into being here
+            self.calls += 1
+            st = self._side_stream(full)
+            st.wait_stream(torch.cuda.current_stream(st.device))
+            with torch.cuda.stream(st):
+                out = self.fn(*full)
+                self.reducer.finish()
+                self.optimizer.step()
+                self.optimizer.zero_grad(set_to_none=True)
+            torch.cuda.current_stream(st.device).wait_stream(st)
+            return out
+        sig = self._sig(full)
+        lr = _lr_signature(self.optimizer)
+        entry = self._graphs.get(sig)
+        if entry is None:
+            for p in self._params():
+                p.grad = None                      # backward then creates the gradients inside the graph's pool, at fixed addresses
+            self.reducer.suspended = True
+            try:
+                entry = self._capture(full)
+            finally:
+                self.reducer.suspended = False
+            self._graphs[sig] = entry
+        og = self._opt_graphs.get(sig)
+        if og is None or og[1] != lr:              # the learning rate is baked into the optimizer kernels
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.pool, stream=self._side_stream(full)):
+                self.optimizer.step()
+            og = (g, lr)
+            self._opt_graphs[sig] = og
+            # the two captures executed nothing: the replays below perform this call's one real step
+        graph, static_in, static_out, _ = entry
+        for dst, src in zip(static_in, full):
+            self._copy(dst, src)
+        graph.replay()
+        self.reducer.finish()                      # eager: bucket order, static flat buffers, RCCL on the reducer's side stream
+        og[0].replay()
         return static_out

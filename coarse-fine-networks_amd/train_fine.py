@@ -58,14 +58,15 @@ class SyntheticCharades(object):
             yield x, labels, masks, ['synthetic_%d' % i] * self.bs
 
 
-def detection_loss(per_frame_logits, labels, masks, align_corners=True, group=None, crops=1, local_norm=False):
+def detection_loss(per_frame_logits, labels, masks, align_corners=True, group=None, crops=1, local_norm=False, mask_total=None):
     """cls + loc loss of train_fine.py:199-213 for one rank's shard.
 
     ``loc_loss`` is normalised by the GLOBAL sum(masks) and multiplied by the world size, so that the
     average of the ranks' gradients equals the gradient of the reference's gathered-batch loss.
     crops = n > 1: validation-time multi-crop, logits are (b*n, C, T) against (b, ...) labels / masks; the per-frame
     probability is the max over the n crops of a video (train_fine.py:204-207).  local_norm=True (evaluation): this
-    rank's own sum(masks) and no world factor -- no collective, ranks may hold different numbers of videos."""
+    rank's own sum(masks) and no world factor -- no collective, ranks may hold different numbers of videos.
+    mask_total: the global sum(masks) computed beforehand (cfn_hip.graph.GraphedDPStep takes the collective out of the captured part)."""
     tl = labels.size(2)
     if per_frame_logits.is_cuda:
         from cfn_hip import ops
@@ -81,7 +82,7 @@ def detection_loss(per_frame_logits, labels, masks, align_corners=True, group=No
     world = 1
     if not local_norm and torch.distributed.is_initialized():
         world = torch.distributed.get_world_size(group)
-    norm = cdist.global_mask_count(masks, group, local=local_norm) * labels.shape[1]
+    norm = (cdist.global_mask_count(masks, group, local=local_norm) if mask_total is None else mask_total) * labels.shape[1]
     loc_loss = F.binary_cross_entropy(probs, labels, reduction='sum') / norm * world
     return cls_loss, loc_loss, probs
 
@@ -112,21 +113,28 @@ def build_model(device, n_classes=NUM_CLASSES, pretrained=None, dropout=0.5, act
     return net.to(device)
 
 
+def forward_backward(net, inputs, labels, masks, gamma_tau=5, mask_total=None):
+    """forward + loss + backward of one shard (no collective when mask_total is given, no optimizer): the capturable part of a
+    data-parallel step (cfn_hip.graph.GraphedDPStep)"""
+    masks_clip = masks[:, ::gamma_tau * 2]
+    logits = net([inputs, masks_clip])
+    cls_loss, loc_loss, probs = detection_loss(logits, labels, masks, True, mask_total=mask_total)
+    loss = (cls_loss + loc_loss) / 2
+    loss.backward()
+    return cls_loss.detach(), loc_loss.detach(), probs.detach()
+
+
 def train_step(net, reducer, optimizer, inputs, labels, masks, gamma_tau=5, pre_step=None):
     """one optimisation step on this rank's shard; returns (cls_loss, loc_loss, probs).  pre_step() runs between the
     gradient reduction and optimizer.step() -- where the reference adjusts the warm-up learning rate
     (train_fine.py:241-244)."""
-    masks_clip = masks[:, ::gamma_tau * 2]
-    logits = net([inputs, masks_clip])
-    cls_loss, loc_loss, probs = detection_loss(logits, labels, masks, True)
-    loss = (cls_loss + loc_loss) / 2
-    loss.backward()
+    cls_loss, loc_loss, probs = forward_backward(net, inputs, labels, masks, gamma_tau)
     reducer.finish()
     if pre_step is not None:
         pre_step()
     optimizer.step()
     optimizer.zero_grad(set_to_none=True)
-    return cls_loss.detach(), loc_loss.detach(), probs.detach()
+    return cls_loss, loc_loss, probs
 
 
 def _ap_rows(probs, labels, valid_t):

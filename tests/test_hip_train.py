@@ -281,7 +281,7 @@ def test_graphed_step_equals_eager_step(stream):
     assert moved == 0.0         # SGD at lr 0 leaves every parameter where it was: the re-captured graph holds the new rate
 
 
-@pytest.mark.parametrize('launcher', ['torchrun', 'self'])
+@pytest.mark.parametrize('launcher', ['torchrun', 'self', 'self-graph'])
 def test_bench_two_ranks_sharing_the_gpu(tmp_path, launcher):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), with the two
     ranks sharing the box's single GPU over gloo (RCCL needs a device per rank): parameter sync from rank 0, the bucketed
@@ -296,8 +296,11 @@ def test_bench_two_ranks_sharing_the_gpu(tmp_path, launcher):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29541', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--frames', '16',
            '--batch', '2']
-    if launcher == 'self':
+    if launcher.startswith('self'):
         cmd = [sys.executable] + cmd[cmd.index(os.path.join(ROOT, 'bench.py')):]
+    if launcher == 'self-graph':      # two hipGraphs per rank around the eager all-reduce (GraphedDPStep); one more step so that replays are timed
+        cmd += ['--graph']
+        cmd[cmd.index('--steps') + 1] = '3' 
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
@@ -306,6 +309,7 @@ def test_bench_two_ranks_sharing_the_gpu(tmp_path, launcher):
     assert doc['n_gpus'] == 2 and doc['config']['dist']['world_size'] == 2 and doc['config']['parallelism'] == 'dp2'
     assert doc['value'] > 0 and all(v == v for v in doc['loss']['last_step_cls_loc'])
     assert 'cpu_baseline' not in doc          # N > 1: no CPU leg
+    assert doc['config']['launch'] == ('hipGraph replay' if launcher == 'self-graph' else 'eager')
 
 
 def test_joint_step_with_bf16_fine_tower():
@@ -366,3 +370,45 @@ def test_forward_video_chunks_long_videos_like_the_reference():
     assert int(meta[0, 0]) == 10                                   # the caller's meta is not modified
     assert not torch.equal(b, b_wrong)                             # the start offset matters
     assert torch.equal(short, whole)
+
+
+def test_graphed_dp_step_equals_eager_step():
+    """GraphedDPStep (graph A: forward + loss + backward with the reducer suspended; eager bucketed all-reduce on the reducer's static
+    flat buffers; graph B: optimizer step) against plain eager steps with the same reducer path, one rank with forced hooks: same
+    losses, parameters and BN statistics after three steps."""
+    import copy
+    import torch.distributed as dist
+    import torch.optim as optim
+    import train_fine
+    from cfn_hip import dist as cdist
+    from cfn_hip.graph import GraphedDPStep
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29534')
+        dist.init_process_group('nccl', rank=0, world_size=1)
+        created = True
+    try:
+        torch.manual_seed(0)
+        net = train_fine.build_model(DEV, pretrained=None, dropout=0.0)
+        net.train(True)
+        net2 = copy.deepcopy(net)
+        batches = [(x.view((x.shape[0],) + tuple(x.shape[2:])).to(DEV), l.to(DEV), m.to(DEV))
+                   for x, l, m, _ in train_fine.SyntheticCharades(2, 4, frames=8, crop=64)]
+        o1 = optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-5)
+        o2 = optim.SGD(net2.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-5)
+        r1 = cdist.GradReducer(net.parameters(), force=True)
+        r2 = cdist.GradReducer(net2.parameters(), force=True)
+        graphed = GraphedDPStep(lambda x, l, m, tot: train_fine.forward_backward(net2, x, l, m, mask_total=tot)[:2], r2, o2,
+                                pre=lambda x, l, m: (cdist.global_mask_count(m),))
+        for b in batches:
+            le = [float(v) for v in train_fine.train_step(net, r1, o1, *b)[:2]]
+            lg = [float(v) for v in graphed(*b)]
+            assert all(abs(a - c) <= 1e-5 * max(abs(a), 1.0) for a, c in zip(le, lg)), (le, lg)
+        assert len(graphed._graphs) == 1 and len(graphed._opt_graphs) == 1
+        for (n1, p1), (_, p2) in zip(net.state_dict().items(), net2.state_dict().items()):
+            d = float((p1.double() - p2.double()).abs().max())
+            assert d <= 1e-5 * (float(p1.double().abs().max()) + 1e-3), (n1, d)
+    finally:
+        if created:
+            dist.destroy_process_group()
