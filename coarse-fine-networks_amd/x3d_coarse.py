@@ -31,9 +31,38 @@ def _w5(conv1d):
     return w.view(w.shape[0], w.shape[1], 1, 1, 1)
 
 
+class _Rows64(torch.autograd.Function):
+    """(C,) fp32 parameter -> (n, C) fp64 prologue coefficient in ONE launch (broadcast + widening copy); the backward is one
+    reduction straight to fp32.  (expand + contiguous + the ABI's fp64 conversion and their backwards were five launches.)"""
+
+    @staticmethod
+    def forward(ctx, vec, n):
+        out = torch.empty(n, vec.numel(), dtype=torch.float64, device=vec.device)
+        out.copy_(vec.detach().view(1, -1))
+        ctx.dt = vec.dtype
+        ctx.shape = tuple(vec.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return torch.sum(g, 0, dtype=ctx.dt).view(ctx.shape), None
+
+
 def _rows(vec, n):
-    """(C,) parameter -> (n, C) per-sample prologue coefficient"""
-    return vec.view(1, -1).expand(n, -1).contiguous()
+    """(C,) parameter -> (n, C) per-sample prologue coefficient (fp64 holding fp32 values: what the C ABI takes)"""
+    return _Rows64.apply(vec, n)
+
+
+_ONES = {}
+
+
+def _ones(n, c, device):
+    """constant (n, C) fp64 ones (identity prologue scale), cached per shape and device: no fill / widening launches per use"""
+    key = (n, c, str(device))
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones(n, c, dtype=torch.float64, device=device)
+    return t
 
 
 class RewightLayer(nn.Module):
@@ -54,7 +83,7 @@ class RewightLayer(nn.Module):
     def _mlp(self, z5, first, second):
         n = z5.shape[0]
         h, _, _ = ops.pwconv(z5, _w5(first), stats=False)
-        one = torch.ones(n, h.shape[1], device=z5.device)
+        one = _ones(n, h.shape[1], z5.device)
         if self.pool and self.training and self.dropout.p > 0:     # x3d_coarse.py:232-233 (rw6 only)
             h = self.dropout(ops.affine_act(h, one, _rows(first.bias, n), ACT_RELU))
             out, _, _ = ops.pwconv(h, _w5(second), stats=False)
@@ -70,7 +99,7 @@ class RewightLayer(nn.Module):
             mask = F.adaptive_max_pool1d(mask.unsqueeze(1), t).squeeze(1)
             GX = F.adaptive_avg_pool2d(GX.unsqueeze(1), (t, None)).squeeze(1)
         y1, _, _ = ops.pwconv(x, _w5(self.at1), stats=False)
-        one = torch.ones(b, c, device=x.device)
+        one = _ones(b, c, x.device)
         y2, _, _ = ops.pwconv(y1, _w5(self.at2), one, _rows(self.at1.bias, b), ACT_RELU, stats=False)
         # sigmoid(at2 + bias), the mask multiply and the per-crop repeat happen inside the gather kernel
         z = ops.fusion_gather(x.reshape(b, c, t, h * w), y2.view(b, t, h * w), self.at2.bias, GX, mask, b2 // b)
@@ -146,13 +175,13 @@ class MixingLayer(nn.Module):
         if not self.learned:
             raise NotImplementedError('non-learned mixing (x3d_coarse.py:338-344) is unused by the reference scripts')
         n = bias[0][0].shape[0]
-        one = torch.ones(n, self.in_depth, device=bias[0][0].device)
+        one = _ones(n, self.in_depth, bias[0][0].device)
 
         def mix(items, conv, act):
             raw = torch.cat([r for r, _ in items], dim=1)
-            b = torch.cat([bb for _, bb in items]).view(1, -1).expand(n, -1).contiguous()
+            b = _rows(torch.cat([bb for _, bb in items]), n)
             y, _, _ = ops.pwconv(raw, _w5(conv), one, b, ACT_NONE, stats=False)
-            return ops.affine_act(y, torch.ones(n, y.shape[1], device=y.device), _rows(conv.bias, n), act)
+            return ops.affine_act(y, _ones(n, y.shape[1], y.device), _rows(conv.bias, n), act)
 
         return mix(bias, self.conv_at, ACT_NONE), mix(scale, self.conv_at2, ACT_SIGMOID)
 
@@ -299,7 +328,7 @@ class ResNet(x3d_fine.ResNet):
                 if stages[li] is not None:
                     x = stages[li](x)
                 (x1, b1), (x2, b2_) = m.forward7(feat[k], b2, feat_masks, GX, False)
-                one = torch.ones(b2, x1.shape[1], device=x.device)
+                one = _ones(b2, x1.shape[1], x.device)
                 c7 = ops.affine_act(x1, one, _rows(b1, b2), ACT_NONE)
                 m7 = ops.affine_act(x2, one, _rows(b2_, b2), ACT_SIGMOID)
                 x = ops.film(x, m7, c7, x.shape[3] // FUSION_HW)
