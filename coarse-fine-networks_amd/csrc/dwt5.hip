@@ -240,6 +240,84 @@ __global__ __launch_bounds__(256) void dwt5_fwd_stream_kernel(const T5Args a) {
     }
 }
 
+// FLAT forward (round 3, tools/probe/t5_probe.hip): one thread = TO consecutive output frames of ONE float4 position, all
+// TO + 4 input frames requested up front, blocks in memory order, and each XCD walks one contiguous eighth of the items
+// (cfn_xcd_remap) so that the temporal halo re-reads of the neighbouring frame group hit ITS L2.  Measured on conv1_t
+// (8 x 24 x 256 x 112 x 112): marching kernel 5.0-5.2 TB/s (deeper look-ahead: +2 %), flat TO = 4 / 8: 5.66 / 5.77 TB/s; the same
+// flat kernel without the XCD remap 3.6 TB/s, with the block order scrambled inside each XCD 3.4-4.1 TB/s, TO = 1 (5 x L2 reads)
+// 4.0 TB/s: what this kernel responds to is the ORDER in which the chip walks memory and the L2 re-read factor, not the
+// look-ahead depth.  Ragged T / planes: surplus frames and threads get out-of-range offsets.
+template <bool BF, int TO>
+__global__ __launch_bounds__(256) void dwt5_fwd_flat_kernel(const T5Args a) {
+    typedef __bf16 __attribute__((ext_vector_type(4))) bf4;
+    typedef unsigned __attribute__((ext_vector_type(2))) u2v;
+    constexpr int OOB = 0x7ffffff0, OES = BF ? 2 : 4;
+    __shared__ float sh[8];
+    const unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned bpn = (unsigned)a.pchunks;                     // blocks per (n, c)
+    const long nc = cfn_uni((int)(L / bpn));
+    const unsigned item = (L - (unsigned)nc * bpn) * 256u + threadIdx.x;
+    const int c = (int)(nc % a.C), T = a.T, plane = (int)a.plane, P4 = plane >> 2;
+    const int tg = item / (unsigned)P4, p4 = item - tg * P4;
+    const int t0 = tg * TO;
+    const bool ok = t0 < T;
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(static_cast<const float*>(a.src) + nc * T * a.plane, (unsigned)((long)T * plane * 4));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(static_cast<char*>(a.dst) + nc * T * a.plane * OES, (unsigned)((long)T * plane * OES));
+    float wk[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) wk[k] = cfn_uni(a.w[c * 5 + k]);
+    f4v R[TO + 4];
+#pragma unroll
+    for (int k = 0; k < TO + 4; ++k) {
+        const int t = t0 - 2 + k;
+        const bool tv = ok && t >= 0 && t < T;
+        R[k] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rx, tv ? (t * plane + p4 * 4) * 4 : OOB, 0, 0));
+    }
+    float st1 = 0.f, st2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < TO; ++j) {
+        f4v y = R[j] * wk[0] + R[j + 1] * wk[1] + R[j + 2] * wk[2] + R[j + 3] * wk[3] + R[j + 4] * wk[4];
+        const bool em = ok && t0 + j < T;
+        const int vo = em ? ((t0 + j) * plane + p4 * 4) * OES : OOB;
+        if (BF) {                                                      // statistics over the rounded values the consumer reads
+            const bf4 yb = __builtin_convertvector(y, bf4);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, yb), ry, vo, 0, 0);
+            y = __builtin_convertvector(yb, f4v);
+        } else {
+            cfn_bst128(__builtin_bit_cast(u4v_t5, y), ry, vo, 0);
+        }
+        const f4v ym = y * (em ? 1.0f : 0.0f);
+        st1 += ym.x + ym.y + ym.z + ym.w;
+        st2 += ym.x * y.x + ym.y * y.y + ym.z * y.z + ym.w * y.w;
+    }
+    if (a.s1) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        st1 = cfn_wave_sum(st1); st2 = cfn_wave_sum(st2);
+        if (lane == 0) { sh[wave] = st1; sh[4 + wave] = st2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&a.s1[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
+            atomicAdd(&a.s2[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
+        }
+    }
+}
+
+// -1 = not handled
+template <bool BF>
+static int t5_fwd_flat(T5Args& a, int N, hipStream_t st) {
+    static const int on = getenv("CFN_T5_FLAT") ? atoi(getenv("CFN_T5_FLAT")) : 1;       // 0: marching kernel, 4 / 8: force TO
+    if (!on || a.plane % 4 != 0 || (long)a.T * a.plane * 4 >= 0x7ffffff0L) return -1;
+    if ((((uintptr_t)a.src | (uintptr_t)a.dst) & 15) != 0) return -1;
+    const int TO = on == 4 || on == 8 ? on : (a.T >= 32 ? 8 : 4);
+    const long per_nc = (long)cfn_cdiv(a.T, TO) * (a.plane / 4);
+    const long bpn = cfn_cdiv(per_nc, 256L), blocks = bpn * N * a.C;
+    if (blocks >= 0x7fffffffL || (long)N * a.C >= 0x7fffffffL) return -1;
+    a.pchunks = (int)bpn;
+    if (TO == 8) hipLaunchKernelGGL((dwt5_fwd_flat_kernel<BF, 8>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dwt5_fwd_flat_kernel<BF, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    return cfn_check_launch("dwconv_t5 flat forward");
+}
+
 // Backward, float4 rows: data gradient AND weight gradient in one march (gy, y, x read once, gx written once: 4 tensor
 // passes instead of the 6 of dwt5_kernel<T5_DGRAD> + <T5_WGRAD>), same streaming scheme as dwt5_fwd_stream_kernel: static
 // register rings, unconditional buffer accesses.  Ring slot (k % RING) holds frame t0 - 2 + k of g' = gy + gs + 2 y gq and of
@@ -359,6 +437,10 @@ static int t5_bwd_fused(const void* gy, const void* y, const double* gs, const d
 
 template <int MODE, bool BF = false>
 static int t5_launch(T5Args& a, int N, hipStream_t st) {
+    if (MODE == T5_FWD) {
+        const int rc = t5_fwd_flat<BF>(a, N, st);
+        if (rc != -1) return rc;
+    }
     const long NC = (long)N * a.C;
     unsigned gy_, gz_;
     CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "dwconv_t5: N*C = %ld exceeds grid.y", NC);

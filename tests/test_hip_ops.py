@@ -156,7 +156,8 @@ def test_pwconv(N, Cin, Cout, T, H, W, stride, act, pro):
                lambda a, w_: F.conv3d(a, w_, stride=(1, stride, stride)), x, w, A, B, act, tol_f=3e-5, tol_g=3e-4)
 
 
-@pytest.mark.parametrize('N,C,T,H,W', [(2, 5, 7, 6, 6), (1, 24, 40, 12, 12), (1, 3, 3, 5, 7), (1, 2, 1, 8, 8), (2, 3, 70, 8, 8), (1, 2, 2, 16, 20)])
+@pytest.mark.parametrize('N,C,T,H,W', [(2, 5, 7, 6, 6), (1, 24, 40, 12, 12), (1, 3, 3, 5, 7), (1, 2, 1, 8, 8), (2, 3, 70, 8, 8), (1, 2, 2, 16, 20),
+                                       (1, 2, 33, 28, 28), (3, 2, 8, 20, 20)])
 def test_dwconv_t5(N, C, T, H, W):
     x, w = rnd(1, N, C, T, H, W), rnd(2, C, 1, 5, 1, 1, scale=0.4)
     check_conv(lambda x_, w_, A_, B_: ops().dwconv_t5(x_, w_, True),
