@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * PWS_WAVES) void pws_kernel(const PwArgs a) {
     const size_t img = (size_t)BM * rowb;
     float4* sP = reinterpret_cast<float4*>(Ws + NS * img);                 // [Kp] prologue coefficients
     float2* sE = reinterpret_cast<float2*>(sP + Kp);                       // [BM] epilogue coefficients (DGRAD)
-    float* red = reinterpret_cast<float*>(sE + BM);                        // [PWS_WAVES][16][33] transpose scratch, then [PWS_WAVES][BM][2]
+    float* red = reinterpret_cast<float*>(sE + BM);                        // [PWS_WAVES][32][20] transpose scratch, then [PWS_WAVES][BM][2]
 
     for (int k = tid; k < Kp; k += 64 * PWS_WAVES) {
         float4 c = {1.0f, 0.0f, 1.0f, 0.0f};
@@ -204,6 +204,24 @@ __global__ __launch_bounds__(64 * PWS_WAVES) void pws_kernel(const PwArgs a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) acc[mt][p] = (f16v)0.0f;
 
+        // FORWARD output side (round 3, second pass): the ACTIVATIONS are the MFMA's A operand and the weights its B operand, so the 32x32
+        // result arrives transposed -- lane (j, kg) holds output channel mt*32 + j and, in registers 4 g + i, tile rows (= positions)
+        // 8 g + 4 kg + i: four consecutive positions of ONE channel per register group.  Per-channel statistics are then in-lane
+        // work (no LDS transpose of partial sums, no shuffles: the old
+        // epilogue, one position x 16 rows per lane, was ~1,500 of the ~3,500 instructions per tile, with SGPR spills, and these
+        // kernels are instruction-issue bound at 2 waves per SIMD).  Memory wants the other layout (a 16-byte access per lane over
+        // 32 different rows = 64 separate requests per instruction: measured 10-35 % slower than the old kernel), so tensor data
+        // crosses a wave-private LDS scratch in UNITS of 32 channels x 16 positions: 16-byte LDS accesses both ways, and in the
+        // memory-side layout lane l owns row (l >> 2) + 16 s, 16 bytes at position 4 (l & 3): four lanes cover 64 contiguous bytes,
+        // an instruction 16 rows -- 2 stores per unit instead of 8 four-byte ones, all whole 64-byte segments.
+        // The DATA GRADIENT keeps the weights as the A operand and the epilogue below it: the same scheme with the act' epilogue's
+        // forward input crossing the scratch the other way was built and produced run-to-run different gradients (one position of
+        // 16 channels of a tile's first row tile, 15-50 % of launches; tools/ab_pw.py) that full vmcnt / lgkmcnt drains, wait states
+        // around the wide LDS / buffer accesses, the MFMA groups and the transcendentals did not remove -- not in the tree.
+        constexpr int UPT = 2 * NP;                                         // units per row tile
+        float* scr = red + wave * (32 * 20);                                // [32 channels][16 positions + 4 pad]
+        const int mrow = lane >> 2, mcol = 4 * (lane & 3);                  // memory-side role of this lane
+        const int lane_mem = mrow * Q * 4 + mcol * 4;                       // + 16 rows for s = 1
         // Row addressing of the epilogue: the lane part (column, kg's 4-row offset) sits in the vector offset, the
         // wave-uniform row base in the scalar offset; a row base beyond the slab's valid rows would push the scalar offset
         // past the range (which wraps instead of failing the check), so such rows are switched off through the vector offset.
@@ -253,7 +271,8 @@ __global__ __launch_bounds__(64 * PWS_WAVES) void pws_kernel(const PwArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
 #define PWS_MM(SA, SB)                                                                                                     \
                 _Pragma("unroll") for (int p = 0; p < NP; ++p)                                                             \
-                    acc[mt][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt & 1][SA], __builtin_bit_cast(bf16x8, pb[p][SB]), acc[mt][p], 0, 0, 0)
+                    acc[mt][p] = MODE == PW_FWD ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pb[p][SB]), A[mt & 1][SA], acc[mt][p], 0, 0, 0) \
+                                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt & 1][SA], __builtin_bit_cast(bf16x8, pb[p][SB]), acc[mt][p], 0, 0, 0)
                 if constexpr (NS == 3) { PWS_MM(2, 0); PWS_MM(0, 2); PWS_MM(1, 1); }
                 PWS_MM(1, 0); PWS_MM(0, 1); PWS_MM(0, 0);
 #undef PWS_MM
@@ -269,6 +288,55 @@ __global__ __launch_bounds__(64 * PWS_WAVES) void pws_kernel(const PwArgs a) {
             compute(kb + 2, ld[2], ld2[2]);
         }
 
+        // ---- forward epilogue (transposed C layout, see above)
+        auto wsync = [&]() {                                           // LDS ops of a wave run in order; only the compiler is told
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        // memory-side offsets of unit u of row tile mt: rows mt*32 + mrow (+16), positions q0 + 16 u + mcol .. +3
+        auto mem_vo = [&](auto full_tag, int mt, int u, int s) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            const bool ok = FULL || (mt * 32 + 16 * s + mrow < mrows && q0 + 16 * u + mcol < Q);
+            return ok ? lane_mem + s * 16 * Q * 4 : PWS_OOB;
+        };
+        auto epilogue_fwd = [&](auto full_tag, int mt) {
+            constexpr bool FULL = decltype(full_tag)::value;          // all 32 channels and all 32 NP positions of the tile exist
+            const bool chv = FULL || mt * 32 + j < mrows;
+            const int so = (mt * 32 * Q + q0) * 4;                     // wave uniform
+            float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+            for (int u = 0; u < UPT; ++u) {
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    // NP == 1: slot sl = register group g = 2 u + sl (positions 8 g + 4 kg + i);  NP == 2: g = u, the lane's 8 consecutive
+                    // positions interleave the even-position tile (p = 0) and the odd one: slot sl = (even, odd) of rows 2 sl, 2 sl + 1
+                    const int pos0 = q0 + 16 * u + (NP == 1 ? 8 * sl + 4 * kg : 8 * kg + 4 * sl);
+                    const float gmask = (chv && (FULL || pos0 < Q)) ? 1.0f : 0.0f;
+                    f4v o;
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const int r = NP == 1 ? 4 * (2 * u + sl) + e4 : 4 * u + 2 * sl + (e4 >> 1);
+                        float e = acc[mt][NP == 1 ? 0 : (e4 & 1)][r];
+                        if (STATS) {
+                            const float em = FULL ? e : e * gmask;
+                            t1 += em;
+                            t2 = fmaf(em, em, t2);
+                        }
+                        o[e4] = e;
+                    }
+                    *reinterpret_cast<f4v*>(scr + j * 20 + (NP == 1 ? 8 * sl + 4 * kg : 8 * kg + 4 * sl)) = o;
+                }
+                wsync();
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const f4v v = *reinterpret_cast<const f4v*>(scr + (mrow + 16 * s) * 20 + mcol);
+                    cfn_bst128(__builtin_bit_cast(u4v, v), rd, mem_vo(full_tag, mt, u, s) + u * 64, so);
+                }
+                wsync();
+            }
+            if (STATS) { ssum[mt] += t1; qsum[mt] += t2; }
+        };
         // ---- epilogue: C layout of the 32x32 tile: column = lane & 31 (position [pair] j), row = (r & 3) + 8 (r >> 2) + 4 kg
         // FULL (wave uniform): all 32 rows of the tile exist and all 32 NP columns lie inside the row -- no per-row / per-column
         // selects on the store offsets and the statistics operands (38 v_cndmask per row tile otherwise)
@@ -366,16 +434,35 @@ __global__ __launch_bounds__(64 * PWS_WAVES) void pws_kernel(const PwArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             if (m0 + mt * 32 >= M) continue;
-            if (colfull && mrows - mt * 32 >= 32) epilogue(std::true_type{}, mt);
-            else epilogue(std::false_type{}, mt);
+            if constexpr (MODE == PW_FWD) {
+                if (colfull && mrows - mt * 32 >= 32) epilogue_fwd(std::true_type{}, mt);
+                else epilogue_fwd(std::false_type{}, mt);
+            } else {
+                if (colfull && mrows - mt * 32 >= 32) epilogue(std::true_type{}, mt);
+                else epilogue(std::false_type{}, mt);
+            }
         }
     }
 
     if (STATS && a.s1) {
-        // lane l holds the sums of row 16 (l & 1) + (l >> 2) of every row tile (lanes with l & 2 hold copies); `red` doubles as
-        // the transpose scratch of the other waves, hence the barrier before it is re-used for the cross-wave combine
+        // `red` doubles as the waves' transpose scratch, hence the barrier before it is re-used for the cross-wave combine
         __syncthreads();
-        if ((lane & 2) == 0) {
+        if constexpr (MODE == PW_FWD) {
+            // lane (j, kg) holds the sums of channel mt*32 + j over ITS positions: the two halves are added first
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                ssum[mt] += __shfl_xor(ssum[mt], 32, 64);
+                qsum[mt] += __shfl_xor(qsum[mt], 32, 64);
+            }
+            if (kg == 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    red[(wave * BM + mt * 32 + j) * 2] = ssum[mt];
+                    red[(wave * BM + mt * 32 + j) * 2 + 1] = qsum[mt];
+                }
+            }
+        } else if ((lane & 2) == 0) {
+            // lane l holds the sums of row 16 (l & 1) + (l >> 2) of every row tile (lanes with l & 2 hold copies)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int row = mt * 32 + 16 * (lane & 1) + (lane >> 2);
@@ -416,7 +503,7 @@ extern "C" int cfn_pw_split_terms(int terms) {
 }
 
 static size_t pws_lds(int BM, int Kp, int rowb, int NS) {
-    const size_t red = (size_t)PWS_WAVES * 4 * (BM * 2 > 16 * 33 ? BM * 2 : 16 * 33);
+    const size_t red = (size_t)PWS_WAVES * 4 * (BM * 2 > 32 * 20 ? BM * 2 : 32 * 20);
     return (size_t)NS * BM * rowb + (size_t)Kp * 16 + (size_t)BM * 8 + red;
 }
 
@@ -472,7 +559,7 @@ int pws_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
     if (terms == 0) return -1;
     // the compact shortcut gradient `acc` (first block of a stage: 3 calls per step) stays on the fp32-MFMA kernel: its lattice
     // loads cost the many-row variants 90+ registers
-    if (a.stem || a.stride != 1 || a.K < 48 || a.M <= 32 || (a.Q & 1) || a.acc) return -1;
+    if (a.stem || a.stride != 1 || a.K < 48 || a.M <= 32 || (a.Q & 3) || a.acc) return -1;      // Q % 4: whole 16-byte groups
     if (a.act != CFN_ACT_NONE && a.act != CFN_ACT_RELU && a.act != CFN_ACT_SWISH) return -1;
     // The split costs VALU work per CONTRACTION-side element (prologue + 9 instructions per pair for three terms) and saves matrix
     // time per product: measured (8 clips, T = 256, profiles/r03_microbench_b8.txt) it wins up to K = 108 (layer 2 both convs,
@@ -481,7 +568,7 @@ int pws_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
     static const int maxk_env = getenv("CFN_PWS_MAXK") ? atoi(getenv("CFN_PWS_MAXK")) : 128;
     if (a.K > maxk_env) return -1;
     if ((long)a.K * a.Q * 4 >= 0x3ffffff0L || (long)a.M * a.Q * 4 >= 0x3ffffff0L) return -1;
-    if (((uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)(a.src2 ? a.src2 : a.src) | (uintptr_t)(a.ex ? a.ex : a.src)) & 7) return -1;
+    if (((uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)(a.src2 ? a.src2 : a.src) | (uintptr_t)(a.ex ? a.ex : a.src)) & 15) return -1;
     const int NS = terms == 3 ? 2 : 3;
     PwArgs b = a;
     b.Kpad = (a.K + 47) / 48 * 48;
