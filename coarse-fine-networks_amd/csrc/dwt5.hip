@@ -409,6 +409,86 @@ __global__ __launch_bounds__(256) void dwt5_bwd_fused_kernel(const T5Args a) {
         atomicAdd(&a.s1[c * 5 + threadIdx.x], (double)(sh[threadIdx.x * 4] + sh[threadIdx.x * 4 + 1] + sh[threadIdx.x * 4 + 2] + sh[threadIdx.x * 4 + 3]));
 }
 
+// FLAT fused backward (same mapping as dwt5_fwd_flat_kernel): one thread = TO consecutive frames of one float4 position.
+//   gx(t) = sum_k g'(t - 2 + k) w[4 - k]                      t in the thread's TO frames (g' over TO + 4 frames)
+//   gw[k] += sum_s x(s) g'(s + 2 - k)                          s in the thread's TO frames -- the weight-gradient sum re-indexed by
+// the frame of x, so that x needs NO halo (gy and y are read (TO + 4) / TO times out of L2, x once).
+template <bool BF, bool HASY, int TO>
+__global__ __launch_bounds__(256) void dwt5_bwd_flat_kernel(const T5Args a) {
+    typedef unsigned __attribute__((ext_vector_type(2))) u2v;
+    constexpr int OOB = 0x7ffffff0, GES = BF ? 2 : 4;
+    __shared__ float sh[20];
+    const unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned bpn = (unsigned)a.pchunks;                     // blocks per (n, c)
+    const long nc = cfn_uni((int)(L / bpn));
+    const unsigned item = (L - (unsigned)nc * bpn) * 256u + threadIdx.x;
+    const int c = (int)(nc % a.C), T = a.T, plane = (int)a.plane, P4 = plane >> 2;
+    const int tg = item / (unsigned)P4, p4 = item - tg * P4;
+    const int t0 = tg * TO;
+    const bool ok = t0 < T;
+    // a.src = gy, a.src2 = y (output side: fp32 | bf16), a.yout = x (fp32), a.dst = gx (fp32), a.s1 = gw
+    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(static_cast<const char*>(a.src) + nc * T * a.plane * GES, (unsigned)((long)T * plane * GES));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(static_cast<const char*>(HASY ? a.src2 : a.src) + nc * T * a.plane * GES, (unsigned)((long)T * plane * GES));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(static_cast<const float*>(a.yout) + nc * T * a.plane, (unsigned)((long)T * plane * 4));
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(static_cast<float*>(a.dst) + nc * T * a.plane, (unsigned)((long)T * plane * 4));
+    float wk[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) wk[k] = cfn_uni(a.w[c * 5 + 4 - k]);        // flipped taps
+    const float gsv = cfn_uni(a.gs ? (float)a.gs[nc] : 0.0f);
+    const float gqv = cfn_uni((HASY && a.gq) ? 2.0f * (float)a.gq[nc] : 0.0f);
+    auto ldg = [&](__amdgpu_buffer_rsrc_t r, int vo) -> f4v {
+        if (BF) {
+            const u2v u = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(r, vo, 0, 0));
+            return (f4v){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                         __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+        }
+        return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, vo, 0, 0));
+    };
+    f4v G[TO + 4], Y[HASY ? TO + 4 : 1], X[TO];
+#pragma unroll
+    for (int k = 0; k < TO + 4; ++k) {
+        const int t = t0 - 2 + k;
+        const bool tv = ok && t >= 0 && t < T;
+        const int vo = tv ? (t * plane + p4 * 4) * GES : OOB;
+        G[k] = ldg(rg, vo);
+        if (HASY) Y[k] = ldg(ry, vo);
+    }
+#pragma unroll
+    for (int j = 0; j < TO; ++j) {
+        const bool tv = ok && t0 + j < T;
+        X[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rx, tv ? ((t0 + j) * plane + p4 * 4) * 4 : OOB, 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < TO + 4; ++k) {                                     // g' (zero outside the clip)
+        const int t = t0 - 2 + k;
+        const float m = (ok && t >= 0 && t < T) ? 1.0f : 0.0f;
+        f4v v = G[k] + gsv;
+        if (HASY) v += Y[k] * gqv;
+        G[k] = v * m;
+    }
+    f4v acc[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc[k] = (f4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TO; ++j) {
+        const f4v gx = G[j] * wk[0] + G[j + 1] * wk[1] + G[j + 2] * wk[2] + G[j + 3] * wk[3] + G[j + 4] * wk[4];
+        const bool em = ok && t0 + j < T;
+        cfn_bst128(__builtin_bit_cast(u4v_t5, gx), rd, em ? ((t0 + j) * plane + p4 * 4) * 4 : OOB, 0);
+        // x(s), s = t0 + j (zero beyond the clip: its load was switched off): g'(s + 2 - k) = G[j + 4 - k]
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[k] += X[j] * G[j + 4 - k];
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float v = cfn_wave_sum(acc[k].x + acc[k].y + acc[k].z + acc[k].w);
+        if (lane == 0) sh[k * 4 + wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5)
+        atomicAdd(&a.s1[c * 5 + threadIdx.x], (double)(sh[threadIdx.x * 4] + sh[threadIdx.x * 4 + 1] + sh[threadIdx.x * 4 + 2] + sh[threadIdx.x * 4 + 3]));
+}
+
 // -1 = not handled (the plane is not a whole number of float4s): the caller runs the two separate kernels
 template <bool BF>
 static int t5_bwd_fused(const void* gy, const void* y, const double* gs, const double* gq, const float* w, const float* x, float* gx,
@@ -421,6 +501,19 @@ static int t5_bwd_fused(const void* gy, const void* y, const double* gs, const d
     a.src = gy; a.src2 = hasy ? y : nullptr; a.gs = gs; a.gq = hasy ? gq : nullptr; a.w = w; a.yout = x; a.dst = gx; a.s1 = gw;
     a.C = C; a.T = T; a.plane = plane;
     const long NC = (long)N * C;
+    static const int flat = getenv("CFN_T5_FLAT_BWD") ? atoi(getenv("CFN_T5_FLAT_BWD")) : 8;    // 0: marching kernel, 4 / 8: frames per thread
+    if (flat == 4 || flat == 8) {
+        const long per_nc = (long)cfn_cdiv(T, flat) * (plane / 4);
+        const long bpn = cfn_cdiv(per_nc, 256L), blocks = bpn * NC;
+        if (blocks < 0x7fffffffL && NC < 0x7fffffffL) {
+            a.pchunks = (int)bpn;
+#define T5_FB(TOV) do { if (hasy) hipLaunchKernelGGL((dwt5_bwd_flat_kernel<BF, true, TOV>), dim3((unsigned)blocks), dim3(256), 0, st, a); \
+                        else hipLaunchKernelGGL((dwt5_bwd_flat_kernel<BF, false, TOV>), dim3((unsigned)blocks), dim3(256), 0, st, a); } while (0)
+            if (flat == 8) T5_FB(8); else T5_FB(4);
+#undef T5_FB
+            return cfn_check_launch("dwconv_t5 flat backward");
+        }
+    }
     unsigned gy_, gz_;
     CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "dwconv_t5: N*C = %ld exceeds grid.y", NC);
     a.pchunks = cfn_cdiv(plane, 1024L);
