@@ -211,9 +211,17 @@ def case_subbn():
              rm=m.bn.running_mean, rv=m.bn.running_var)
 
 
+# (tag, index, stride, cin, planes, input shape).  The first four are X3D layer-1 / 2 widths on 8x8 planes; the `l3_*` / `l4_*`
+# cases are the layer-3 / 4 widths (216- and 432-channel conv2 / SE, the split-bf16 and fp32-MFMA pointwise kernels, the 14x14 /
+# 7x7 depthwise kernels) at their real plane sizes: train-mode forward + backward pinned to the REFERENCE, not only per op.
+BOTTLENECK_CASES = (('even_s1', 0, 1, 24, (54, 24), (2, 24, 4, 8, 8)), ('odd_s1', 1, 1, 24, (54, 24), (2, 24, 4, 8, 8)),
+                    ('even_s2', 0, 2, 24, (54, 48), (2, 24, 4, 8, 8)), ('odd_s2', 1, 2, 48, (108, 48), (2, 48, 4, 8, 8)),
+                    ('l3_even_s2', 0, 2, 48, (216, 96), (2, 48, 2, 28, 28)), ('l3_odd_s1', 1, 1, 96, (216, 96), (2, 96, 2, 14, 14)),
+                    ('l4_even_s2', 0, 2, 96, (432, 192), (2, 96, 2, 14, 14)), ('l4_odd_s1', 1, 1, 192, (432, 192), (2, 192, 2, 7, 7)))
+
+
 def case_bottleneck():
-    for tag, index, stride, cin, planes in (('even_s1', 0, 1, 24, (54, 24)), ('odd_s1', 1, 1, 24, (54, 24)),
-                                            ('even_s2', 0, 2, 24, (54, 48)), ('odd_s2', 1, 2, 48, (108, 48))):
+    for tag, index, stride, cin, planes, shape in BOTTLENECK_CASES:
         ds = None
         if stride != 1 or cin != planes[1]:
             ds = torch.nn.Sequential(ref_fine.conv1x1x1(cin, planes[1], stride),
@@ -221,7 +229,7 @@ def case_bottleneck():
         m = ref_fine.Bottleneck(cin, planes, stride, ds, index=index, base_bn_splits=1)
         spec.fill_module_(m)
         m.train(True)
-        x = F.relu(spec.rand_input(91, (2, cin, 4, 8, 8))).requires_grad_(True)
+        x = F.relu(spec.rand_input(91, shape)).requires_grad_(True)
         y = m(x)
         r = spec.rand_input(92, tuple(y.shape))
         (y * r).sum().backward()

@@ -173,12 +173,12 @@ def _oracle_bottleneck(z, tag_args, quant):
     """(y, gx, {param: grad}) of the CPU oracle on the fixture's inputs; quant=True: with bf16 storage emulated"""
     from oracle import spec, x3d_ref as R
     from bf16_emul import bf16_storage, RoundBf16
-    index, stride, cin = tag_args
+    index, stride, cin, shape = tag_args
     sd = {'b.' + k: v.clone() for k, v in golden_sd(z).items()}
     for k, v in sd.items():
         if v.is_floating_point() and 'running' not in k:
             v.requires_grad_(True)
-    x = F.relu(spec.rand_input(91, (2, cin, 4, 8, 8)))
+    x = F.relu(spec.rand_input(91, shape))
     if quant:
         x = q(x)
     x.requires_grad_(True)
@@ -191,9 +191,12 @@ def _oracle_bottleneck(z, tag_args, quant):
     return y.detach(), x.grad, {k[2:]: v.grad for k, v in sd.items() if v.grad is not None}
 
 
-@pytest.mark.parametrize('tag,index,stride,cin,planes', [('even_s1', 0, 1, 24, (54, 24)), ('odd_s1', 1, 1, 24, (54, 24)),
-                                                         ('even_s2', 0, 2, 24, (54, 48)), ('odd_s2', 1, 2, 48, (108, 48))])
-def test_bottleneck_bf16_vs_reference(tag, index, stride, cin, planes):
+@pytest.mark.parametrize('tag,index,stride,cin,planes,shape', [
+    ('even_s1', 0, 1, 24, (54, 24), (2, 24, 4, 8, 8)), ('odd_s1', 1, 1, 24, (54, 24), (2, 24, 4, 8, 8)),
+    ('even_s2', 0, 2, 24, (54, 48), (2, 24, 4, 8, 8)), ('odd_s2', 1, 2, 48, (108, 48), (2, 48, 4, 8, 8)),
+    ('l3_even_s2', 0, 2, 48, (216, 96), (2, 48, 2, 28, 28)), ('l3_odd_s1', 1, 1, 96, (216, 96), (2, 96, 2, 14, 14))])
+# (the l4_* fixtures have T*H*W = 98 positions: the bf16 weight gradient needs a multiple of 8 and refuses them loudly)
+def test_bottleneck_bf16_vs_reference(tag, index, stride, cin, planes, shape):
     """whole bottleneck (train mode: batch statistics, SE, Swish, shortcut conv, tail) on bf16 tensors against the vectors the
     fp32 REFERENCE produced (tests/golden/bottleneck_*).  Output: <= 1e-2 of max|y|.  Gradients pass through three
     train-mode batch norms over 512 positions: bf16 STORAGE alone (the CPU oracle with every conv output / gradient rounded
@@ -211,13 +214,13 @@ def test_bottleneck_bf16_vs_reference(tag, index, stride, cin, planes):
     m = x3d_fine.Bottleneck(cin, planes, stride, ds, index=index, base_bn_splits=1)
     m.load_state_dict({k: v.clone() for k, v in golden_sd(z).items()})
     m.to(DEV).train(True)
-    x = F.relu(spec.rand_input(91, (2, cin, 4, 8, 8))).to(BF).to(DEV).requires_grad_(True)
+    x = F.relu(spec.rand_input(91, shape)).to(BF).to(DEV).requires_grad_(True)
     y = m(x)
     assert y.dtype == BF
     (y.float() * spec.rand_input(92, tuple(y.shape)).to(DEV)).sum().backward()
     named = dict(m.named_parameters())
-    yr, gxr, gr = _oracle_bottleneck(z, (index, stride, cin), False)       # fp32 oracle == reference (pinned elsewhere)
-    ye, gxe, ge = _oracle_bottleneck(z, (index, stride, cin), True)        # bf16-storage floor
+    yr, gxr, gr = _oracle_bottleneck(z, (index, stride, cin, shape), False)       # fp32 oracle == reference (pinned elsewhere)
+    ye, gxe, ge = _oracle_bottleneck(z, (index, stride, cin, shape), True)        # bf16-storage floor
     assert maxdiff(yr, z['y']) <= 5e-6
     e_y, f_y = relerr(y.float(), z['y']), relerr(ye, z['y'])
     e_gx, f_gx = nrel(x.grad.float(), gxr), nrel(gxe, gxr)

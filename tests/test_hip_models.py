@@ -41,10 +41,15 @@ def test_subbn_module(S):
     assert maxdiff(m(x1), z['y3']) <= 5e-6
 
 
-@pytest.mark.parametrize('tag,index,stride,cin,planes', [('even_s1', 0, 1, 24, (54, 24)), ('odd_s1', 1, 1, 24, (54, 24)),
-                                                         ('even_s2', 0, 2, 24, (54, 48)), ('odd_s2', 1, 2, 48, (108, 48))])
+# l3_* / l4_*: layer-3 / 4 widths at their real planes (216- / 432-channel depthwise + SE, split-bf16 and fp32-MFMA pointwise kernels,
+# 14x14 / 7x7 / 28->14 / 14->7 depthwise kernels): train-mode forward + backward against the REFERENCE's vectors
+@pytest.mark.parametrize('tag,index,stride,cin,planes,shape', [
+    ('even_s1', 0, 1, 24, (54, 24), (2, 24, 4, 8, 8)), ('odd_s1', 1, 1, 24, (54, 24), (2, 24, 4, 8, 8)),
+    ('even_s2', 0, 2, 24, (54, 48), (2, 24, 4, 8, 8)), ('odd_s2', 1, 2, 48, (108, 48), (2, 48, 4, 8, 8)),
+    ('l3_even_s2', 0, 2, 48, (216, 96), (2, 48, 2, 28, 28)), ('l3_odd_s1', 1, 1, 96, (216, 96), (2, 96, 2, 14, 14)),
+    ('l4_even_s2', 0, 2, 96, (432, 192), (2, 96, 2, 14, 14)), ('l4_odd_s1', 1, 1, 192, (432, 192), (2, 192, 2, 7, 7))])
 @pytest.mark.parametrize('torch_ops', [False, True])
-def test_bottleneck_vs_reference(tag, index, stride, cin, planes, torch_ops, monkeypatch):
+def test_bottleneck_vs_reference(tag, index, stride, cin, planes, shape, torch_ops, monkeypatch):
     """torch_ops=True: the same block through the registered dispatcher operators torch.ops.cfn.* (x3d_fine.USE_TORCH_OPS)"""
     import x3d_fine
     from oracle import spec
@@ -56,7 +61,7 @@ def test_bottleneck_vs_reference(tag, index, stride, cin, planes, torch_ops, mon
                                  x3d_fine.SubBatchNorm3d(num_splits=1, num_features=planes[1], affine=True))
     m = _load(x3d_fine.Bottleneck(cin, planes, stride, ds, index=index, base_bn_splits=1), golden_sd(z))
     m.train(True)
-    x = F.relu(spec.rand_input(91, (2, cin, 4, 8, 8))).to(DEV).requires_grad_(True)
+    x = F.relu(spec.rand_input(91, shape)).to(DEV).requires_grad_(True)
     y = m(x)
     assert maxdiff(y, z['y']) <= 2e-5
     (y * spec.rand_input(92, tuple(y.shape)).to(DEV)).sum().backward()

@@ -148,17 +148,20 @@ def test_subbn(S):
     assert maxdiff(R.sub_bn(x1, sd, 'bn', False, S), z['y3']) <= TOL
 
 
-BOTTLENECKS = [('even_s1', 0, 1, 24), ('odd_s1', 1, 1, 24), ('even_s2', 0, 2, 24), ('odd_s2', 1, 2, 48)]
+# (tag, index, stride, cin, input shape): as tests/golden/make_golden.py BOTTLENECK_CASES (l3_* / l4_*: layer-3 / 4 widths at 14x14 / 7x7)
+BOTTLENECKS = [('even_s1', 0, 1, 24, (2, 24, 4, 8, 8)), ('odd_s1', 1, 1, 24, (2, 24, 4, 8, 8)), ('even_s2', 0, 2, 24, (2, 24, 4, 8, 8)),
+               ('odd_s2', 1, 2, 48, (2, 48, 4, 8, 8)), ('l3_even_s2', 0, 2, 48, (2, 48, 2, 28, 28)), ('l3_odd_s1', 1, 1, 96, (2, 96, 2, 14, 14)),
+               ('l4_even_s2', 0, 2, 96, (2, 96, 2, 14, 14)), ('l4_odd_s1', 1, 1, 192, (2, 192, 2, 7, 7))]
 
 
-@pytest.mark.parametrize('tag,index,stride,cin', BOTTLENECKS)
-def test_bottleneck_fwd_bwd(tag, index, stride, cin):
+@pytest.mark.parametrize('tag,index,stride,cin,shape', BOTTLENECKS)
+def test_bottleneck_fwd_bwd(tag, index, stride, cin, shape):
     z = load_golden('bottleneck_' + tag)
     sd = {'b.' + k: v for k, v in golden_sd(z).items()}
     for k, v in sd.items():
         if v.is_floating_point() and 'running' not in k:
             v.requires_grad_(True)
-    x = F.relu(spec.rand_input(91, (2, cin, 4, 8, 8))).requires_grad_(True)
+    x = F.relu(spec.rand_input(91, shape)).requires_grad_(True)
     y = R.bottleneck(x, sd, 'b', stride, index, True, 1)
     assert maxdiff(y, z['y']) <= 5e-6
     (y * spec.rand_input(92, tuple(y.shape))).sum().backward()

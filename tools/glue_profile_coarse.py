@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Attribute the small ATen kernels (casts, fills, copies, adds) of one x3d_coarse fineFEAT train step to their call sites (GPU box)."""
+import os
+import sys
+from collections import Counter
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'coarse-fine-networks_amd'))
+import torch
+import torch.optim as optim
+from torch.profiler import profile, ProfilerActivity
+import cfn_hip
+from cfn_hip import dist as cdist
+import train_coarse_fineFEAT as tc
+
+dev = torch.device('cuda')
+cfn_hip.load()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+net = tc.build_model(dev, pretrained=None)
+net.train(True)
+opt = optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-5)
+red = cdist.GradReducer(net.parameters())
+x, labels, masks, feat, fm, meta, _, _ = next(iter(tc.SyntheticCoarse(B, 1, 64)))
+x = x.view((x.shape[0] * x.shape[1],) + tuple(x.shape[2:]))
+x, labels, masks, fm, meta = x.to(dev), labels.to(dev), masks.to(dev), fm.to(dev), meta.to(dev)
+feat = {k: v.to(dev) for k, v in feat.items()}
+for _ in range(2):
+    tc.train_step(net, red, opt, x, labels, masks, feat, fm, meta)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    tc.train_step(net, red, opt, x, labels, masks, feat, fm, meta)
+    torch.cuda.synchronize()
+evs = prof.events()
+kern = [e for e in evs if e.device_type == torch.autograd.DeviceType.CUDA]
+print('device kernels / memcpys in the step:', len(kern))
+kc = Counter(e.name[:70] for e in kern)
+for k, v in kc.most_common(25):
+    print('%5d  %s' % (v, k))
+# ATen ops that launch something, by call site (second pass, CPU activity only: python stacks are recorded)
+with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof2:
+    tc.train_step(net, red, opt, x, labels, masks, feat, fm, meta)
+    torch.cuda.synchronize()
+evs = prof2.events()
+names = ('aten::copy_', 'aten::fill_', 'aten::zero_', 'aten::add', 'aten::add_', 'aten::_to_copy', 'aten::clone', 'aten::mul', 'aten::sum',
+         'aten::div', 'aten::cat', 'aten::sub', 'aten::neg', 'aten::mul_', 'aten::div_', 'aten::index_select', 'aten::sigmoid', 'aten::exp',
+         'aten::mean', 'aten::where', 'aten::masked_fill_', 'aten::index', 'aten::gather', 'aten::cumsum', 'aten::max', 'aten::clamp', 'aten::rsub',
+         'aten::_foreach_add_', 'aten::_foreach_mul_', 'aten::_foreach_addcdiv_', 'aten::addcmul_', 'aten::sqrt', 'aten::pow', 'aten::relu',
+         'aten::binary_cross_entropy_with_logits', 'aten::upsample_linear1d', 'aten::max_pool3d_with_indices', 'aten::avg_pool3d', 'aten::bmm', 'aten::mm', 'aten::addmm')
+cnt = Counter()
+for ev in evs:
+    if ev.device_type == torch.autograd.DeviceType.CPU and ev.name in names:
+        st = [x for x in (ev.stack or []) if '.py' in x and 'profiler' not in x][:4]
+        cnt[(ev.name, ' <- '.join(x.split('/')[-1][:58] for x in st))] += 1
+print('--- ATen ops by call site')
+for (k, st), v in cnt.most_common(100):
+    print('%5d %-18s %s' % (v, k, st))
