@@ -35,21 +35,17 @@ print('device kernels / memcpys in the step:', len(kern))
 kc = Counter(e.name[:70] for e in kern)
 for k, v in kc.most_common(25):
     print('%5d  %s' % (v, k))
-# ATen ops that launch something, by call site (second pass, CPU activity only: python stacks are recorded)
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof2:
+# ATen ops by python call site (second pass, CPU activity only)
+with profile(activities=[ProfilerActivity.CPU], with_stack=True, experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof2:
     tc.train_step(net, red, opt, x, labels, masks, feat, fm, meta)
     torch.cuda.synchronize()
-evs = prof2.events()
 names = ('aten::copy_', 'aten::fill_', 'aten::zero_', 'aten::add', 'aten::add_', 'aten::_to_copy', 'aten::clone', 'aten::mul', 'aten::sum',
-         'aten::div', 'aten::cat', 'aten::sub', 'aten::neg', 'aten::mul_', 'aten::div_', 'aten::index_select', 'aten::sigmoid', 'aten::exp',
-         'aten::mean', 'aten::where', 'aten::masked_fill_', 'aten::index', 'aten::gather', 'aten::cumsum', 'aten::max', 'aten::clamp', 'aten::rsub',
-         'aten::_foreach_add_', 'aten::_foreach_mul_', 'aten::_foreach_addcdiv_', 'aten::addcmul_', 'aten::sqrt', 'aten::pow', 'aten::relu',
-         'aten::binary_cross_entropy_with_logits', 'aten::upsample_linear1d', 'aten::max_pool3d_with_indices', 'aten::avg_pool3d', 'aten::bmm', 'aten::mm', 'aten::addmm')
+         'aten::div', 'aten::cat', 'aten::sub', 'aten::neg', 'aten::mul_', 'aten::div_', 'aten::mean', 'aten::sigmoid', 'aten::max')
 cnt = Counter()
-for ev in evs:
-    if ev.device_type == torch.autograd.DeviceType.CPU and ev.name in names:
-        st = [x for x in (ev.stack or []) if '.py' in x and 'profiler' not in x][:4]
-        cnt[(ev.name, ' <- '.join(x.split('/')[-1][:58] for x in st))] += 1
+for ev in prof2.key_averages(group_by_stack_n=6):
+    if ev.key in names:
+        st = [x for x in (ev.stack or []) if '.py' in x and 'profiler' not in x and 'torch/' not in x][:3]
+        cnt[(ev.key, ' <- '.join(x.split('/')[-1][:60] for x in st))] += ev.count
 print('--- ATen ops by call site')
 for (k, st), v in cnt.most_common(100):
-    print('%5d %-18s %s' % (v, k, st))
+    print('%5d %-16s %s' % (v, k, st))
