@@ -250,6 +250,10 @@ int CPN(dw_cp_fwd_try)(const cpe_t* x, const double* A, const double* B, int act
     int TT = (int)((T + nch - 1) / nch);
     TT = ((TT + 2 + U - 1) / U) * U - 2;                                            // TT + 2 = k * U
     if (TT < 16) TT = 16;                                                           // (measured at T = 16, 8 clips: chunks of 4 frames cost 15-40 % against one chunk of 16)
+    // stride 2 (4:1 read:write, parked on memory rather than issue bound): shorter chunks = more, shorter-lived waves; same-box sweep
+    // at 8 clips x T = 256 (16 / 22 / 28 / 34 / 52 frames): 112->56 1.409 / 1.449 / 1.457 / 1.452 / 1.434 ms, 56->28 0.689 / 0.705 /
+    // 0.730 / 0.731 / 0.723, 28->14 0.357 / 0.365 / 0.380 / 0.374 / 0.377; the stride-1 planes are within +-2 % from 16 up
+    if (stride == 2 && TT > 16) TT = 16;
     if (tt_env > 0) TT = tt_env;
     if (TT > T) TT = T;
     a.TT = TT;
