@@ -340,8 +340,8 @@ int CPN(dw_cpb_try)(const cpe_t* gy, const cpe_t* y, const double* gs, const dou
     // (measured, 8 clips x T=256, 56x56: chunks of 9 / 21 / 33 / 63 frames: 4.5 / 2.3 / 1.7 / 1.3 ms); more chunks only while
     // the grid has fewer than ~2 rounds of the resident waves (12 per CU)
     const long units = (long)N * C * NB;
-    long nch = (T + 26) / 52;
-    if (nch < 1) nch = 1;
+    long nch = (T + 32) / 64;                                                       // (52 -> 64 frames: same-box sweep 16 / 24 / 32 / 48 / 52 / 64: 56x56 1.39 / 1.29 / 1.23 / 1.26 / 1.22 / 1.20 ms,
+    if (nch < 1) nch = 1;                                                           //  28x28 0.76 / 0.70 / 0.64 / 0.65 / 0.64 / 0.61, 14x14 0.34 / 0.32 / 0.32 / 0.33 / 0.32 / 0.31, 7x7 0.37 / 0.34 / 0.32 / 0.33 / 0.31 / 0.30)
     while (units * nch < 2L * 256 * 12 && (T + nch) / (nch + 1) >= 16) ++nch;
     int TT = (int)((T + nch - 1) / nch);
     if (tt_env > 0) TT = tt_env;

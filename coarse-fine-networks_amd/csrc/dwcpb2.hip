@@ -323,6 +323,9 @@ int CPN(dw_cpb2_try)(const cpe_t* gy, const cpe_t* y, const double* gs, const do
     if (nch < 1) nch = 1;
     while (units * nch < 2L * 256 * 12 && (T + nch) / (nch + 1) >= 16) ++nch;
     int TT = (int)((T + nch - 1) / nch);
+    // same-box sweep at 8 clips x T = 256 (16 / 24 / 32 / 48 / 52 / 64 frames): 112->56 2.76 / 2.68 / 2.76 / 2.82 / 2.88 / 2.76 ms,
+    // 56->28 1.36 / 1.38 / 1.40 / 1.44 / 1.40 / 1.41, 28->14 0.71 / 0.71 / 0.72 / 0.74 / 0.73 / 0.74
+    if (TT > 24) TT = 24;
     if (tt_env > 0) TT = tt_env;
     if (TT > T) TT = T;
     a.TT = TT;
