@@ -15,6 +15,7 @@
 // Shapes: forward, stride 1, K <= 96, 128 < M <= 256 (5-8 row tiles = waves), Q % 4 == 0; everything else stays with pws / pw_deep.
 #include "pw_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2r __attribute__((ext_vector_type(2)));
@@ -44,7 +45,7 @@ __device__ __forceinline__ void pwr_split8(const float (&v)[8], u4r (&t)[3]) {
 }
 
 template <int NKB, int ACT, bool STATS>
-__global__ __launch_bounds__(64 * PWR_WAVES, 4) void pwr_fwd_kernel(const PwArgs a) {
+__global__ __launch_bounds__(64 * PWR_WAVES) void pwr_fwd_kernel(const PwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KP = 16 * NKB;
     constexpr int PITCH = KP * 2 + 16;                                      // bytes per position row of one image: an odd number of 16-byte slots
@@ -57,26 +58,44 @@ __global__ __launch_bounds__(64 * PWR_WAVES, 4) void pwr_fwd_kernel(const PwArgs
 
     unsigned char* Bs = smem;                                               // [2 buffers][3 terms][32 positions][PITCH]
     float2* sP = reinterpret_cast<float2*>(Bs + 2 * 3 * IMG);              // [KP] prologue coefficients
-    float* scr = reinterpret_cast<float*>(sP + KP) + wave * (32 * 20);      // per wave [32 channels][16 positions + 4 pad]
-
-    for (int k = tid; k < KP; k += 64 * PWR_WAVES)
-        sP[k] = float2{(k < K && a.pa) ? (float)a.pa[(long)n * K + k] : 1.0f, (k < K && a.pb) ? (float)a.pb[(long)n * K + k] : 0.0f};
+    float* scr = reinterpret_cast<float*>(sP + KP) + wave * (2 * 32 * 36);  // per wave [2 tiles][32 channels][32 positions + 4 pad]
 
     // this wave's 32 weight rows, all k-blocks, three terms: the MFMA's B operand (column = channel j, k = kb*16 + kg*8 + i)
     const int mt = wave, row = mt * 32 + j;
     const bool has_rows = mt * 32 < M;                                      // wave uniform
     u4r Wr[NKB][3];
-    const int abl = a.tpb;                                                  // ABLATION (temporary)
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = kb * 16 + kg * 8 + i;
-            v[i] = (row < M && k < K && !(abl & 8)) ? a.w[(long)row * a.Cin + k] : 0.0f;
+    {
+        // the wave's 32 x K block of w through LDS: coalesced 16-byte loads (consecutive lanes along k), then each lane reads its row
+        // (a row-per-lane gather straight from memory is 64 separate requests per load instruction: ~16 us of a 0.15 ms launch).
+        // The whole dynamic LDS is free at this point: 8 waves x 32 rows x (KP + 4) floats <= 2 x 3 x IMG + scratch.
+        float* wtmp = reinterpret_cast<float*>(smem) + wave * (32 * (KP + 4));
+        const bool vec = (a.Cin & 3) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
+        for (int e = lane; e < 32 * (KP / 4); e += 64) {
+            const int rr = e / (KP / 4), k4 = (e - rr * (KP / 4)) * 4;
+            f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (mt * 32 + rr < M) {
+                const float* src = a.w + (long)(mt * 32 + rr) * a.Cin + k4;
+                if (vec && k4 + 3 < K) v = *reinterpret_cast<const f4v*>(src);
+                else { if (k4 < K) v.x = src[0]; if (k4 + 1 < K) v.y = src[1]; if (k4 + 2 < K) v.z = src[2]; if (k4 + 3 < K) v.w = src[3]; }
+            }
+            *reinterpret_cast<f4v*>(wtmp + rr * (KP + 4) + k4) = v;
         }
-        pwr_split8(v, Wr[kb]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            float v[8];
+            const float* p = wtmp + j * (KP + 4) + kb * 16 + kg * 8;
+            const f4v lo = *reinterpret_cast<const f4v*>(p), hi = *reinterpret_cast<const f4v*>(p + 4);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            pwr_split8(v, Wr[kb]);
+        }
     }
+    __syncthreads();                                                        // the staging area is re-used: coefficients, activation buffers
+    for (int k = tid; k < KP; k += 64 * PWR_WAVES)
+        sP[k] = float2{(k < K && a.pa) ? (float)a.pa[(long)n * K + k] : 1.0f, (k < K && a.pb) ? (float)a.pb[(long)n * K + k] : 0.0f};
+
     __syncthreads();
 
     __amdgpu_buffer_rsrc_t rs = cfn_rsrc(const_cast<float*>(a.src + (long)n * K * Q), (unsigned)((long)K * Q * 4));
@@ -87,19 +106,18 @@ __global__ __launch_bounds__(64 * PWR_WAVES, 4) void pwr_fwd_kernel(const PwArgs
     const int lane_ld = kg * 8 * Q * 4 + j * 4;
     const int st_off = j * PITCH + (wave * 16 + kg * 8) * 2;                // where this lane's 8 k's of position j live in an image
     const int rd_off = j * PITCH + kg * 16;                                 // + kb * 32: A operand (row = position j, k = kb*16 + kg*8 + i)
-    const int mrow = lane >> 2, mcol = 4 * (lane & 3);                      // memory-side role in the epilogue
+    const int mrow = lane >> 3, mcol = 4 * (lane & 7);                      // memory-side role: row mrow + 8 s, 16 bytes at position mcol (8 lanes = one 128-byte line)
     const int lane_mem = mrow * Q * 4 + mcol * 4;
     float ssum = 0.0f, qsum = 0.0f;
 
-    float ld[8];
-    auto issue = [&](int tile) {                                            // unconditional loads: a dead tile / row reads zeros
+    auto issue = [&](int tile, float (&ld)[8]) {                                            // unconditional loads: a dead tile / row reads zeros
         const bool live = stager && tile < ntiles;
-        const int vo = (live && tile * 32 + j < Q && !(abl & 4)) ? lane_ld : PWR_OOB;
+        const int vo = (live && tile * 32 + j < Q) ? lane_ld : PWR_OOB;
         const int base = live ? tile * 32 * 4 : 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r = wave * 16 + i;                                    // + 8 kg through the lane offset
-            const int so = (live && r < K) ? r * Q * 4 + base : base;       // (a row base beyond the range must not enter the scalar offset)
+            const int so = cfn_uni((live && r < K) ? r * Q * 4 + base : base);   // wave uniform (stated: otherwise every load is a waterfall loop); a row base beyond the range must not enter it
             ld[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (live && r + 8 * kg < K) ? vo : PWR_OOB, so, 0));
         }
     };
@@ -109,75 +127,114 @@ __global__ __launch_bounds__(64 * PWR_WAVES, 4) void pwr_fwd_kernel(const PwArgs
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
-    int tile = wg;
-    if (abl & 16) {                                                         // EXPERIMENT: the second workgroup of a CU starts half an iteration late
-        if ((blockIdx.x >> 8) & 1) { __builtin_amdgcn_s_sleep(55); }
-    }
-    if (abl & 32) {
-        if ((blockIdx.x >> 8) & 1) { __builtin_amdgcn_s_sleep(110); }
-    }
-    issue(tile);
-    for (int it = 0; tile < ntiles; ++it, tile += tstep) {
-        unsigned char* buf = Bs + (it & 1) * 3 * IMG;
+    // Two tiles per loop trip: the LDS buffers, the scratch halves and the two load sets (a set is re-issued for the tile two ahead
+    // right after it was consumed) are static in each half -- no register moves, no dynamic LDS offsets.
+    int pq0 = -1, last_buf = 0;                                             // previous tile's first position (-1: none), its scratch buffer
+    auto drain_read = [&](int pbuf, int sx) -> f4v { return *reinterpret_cast<const f4v*>(scr + pbuf * (32 * 36) + (mrow + 8 * sx) * 36 + mcol); };
+    auto drain_store = [&](f4v v, int sx) {
+        const bool ok = 8 * sx + mrow < mrows && pq0 + mcol < Q;            // pq0 < 0 (no previous tile): switched off through the scalar branch below
+        cfn_bst128(__builtin_bit_cast(u4r, v), rd, (ok && pq0 >= 0) ? lane_mem + sx * 8 * Q * 4 : PWR_OOB, cfn_uni(pq0 >= 0 ? pq0 * 4 : 0));
+    };
+    // statistics in-lane + transposed tile into scratch half PARV (it leaves during the next tile's MFMAs)
+    f16v acc;
+    auto finish = [&](int PARV, int q0) {
+        const bool full = q0 + 32 <= Q && mrows == 32;                      // wave uniform
+        float* sb = scr + PARV * (32 * 36);
+        f4v s1v = {0.0f, 0.0f, 0.0f, 0.0f}, s2v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (full) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f4v o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                if (STATS) { s1v += o; s2v = __builtin_elementwise_fma(o, o, s2v); }
+                *reinterpret_cast<f4v*>(sb + j * 36 + 8 * g + 4 * kg) = o;
+            }
+        } else {
+            const bool chv = j < mrows;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float gmask = (chv && q0 + 8 * g + 4 * kg < Q) ? 1.0f : 0.0f;
+                const f4v o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                const f4v om = o * gmask;
+                if (STATS) { s1v += om; s2v = __builtin_elementwise_fma(om, om, s2v); }
+                *reinterpret_cast<f4v*>(sb + j * 36 + 8 * g + 4 * kg) = o;
+            }
+        }
+        wsync();
+        if (STATS) { ssum += (s1v.x + s1v.y) + (s1v.z + s1v.w); qsum += (s2v.x + s2v.y) + (s2v.z + s2v.w); }
+        pq0 = q0; last_buf = PARV;
+    };
+    const bool late = wave >= 4;                                            // wave uniform
+    bool have = false; int hq0 = 0;                                         // (late waves) a tile waits to be finished
+    auto step = [&](auto par_tag, float (&lc)[8], int tile) {
+        constexpr int PAR = decltype(par_tag)::value;
+        unsigned char* buf = Bs + PAR * 3 * IMG;
         if (stager) {                                                       // activate, split once, publish
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float2 c = sP[wave * 16 + kg * 8 + i];
-                v[i] = cfn_act<ACT>(fmaf(ld[i], c.x, c.y));
+                v[i] = cfn_act<ACT>(fmaf(lc[i], c.x, c.y));
             }
             u4r t[3];
             pwr_split8(v, t);
 #pragma unroll
             for (int s = 0; s < 3; ++s) *reinterpret_cast<u4r*>(buf + s * IMG + st_off) = t[s];
         }
-        issue(tile + tstep);                                               // the next tile's rows travel during this tile's MFMAs
+        issue(tile + 2 * tstep, lc);                                        // two tiles ahead, into the set just consumed
         __syncthreads();
-        if (!has_rows) continue;
-        f16v acc = (f16v)0.0f;
+        if (!has_rows) return;
+        constexpr int pbuf = PAR ^ 1;
+        if (late && have) finish(pbuf, hq0);
+        f4v dv[4];
+        bf16x8r AA[2][3];                                                   // the operands of k-block kb + 1 are read before the MFMAs of kb issue
+#pragma unroll
+        for (int s = 0; s < 3; ++s) AA[0][s] = *reinterpret_cast<const bf16x8r*>(buf + s * IMG + rd_off);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            bf16x8r A[3];
+            bf16x8r (&A)[3] = AA[kb & 1];
+            if (kb + 1 < NKB) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) A[s] = *reinterpret_cast<const bf16x8r*>(buf + s * IMG + rd_off + kb * 32);
+                for (int s = 0; s < 3; ++s) AA[(kb + 1) & 1][s] = *reinterpret_cast<const bf16x8r*>(buf + s * IMG + rd_off + (kb + 1) * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #define PWR_MM(SA, SW) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA], __builtin_bit_cast(bf16x8r, Wr[kb][SW]), acc, 0, 0, 0)
-            if (!(abl & 2)) { PWR_MM(0, 2); PWR_MM(2, 0); PWR_MM(1, 1); PWR_MM(0, 1); PWR_MM(1, 0); PWR_MM(0, 0); }
+            if (kb == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], __builtin_bit_cast(bf16x8r, Wr[kb][2]), (f16v)0.0f, 0, 0, 0);
+            else PWR_MM(0, 2);
+            PWR_MM(2, 0); PWR_MM(1, 1);
+            // drain: one 16-byte read / store of the previous tile per half group of MFMAs (NKB >= 3: 2 NKB >= 6 slots for 4 reads + 4 stores)
+            if (2 * kb < 4) dv[2 * kb] = drain_read(pbuf, 2 * kb);
+            if (2 * kb >= 1 && 2 * kb - 1 < 4) drain_store(dv[2 * kb - 1], 2 * kb - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            PWR_MM(0, 1); PWR_MM(1, 0); PWR_MM(0, 0);
 #undef PWR_MM
+            if (2 * kb + 1 < 4) dv[2 * kb + 1] = drain_read(pbuf, 2 * kb + 1);
+            if (2 * kb < 4) drain_store(dv[2 * kb], 2 * kb);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- epilogue: lane (j, kg) holds channel mt*32 + j, positions 8 g + 4 kg + e in registers 4 g + e (see pwsplit.hip)
-        const int q0 = tile * 32;
-        const bool full = q0 + 32 <= Q && mrows == 32;                      // wave uniform
-        const bool chv = j < mrows;
-        const int so = q0 * 4;
-        float t1 = 0.0f, t2 = 0.0f;
+        // The two waves of a SIMD (w and w + 4) would otherwise multiply at the same time and do their vector work at the same time:
+        // waves 0-3 finish their tile right behind its MFMAs, waves 4-7 carry it over the next barrier and finish it in front of the
+        // next tile's MFMAs -- while one wave of a SIMD feeds the matrix pipe the other does statistics / LDS / stores.
+        if (!late) finish(PAR, cfn_uni(tile * 32));
+        else { have = true; hq0 = cfn_uni(tile * 32); }
+    };
+    int tile = cfn_uni(wg), last_par = 0;
+    float ldA[8], ldB[8];
+    issue(tile, ldA);
+    issue(tile + tstep, ldB);
+    for (;;) {
+        if (tile >= ntiles) break;
+        step(std::integral_constant<int, 0>{}, ldA, tile);
+        last_par = 0;
+        tile += tstep;
+        if (tile >= ntiles) break;
+        step(std::integral_constant<int, 1>{}, ldB, tile);
+        last_par = 1;
+        tile += tstep;
+    }
+    if (has_rows && late && have) finish(last_par, hq0);
+    if (has_rows && pq0 >= 0) {                                             // the last tile leaves now
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-#pragma unroll
-            for (int sl = 0; sl < 2; ++sl) {
-                const float gmask = (full || (chv && q0 + 16 * u + 8 * sl + 4 * kg < Q)) ? 1.0f : 0.0f;
-                f4v o;
-#pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) {
-                    const float e = acc[4 * (2 * u + sl) + e4];
-                    if (STATS) {
-                        const float em = e * gmask;
-                        t1 += em;
-                        t2 = fmaf(em, em, t2);
-                    }
-                    o[e4] = e;
-                }
-                *reinterpret_cast<f4v*>(scr + j * 20 + 8 * sl + 4 * kg) = o;
-            }
-            wsync();
-#pragma unroll
-            for (int sx = 0; sx < 2; ++sx) {
-                const f4v v = *reinterpret_cast<const f4v*>(scr + (mrow + 16 * sx) * 20 + mcol);
-                const bool ok = (full || (16 * sx + mrow < mrows && q0 + 16 * u + mcol < Q)) && !(abl & 1);
-                cfn_bst128(__builtin_bit_cast(u4r, v), rd, (ok ? lane_mem + sx * 16 * Q * 4 : PWR_OOB) + u * 64, so);
-            }
-            wsync();
-        }
-        ssum += t1; qsum += t2;
+        for (int sx = 0; sx < 4; ++sx) drain_store(drain_read(last_buf, sx), sx);
     }
     if (STATS && a.s1 && has_rows) {
         ssum += __shfl_xor(ssum, 32, 64);
@@ -216,15 +273,14 @@ int pwr_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
     if (((uintptr_t)a.src | (uintptr_t)a.dst) & 15) return -1;
     const int nkb = cfn_cdiv(a.K, 16);
     const int KP = 16 * nkb;
-    const size_t lds = (size_t)2 * 3 * 32 * (KP * 2 + 16) + (size_t)KP * 8 + (size_t)PWR_WAVES * 32 * 20 * 4;
+    const size_t lds = (size_t)2 * 3 * 32 * (KP * 2 + 16) + (size_t)KP * 8 + (size_t)PWR_WAVES * 2 * 32 * 36 * 4;
     PwArgs b = a;
     const int ntiles = cfn_cdiv(a.Q, 32);
     static const int wg_env = getenv("CFN_PWR_WGS") ? atoi(getenv("CFN_PWR_WGS")) : 0;
-    long wgs = cfn_cdiv(wg_env > 0 ? wg_env : 512, (long)a.N);              // two workgroups per CU
+    long wgs = cfn_cdiv(wg_env > 0 ? wg_env : 256, (long)a.N);              // one workgroup per CU
     if (wgs > ntiles) wgs = ntiles;
     if (wgs < 1) wgs = 1;
     b.nstrips = (int)wgs;
-    b.tpb = getenv("CFN_PWR_ABL") ? atoi(getenv("CFN_PWR_ABL")) : 0;
     const unsigned blocks = (unsigned)((long)a.N * wgs);
     switch (nkb) {
         case 3: return stats ? pwr_go<3, true>(b, blocks, lds, st) : pwr_go<3, false>(b, blocks, lds, st);
