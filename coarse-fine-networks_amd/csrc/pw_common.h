@@ -51,6 +51,9 @@ int pwd_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st);
 // pwsplit.hip / pwsplitw.hip: the same contractions with split-bf16 arithmetic (fp32 tensors, operands split into 2-3 bf16
 // terms on load, 3 or 6 bf16 MFMAs per k-block); tried first, -1 = shape not handled or the split is switched off
 int pws_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st);
+// pwregk.hip: split-bf16 forward with register-resident weights, two k slices per row tile (128 < K <= 224, M <= 128); tried first
+int pwk_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st);
+int pws_terms_now();     // 0 = fp32 MFMA kernels, 3 / 6 = bf16 MFMAs per k-block (cfn_pw_split_terms / CFN_PW_SPLIT)
 int pws_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const double* gsc, const float* x,
                          const double* pa, const double* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st);
 

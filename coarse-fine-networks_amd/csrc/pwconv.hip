@@ -598,6 +598,7 @@ extern "C" int cfn_pwconv_fwd(const float* x, const double* A, const double* B, 
     CFN_REQUIRE((long)T * Hi * Wi < (1L << 31), "cfn_pwconv_fwd: per-sample volume too large");
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_FWD, st, 4.0 * N * ((double)Cin * a.Q + (double)Cout * a.Q) + 4.0 * Cin * Cout);
+    { const int rc = pwk_try_launch(a, PW_FWD, sum != nullptr, st); if (rc >= 0) return rc; }
     { const int rc = pws_try_launch(a, PW_FWD, sum != nullptr, st); if (rc >= 0) return rc; }
     { const int rc = pwd_try_launch(a, PW_FWD, sum != nullptr, st); if (rc >= 0) return rc; }
     int MT; unsigned blocks; size_t lds;

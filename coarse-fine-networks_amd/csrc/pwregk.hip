@@ -1,0 +1,307 @@
+// Pointwise (1x1x1) forward contraction on fp32 tensors with split-bf16 arithmetic (pwsplit.hip's 6-term product), REGISTER-RESIDENT
+// WEIGHTS, two k slices per row tile: the deep-contraction / few-row shapes (x3d_fine.py:100-105 conv3 of layer 3: 216 -> 96 @14x14),
+// which pws_kernel loses on (its VALU work grows with K) and which therefore ran on the fp32-MFMA pw_deep_kernel.
+//
+// pws_kernel gives a wave ALL output rows of its 32 positions and runs its phases -- load, activate + split, MFMAs, epilogue -- one
+// after the other.  Here the roles are turned round (prototype and its ablations: tools/probe/pwreg_prototype):
+//   * wave w = (row tile mt = w % 4, k slice ks = w / 4) keeps the weights of (mt, ks) in registers, fetched coalesced through LDS and
+//     split once into 3 bf16 terms (7 k-blocks x 3 x 4 = 84 VGPRs at K = 216): no weight image in LDS, no LDS read per weight operand;
+//   * the 8 waves share the ACTIVATIONS of a 32-position tile: wave w loads k-blocks w and w + 8 (loads two tiles ahead, static
+//     register sets), applies the prologue, splits ONCE and publishes the three operand images in LDS (double buffered, ONE barrier
+//     per tile); every wave reads its slice back as 16-byte MFMA operands, one k-block ahead of the MFMAs;
+//   * the ks = 1 wave hands its 32x32 partial result to the ks = 0 wave of the same row tile through LDS (double buffered, picked up
+//     behind the NEXT tile's barrier: no extra synchronisation); that wave adds it, takes the statistics in-lane (transposed result:
+//     lane = output channel), puts the tile into its scratch and drains it -- 16-byte stores of whole 128-byte lines -- between the
+//     MFMA groups of the next tile;
+//   * two tiles per loop trip: LDS buffers, scratch halves and load sets are static (no register moves, no waterfall loops).
+// Shapes: forward, stride 1, 128 < K <= 224 (an even number of k-blocks), 32 < M <= 128, Q % 4 == 0; everything else stays with
+// pws_kernel / pw_deep_kernel.  Measured (8 clips x T = 256, 216 -> 96 @14x14, same box): 0.176-0.179 ms against 0.218-0.219 ms.
+#include "pw_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef __bf16 bf16x8k __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2k __attribute__((ext_vector_type(2)));
+typedef float f2k __attribute__((ext_vector_type(2)));
+typedef unsigned u4k __attribute__((ext_vector_type(4)));
+
+#define PWK_WAVES 8
+#define PWK_OOB 0x40000000
+
+__device__ __forceinline__ float pwk_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float pwk_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ unsigned pwk_pack(float lo, float hi) {
+    const bf16x2k b = __builtin_convertvector((f2k){lo, hi}, bf16x2k);      // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, b);
+}
+// 8 fp32 values -> three 16-byte operands (terms 1..3 of each value, 8 consecutive k)
+__device__ __forceinline__ void pwk_split8(const float (&v)[8], u4k (&t)[3]) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        float a = v[2 * h], b = v[2 * h + 1];
+        const unsigned p0 = pwk_pack(a, b);
+        a -= pwk_lo(p0); b -= pwk_hi(p0);
+        const unsigned p1 = pwk_pack(a, b);
+        a -= pwk_lo(p1); b -= pwk_hi(p1);
+        t[0][h] = p0; t[1][h] = p1; t[2][h] = pwk_pack(a, b);
+    }
+}
+
+template <int NKB, int ACT, bool STATS>
+__global__ __launch_bounds__(64 * PWK_WAVES) void pwk_fwd_kernel(const PwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KP = 16 * NKB;
+    constexpr int NKS = (NKB + 1) / 2;                                      // k-blocks per slice (two slices)
+    constexpr int PITCH = KP * 2 + 16;                                      // bytes per position row of one image: an odd number of 16-byte slots
+    static_assert(((PITCH / 16) & 1) == 1, "conflict-free pitch");
+    constexpr int IMG = 32 * PITCH;                                         // one term, 32 positions
+    constexpr int NST = (NKB + PWK_WAVES - 1) / PWK_WAVES;                  // k-blocks a wave stages per tile (<= 2)
+    static_assert(NST <= 2, "at most 16 k-blocks");
+    const int tid = threadIdx.x, wave = cfn_uni(tid >> 6), lane = tid & 63, kg = lane >> 5, j = lane & 31;
+    const int K = a.K, M = a.M, Q = a.Q;
+    const unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    const int wg = L % a.nstrips, n = L / a.nstrips;
+    const int nrt = (M + 31) >> 5;                                          // row tiles (<= 4)
+
+    unsigned char* Bs = smem;                                               // [2 buffers][3 terms][32 positions][PITCH]
+    float2* sP = reinterpret_cast<float2*>(Bs + 2 * 3 * IMG);              // [KP] prologue coefficients
+    const int mt = wave & 3, ks = wave >> 2, row = mt * 32 + j;
+    float* scr = reinterpret_cast<float*>(sP + KP) + mt * (2 * 32 * 36);    // owner (ks = 0) of row tile mt: [2 tiles][32 channels][36]
+    float* red = reinterpret_cast<float*>(sP + KP) + (nrt + mt) * (2 * 32 * 36);   // partial results of the ks = 1 wave: [2 tiles][32][36]
+    const bool has_rows = mt * 32 < M;                                      // wave uniform
+    const bool owner = ks == 0;
+
+    u4k Wr[NKS][3];
+    {
+        // this wave's 32 rows x its k slice of w through LDS (coalesced 16-byte loads, then each lane reads its row)
+        constexpr int WC = NKS * 16;                                        // columns of the slice
+        float* wtmp = reinterpret_cast<float*>(smem) + wave * (32 * (WC + 4));
+        const int kbase = ks * WC;
+        const bool vec = (a.Cin & 3) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
+        for (int e = lane; e < 32 * (WC / 4); e += 64) {
+            const int rr = e / (WC / 4), k4 = (e - rr * (WC / 4)) * 4, k = kbase + k4;
+            f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (mt * 32 + rr < M) {
+                const float* src = a.w + (long)(mt * 32 + rr) * a.Cin + k;
+                if (vec && k + 3 < K) v = *reinterpret_cast<const f4v*>(src);
+                else { if (k < K) v.x = src[0]; if (k + 1 < K) v.y = src[1]; if (k + 2 < K) v.z = src[2]; if (k + 3 < K) v.w = src[3]; }
+            }
+            *reinterpret_cast<f4v*>(wtmp + rr * (WC + 4) + k4) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int kbl = 0; kbl < NKS; ++kbl) {
+            float v[8];
+            const float* p = wtmp + j * (WC + 4) + kbl * 16 + kg * 8;
+            const f4v lo = *reinterpret_cast<const f4v*>(p), hi = *reinterpret_cast<const f4v*>(p + 4);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            pwk_split8(v, Wr[kbl]);
+        }
+    }
+    __syncthreads();                                                        // the staging area is re-used: coefficients, activation buffers
+    for (int k = tid; k < KP; k += 64 * PWK_WAVES)
+        sP[k] = float2{(k < K && a.pa) ? (float)a.pa[(long)n * K + k] : 1.0f, (k < K && a.pb) ? (float)a.pb[(long)n * K + k] : 0.0f};
+    __syncthreads();
+
+    __amdgpu_buffer_rsrc_t rs = cfn_rsrc(const_cast<float*>(a.src + (long)n * K * Q), (unsigned)((long)K * Q * 4));
+    const int mrows = max(min(32, M - mt * 32), 0);
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.dst + (long)n * M * Q + (long)mt * 32 * Q, (unsigned)((long)mrows * Q * 4));
+    const int ntiles = (Q + 31) / 32, tstep = a.nstrips;
+    const int lane_ld = kg * 8 * Q * 4 + j * 4;
+    const int rd_off = j * PITCH + kg * 16;                                 // + kb * 32: A operand (row = position j, k = kb*16 + kg*8 + i)
+    const int mrow = lane >> 3, mcol = 4 * (lane & 7);                      // memory-side role: row mrow + 8 s, 16 bytes at position mcol
+    const int lane_mem = mrow * Q * 4 + mcol * 4;
+    float ssum = 0.0f, qsum = 0.0f;
+
+    // staging: wave w loads k-blocks w and w + 8 (position j, channels kb*16 + kg*8 + i), two tiles ahead
+    auto issue = [&](int tile, float (&ld)[NST][8]) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int kb = wave + PWK_WAVES * u;
+            const bool live = kb < NKB && tile < ntiles;
+            const int vo = (live && tile * 32 + j < Q) ? lane_ld : PWK_OOB;
+            const int base = live ? tile * 32 * 4 : 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = kb * 16 + i;                                  // + 8 kg through the lane offset
+                const int so = cfn_uni((live && r < K) ? r * Q * 4 + base : base);
+                ld[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (live && r + 8 * kg < K) ? vo : PWK_OOB, so, 0));
+            }
+        }
+    };
+    auto wsync = [&]() {                                                   // LDS ops of a wave run in order; only the compiler is told
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    int pq0 = -1, last_buf = 0;                                             // (owner) the tile waiting in the scratch: first position, scratch half
+    auto drain_read = [&](int pbuf, int sx) -> f4v { return *reinterpret_cast<const f4v*>(scr + pbuf * (32 * 36) + (mrow + 8 * sx) * 36 + mcol); };
+    auto drain_store = [&](f4v v, int sx) {
+        const bool ok = 8 * sx + mrow < mrows && pq0 + mcol < Q;
+        cfn_bst128(__builtin_bit_cast(u4k, v), rd, (ok && pq0 >= 0) ? lane_mem + sx * 8 * Q * 4 : PWK_OOB, cfn_uni(pq0 >= 0 ? pq0 * 4 : 0));
+    };
+    f16v acc;
+    // owner: own accumulators + the partner's partial (scratch half PARV of `red`) -> statistics, transposed tile into scratch half PARV
+    auto finish = [&](int PARV, int q0) {
+        const bool full = q0 + 32 <= Q && mrows == 32;                      // wave uniform
+        float* sb = scr + PARV * (32 * 36);
+        const float* pr = red + PARV * (32 * 36);
+        const bool chv = j < mrows;
+        f4v s1v = {0.0f, 0.0f, 0.0f, 0.0f}, s2v = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f4v p = *reinterpret_cast<const f4v*>(pr + j * 36 + 8 * g + 4 * kg);
+            const f4v o = (f4v){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]} + p;
+            if (STATS) {
+                const float gmask = (full || (chv && q0 + 8 * g + 4 * kg < Q)) ? 1.0f : 0.0f;
+                const f4v om = o * gmask;
+                s1v += om; s2v = __builtin_elementwise_fma(om, om, s2v);
+            }
+            *reinterpret_cast<f4v*>(sb + j * 36 + 8 * g + 4 * kg) = o;
+        }
+        wsync();
+        if (STATS) { ssum += (s1v.x + s1v.y) + (s1v.z + s1v.w); qsum += (s2v.x + s2v.y) + (s2v.z + s2v.w); }
+        pq0 = q0; last_buf = PARV;
+    };
+    bool have = false; int hq0 = 0;                                         // (owner) a tile waits for its partner's partial behind the next barrier
+    auto step = [&](auto par_tag, float (&lc)[NST][8], int tile) {
+        constexpr int PAR = decltype(par_tag)::value;
+        unsigned char* buf = Bs + PAR * 3 * IMG;
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int kb = wave + PWK_WAVES * u;
+            if (kb < NKB) {                                                 // activate, split once, publish
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float2 c = sP[kb * 16 + kg * 8 + i];
+                    v[i] = cfn_act<ACT>(fmaf(lc[u][i], c.x, c.y));
+                }
+                u4k t[3];
+                pwk_split8(v, t);
+#pragma unroll
+                for (int s = 0; s < 3; ++s) *reinterpret_cast<u4k*>(buf + s * IMG + j * PITCH + (kb * 16 + kg * 8) * 2) = t[s];
+            }
+        }
+        issue(tile + 2 * tstep, lc);                                        // two tiles ahead, into the sets just consumed
+        __syncthreads();
+        if (!has_rows) return;
+        constexpr int pbuf = PAR ^ 1;
+        if (owner && have) finish(pbuf, hq0);                               // the previous tile: its partner's partial was written before this barrier
+        f4v dv[4];
+        bf16x8k AA[2][3];                                                   // the operands of k-block kbl + 1 are read before the MFMAs of kbl issue
+        const int kb0 = ks * NKS;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) AA[0][s] = *reinterpret_cast<const bf16x8k*>(buf + s * IMG + rd_off + kb0 * 32);
+#pragma unroll
+        for (int kbl = 0; kbl < NKS; ++kbl) {
+            bf16x8k (&A)[3] = AA[kbl & 1];
+            if (kbl + 1 < NKS) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s) AA[(kbl + 1) & 1][s] = *reinterpret_cast<const bf16x8k*>(buf + s * IMG + rd_off + (kb0 + kbl + 1) * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#define PWK_MM(SA, SW) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA], __builtin_bit_cast(bf16x8k, Wr[kbl][SW]), acc, 0, 0, 0)
+            if (kbl == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], __builtin_bit_cast(bf16x8k, Wr[kbl][2]), (f16v)0.0f, 0, 0, 0);
+            else PWK_MM(0, 2);
+            PWK_MM(2, 0); PWK_MM(1, 1);
+            if (owner) {                                                    // drain the previous tile between the MFMA groups
+                if (2 * kbl < 4) dv[2 * kbl] = drain_read(pbuf, 2 * kbl);
+                if (2 * kbl >= 1 && 2 * kbl - 1 < 4) drain_store(dv[2 * kbl - 1], 2 * kbl - 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            PWK_MM(0, 1); PWK_MM(1, 0); PWK_MM(0, 0);
+#undef PWK_MM
+            if (owner) {
+                if (2 * kbl + 1 < 4) dv[2 * kbl + 1] = drain_read(pbuf, 2 * kbl + 1);
+                if (2 * kbl < 4) drain_store(dv[2 * kbl], 2 * kbl);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (owner) { have = true; hq0 = cfn_uni(tile * 32); }
+        else {                                                              // hand the partial over (picked up behind the next barrier)
+            float* pw = red + PAR * (32 * 36);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f4v*>(pw + j * 36 + 8 * g + 4 * kg) = (f4v){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        }
+    };
+    int tile = cfn_uni(wg), last_par = 0;
+    float ldA[NST][8], ldB[NST][8];
+    issue(tile, ldA);
+    issue(tile + tstep, ldB);
+    for (;;) {
+        if (tile >= ntiles) break;
+        step(std::integral_constant<int, 0>{}, ldA, tile);
+        last_par = 0;
+        tile += tstep;
+        if (tile >= ntiles) break;
+        step(std::integral_constant<int, 1>{}, ldB, tile);
+        last_par = 1;
+        tile += tstep;
+    }
+    __syncthreads();                                                        // the last partials are in place
+    if (has_rows && owner && have) finish(last_par, hq0);
+    if (has_rows && owner && pq0 >= 0) {                                    // the last tile leaves now
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) drain_store(drain_read(last_buf, sx), sx);
+    }
+    if (STATS && a.s1 && has_rows && owner) {
+        ssum += __shfl_xor(ssum, 32, 64);
+        qsum += __shfl_xor(qsum, 32, 64);
+        if (kg == 0 && row < M) {
+            atomicAdd(&a.s1[(long)n * M + row], (double)ssum);
+            atomicAdd(&a.s2[(long)n * M + row], (double)qsum);
+        }
+    }
+}
+
+template <int NKB, bool STATS>
+static int pwk_go(const PwArgs& a, unsigned blocks, size_t lds, hipStream_t st) {
+#define PWK_GO(ACTV)                                                                                                        \
+    do {                                                                                                                    \
+        auto k = pwk_fwd_kernel<NKB, ACTV, STATS>;                                                                          \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * PWK_WAVES), lds, st, a);                                              \
+    } while (0)
+    switch (a.act) {
+        case CFN_ACT_RELU: PWK_GO(CFN_ACT_RELU); break;
+        case CFN_ACT_SWISH: PWK_GO(CFN_ACT_SWISH); break;
+        default: PWK_GO(CFN_ACT_NONE); break;
+    }
+#undef PWK_GO
+    return cfn_check_launch("pwconv(split bf16, register-resident weights, k-sliced)");
+}
+
+// returns -1 when the shape is not handled
+int pwk_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
+    static const int on = getenv("CFN_PWK") ? atoi(getenv("CFN_PWK")) : 1;
+    if (!on || pws_terms_now() != 6 || mode != PW_FWD || a.stem || a.stride != 1 || a.acc) return -1;
+    if (a.K <= 128 || a.K > 224 || a.M <= 32 || a.M > 128 || (a.Q & 3)) return -1;
+    if (a.act != CFN_ACT_NONE && a.act != CFN_ACT_RELU && a.act != CFN_ACT_SWISH) return -1;
+    if ((long)a.K * a.Q * 4 >= 0x3ffffff0L || (long)a.M * a.Q * 4 >= 0x3ffffff0L) return -1;
+    if (((uintptr_t)a.src | (uintptr_t)a.dst) & 15) return -1;
+    const int nkb = cfn_cdiv(a.K, 16);
+    if (nkb & 1) return -1;                                                 // two equal slices
+    const int KP = 16 * nkb, nrt = cfn_cdiv(a.M, 32), NKS = (nkb + 1) / 2;
+    size_t lds = (size_t)2 * 3 * 32 * (KP * 2 + 16) + (size_t)KP * 8 + (size_t)2 * nrt * 2 * 32 * 36 * 4;
+    const size_t wtmp = (size_t)PWK_WAVES * 32 * (NKS * 16 + 4) * 4;
+    if (wtmp > lds) lds = wtmp;
+    if (lds > 160 * 1024) return -1;
+    PwArgs b = a;
+    const int ntiles = cfn_cdiv(a.Q, 32);
+    static const int wg_env = getenv("CFN_PWK_WGS") ? atoi(getenv("CFN_PWK_WGS")) : 0;
+    long wgs = cfn_cdiv(wg_env > 0 ? wg_env : 256, (long)a.N);              // one workgroup per CU
+    if (wgs > ntiles) wgs = ntiles;
+    if (wgs < 1) wgs = 1;
+    b.nstrips = (int)wgs;
+    const unsigned blocks = (unsigned)((long)a.N * wgs);
+    switch (nkb) {
+        case 10: return stats ? pwk_go<10, true>(b, blocks, lds, st) : pwk_go<10, false>(b, blocks, lds, st);
+        case 12: return stats ? pwk_go<12, true>(b, blocks, lds, st) : pwk_go<12, false>(b, blocks, lds, st);
+        case 14: return stats ? pwk_go<14, true>(b, blocks, lds, st) : pwk_go<14, false>(b, blocks, lds, st);
+        default: return -1;
+    }
+}

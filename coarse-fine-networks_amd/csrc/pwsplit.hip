@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64 * PWS_WAVES) void pws_kernel(const PwArgs a) {
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 static int g_pws_terms = -1;      // 0 = off (fp32 MFMA kernels), 3 / 6 = MFMAs per k-block
-static int pws_terms_now() {
+int pws_terms_now() {
     if (g_pws_terms < 0) {
         const char* e = getenv("CFN_PW_SPLIT");
         g_pws_terms = e ? atoi(e) : 6;
