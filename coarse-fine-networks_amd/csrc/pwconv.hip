@@ -627,6 +627,7 @@ extern "C" int cfn_pwconv_bwd_data_acc(const float* gy, const float* y, const do
     if (acc) { a.acc = acc; a.acc_s = acc_stride; a.acc_Ho = (Hi - 1) / acc_stride + 1; a.acc_Wo = (Wi - 1) / acc_stride + 1; }
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_BWD, st, 4.0 * N * ((double)Cout * a.Q * (a.src2 ? 2 : 1) + (double)Cin * a.Q * (A ? 2 : 1)));
+    { const int rc = pwk_try_launch(a, PW_DGRAD, A != nullptr, st); if (rc >= 0) return rc; }
     { const int rc = pws_try_launch(a, PW_DGRAD, A != nullptr, st); if (rc >= 0) return rc; }
     { const int rc = pwd_try_launch(a, PW_DGRAD, A != nullptr, st); if (rc >= 0) return rc; }
     int MT; unsigned blocks; size_t lds;

@@ -14,8 +14,10 @@
 //     lane = output channel), puts the tile into its scratch and drains it -- 16-byte stores of whole 128-byte lines -- between the
 //     MFMA groups of the next tile;
 //   * two tiles per loop trip: LDS buffers, scratch halves and load sets are static (no register moves, no waterfall loops).
-// Shapes: forward, stride 1, 128 < K <= 224 (an even number of k-blocks), 32 < M <= 128, Q % 4 == 0; everything else stays with
-// pws_kernel / pw_deep_kernel.  Measured (8 clips x T = 256, 216 -> 96 @14x14, same box): 0.176-0.179 ms against 0.218-0.219 ms.
+// Shapes: stride 1, 128 < K <= 224 (an even number of k-blocks), 32 < M <= 128, Q % 4 == 0; forward (layer-3 conv3: 216 -> 96) and the
+// data gradient without act' epilogue / compact shortcut gradient (layer-3 conv1: contraction over its 216 output channels, two staged
+// tensors); everything else stays with pws_kernel / pw_deep_kernel.  Measured (8 clips x T = 256, @14x14, same box, against the
+// fp32-MFMA pw_deep_kernel): forward 0.176-0.179 vs 0.218-0.219 ms, data gradient 0.214-0.215 vs 0.232-0.233 ms.
 #include "pw_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -47,8 +49,10 @@ __device__ __forceinline__ void pwk_split8(const float (&v)[8], u4k (&t)[3]) {
     }
 }
 
-template <int NKB, int ACT, bool STATS>
-__global__ __launch_bounds__(64 * PWK_WAVES) void pwk_fwd_kernel(const PwArgs a) {
+// MODE = PW_DGRAD (no act' epilogue, no compact shortcut gradient): the contraction runs over the conv's OUTPUT channels, w is (K, M) row
+// major, the staged operand is g' = gsc gy + gs + 2 gq y (TWO: with the y term).
+template <int NKB, int MODE, int ACT, bool STATS, bool TWO>
+__global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KP = 16 * NKB;
     constexpr int NKS = (NKB + 1) / 2;                                      // k-blocks per slice (two slices)
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_fwd_kernel(const PwArgs a)
     const int nrt = (M + 31) >> 5;                                          // row tiles (<= 4)
 
     unsigned char* Bs = smem;                                               // [2 buffers][3 terms][32 positions][PITCH]
-    float2* sP = reinterpret_cast<float2*>(Bs + 2 * 3 * IMG);              // [KP] prologue coefficients
+    float4* sP = reinterpret_cast<float4*>(Bs + 2 * 3 * IMG);              // [KP] prologue coefficients (FWD: A, B; DGRAD: gs, 2 gq, gsc)
     const int mt = wave & 3, ks = wave >> 2, row = mt * 32 + j;
     float* scr = reinterpret_cast<float*>(sP + KP) + mt * (2 * 32 * 36);    // owner (ks = 0) of row tile mt: [2 tiles][32 channels][36]
     float* red = reinterpret_cast<float*>(sP + KP) + (nrt + mt) * (2 * 32 * 36);   // partial results of the ks = 1 wave: [2 tiles][32][36]
@@ -75,37 +79,72 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_fwd_kernel(const PwArgs a)
     {
         // this wave's 32 rows x its k slice of w through LDS (coalesced 16-byte loads, then each lane reads its row)
         constexpr int WC = NKS * 16;                                        // columns of the slice
-        float* wtmp = reinterpret_cast<float*>(smem) + wave * (32 * (WC + 4));
         const int kbase = ks * WC;
         const bool vec = (a.Cin & 3) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
-        for (int e = lane; e < 32 * (WC / 4); e += 64) {
-            const int rr = e / (WC / 4), k4 = (e - rr * (WC / 4)) * 4, k = kbase + k4;
-            f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (mt * 32 + rr < M) {
-                const float* src = a.w + (long)(mt * 32 + rr) * a.Cin + k;
-                if (vec && k + 3 < K) v = *reinterpret_cast<const f4v*>(src);
-                else { if (k < K) v.x = src[0]; if (k + 1 < K) v.y = src[1]; if (k + 2 < K) v.z = src[2]; if (k + 3 < K) v.w = src[3]; }
+        if (MODE == PW_FWD) {                                               // w is (M, K): the wave's rows are contiguous runs along k
+            float* wtmp = reinterpret_cast<float*>(smem) + wave * (32 * (WC + 4));
+            for (int e = lane; e < 32 * (WC / 4); e += 64) {
+                const int rr = e / (WC / 4), k4 = (e - rr * (WC / 4)) * 4, k = kbase + k4;
+                f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (mt * 32 + rr < M) {
+                    const float* src = a.w + (long)(mt * 32 + rr) * a.Cin + k;
+                    if (vec && k + 3 < K) v = *reinterpret_cast<const f4v*>(src);
+                    else { if (k < K) v.x = src[0]; if (k + 1 < K) v.y = src[1]; if (k + 2 < K) v.z = src[2]; if (k + 3 < K) v.w = src[3]; }
+                }
+                *reinterpret_cast<f4v*>(wtmp + rr * (WC + 4) + k4) = v;
             }
-            *reinterpret_cast<f4v*>(wtmp + rr * (WC + 4) + k4) = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int kbl = 0; kbl < NKS; ++kbl) {
-            float v[8];
-            const float* p = wtmp + j * (WC + 4) + kbl * 16 + kg * 8;
-            const f4v lo = *reinterpret_cast<const f4v*>(p), hi = *reinterpret_cast<const f4v*>(p + 4);
-            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-            pwk_split8(v, Wr[kbl]);
+            for (int kbl = 0; kbl < NKS; ++kbl) {
+                float v[8];
+                const float* p = wtmp + j * (WC + 4) + kbl * 16 + kg * 8;
+                const f4v lo = *reinterpret_cast<const f4v*>(p), hi = *reinterpret_cast<const f4v*>(p + 4);
+                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+                pwk_split8(v, Wr[kbl]);
+            }
+        } else {                                                            // w is (K, M): 32 consecutive m per k row
+            float* wtmp = reinterpret_cast<float*>(smem) + wave * (WC * 36);
+            for (int e = lane; e < WC * 8; e += 64) {
+                const int kk = e >> 3, m4 = (e & 7) * 4, k = kbase + kk, m = mt * 32 + m4;
+                f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (k < K) {
+                    const float* src = a.w + (long)k * a.Cin + m;
+                    if (vec && m + 3 < M) v = *reinterpret_cast<const f4v*>(src);
+                    else { if (m < M) v.x = src[0]; if (m + 1 < M) v.y = src[1]; if (m + 2 < M) v.z = src[2]; if (m + 3 < M) v.w = src[3]; }
+                }
+                *reinterpret_cast<f4v*>(wtmp + kk * 36 + m4) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int kbl = 0; kbl < NKS; ++kbl) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = wtmp[(kbl * 16 + kg * 8 + i) * 36 + j];
+                pwk_split8(v, Wr[kbl]);
+            }
         }
     }
     __syncthreads();                                                        // the staging area is re-used: coefficients, activation buffers
-    for (int k = tid; k < KP; k += 64 * PWK_WAVES)
-        sP[k] = float2{(k < K && a.pa) ? (float)a.pa[(long)n * K + k] : 1.0f, (k < K && a.pb) ? (float)a.pb[(long)n * K + k] : 0.0f};
+    for (int k = tid; k < KP; k += 64 * PWK_WAVES) {
+        float4 c = {1.0f, 0.0f, 1.0f, 0.0f};
+        if (MODE == PW_FWD) {
+            c.x = (k < K && a.pa) ? (float)a.pa[(long)n * K + k] : 1.0f;
+            c.y = (k < K && a.pb) ? (float)a.pb[(long)n * K + k] : 0.0f;
+        } else {
+            c.x = (k < K && a.gs) ? (float)a.gs[(long)n * K + k] : 0.0f;
+            c.y = (k < K && a.gq && a.src2) ? 2.0f * (float)a.gq[(long)n * K + k] : 0.0f;
+            c.z = (k < K && a.gsc) ? (float)a.gsc[(long)n * K + k] : 1.0f;
+        }
+        sP[k] = c;
+    }
     __syncthreads();
 
     __amdgpu_buffer_rsrc_t rs = cfn_rsrc(const_cast<float*>(a.src + (long)n * K * Q), (unsigned)((long)K * Q * 4));
+    __amdgpu_buffer_rsrc_t rs2 = cfn_rsrc(const_cast<float*>((TWO ? a.src2 : a.src) + (long)n * K * Q), (unsigned)((long)K * Q * 4));
     const int mrows = max(min(32, M - mt * 32), 0);
     __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.dst + (long)n * M * Q + (long)mt * 32 * Q, (unsigned)((long)mrows * Q * 4));
     const int ntiles = (Q + 31) / 32, tstep = a.nstrips;
@@ -116,7 +155,7 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_fwd_kernel(const PwArgs a)
     float ssum = 0.0f, qsum = 0.0f;
 
     // staging: wave w loads k-blocks w and w + 8 (position j, channels kb*16 + kg*8 + i), two tiles ahead
-    auto issue = [&](int tile, float (&ld)[NST][8]) {
+    auto issue = [&](int tile, float (&ld)[NST][8], float (&ld2)[TWO ? NST : 1][8]) {
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
             const int kb = wave + PWK_WAVES * u;
@@ -128,6 +167,7 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_fwd_kernel(const PwArgs a)
                 const int r = kb * 16 + i;                                  // + 8 kg through the lane offset
                 const int so = cfn_uni((live && r < K) ? r * Q * 4 + base : base);
                 ld[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (live && r + 8 * kg < K) ? vo : PWK_OOB, so, 0));
+                if (TWO) ld2[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, (live && r + 8 * kg < K) ? vo : PWK_OOB, so, 0));
             }
         }
     };
@@ -166,7 +206,7 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_fwd_kernel(const PwArgs a)
         pq0 = q0; last_buf = PARV;
     };
     bool have = false; int hq0 = 0;                                         // (owner) a tile waits for its partner's partial behind the next barrier
-    auto step = [&](auto par_tag, float (&lc)[NST][8], int tile) {
+    auto step = [&](auto par_tag, float (&lc)[NST][8], float (&lc2)[TWO ? NST : 1][8], int tile) {
         constexpr int PAR = decltype(par_tag)::value;
         unsigned char* buf = Bs + PAR * 3 * IMG;
 #pragma unroll
@@ -176,8 +216,9 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_fwd_kernel(const PwArgs a)
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const float2 c = sP[kb * 16 + kg * 8 + i];
-                    v[i] = cfn_act<ACT>(fmaf(lc[u][i], c.x, c.y));
+                    const float4 c = sP[kb * 16 + kg * 8 + i];
+                    if (MODE == PW_FWD) v[i] = cfn_act<ACT>(fmaf(lc[u][i], c.x, c.y));
+                    else { v[i] = fmaf(lc[u][i], c.z, c.x); if (TWO) v[i] = fmaf(lc2[u][i], c.y, v[i]); }
                 }
                 u4k t[3];
                 pwk_split8(v, t);
@@ -185,7 +226,7 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_fwd_kernel(const PwArgs a)
                 for (int s = 0; s < 3; ++s) *reinterpret_cast<u4k*>(buf + s * IMG + j * PITCH + (kb * 16 + kg * 8) * 2) = t[s];
             }
         }
-        issue(tile + 2 * tstep, lc);                                        // two tiles ahead, into the sets just consumed
+        issue(tile + 2 * tstep, lc, lc2);                                   // two tiles ahead, into the sets just consumed
         __syncthreads();
         if (!has_rows) return;
         constexpr int pbuf = PAR ^ 1;
@@ -229,16 +270,16 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_fwd_kernel(const PwArgs a)
         }
     };
     int tile = cfn_uni(wg), last_par = 0;
-    float ldA[NST][8], ldB[NST][8];
-    issue(tile, ldA);
-    issue(tile + tstep, ldB);
+    float ldA[NST][8], ldB[NST][8], ldA2[TWO ? NST : 1][8], ldB2[TWO ? NST : 1][8];
+    issue(tile, ldA, ldA2);
+    issue(tile + tstep, ldB, ldB2);
     for (;;) {
         if (tile >= ntiles) break;
-        step(std::integral_constant<int, 0>{}, ldA, tile);
+        step(std::integral_constant<int, 0>{}, ldA, ldA2, tile);
         last_par = 0;
         tile += tstep;
         if (tile >= ntiles) break;
-        step(std::integral_constant<int, 1>{}, ldB, tile);
+        step(std::integral_constant<int, 1>{}, ldB, ldB2, tile);
         last_par = 1;
         tile += tstep;
     }
@@ -258,50 +299,61 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_fwd_kernel(const PwArgs a)
     }
 }
 
-template <int NKB, bool STATS>
-static int pwk_go(const PwArgs& a, unsigned blocks, size_t lds, hipStream_t st) {
-#define PWK_GO(ACTV)                                                                                                        \
+template <int NKB>
+static int pwk_go(const PwArgs& a, int mode, bool stats, unsigned blocks, size_t lds, hipStream_t st) {
+#define PWK_GO(...)                                                                                                         \
     do {                                                                                                                    \
-        auto k = pwk_fwd_kernel<NKB, ACTV, STATS>;                                                                          \
+        auto k = pwk_kernel<NKB, __VA_ARGS__>;                                                                              \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * PWK_WAVES), lds, st, a);                                              \
     } while (0)
-    switch (a.act) {
-        case CFN_ACT_RELU: PWK_GO(CFN_ACT_RELU); break;
-        case CFN_ACT_SWISH: PWK_GO(CFN_ACT_SWISH); break;
-        default: PWK_GO(CFN_ACT_NONE); break;
+    if (mode == PW_DGRAD) {
+        if (a.src2) PWK_GO(PW_DGRAD, CFN_ACT_NONE, false, true); else PWK_GO(PW_DGRAD, CFN_ACT_NONE, false, false);
+    } else if (stats) {
+        switch (a.act) {
+            case CFN_ACT_RELU: PWK_GO(PW_FWD, CFN_ACT_RELU, true, false); break;
+            case CFN_ACT_SWISH: PWK_GO(PW_FWD, CFN_ACT_SWISH, true, false); break;
+            default: PWK_GO(PW_FWD, CFN_ACT_NONE, true, false); break;
+        }
+    } else {
+        switch (a.act) {
+            case CFN_ACT_RELU: PWK_GO(PW_FWD, CFN_ACT_RELU, false, false); break;
+            case CFN_ACT_SWISH: PWK_GO(PW_FWD, CFN_ACT_SWISH, false, false); break;
+            default: PWK_GO(PW_FWD, CFN_ACT_NONE, false, false); break;
+        }
     }
 #undef PWK_GO
     return cfn_check_launch("pwconv(split bf16, register-resident weights, k-sliced)");
 }
 
-// returns -1 when the shape is not handled
+// returns -1 when the shape is not handled.  DGRAD: only without the act' epilogue (stats == false) and without the compact shortcut gradient
 int pwk_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
-    static const int on = getenv("CFN_PWK") ? atoi(getenv("CFN_PWK")) : 1;
-    if (!on || pws_terms_now() != 6 || mode != PW_FWD || a.stem || a.stride != 1 || a.acc) return -1;
+    static const int on = getenv("CFN_PWK") ? atoi(getenv("CFN_PWK")) : 3;              // bit 0: forward, bit 1: data gradient
+    if (pws_terms_now() != 6 || a.stem || a.stride != 1 || a.acc) return -1;
+    if (mode == PW_FWD ? !(on & 1) : (!(on & 2) || stats || a.ea)) return -1;
     if (a.K <= 128 || a.K > 224 || a.M <= 32 || a.M > 128 || (a.Q & 3)) return -1;
     if (a.act != CFN_ACT_NONE && a.act != CFN_ACT_RELU && a.act != CFN_ACT_SWISH) return -1;
     if ((long)a.K * a.Q * 4 >= 0x3ffffff0L || (long)a.M * a.Q * 4 >= 0x3ffffff0L) return -1;
-    if (((uintptr_t)a.src | (uintptr_t)a.dst) & 15) return -1;
+    if (((uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)(a.src2 ? a.src2 : a.src)) & 15) return -1;
     const int nkb = cfn_cdiv(a.K, 16);
     if (nkb & 1) return -1;                                                 // two equal slices
     const int KP = 16 * nkb, nrt = cfn_cdiv(a.M, 32), NKS = (nkb + 1) / 2;
-    size_t lds = (size_t)2 * 3 * 32 * (KP * 2 + 16) + (size_t)KP * 8 + (size_t)2 * nrt * 2 * 32 * 36 * 4;
-    const size_t wtmp = (size_t)PWK_WAVES * 32 * (NKS * 16 + 4) * 4;
+    size_t lds = (size_t)2 * 3 * 32 * (KP * 2 + 16) + (size_t)KP * 16 + (size_t)2 * nrt * 2 * 32 * 36 * 4;
+    const size_t wtmp = (size_t)PWK_WAVES * (mode == PW_FWD ? 32 * (NKS * 16 + 4) : NKS * 16 * 36) * 4;
     if (wtmp > lds) lds = wtmp;
     if (lds > 160 * 1024) return -1;
     PwArgs b = a;
     const int ntiles = cfn_cdiv(a.Q, 32);
     static const int wg_env = getenv("CFN_PWK_WGS") ? atoi(getenv("CFN_PWK_WGS")) : 0;
-    long wgs = cfn_cdiv(wg_env > 0 ? wg_env : 256, (long)a.N);              // one workgroup per CU
+    long wgs = cfn_cdiv(wg_env > 0 ? wg_env : 256, (long)a.N);              // one workgroup per CU (128 / 192 / 256 / 384 / 512: 0.30 / 0.22 / 0.176 / 0.23 / 0.185 ms)
     if (wgs > ntiles) wgs = ntiles;
     if (wgs < 1) wgs = 1;
     b.nstrips = (int)wgs;
     const unsigned blocks = (unsigned)((long)a.N * wgs);
     switch (nkb) {
-        case 10: return stats ? pwk_go<10, true>(b, blocks, lds, st) : pwk_go<10, false>(b, blocks, lds, st);
-        case 12: return stats ? pwk_go<12, true>(b, blocks, lds, st) : pwk_go<12, false>(b, blocks, lds, st);
-        case 14: return stats ? pwk_go<14, true>(b, blocks, lds, st) : pwk_go<14, false>(b, blocks, lds, st);
+        case 10: return pwk_go<10>(b, mode, stats, blocks, lds, st);
+        case 12: return pwk_go<12>(b, mode, stats, blocks, lds, st);
+        case 14: return pwk_go<14>(b, mode, stats, blocks, lds, st);
         default: return -1;
     }
 }
