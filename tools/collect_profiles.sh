@@ -19,7 +19,7 @@ python tools/pmc_traffic.py $F $W $P/${TAG}_pmc_dwfwd.json 8 256
 cp $F $P/${TAG}_pmc_dwfwd_FETCH_SIZE.csv; cp $W $P/${TAG}_pmc_dwfwd_WRITE_SIZE.csv
 python tools/pmc_sq.py $P/${TAG}_pmc_dw_valu.json $(latest "$R/pmc_sq1/runc/*counter_collection.csv") $(latest "$R/pmc_sq2/runc/*counter_collection.csv") --filter dw3d_,dwt5_ > /dev/null
 for v in fp32mfma split6 bf16; do
-  python tools/pmc_sq.py $P/${TAG}_pmc_pw_${v}.json $(latest "$R/pmc_pw1_$v/runc/*counter_collection.csv") $(latest "$R/pmc_pw2_$v/runc/*counter_collection.csv") --filter pw_,pws_,pwb_ > /dev/null
+  python tools/pmc_sq.py $P/${TAG}_pmc_pw_${v}.json $(latest "$R/pmc_pw1_$v/runc/*counter_collection.csv") $(latest "$R/pmc_pw2_$v/runc/*counter_collection.csv") --filter pw_,pws_,pwb_,pwk_ > /dev/null
 done
 python - <<PY
 import json
