@@ -150,3 +150,72 @@ def test_split_bitwise_reproducible(split, terms):
     for other in runs[1:]:
         for a, b in zip(runs[0], other):
             assert torch.equal(a, b)
+
+
+# ---- register-resident-weights kernel (csrc/pwregk.hip): 128 < Cin (contraction) <= 224 with an even number of 16-channel blocks,
+# 32 < rows <= 128, position count a multiple of 4; forward and the data gradient without act' epilogue
+PWK_CASES = [
+    # N, K (contraction), M (rows), T, H, W
+    (2, 216, 96, 2, 14, 14),      # X3D layer-3 conv3 forward / conv1 data gradient
+    (1, 216, 96, 5, 14, 14),      # 30.6 position tiles: ragged last tile, several tiles per workgroup
+    (3, 216, 96, 1, 14, 14),      # one frame
+    (2, 160, 64, 3, 6, 6),        # 10 k-blocks, two row tiles
+    (1, 224, 128, 2, 4, 4),       # the largest shape served: 14 full k-blocks, 4 full row tiles, ONE position tile
+    (1, 192, 33, 2, 4, 4),        # 33 rows: a row tile of a single row
+    (1, 210, 100, 3, 10, 10),     # K % 16 = 2 (zero-padded contraction), 100 rows (ragged row tile), 300 positions
+]
+
+
+@pytest.mark.parametrize('N,K,M,T,H,W', PWK_CASES)
+@pytest.mark.parametrize('act', [0, 2])
+def test_pwk_forward_vs_fp64(split, N, K, M, T, H, W, act):
+    """forward with prologue + statistics against fp64: an fp32-accurate product (6-term split), sums within fp32 rounding of the
+    fp64 sums, and the same bits on a second run (no atomics on y)"""
+    split(6)
+    x, w = rnd(1, N, K, T, H, W).to(DEV), rnd(2, M, K, 1, 1, 1, scale=(2.0 / K) ** 0.5).to(DEV)
+    A, B = (1 + 0.2 * rnd(3, N, K)).to(DEV), (0.3 * rnd(4, N, K)).to(DEV)
+    y, s, q = ops().pwconv(x, w, A, B, act, 1, True)
+    y2, _, _ = ops().pwconv(x, w, A, B, act, 1, True)
+    assert torch.equal(y, y2)
+    z = x.double() * A.double().view(N, K, 1, 1, 1) + B.double().view(N, K, 1, 1, 1)
+    z = z * torch.sigmoid(z) if act == 2 else z
+    yr = torch.einsum('nkthw,mk->nmthw', z, w.double().view(M, K))
+    assert relerr(y.double(), yr) <= 1e-6
+    assert relerr(s, yr.sum((2, 3, 4))) <= 2e-6 and relerr(q, (yr * yr).sum((2, 3, 4))) <= 2e-6
+
+
+@pytest.mark.parametrize('N,K,M,T,H,W', PWK_CASES)
+@pytest.mark.parametrize('two', [True, False])
+def test_pwk_data_gradient_vs_fp64(split, N, K, M, T, H, W, two):
+    """data gradient of a prologue-free conv M -> K channels (contraction over its K output channels, statistics gradients folded into
+    the staged operand g' = gy + gs + 2 gq y; `two`: with the y term) against fp64, bit-repeatable"""
+    split(6)
+    x = rnd(1, N, M, T, H, W).to(DEV).requires_grad_(True)
+    w = rnd(2, K, M, 1, 1, 1, scale=(2.0 / M) ** 0.5).to(DEV).requires_grad_(True)
+    y, s, q = ops().pwconv(x, w, None, None, 0, 1, True)
+    gy, gs, gq = rnd(5, *y.shape).to(DEV), (0.01 * rnd(6, *s.shape)).to(DEV).to(s.dtype), (0.001 * rnd(7, *q.shape)).to(DEV).to(q.dtype)
+    outs, gos = ((y, s, q), (gy, gs, gq)) if two else ((y, s), (gy, gs))
+    gx, = torch.autograd.grad(outs, (x,), gos, retain_graph=True)
+    gx2, = torch.autograd.grad(outs, (x,), gos, retain_graph=True)
+    assert torch.equal(gx, gx2)
+    wd = w.detach().double().view(K, M)
+    yd = torch.einsum('nmthw,km->nkthw', x.detach().double(), wd)
+    gp = gy.double() + gs.double().view(N, K, 1, 1, 1) + (2.0 * yd * gq.double().view(N, K, 1, 1, 1) if two else 0.0)
+    gxr = torch.einsum('nkthw,km->nmthw', gp, wd)
+    assert relerr(gx.double(), gxr) <= 1e-6
+
+
+def test_pwk_is_the_kernel_that_runs():
+    """pwk_kernel only runs when the 6-term split is selected: with the fp32-MFMA arithmetic requested the same call goes to
+    pw_deep_kernel, and the two results agree to fp32 rounding but differ in the low bits"""
+    import cfn_hip
+    x, w = rnd(1, 1, 216, 2, 14, 14).to(DEV), rnd(2, 96, 216, 1, 1, 1, scale=0.1).to(DEV)
+    prev = cfn_hip.query('cfn_pw_split_terms', -1)
+    try:
+        cfn_hip.query('cfn_pw_split_terms', 6)
+        y6, _, _ = ops().pwconv(x, w, None, None, 0, 1, True)
+        cfn_hip.query('cfn_pw_split_terms', 0)
+        y0, _, _ = ops().pwconv(x, w, None, None, 0, 1, True)
+    finally:
+        cfn_hip.query('cfn_pw_split_terms', prev)
+    assert relerr(y6, y0) <= 3e-6 and not torch.equal(y6, y0)
