@@ -14,7 +14,9 @@
 //     lane = output channel), puts the tile into its scratch and drains it -- 16-byte stores of whole 128-byte lines -- between the
 //     MFMA groups of the next tile;
 //   * two tiles per loop trip: LDS buffers, scratch halves and load sets are static (no register moves, no waterfall loops).
-// Shapes: stride 1, 128 < K <= 224 (an even number of k-blocks), 32 < M <= 128, Q % 4 == 0; forward (layer-3 conv3: 216 -> 96) and the
+// One-slice mode (K <= 112, 128 < M <= 256: layer-3 conv1 forward, 96 -> 216): wave = row tile, the whole contraction in its registers, no
+// partner: 0.143-0.144 ms against 0.157-0.158 ms for pws_kernel.
+// Two-slice shapes: stride 1, 128 < K <= 224 (an even number of k-blocks), 32 < M <= 128, Q % 4 == 0; forward (layer-3 conv3: 216 -> 96) and the
 // data gradient without act' epilogue / compact shortcut gradient (layer-3 conv1: contraction over its 216 output channels, two staged
 // tensors); everything else stays with pws_kernel / pw_deep_kernel.  Measured (8 clips x T = 256, @14x14, same box, against the
 // fp32-MFMA pw_deep_kernel): forward 0.176-0.179 vs 0.218-0.219 ms, data gradient 0.214-0.215 vs 0.232-0.233 ms.
@@ -51,11 +53,13 @@ __device__ __forceinline__ void pwk_split8(const float (&v)[8], u4k (&t)[3]) {
 
 // MODE = PW_DGRAD (no act' epilogue, no compact shortcut gradient): the contraction runs over the conv's OUTPUT channels, w is (K, M) row
 // major, the staged operand is g' = gsc gy + gs + 2 gq y (TWO: with the y term).
-template <int NKB, int MODE, int ACT, bool STATS, bool TWO>
+// KS = 1 (shallow contraction, many rows: K <= 112, 128 < M <= 256, layer-3 conv1 forward 96 -> 216): wave w = row tile w, the whole
+// contraction in its registers, no partner.
+template <int NKB, int KS, int MODE, int ACT, bool STATS, bool TWO>
 __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KP = 16 * NKB;
-    constexpr int NKS = (NKB + 1) / 2;                                      // k-blocks per slice (two slices)
+    constexpr int NKS = (NKB + KS - 1) / KS;                                // k-blocks per slice
     constexpr int PITCH = KP * 2 + 16;                                      // bytes per position row of one image: an odd number of 16-byte slots
     static_assert(((PITCH / 16) & 1) == 1, "conflict-free pitch");
     constexpr int IMG = 32 * PITCH;                                         // one term, 32 positions
@@ -65,11 +69,11 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
     const int K = a.K, M = a.M, Q = a.Q;
     const unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
     const int wg = L % a.nstrips, n = L / a.nstrips;
-    const int nrt = (M + 31) >> 5;                                          // row tiles (<= 4)
+    const int nrt = (M + 31) >> 5;                                          // row tiles (<= 8 / KS)
 
     unsigned char* Bs = smem;                                               // [2 buffers][3 terms][32 positions][PITCH]
     float4* sP = reinterpret_cast<float4*>(Bs + 2 * 3 * IMG);              // [KP] prologue coefficients (FWD: A, B; DGRAD: gs, 2 gq, gsc)
-    const int mt = wave & 3, ks = wave >> 2, row = mt * 32 + j;
+    const int mt = KS == 2 ? (wave & 3) : wave, ks = KS == 2 ? (wave >> 2) : 0, row = mt * 32 + j;
     float* scr = reinterpret_cast<float*>(sP + KP) + mt * (2 * 32 * 36);    // owner (ks = 0) of row tile mt: [2 tiles][32 channels][36]
     float* red = reinterpret_cast<float*>(sP + KP) + (nrt + mt) * (2 * 32 * 36);   // partial results of the ks = 1 wave: [2 tiles][32][36]
     const bool has_rows = mt * 32 < M;                                      // wave uniform
@@ -192,8 +196,8 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
         f4v s1v = {0.0f, 0.0f, 0.0f, 0.0f}, s2v = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f4v p = *reinterpret_cast<const f4v*>(pr + j * 36 + 8 * g + 4 * kg);
-            const f4v o = (f4v){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]} + p;
+            f4v o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            if (KS == 2) o += *reinterpret_cast<const f4v*>(pr + j * 36 + 8 * g + 4 * kg);
             if (STATS) {
                 const float gmask = (full || (chv && q0 + 8 * g + 4 * kg < Q)) ? 1.0f : 0.0f;
                 const f4v om = o * gmask;
@@ -299,11 +303,11 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
     }
 }
 
-template <int NKB>
+template <int NKB, int KS>
 static int pwk_go(const PwArgs& a, int mode, bool stats, unsigned blocks, size_t lds, hipStream_t st) {
 #define PWK_GO(...)                                                                                                         \
     do {                                                                                                                    \
-        auto k = pwk_kernel<NKB, __VA_ARGS__>;                                                                              \
+        auto k = pwk_kernel<NKB, KS, __VA_ARGS__>;                                                                          \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * PWK_WAVES), lds, st, a);                                              \
     } while (0)
@@ -323,22 +327,26 @@ static int pwk_go(const PwArgs& a, int mode, bool stats, unsigned blocks, size_t
         }
     }
 #undef PWK_GO
-    return cfn_check_launch("pwconv(split bf16, register-resident weights, k-sliced)");
+    return cfn_check_launch("pwconv(split bf16, register-resident weights)");
 }
 
 // returns -1 when the shape is not handled.  DGRAD: only without the act' epilogue (stats == false) and without the compact shortcut gradient
 int pwk_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
-    static const int on = getenv("CFN_PWK") ? atoi(getenv("CFN_PWK")) : 3;              // bit 0: forward, bit 1: data gradient
+    static const int on = getenv("CFN_PWK") ? atoi(getenv("CFN_PWK")) : 7;              // bit 0: forward (two k slices), bit 1: data gradient, bit 2: forward (one slice)
     if (pws_terms_now() != 6 || a.stem || a.stride != 1 || a.acc) return -1;
-    if (mode == PW_FWD ? !(on & 1) : (!(on & 2) || stats || a.ea)) return -1;
-    if (a.K <= 128 || a.K > 224 || a.M <= 32 || a.M > 128 || (a.Q & 3)) return -1;
+    if (mode == PW_DGRAD && (stats || a.ea)) return -1;
+    if (a.Q & 3) return -1;
+    const int nkb = cfn_cdiv(a.K, 16);
+    int KS;
+    if (a.K > 128 && a.K <= 224 && a.M > 32 && a.M <= 128 && !(nkb & 1)) KS = 2;        // two equal slices
+    else if (a.K >= 48 && a.K <= 112 && a.M > 128 && a.M <= 256 && mode == PW_FWD) KS = 1;
+    else return -1;
+    if (mode == PW_DGRAD ? !(on & 2) : !(on & (KS == 2 ? 1 : 4))) return -1;
     if (a.act != CFN_ACT_NONE && a.act != CFN_ACT_RELU && a.act != CFN_ACT_SWISH) return -1;
     if ((long)a.K * a.Q * 4 >= 0x3ffffff0L || (long)a.M * a.Q * 4 >= 0x3ffffff0L) return -1;
     if (((uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)(a.src2 ? a.src2 : a.src)) & 15) return -1;
-    const int nkb = cfn_cdiv(a.K, 16);
-    if (nkb & 1) return -1;                                                 // two equal slices
-    const int KP = 16 * nkb, nrt = cfn_cdiv(a.M, 32), NKS = (nkb + 1) / 2;
-    size_t lds = (size_t)2 * 3 * 32 * (KP * 2 + 16) + (size_t)KP * 16 + (size_t)2 * nrt * 2 * 32 * 36 * 4;
+    const int KP = 16 * nkb, nrt = cfn_cdiv(a.M, 32), NKS = (nkb + KS - 1) / KS;
+    size_t lds = (size_t)2 * 3 * 32 * (KP * 2 + 16) + (size_t)KP * 16 + (size_t)KS * nrt * 2 * 32 * 36 * 4;
     const size_t wtmp = (size_t)PWK_WAVES * (mode == PW_FWD ? 32 * (NKS * 16 + 4) : NKS * 16 * 36) * 4;
     if (wtmp > lds) lds = wtmp;
     if (lds > 160 * 1024) return -1;
@@ -350,10 +358,20 @@ int pwk_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
     if (wgs < 1) wgs = 1;
     b.nstrips = (int)wgs;
     const unsigned blocks = (unsigned)((long)a.N * wgs);
+    if (KS == 2) {
+        switch (nkb) {
+            case 10: return pwk_go<10, 2>(b, mode, stats, blocks, lds, st);
+            case 12: return pwk_go<12, 2>(b, mode, stats, blocks, lds, st);
+            case 14: return pwk_go<14, 2>(b, mode, stats, blocks, lds, st);
+            default: return -1;
+        }
+    }
     switch (nkb) {
-        case 10: return pwk_go<10>(b, mode, stats, blocks, lds, st);
-        case 12: return pwk_go<12>(b, mode, stats, blocks, lds, st);
-        case 14: return pwk_go<14>(b, mode, stats, blocks, lds, st);
+        case 3: return pwk_go<3, 1>(b, mode, stats, blocks, lds, st);
+        case 4: return pwk_go<4, 1>(b, mode, stats, blocks, lds, st);
+        case 5: return pwk_go<5, 1>(b, mode, stats, blocks, lds, st);
+        case 6: return pwk_go<6, 1>(b, mode, stats, blocks, lds, st);
+        case 7: return pwk_go<7, 1>(b, mode, stats, blocks, lds, st);
         default: return -1;
     }
 }

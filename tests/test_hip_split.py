@@ -166,7 +166,19 @@ PWK_CASES = [
 ]
 
 
-@pytest.mark.parametrize('N,K,M,T,H,W', PWK_CASES)
+# one-slice mode (forward only): K <= 112, 128 < rows <= 256 -- wave = row tile, the whole contraction in its registers
+PWK1_CASES = [
+    (2, 96, 216, 2, 14, 14),      # X3D layer-3 conv1 forward
+    (1, 96, 216, 5, 14, 14),
+    (2, 48, 160, 3, 6, 6),        # 3 k-blocks, 5 row tiles
+    (1, 80, 250, 3, 10, 10),      # 250 rows: 8 row tiles, the last ragged
+    (1, 112, 256, 2, 4, 4),       # the largest shape served
+    (1, 64, 129, 2, 4, 4),        # 129 rows: a row tile of a single row
+    (1, 100, 200, 1, 6, 6),       # K % 16 = 4
+]
+
+
+@pytest.mark.parametrize('N,K,M,T,H,W', PWK_CASES + PWK1_CASES)
 @pytest.mark.parametrize('act', [0, 2])
 def test_pwk_forward_vs_fp64(split, N, K, M, T, H, W, act):
     """forward with prologue + statistics against fp64: an fp32-accurate product (6-term split), sums within fp32 rounding of the
