@@ -14,8 +14,9 @@
 //     lane = output channel), puts the tile into its scratch and drains it -- 16-byte stores of whole 128-byte lines -- between the
 //     MFMA groups of the next tile;
 //   * two tiles per loop trip: LDS buffers, scratch halves and load sets are static (no register moves, no waterfall loops).
-// One-slice mode (K <= 112, 128 < M <= 256: layer-3 conv1 forward, 96 -> 216): wave = row tile, the whole contraction in its registers, no
-// partner: 0.143-0.144 ms against 0.157-0.158 ms for pws_kernel.
+// One-slice mode (forward; K <= 112, 128 < M <= 256: layer-3 conv1, 96 -> 216; K <= 192 in row slabs of <= 8 row tiles for M <= 512: layer-4
+// conv1, 192 -> 432 as 2 x 7 row tiles with 144 weight registers per wave): wave = row tile, the whole contraction in its registers, no partner:
+// 96 -> 216 0.143-0.144 ms against 0.157-0.158 ms (pws_kernel), 192 -> 432 @7x7 0.131-0.133 ms against 0.217-0.221 ms (pw_deep_kernel).
 // Two-slice shapes: stride 1, 128 < K <= 224 (an even number of k-blocks), 32 < M <= 128, Q % 4 == 0; forward (layer-3 conv3: 216 -> 96) and the
 // data gradient without act' epilogue / compact shortcut gradient (layer-3 conv1: contraction over its 216 output channels, two staged
 // tensors); everything else stays with pws_kernel / pw_deep_kernel.  Measured (8 clips x T = 256, @14x14, same box, against the
@@ -66,9 +67,13 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
     constexpr int NST = (NKB + PWK_WAVES - 1) / PWK_WAVES;                  // k-blocks a wave stages per tile (<= 2)
     static_assert(NST <= 2, "at most 16 k-blocks");
     const int tid = threadIdx.x, wave = cfn_uni(tid >> 6), lane = tid & 63, kg = lane >> 5, j = lane & 31;
-    const int K = a.K, M = a.M, Q = a.Q;
+    const int K = a.K, Mfull = a.M, Q = a.Q;
     const unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
-    const int wg = L % a.nstrips, n = L / a.nstrips;
+    // row slabs (one-slice forward with more than 8 row tiles: layer-4 conv1, 192 -> 432 as 2 x 7 row tiles) run side by side on the
+    // same positions: the second slab's activation reads hit the XCD's L2
+    const int slab = L % a.mtiles, Lr = L / a.mtiles;
+    const int wg = Lr % a.nstrips, n = Lr / a.nstrips;
+    const int m0 = slab * a.kres, M = min(a.kres, Mfull - m0);             // this workgroup's rows m0 .. m0 + M - 1
     const int nrt = (M + 31) >> 5;                                          // row tiles (<= 8 / KS)
 
     unsigned char* Bs = smem;                                               // [2 buffers][3 terms][32 positions][PITCH]
@@ -86,27 +91,36 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
         const int kbase = ks * WC;
         const bool vec = (a.Cin & 3) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
         if (MODE == PW_FWD) {                                               // w is (M, K): the wave's rows are contiguous runs along k
-            float* wtmp = reinterpret_cast<float*>(smem) + wave * (32 * (WC + 4));
-            for (int e = lane; e < 32 * (WC / 4); e += 64) {
-                const int rr = e / (WC / 4), k4 = (e - rr * (WC / 4)) * 4, k = kbase + k4;
-                f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (mt * 32 + rr < M) {
-                    const float* src = a.w + (long)(mt * 32 + rr) * a.Cin + k;
-                    if (vec && k + 3 < K) v = *reinterpret_cast<const f4v*>(src);
-                    else { if (k < K) v.x = src[0]; if (k + 1 < K) v.y = src[1]; if (k + 2 < K) v.z = src[2]; if (k + 3 < K) v.w = src[3]; }
-                }
-                *reinterpret_cast<f4v*>(wtmp + rr * (WC + 4) + k4) = v;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            constexpr int CH = NKS > 6 ? 6 : NKS, WCC = CH * 16;           // k-blocks per pass (8 waves x 32 rows x 100 floats = 100 KB of LDS)
+            float* wtmp = reinterpret_cast<float*>(smem) + wave * (32 * (WCC + 4));
 #pragma unroll
-            for (int kbl = 0; kbl < NKS; ++kbl) {
-                float v[8];
-                const float* p = wtmp + j * (WC + 4) + kbl * 16 + kg * 8;
-                const f4v lo = *reinterpret_cast<const f4v*>(p), hi = *reinterpret_cast<const f4v*>(p + 4);
-                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-                pwk_split8(v, Wr[kbl]);
+            for (int c0 = 0; c0 < NKS; c0 += CH) {
+                for (int e = lane; e < 32 * (WCC / 4); e += 64) {
+                    const int rr = e / (WCC / 4), k4 = (e - rr * (WCC / 4)) * 4, k = kbase + c0 * 16 + k4;
+                    f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (mt * 32 + rr < M) {
+                        const float* src = a.w + (long)(m0 + mt * 32 + rr) * a.Cin + k;
+                        if (vec && k + 3 < K) v = *reinterpret_cast<const f4v*>(src);
+                        else { if (k < K) v.x = src[0]; if (k + 1 < K) v.y = src[1]; if (k + 2 < K) v.z = src[2]; if (k + 3 < K) v.w = src[3]; }
+                    }
+                    *reinterpret_cast<f4v*>(wtmp + rr * (WCC + 4) + k4) = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int kbl = 0; kbl < CH; ++kbl) {
+                    if (c0 + kbl < NKS) {
+                        float v[8];
+                        const float* p = wtmp + j * (WCC + 4) + kbl * 16 + kg * 8;
+                        const f4v lo = *reinterpret_cast<const f4v*>(p), hi = *reinterpret_cast<const f4v*>(p + 4);
+                        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+                        pwk_split8(v, Wr[c0 + kbl]);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         } else {                                                            // w is (K, M): 32 consecutive m per k row
             float* wtmp = reinterpret_cast<float*>(smem) + wave * (WC * 36);
@@ -114,7 +128,7 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
                 const int kk = e >> 3, m4 = (e & 7) * 4, k = kbase + kk, m = mt * 32 + m4;
                 f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (k < K) {
-                    const float* src = a.w + (long)k * a.Cin + m;
+                    const float* src = a.w + (long)k * a.Cin + m0 + m;
                     if (vec && m + 3 < M) v = *reinterpret_cast<const f4v*>(src);
                     else { if (m < M) v.x = src[0]; if (m + 1 < M) v.y = src[1]; if (m + 2 < M) v.z = src[2]; if (m + 3 < M) v.w = src[3]; }
                 }
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
     __amdgpu_buffer_rsrc_t rs = cfn_rsrc(const_cast<float*>(a.src + (long)n * K * Q), (unsigned)((long)K * Q * 4));
     __amdgpu_buffer_rsrc_t rs2 = cfn_rsrc(const_cast<float*>((TWO ? a.src2 : a.src) + (long)n * K * Q), (unsigned)((long)K * Q * 4));
     const int mrows = max(min(32, M - mt * 32), 0);
-    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.dst + (long)n * M * Q + (long)mt * 32 * Q, (unsigned)((long)mrows * Q * 4));
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.dst + (long)n * Mfull * Q + (long)(m0 + mt * 32) * Q, (unsigned)((long)mrows * Q * 4));
     const int ntiles = (Q + 31) / 32, tstep = a.nstrips;
     const int lane_ld = kg * 8 * Q * 4 + j * 4;
     const int rd_off = j * PITCH + kg * 16;                                 // + kb * 32: A operand (row = position j, k = kb*16 + kg*8 + i)
@@ -297,8 +311,8 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
         ssum += __shfl_xor(ssum, 32, 64);
         qsum += __shfl_xor(qsum, 32, 64);
         if (kg == 0 && row < M) {
-            atomicAdd(&a.s1[(long)n * M + row], (double)ssum);
-            atomicAdd(&a.s2[(long)n * M + row], (double)qsum);
+            atomicAdd(&a.s1[(long)n * Mfull + m0 + row], (double)ssum);
+            atomicAdd(&a.s2[(long)n * Mfull + m0 + row], (double)qsum);
         }
     }
 }
@@ -339,25 +353,27 @@ int pwk_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
     const int nkb = cfn_cdiv(a.K, 16);
     int KS;
     if (a.K > 128 && a.K <= 224 && a.M > 32 && a.M <= 128 && !(nkb & 1)) KS = 2;        // two equal slices
-    else if (a.K >= 48 && a.K <= 112 && a.M > 128 && a.M <= 256 && mode == PW_FWD) KS = 1;
+    else if (a.K >= 48 && a.K <= (a.M > 256 ? 192 : 112) && a.M > 128 && a.M <= 512 && mode == PW_FWD) KS = 1;   // deep + many rows: two slabs
     else return -1;
     if (mode == PW_DGRAD ? !(on & 2) : !(on & (KS == 2 ? 1 : 4))) return -1;
     if (a.act != CFN_ACT_NONE && a.act != CFN_ACT_RELU && a.act != CFN_ACT_SWISH) return -1;
     if ((long)a.K * a.Q * 4 >= 0x3ffffff0L || (long)a.M * a.Q * 4 >= 0x3ffffff0L) return -1;
     if (((uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)(a.src2 ? a.src2 : a.src)) & 15) return -1;
     const int KP = 16 * nkb, nrt = cfn_cdiv(a.M, 32), NKS = (nkb + KS - 1) / KS;
-    size_t lds = (size_t)2 * 3 * 32 * (KP * 2 + 16) + (size_t)KP * 16 + (size_t)KS * nrt * 2 * 32 * 36 * 4;
-    const size_t wtmp = (size_t)PWK_WAVES * (mode == PW_FWD ? 32 * (NKS * 16 + 4) : NKS * 16 * 36) * 4;
+    size_t lds = (size_t)2 * 3 * 32 * (KP * 2 + 16) + (size_t)KP * 16 + (size_t)KS * (nrt > 8 ? cfn_cdiv(nrt, cfn_cdiv(nrt, 8)) : nrt) * 2 * 32 * 36 * 4;
+    const size_t wtmp = (size_t)PWK_WAVES * (mode == PW_FWD ? 32 * ((NKS > 6 ? 6 : NKS) * 16 + 4) : NKS * 16 * 36) * 4;
     if (wtmp > lds) lds = wtmp;
     if (lds > 160 * 1024) return -1;
     PwArgs b = a;
+    const int slabs = KS == 1 ? cfn_cdiv(nrt, 8) : 1, rts = cfn_cdiv(nrt, slabs);       // row tiles per slab (<= 8)
+    b.mtiles = slabs; b.kres = KS == 1 ? 32 * rts : a.M;
     const int ntiles = cfn_cdiv(a.Q, 32);
     static const int wg_env = getenv("CFN_PWK_WGS") ? atoi(getenv("CFN_PWK_WGS")) : 0;
-    long wgs = cfn_cdiv(wg_env > 0 ? wg_env : 256, (long)a.N);              // one workgroup per CU (128 / 192 / 256 / 384 / 512: 0.30 / 0.22 / 0.176 / 0.23 / 0.185 ms)
+    long wgs = cfn_cdiv(wg_env > 0 ? wg_env : 256, (long)a.N * slabs);      // one workgroup per CU (128 / 192 / 256 / 384 / 512: 0.30 / 0.22 / 0.176 / 0.23 / 0.185 ms)
     if (wgs > ntiles) wgs = ntiles;
     if (wgs < 1) wgs = 1;
     b.nstrips = (int)wgs;
-    const unsigned blocks = (unsigned)((long)a.N * wgs);
+    const unsigned blocks = (unsigned)((long)a.N * wgs * slabs);
     if (KS == 2) {
         switch (nkb) {
             case 10: return pwk_go<10, 2>(b, mode, stats, blocks, lds, st);
@@ -372,6 +388,7 @@ int pwk_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
         case 5: return pwk_go<5, 1>(b, mode, stats, blocks, lds, st);
         case 6: return pwk_go<6, 1>(b, mode, stats, blocks, lds, st);
         case 7: return pwk_go<7, 1>(b, mode, stats, blocks, lds, st);
+        case 12: return pwk_go<12, 1>(b, mode, stats, blocks, lds, st);
         default: return -1;
     }
 }

@@ -175,6 +175,10 @@ PWK1_CASES = [
     (1, 112, 256, 2, 4, 4),       # the largest shape served
     (1, 64, 129, 2, 4, 4),        # 129 rows: a row tile of a single row
     (1, 100, 200, 1, 6, 6),       # K % 16 = 4
+    (2, 192, 432, 2, 7, 7),       # X3D layer-4 conv1 forward: two slabs of 7 row tiles, 12 k-blocks in registers, 98 positions (not % 4: declined)
+    (1, 192, 432, 4, 7, 7),       # the same with 196 positions
+    (1, 176, 300, 2, 4, 4),       # 11 k-blocks: not instantiated, falls through
+    (1, 192, 512, 1, 4, 4),       # 16 row tiles: two slabs of 8
 ]
 
 
