@@ -19,7 +19,9 @@
 // 96 -> 216 0.143-0.144 ms against 0.157-0.158 ms (pws_kernel), 192 -> 432 @7x7 0.131-0.133 ms against 0.217-0.221 ms (pw_deep_kernel).
 // Two-slice shapes: stride 1, 128 < K <= 224 (an even number of k-blocks), 32 < M <= 128, Q % 4 == 0; forward (layer-3 conv3: 216 -> 96) and the
 // data gradient without act' epilogue / compact shortcut gradient (layer-3 conv1: contraction over its 216 output channels, two staged
-// tensors); everything else stays with pws_kernel / pw_deep_kernel.  Measured (8 clips x T = 256, @14x14, same box, against the
+// tensors); one-slice shapes without slabs also WITH the act' epilogue (layer-3 conv3 data gradient, K = 96 -> 216 rows: the forward input
+// of the tile is fetched in whole lines during the tile's MFMAs and crosses the wave's scratch into the lane = channel layout; 0.248 -> 0.234 ms
+// against pws_kernel); everything else stays with pws_kernel / pw_deep_kernel.  Measured (8 clips x T = 256, @14x14, same box, against the
 // fp32-MFMA pw_deep_kernel): forward 0.176-0.179 vs 0.218-0.219 ms, data gradient 0.214-0.215 vs 0.232-0.233 ms.
 #include "pw_common.h"
 #include <stdlib.h>
@@ -165,6 +167,12 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
     __amdgpu_buffer_rsrc_t rs2 = cfn_rsrc(const_cast<float*>((TWO ? a.src2 : a.src) + (long)n * K * Q), (unsigned)((long)K * Q * 4));
     const int mrows = max(min(32, M - mt * 32), 0);
     __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.dst + (long)n * Mfull * Q + (long)(m0 + mt * 32) * Q, (unsigned)((long)mrows * Q * 4));
+    // DGRAD + STATS: act' epilogue.  dz = e act'(ea x + eb), out = dz ea, sums of dz x and dz per row; x = the conv's forward input
+    // (rows = this kernel's output rows).  The lane's channel is fixed for the whole launch: its two coefficients live in registers.
+    constexpr bool EPI = MODE == PW_DGRAD && STATS;
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<float*>(EPI ? a.ex + (long)n * Mfull * Q + (long)(m0 + mt * 32) * Q : a.src), EPI ? (unsigned)((long)mrows * Q * 4) : 0u);
+    const float cea = (EPI && row < M) ? (float)a.ea[(long)n * Mfull + m0 + row] : 1.0f;
+    const float ceb = (EPI && row < M) ? (float)a.eb[(long)n * Mfull + m0 + row] : 0.0f;
     const int ntiles = (Q + 31) / 32, tstep = a.nstrips;
     const int lane_ld = kg * 8 * Q * 4 + j * 4;
     const int rd_off = j * PITCH + kg * 16;                                 // + kb * 32: A operand (row = position j, k = kb*16 + kg*8 + i)
@@ -201,6 +209,14 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
         cfn_bst128(__builtin_bit_cast(u4k, v), rd, (ok && pq0 >= 0) ? lane_mem + sx * 8 * Q * 4 : PWK_OOB, cfn_uni(pq0 >= 0 ? pq0 * 4 : 0));
     };
     f16v acc;
+    f4v xe[EPI ? 4 : 1];                                                    // (EPI) forward input of the tile being multiplied, memory-side layout
+    auto xe_issue = [&](int q0) {                                           // whole 128-byte lines: lane = (row mrow + 8 sx, 16 bytes at position mcol)
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) {
+            const bool ok = 8 * sx + mrow < mrows && q0 + mcol < Q;
+            xe[sx] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? lane_mem + sx * 8 * Q * 4 : PWK_OOB, cfn_uni(q0 * 4), 0));
+        }
+    };
     // owner: own accumulators + the partner's partial (scratch half PARV of `red`) -> statistics, transposed tile into scratch half PARV
     auto finish = [&](int PARV, int q0) {
         const bool full = q0 + 32 <= Q && mrows == 32;                      // wave uniform
@@ -208,12 +224,24 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
         const float* pr = red + PARV * (32 * 36);
         const bool chv = j < mrows;
         f4v s1v = {0.0f, 0.0f, 0.0f, 0.0f}, s2v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (EPI) {                                                          // x of this tile: memory-side registers -> scratch -> lane = channel
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) *reinterpret_cast<f4v*>(sb + (mrow + 8 * sx) * 36 + mcol) = xe[sx];
+            wsync();
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f4v o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
             if (KS == 2) o += *reinterpret_cast<const f4v*>(pr + j * 36 + 8 * g + 4 * kg);
-            if (STATS) {
-                const float gmask = (full || (chv && q0 + 8 * g + 4 * kg < Q)) ? 1.0f : 0.0f;
+            const float gmask = (full || (chv && q0 + 8 * g + 4 * kg < Q)) ? 1.0f : 0.0f;
+            if (EPI) {
+                const f4v xs = *reinterpret_cast<const f4v*>(sb + j * 36 + 8 * g + 4 * kg);     // read before the cell is overwritten below
+                f4v dz;
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) dz[e4] = o[e4] * cfn_act_grad<ACT>(fmaf(xs[e4], cea, ceb)) * gmask;
+                s1v = __builtin_elementwise_fma(dz, xs, s1v); s2v += dz;
+                o = dz * cea;
+            } else if (STATS) {
                 const f4v om = o * gmask;
                 s1v += om; s2v = __builtin_elementwise_fma(om, om, s2v);
             }
@@ -249,6 +277,7 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
         if (!has_rows) return;
         constexpr int pbuf = PAR ^ 1;
         if (owner && have) finish(pbuf, hq0);                               // the previous tile: its partner's partial was written before this barrier
+        if (EPI && owner) xe_issue(cfn_uni(tile * 32));                     // this tile's forward input travels during its MFMAs
         f4v dv[4];
         bf16x8k AA[2][3];                                                   // the operands of k-block kbl + 1 are read before the MFMAs of kbl issue
         const int kb0 = ks * NKS;
@@ -325,7 +354,15 @@ static int pwk_go(const PwArgs& a, int mode, bool stats, unsigned blocks, size_t
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * PWK_WAVES), lds, st, a);                                              \
     } while (0)
-    if (mode == PW_DGRAD) {
+    if (mode == PW_DGRAD && stats) {
+        if constexpr (KS == 1 && NKB <= 7) {
+            switch (a.act) {
+                case CFN_ACT_RELU: if (a.src2) PWK_GO(PW_DGRAD, CFN_ACT_RELU, true, true); else PWK_GO(PW_DGRAD, CFN_ACT_RELU, true, false); break;
+                case CFN_ACT_SWISH: if (a.src2) PWK_GO(PW_DGRAD, CFN_ACT_SWISH, true, true); else PWK_GO(PW_DGRAD, CFN_ACT_SWISH, true, false); break;
+                default: if (a.src2) PWK_GO(PW_DGRAD, CFN_ACT_NONE, true, true); else PWK_GO(PW_DGRAD, CFN_ACT_NONE, true, false); break;
+            }
+        }
+    } else if (mode == PW_DGRAD) {
         if (a.src2) PWK_GO(PW_DGRAD, CFN_ACT_NONE, false, true); else PWK_GO(PW_DGRAD, CFN_ACT_NONE, false, false);
     } else if (stats) {
         switch (a.act) {
@@ -346,16 +383,19 @@ static int pwk_go(const PwArgs& a, int mode, bool stats, unsigned blocks, size_t
 
 // returns -1 when the shape is not handled.  DGRAD: only without the act' epilogue (stats == false) and without the compact shortcut gradient
 int pwk_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
-    static const int on = getenv("CFN_PWK") ? atoi(getenv("CFN_PWK")) : 7;              // bit 0: forward (two k slices), bit 1: data gradient, bit 2: forward (one slice)
+    static const int on = getenv("CFN_PWK") ? atoi(getenv("CFN_PWK")) : 15;             // bit 0: forward (two k slices), bit 1: data gradient, bit 2: forward (one slice), bit 3: data gradient with act' epilogue
     if (pws_terms_now() != 6 || a.stem || a.stride != 1 || a.acc) return -1;
-    if (mode == PW_DGRAD && (stats || a.ea)) return -1;
+    if (mode == PW_DGRAD && stats && !(a.ea && a.ex && a.s1)) return -1;
     if (a.Q & 3) return -1;
     const int nkb = cfn_cdiv(a.K, 16);
     int KS;
     if (a.K > 128 && a.K <= 224 && a.M > 32 && a.M <= 128 && !(nkb & 1)) KS = 2;        // two equal slices
-    else if (a.K >= 48 && a.K <= (a.M > 256 ? 192 : 112) && a.M > 128 && a.M <= 512 && mode == PW_FWD) KS = 1;   // deep + many rows: two slabs
+    else if (a.K >= 48 && a.K <= (a.M > 256 ? 192 : 112) && a.M > 128 && a.M <= 512 && (mode == PW_FWD || stats)) KS = 1;   // deep + many rows: two slabs
     else return -1;
-    if (mode == PW_DGRAD ? !(on & 2) : !(on & (KS == 2 ? 1 : 4))) return -1;
+    if (mode == PW_DGRAD ? !(on & (stats ? 8 : 2)) : !(on & (KS == 2 ? 1 : 4))) return -1;
+    if (mode == PW_DGRAD && stats && (KS != 1 || a.M > 256)) return -1;     // act' epilogue: one-slice shapes without slabs (192 -> 432 rows: 256 VGPRs + 63 spilled
+                                                                            // dwords, 0.256 vs 0.260 ms for pw_deep_kernel: not instantiated)
+    if (mode == PW_DGRAD && stats && (((uintptr_t)a.ex) & 15)) return -1;
     if (a.act != CFN_ACT_NONE && a.act != CFN_ACT_RELU && a.act != CFN_ACT_SWISH) return -1;
     if ((long)a.K * a.Q * 4 >= 0x3ffffff0L || (long)a.M * a.Q * 4 >= 0x3ffffff0L) return -1;
     if (((uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)(a.src2 ? a.src2 : a.src)) & 15) return -1;
