@@ -92,6 +92,8 @@ class GradReducer(object):
         self._flat = [None] * nb     # static flat buffer per bucket: [gradients ..., one flag per parameter]
         self._views = [None] * nb
         self._inflight = []
+        self._rerun = False          # a gradient arrived for a bucket that had already been sent (a second backward before finish())
+        self.filled = []
         self._stream = None
         self._hooks = []
         self.suspended = False       # True while a backward is being CAPTURED (cfn_hip.graph.GraphedDPStep): no collective may enter the graph
@@ -124,11 +126,42 @@ class GradReducer(object):
             self._flat[bi], self._views[bi] = flat, views
         return self._flat[bi], self._views[bi]
 
+    def no_sync(self):
+        """Context manager for gradient accumulation (the reference's `num_steps_per_update` knob, train_fine.py:65): backward
+        passes inside it only accumulate into p.grad, nothing is sent; the LAST micro-batch's backward runs outside it and is
+        followed by finish(), which reduces the accumulated gradients.  Every rank must use it the same way."""
+        reducer = self
+
+        class _NoSync(object):
+            def __enter__(self):
+                self.prev, reducer.suspended = reducer.suspended, True
+
+            def __exit__(self, *exc):
+                reducer.suspended = self.prev
+                return False
+        return _NoSync()
+
+    def close(self):
+        """Detach from the parameters: removes the bucket hooks and withdraws the lazy-gradient-cast opt-in (it is only safe
+        while THIS reducer, which flushes before it reads, is the one reading the gradients: a torch DDP wrapped around the
+        same model afterwards reads them from hooks nobody can see)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        from . import ops
+        ops.allow_lazy_grad_cast(self.params, False)
+
     def _on_grad(self, p):
         if self.suspended:
             return
         bi = self._bucket_of[p]
         self._pending[bi] -= 1
+        if bi < self._next or self._pending[bi] < 0:
+            # gradient accumulation without no_sync(): this bucket's collective is already in flight with the FIRST backward's
+            # gradients.  p.grad holds the local sum of all passes (results are only written back in finish()), so finish()
+            # sends every bucket again, in bucket order on every rank, and the stale results are dropped.
+            self._rerun = True
+            return
         # collectives are matched across ranks by issue order: buckets are launched strictly in bucket order, a complete
         # bucket behind an incomplete one waits (for that one, or for finish())
         while self._next < len(self.buckets) and self._pending[self._next] == 0:
@@ -170,6 +203,13 @@ class GradReducer(object):
             return
         while self._next < len(self.buckets):
             self._launch(self._next)
+        if self._rerun:              # several backward passes since the last finish(): reduce the accumulated gradients
+            for work, bi in self._inflight:
+                work.wait()
+            self._inflight, self._next, self._rerun = [], 0, False
+            while self._next < len(self.buckets):
+                self._launch(self._next)
+        self.filled = []             # parameters that had no local gradient and received another rank's (GraphedDPStep checks)
         for work, bi in self._inflight:
             work.wait()
             b, flat, views = self.buckets[bi], self._flat[bi], self._views[bi]
@@ -181,6 +221,7 @@ class GradReducer(object):
                 for i, p in enumerate(b):
                     if p.grad is None and flags[i] > 0:
                         p.grad = views[i].clone()
+                        self.filled.append(p)
         self._inflight = []
         self._pending = [len(b) for b in self.buckets]
         self._next = 0

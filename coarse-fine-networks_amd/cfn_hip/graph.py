@@ -121,7 +121,15 @@ class GraphedDPStep(GraphedStep):
     `fwd_bwd(*args, *pre(*args))` must do forward + loss + backward and NOTHING collective (`pre` runs eagerly before it every step:
     the global loss normaliser); the reducer's hooks are suspended while it is captured; after every replay `reducer.finish()`
     packs / all-reduces / unpacks on its static flat buffers (gradients live at fixed addresses in the graph's pool) and a second
-    graph replays `optimizer.step()`.  Gradients are never set to None between replays."""
+    graph replays `optimizer.step()`.  Gradients are never set to None between replays.
+
+    ONE input signature is live at a time: the gradients are re-created (new addresses) by every capture, so capturing a new
+    signature DROPS the graphs of every earlier one (they and their optimizer graphs hold the old addresses: replayed, they would
+    write buffers p.grad no longer points to and the ranks would silently diverge); a signature that comes back is re-captured.
+    Every rank must produce the same set of gradients: a parameter that got its gradient from another rank only
+    (`reducer.filled`) is not part of this rank's captured optimizer graph -- that raises instead of letting the replicas drift.
+    The all-reduce runs AFTER the replayed backward (the reducer is suspended inside the capture), i.e. it is not overlapped with
+    backward as in the eager path: 13-18 MB per step, ~0.2 ms against >= 10 ms of step."""
 
     def __init__(self, fwd_bwd, reducer, optimizer, pre=None, eager_first=1, pool=None):
         super(GraphedDPStep, self).__init__(fwd_bwd, optimizer=optimizer, eager_first=eager_first, pool=pool)
@@ -149,6 +157,8 @@ class GraphedDPStep(GraphedStep):
         lr = _lr_signature(self.optimizer)
         entry = self._graphs.get(sig)
         if entry is None:
+            self._graphs.clear()                   # see the class docstring: earlier signatures hold the gradient addresses of THEIR capture
+            self._opt_graphs.clear()
             for p in self._params():
                 p.grad = None                      # backward then creates the gradients inside the graph's pool, at fixed addresses
             self.reducer.suspended = True
@@ -171,5 +181,12 @@ class GraphedDPStep(GraphedStep):
             self._copy(dst, src)
         graph.replay()
         self.reducer.finish()                      # eager: bucket order, static flat buffers, RCCL on the reducer's side stream
+        if self.reducer.filled:
+            names = len(self.reducer.filled)
+            for p in self.reducer.filled:
+                p.grad = None
+            raise RuntimeError('GraphedDPStep: %d parameter(s) have a gradient on another rank but none in this rank\'s captured '
+                               'step; the captured optimizer graph would skip them and the replicas would diverge -- run this '
+                               'model with the eager GradReducer path' % names)
         og[0].replay()
         return static_out

@@ -145,14 +145,14 @@ def flush_grad_casts():
     _tls.gradcast.flush()
 
 
-def allow_lazy_grad_cast(params):
+def allow_lazy_grad_cast(params, ok=True):
     """Opt parameters in to the lazily cast weight gradients (_GradCast): their gradient may be handed to autograd as a view
     that is filled at the end of the backward pass.  ONLY for parameters whose every reader inside the pass calls
     flush_grad_casts() first -- cfn_hip.dist.GradReducer does and opts its parameters in.  Anything else (torch DDP / FSDP
     reducers and other hooks on the AccumulateGrad node, which cannot be detected from here) keeps the default: an immediate
     cast, one small kernel per weight gradient."""
     for p in params:
-        p._cfn_lazy_grad_ok = True
+        p._cfn_lazy_grad_ok = bool(ok)
 
 
 def _lazy_ok(w):
@@ -386,6 +386,9 @@ def pwconv(x, w, A=None, B=None, act=ACT_NONE, stride=1, stats=True, token=None,
     step = max((lim - 1) // span, 1)
     odd_plane = es == 2 and (Ho * Wo) % 2 == 1       # bf16 kernels need an even position count: even frame counts then
     if odd_plane:
+        if 2 * span >= lim:
+            raise RuntimeError('pwconv: two frames of %d x %d x %d bf16 elements exceed the 1 GiB buffer range the frame-range '
+                               'chunking has to respect (odd plane: frames travel in pairs)' % (max(Cin, w.shape[0]), H, W))
         step = max(step & ~1, 2)
     y = torch.empty(N, w.shape[0], T, Ho, Wo, dtype=x.dtype, device=x.device)
     s = q = None
@@ -394,7 +397,7 @@ def pwconv(x, w, A=None, B=None, act=ACT_NONE, stride=1, stats=True, token=None,
         t1 = min(t0 + step, T)
         if odd_plane and (t1 - t0) % 2 and t1 - t0 > 1:
             t1 -= 1                               # keep the chunk even; a single odd frame is left for the end
-        pad = odd_plane and (t1 - t0) % 2 == 1     # T itself odd: the last frame travels with a zero frame (zero prologue too)
+        pad = odd_plane and (t1 - t0) % 2 == 1     # T itself odd: the last frame travels with a pad frame (its output, act(B), is sliced off below and the statistics are recomputed)
         xc = x[:, :, t0:t1].contiguous()
         if pad:
             xc = torch.cat([xc, torch.zeros_like(xc)], 2)

@@ -61,7 +61,10 @@ def _ones(n, c, device):
     key = (n, c, str(device))
     t = _ONES.get(key)
     if t is None:
-        t = _ONES[key] = torch.ones(n, c, dtype=torch.float64, device=device)
+        t = torch.ones(n, c, dtype=torch.float64, device=device)
+        if torch.device(device).type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            return t      # born in a hipGraph's private pool, filled on replay only: never shared with eager code / other graphs
+        _ONES[key] = t
     return t
 
 

@@ -237,3 +237,55 @@ def test_ranks_that_saw_different_gradients_issue_the_same_collectives():
             assert torch.allclose(ga, torch.full((3, 4), 3.0))         # mean of 2 * (rank + 1)
             assert gb is not None and torch.allclose(gb, torch.full((3, 4), 2.0))   # rank 1's 2 * 2, averaged with rank 0's zero
             assert gc is None                                          # nobody had one: stays None, as in the reference
+
+
+def _worker_accum(rank, port, out):
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD), LOCAL_RANK=str(rank))
+    from cfn_hip import dist as cdist
+    import train_fine
+    cdist.init_from_env(backend='gloo')
+    x, labels, masks = _batch()
+    res = {}
+    for mode in ('plain', 'no_sync'):
+        net = _model()
+        reducer = cdist.GradReducer(net.parameters(), bucket_bytes=256)
+        for _ in range(2):                                                # two updates: the state resets after an accumulated one
+            net.zero_grad()
+            for mb in range(2):                                           # two micro-batches per update (num_steps_per_update = 2)
+                i = rank * 2 + mb
+                cls, loc, _ = train_fine.detection_loss(net(x[i:i + 1]), labels[i:i + 1], masks[i:i + 1], align_corners=False)
+                if mode == 'no_sync' and mb == 0:
+                    with reducer.no_sync():
+                        ((cls + loc) / 4).backward()
+                else:
+                    ((cls + loc) / 4).backward()
+            reducer.finish()
+        res[mode] = [p.grad.clone() for p in net.parameters()]
+        reducer.close()
+        assert not any(getattr(p, '_cfn_lazy_grad_ok', False) for p in net.parameters()) and not reducer._hooks
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulation_two_backwards_per_finish():
+    """a second backward() before finish() used to be dropped (the first pass's averaged snapshot was
+    copied over the accumulated p.grad).  Both spellings -- plain (every bucket is re-sent by finish()) and no_sync() -- must
+    give the mean over ranks of the per-rank accumulated gradients; the reference keeps the knob (train_fine.py:65)."""
+    sys.path.insert(0, PKG)
+    import train_fine
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker_accum, args=(port, out), nprocs=WORLD, join=True)
+    x, labels, masks = _batch()
+    net = _model()
+    for mb in range(2):      # the gathered micro-batch = what DataParallel would have seen: rank 0's and rank 1's sample mb
+        i = [mb, 2 + mb]
+        cls, loc, _ = train_fine.detection_loss(net(x[i]), labels[i], masks[i], align_corners=False)
+        ((cls + loc) / 4).backward()
+    ref = [p.grad for p in net.parameters()]
+    for rank in range(WORLD):
+        for mode in ('plain', 'no_sync'):
+            for g, r in zip(out[rank][mode], ref):
+                assert torch.allclose(g, r, rtol=1e-5, atol=1e-7), mode
