@@ -7,6 +7,11 @@
 //     result up-sampled is identical (measured 3e-8).
 #include "cfn_common.h"
 
+// salconv.hip
+int sal_dgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
+                         const double* A, const double* B, int act, float* gx, double* gA, double* gB, int N, int Cin, int Cout,
+                         int T, int Hi, int Wi, const int* g, hipStream_t st);
+
 // ---------------------------------------------------------------------------------------------------------
 // gx[n,ci,it,ih,iw] = act'(A x + B) * A * sum_{co, taps hitting (it,ih,iw)} W[co,ci,kt,kh,kw] * g'[n,co,to,oh,ow]
 // with g' = gy + gs[n,co] + 2 y gq[n,co];  gA += sum dz*x, gB += sum dz.
@@ -209,6 +214,10 @@ extern "C" int cfn_conv3d_dense_bwd_data(const float* gy, const float* y, const 
     const long pin = (long)T * Hi * Wi;
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_STEM, st, 4.0 * N * ((double)Cin * pin * 2 + (double)Cout * a.To * a.Ho * a.Wo));
+    {   // LDS-tiled MFMA kernel (salconv.hip) for the Grid Pool saliency shapes
+        const int rs = sal_dgrad_try_launch(gy, a.y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, N, Cin, Cout, T, Hi, Wi, geom, st);
+        if (rs >= 0) return rs;
+    }
     const int ncls = a.sT * a.sH * a.sW;
     const long pcls = (long)cfn_cdiv(T, a.sT) * cfn_cdiv(Hi, a.sH) * cfn_cdiv(Wi, a.sW);     // largest class
     {   // all-input-channels variant when the whole layer's weights fit in LDS

@@ -746,11 +746,15 @@ extern "C" int cfn_conv3d_dense_fwd(const float* x, const double* A, const doubl
     int rc = dense_geom(a, Cin, T, Hi, Wi, geom);
     if (rc) return rc;
     a.N = N; a.M = Cout; a.K = Cin * a.kT * a.kH * a.kW; a.Cin = a.K;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DENSE_FWD, st, 4.0 * N * ((double)Cin * a.Pin + (double)Cout * a.Q));
+    {   // LDS-tiled kernel (salconv.hip) for the Grid Pool saliency shapes (24 channels, 3x3x3 stride 2, 56 / 28 wide planes)
+        const int rs = sal_fwd_try_launch(x, A, B, act, w, y, sum, sumsq, N, Cin, Cout, T, Hi, Wi, geom, st);
+        if (rs >= 0) return rs;
+    }
     int MT; unsigned blocks; size_t lds;
     rc = pw_plan(a, MT, blocks, lds);
     if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    CfnProfScope prof(CFN_K_DENSE_FWD, st, 4.0 * N * ((double)Cin * a.Pin + (double)Cout * a.Q));
     if (sum) {
         if (act == CFN_ACT_RELU) return pw_launch_mt<PW_FWD, true, CFN_ACT_RELU, true>(a, MT, blocks, lds, st);
         return pw_launch_mt<PW_FWD, true, CFN_ACT_NONE, true>(a, MT, blocks, lds, st);

@@ -478,6 +478,13 @@ DENSE_CASES = [
     (1, 5, 7, 5, 9, 7, (3, 3, 3), (2, 2, 2), (1, 1, 1), 1, True),
     (1, 24, 24, 6, 16, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1), 1, True),   # Wo % 4 == 0: direct im2col weight gradient
     (2, 6, 40, 5, 16, 24, (1, 3, 3), (1, 2, 2), (0, 1, 1), 1, True),
+    # the Grid Pool saliency shapes at their real planes (csrc/salconv.hip): conv1 56 -> 28 without prologue, conv2 28 -> 14 with
+    # the ReLU prologue; odd / even / single frame counts, several t-chunks, a ragged last band (28-wide: 14 output rows in bands of 8)
+    (2, 24, 24, 9, 56, 56, (3, 3, 3), (2, 2, 2), (1, 1, 1), 0, False),
+    (1, 24, 24, 12, 28, 28, (3, 3, 3), (2, 2, 2), (1, 1, 1), 1, True),
+    (1, 24, 24, 1, 56, 56, (3, 3, 3), (2, 2, 2), (1, 1, 1), 1, True),
+    (1, 24, 20, 34, 28, 28, (3, 3, 3), (2, 2, 2), (1, 1, 1), 0, False),
+    (1, 24, 24, 5, 20, 56, (3, 3, 3), (2, 2, 2), (1, 1, 1), 1, True),
 ]
 
 
