@@ -79,3 +79,6 @@ int stem_fwd_try_launch(const float* x, const float* w, float* y, int N, int Cim
 // planes 56 or 28 wide, even height); -1 = not handled
 int sal_fwd_try_launch(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum,
                        double* sumsq, int N, int Cin, int Cout, int T, int Hi, int Wi, const int* g, hipStream_t st);
+int sal_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const double* A,
+                         const double* B, int act, double* gw, int N, int Cin, int Cout, int T, int Hi, int Wi, const int* g,
+                         hipStream_t st);

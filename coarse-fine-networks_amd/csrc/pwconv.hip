@@ -778,6 +778,10 @@ extern "C" int cfn_conv3d_dense_bwd_weight(const float* gy, const float* y, cons
     wg_plan(a, MTW, NTW);
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_STEM, st, 4.0 * N * ((double)Cin * a.Pin + (double)Cout * a.Q));
+    {   // LDS-tiled persistent kernel (salconv.hip) for the Grid Pool saliency shapes
+        const int rs = sal_wgrad_try_launch(gy, a.y, gsum, gsumsq, x, A, B, act, gw, N, Cin, Cout, T, Hi, Wi, geom, st);
+        if (rs >= 0) return rs;
+    }
     {
         const int rd = pwd_wgrad_try_dense(gy, a.y, gsum, gsumsq, x, A, B, act, gw, N, Cout, Cin, T, Hi, Wi, geom, st);
         if (rd >= 0) return rd;

@@ -518,3 +518,229 @@ int sal_dgrad_try_launch(const float* gy, const float* y, const double* gs, cons
 #undef SAL_DG
     return cfn_check_launch("sal_conv_dgrad");
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight gradient:  gW[co][ci][kt][kh][kw] = sum_{n, to, oh, ow} g'[n][co][to][oh][ow] * a[n][ci][2 to - 1 + kt][2 oh - 1 + kh][2 ow - 1 + kw],
+// a = relu(A x + B) (zero padded).  Implicit GEMM  M = co, N = the 648 columns (ci, tap), K = positions  on v_mfma_f32_32x32x2_f32:
+//   * a PERSISTENT workgroup (8 waves, two per SIMD) walks over work items (sample, band of RB output rows, chunk of output
+//     frames) and keeps its share of gW in registers across all of them: wave w owns the column tiles w, w + 8, w + 16 (21 tiles of
+//     32 columns), 48 accumulator registers; one fp64 atomic per element and workgroup at the very end;
+//   * per output frame the workgroup stages the two new input frames of its band (prologue applied, zero halo) into a ring of
+//     three frame slots (the even frame's slot and the dead odd one) and the band's g' rows as [co][57]; operands of every MFMA:
+//     A = g'[co = lane][position pair] (read once per wave, used by its three tiles), B = image at a per-lane tap base
+//     + immediate position offset;
+//   * loads for step to + 1 are in flight during the MFMAs of step to, written behind a barrier.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int WI, bool PRO, bool HASY>
+__global__ __launch_bounds__(512, 2) void sal_wgrad_kernel(const SalBwdArgs a) {
+    constexpr int WO = WI / 2, RB = 56 / WO, RIN = 2 * RB + 1, PITCH = WI + 4, W4 = WI / 4;
+    constexpr int FR = SAL_CIN * RIN * PITCH, KQ = RB * WO, GPB = KQ + 1, OOB = 0x7fff0000;
+    constexpr int XU = SAL_CIN * RIN * W4, NXU = (XU + 511) / 512;          // float4 units per frame and thread
+    constexpr int GU = SAL_CIN * KQ / 2, NGU = (GU + 511) / 512;            // float2 units of g' per step and thread
+    static_assert(KQ == 56 && WO % 2 == 0, "geometry");
+    extern __shared__ __attribute__((aligned(16))) float smem[];            // img[3 slots][24][RIN][PITCH] | gbuf[24][57] | coefficient tables
+    float* img = smem;
+    float* gbuf = smem + 3 * FR;
+    float* tab = gbuf + SAL_CIN * GPB;                                      // pa[24] pb[24] gs[24] 2gq[24]
+    const int tid = threadIdx.x, lane = tid & 63, wave = cfn_uni(tid >> 6), h = lane >> 5, p = lane & 31;
+    const int T = a.T, To = a.To, Hi = a.Hi, Ho = a.Ho;
+    const long P = (long)Hi * WI, PO = (long)Ho * WO;
+
+    for (int i = tid; i < 3 * FR; i += 512) img[i] = 0.0f;                  // the halo column stays zero for good
+
+    // B operand bases of this wave's column tiles: column = (ci, kt, kh, kw); two slot patterns (parity of the output frame)
+    int bb[2][3];
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) {
+        int col = (wave + 8 * tt) * 32 + p;
+        if (col >= 648) col = 0;
+        const int ci = col / 27, tap = col - ci * 27, kt = tap / 9, kh = (tap - kt * 9) / 3, kw = tap - kt * 9 - kh * 3;
+        const int off = (ci * RIN + kh) * PITCH + kw + 3 + 2 * h;
+        // frames 2 to - 1, 2 to, 2 to + 1 sit in slots (even to) 2, 0, 1 / (odd to) 1, 0, 2
+        bb[0][tt] = (kt == 0 ? 2 : kt == 1 ? 0 : 1) * FR + off;
+        bb[1][tt] = (kt == 0 ? 1 : kt == 1 ? 0 : 2) * FR + off;
+    }
+    const int ab = min(p, 23) * GPB + h;
+    const bool t2 = wave + 16 < 21;                                         // waves 5-7 own two tiles only
+
+    sv16 acc[3];
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
+
+    const int items = a.ngroups;
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int band = item % a.bands, chunk = (item / a.bands) % a.nchunks, n = item / (a.bands * a.nchunks);
+        const int to0 = chunk * a.CH, nst = min(a.CH, To - to0);
+        const int oh0 = band * RB, ih0 = 2 * oh0 - 1;
+        __syncthreads();                                                    // the previous item's reads are done
+        if (tid < 24) {
+            tab[tid] = PRO ? (float)a.pa[(long)n * 24 + tid] : 1.0f;
+            tab[24 + tid] = PRO ? (float)a.pb[(long)n * 24 + tid] : 0.0f;
+            tab[48 + tid] = a.gs ? (float)a.gs[(long)n * 24 + tid] : 0.0f;
+            tab[72 + tid] = (HASY && a.gq) ? 2.0f * (float)a.gq[(long)n * 24 + tid] : 0.0f;
+        }
+        // staging units of this thread
+        int xo[NXU], xl[NXU], xc[NXU];
+#pragma unroll
+        for (int k = 0; k < NXU; ++k) {
+            const int e = k * 512 + tid;
+            const int rowid = e / W4, c4 = e - rowid * W4, ci = rowid / RIN, r = rowid - ci * RIN, ih = ih0 + r;
+            const bool in = e < XU;
+            xo[k] = (in && ih >= 0 && ih < Hi) ? (int)((((long)ci * T * Hi + ih) * WI + c4 * 4) * 4) : OOB;
+            xl[k] = in ? (ci * RIN + r) * PITCH + 4 + c4 * 4 : -1;
+            xc[k] = in ? ci : 0;
+        }
+        int go[NGU], gl[NGU], gc[NGU];
+#pragma unroll
+        for (int k = 0; k < NGU; ++k) {
+            const int e = k * 512 + tid;
+            const int co = e / (KQ / 2), q2 = e - co * (KQ / 2);
+            const bool in = e < GU;
+            const int row = (2 * q2) / WO;
+            go[k] = (in && oh0 + row < Ho) ? (int)((((long)co * To * Ho + oh0) * WO + 2 * q2) * 4) : OOB;
+            gl[k] = in ? co * GPB + 2 * q2 : -1;
+            gc[k] = in ? co : 0;
+        }
+        __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + (long)n * 24 * T * P, (unsigned)((long)24 * T * P * 4));
+        __amdgpu_buffer_rsrc_t rgy = cfn_rsrc(a.gy + (long)n * 24 * To * PO, (unsigned)((long)24 * To * PO * 4));
+        __amdgpu_buffer_rsrc_t ry = cfn_rsrc((HASY ? a.y : a.gy) + (long)n * 24 * To * PO, (unsigned)((long)24 * To * PO * 4));
+        sv4 fx[2][NXU];
+        sv2 fg[NGU], fy[HASY ? NGU : 1];
+        auto fetch_x = [&](int which, int f) {                              // frames outside the clip read nothing
+            const bool want = f >= 0 && f < T;
+            const int so = cfn_uni(want ? (int)(f * P * 4) : 0);
+#pragma unroll
+            for (int k = 0; k < NXU; ++k) fx[which][k] = __builtin_bit_cast(sv4, __builtin_amdgcn_raw_buffer_load_b128(rx, want ? xo[k] : OOB, so, 0));
+        };
+        auto put_x = [&](int which, int slot, int f) {                      // every unit is written: rows / frames outside the clip are zero AFTER the prologue
+            const bool fin = f >= 0 && f < T;
+#pragma unroll
+            for (int k = 0; k < NXU; ++k) {
+                if (xl[k] >= 0) {
+                    sv4 v = fx[which][k];
+                    if (PRO) {
+                        const float ua = tab[xc[k]], ub = tab[24 + xc[k]];
+                        v.x = fmaxf(fmaf(v.x, ua, ub), 0.0f); v.y = fmaxf(fmaf(v.y, ua, ub), 0.0f);
+                        v.z = fmaxf(fmaf(v.z, ua, ub), 0.0f); v.w = fmaxf(fmaf(v.w, ua, ub), 0.0f);
+                    }
+                    if (!fin || xo[k] == OOB) v = (sv4){0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<sv4*>(img + slot * FR + xl[k]) = v;
+                }
+            }
+        };
+        auto fetch_g = [&](int to) {
+            const int so = cfn_uni((int)(to * PO * 4));
+#pragma unroll
+            for (int k = 0; k < NGU; ++k) {
+                fg[k] = __builtin_bit_cast(sv2, __builtin_amdgcn_raw_buffer_load_b64(rgy, go[k], so, 0));
+                if (HASY) fy[k] = __builtin_bit_cast(sv2, __builtin_amdgcn_raw_buffer_load_b64(ry, go[k], so, 0));
+            }
+        };
+        auto put_g = [&]() {
+#pragma unroll
+            for (int k = 0; k < NGU; ++k) {
+                if (gl[k] >= 0) {
+                    sv2 v = {0.0f, 0.0f};
+                    if (go[k] != OOB) {
+                        v = fg[k] + tab[48 + gc[k]];
+                        if (HASY) { const float q0 = tab[72 + gc[k]]; v.x = fmaf(fy[k].x, q0, v.x); v.y = fmaf(fy[k].y, q0, v.y); }
+                    }
+                    gbuf[gl[k]] = v.x; gbuf[gl[k] + 1] = v.y;
+                }
+            }
+        };
+        __syncthreads();                                                    // coefficient tables visible
+        // the chunk's first three frames (to0 is even: frame 2 to0 - 1 -> slot 2, 2 to0 -> slot 0, 2 to0 + 1 -> slot 1) and g'(to0)
+        fetch_x(0, 2 * to0 - 1); fetch_x(1, 2 * to0);
+        fetch_g(to0);
+        put_x(0, 2, 2 * to0 - 1); put_x(1, 0, 2 * to0);
+        fetch_x(0, 2 * to0 + 1);
+        put_g();
+        put_x(0, 1, 2 * to0 + 1);
+        __syncthreads();
+#define SAL_WG_STEP(PV)                                                                                                  \
+        do {                                                                                                              \
+            const int to = to0 + s + PV;                                                                                  \
+            if (s + PV < nst) {                                             /* uniform over the workgroup */              \
+                const bool more = s + PV + 1 < nst;                                                                       \
+                if (more) { fetch_x(0, 2 * to + 2); fetch_x(1, 2 * to + 3); fetch_g(to + 1); }                            \
+                _Pragma("unroll") for (int j = 0; j < KQ / 2; ++j) {                                                      \
+                    const int q = 2 * j, r = q / WO, o = (2 * r) * PITCH + 2 * (q - r * WO);                              \
+                    const float av = gbuf[ab + 2 * j];                                                                    \
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, img[bb[PV][0] + o], acc[0], 0, 0, 0);               \
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, img[bb[PV][1] + o], acc[1], 0, 0, 0);               \
+                    if (t2) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, img[bb[PV][2] + o], acc[2], 0, 0, 0);       \
+                }                                                                                                         \
+                __syncthreads();                                                                                          \
+                if (more) { put_x(0, 0, 2 * to + 2); put_x(1, PV ? 1 : 2, 2 * to + 3); put_g(); }                         \
+                __syncthreads();                                                                                          \
+            }                                                                                                             \
+        } while (0)
+        for (int s = 0; s < nst; s += 2) { SAL_WG_STEP(0); SAL_WG_STEP(1); }
+#undef SAL_WG_STEP
+    }
+    // one fp64 atomic per element and workgroup
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) {
+        const int col = (wave + 8 * tt) * 32 + p;
+        if (wave + 8 * tt < 21 && col < 648) {
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+                atomicAdd(&a.gw[(long)co * 648 + col], (double)acc[tt][r]);
+            }
+        }
+    }
+}
+
+// -1 = shape not handled
+int sal_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const double* A,
+                         const double* B, int act, double* gw, int N, int Cin, int Cout, int T, int Hi, int Wi, const int* g,
+                         hipStream_t st) {
+    static const int want[9] = {3, 3, 3, 2, 2, 2, 1, 1, 1};
+    for (int i = 0; i < 9; ++i) if (g[i] != want[i]) return -1;
+    if (Cin != SAL_CIN || Cout != 24 || (Wi != 56 && Wi != 28) || (Hi & 1) || Hi < 2 || ((uintptr_t)x & 15)) return -1;
+    if (A && act != CFN_ACT_RELU) return -1;
+    if (!A && act != CFN_ACT_NONE) return -1;
+    if (sal_env("CFN_SAL_OFF", 0) || sal_env("CFN_SAL_WGRAD_OFF", 0)) return -1;
+    if ((long)24 * T * Hi * Wi * 4 >= 0x7fff0000L) return -1;
+    SalBwdArgs a = {};
+    a.gy = gy; a.y = gq ? y : nullptr; a.gs = gs; a.gq = gq; a.x = x; a.pa = A; a.pb = B; a.gw = gw;
+    a.N = N; a.T = T; a.To = (T - 1) / 2 + 1; a.Hi = Hi; a.Ho = Hi / 2;
+    const int WO = Wi / 2, RB = 56 / WO, RIN = 2 * RB + 1, PITCH = Wi + 4;
+    a.bands = cfn_cdiv(a.Ho, RB);
+    int cus = 256;
+    { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; }
+    // chunk length (even): items spread evenly over one persistent workgroup per CU; a chunk pays one extra (halo) frame
+    int best = 2; double bestc = 1e30;
+    for (int ch = 2; ch <= 64; ch += 2) {
+        const long items = (long)N * a.bands * cfn_cdiv(a.To, ch);
+        const double per = (double)cfn_cdiv(items, cus);
+        const double cost = per * (ch + 0.75);
+        if (cost < bestc - 1e-9) { bestc = cost; best = ch; }
+    }
+    a.CH = sal_env("CFN_SAL_WG_CH", best);
+    if (a.CH < 2) a.CH = 2;
+    a.CH &= ~1;
+    a.nchunks = cfn_cdiv(a.To, a.CH);
+    const long items = (long)N * a.bands * a.nchunks;
+    if (items >= (1L << 30)) return -1;
+    a.ngroups = (int)items;
+    const long blocks = items < cus ? items : cus;
+    const size_t lds = ((size_t)3 * SAL_CIN * RIN * PITCH + (size_t)SAL_CIN * 57 + 96) * sizeof(float);
+#define SAL_WG(WIV, PROV, YV)                                                                                          \
+    do {                                                                                                               \
+        auto k = sal_wgrad_kernel<WIV, PROV, YV>;                                                                      \
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, st, a);                                          \
+    } while (0)
+#define SAL_WG2(WIV) do { if (A) { if (a.y) SAL_WG(WIV, true, true); else SAL_WG(WIV, true, false); }                  \
+                          else { if (a.y) SAL_WG(WIV, false, true); else SAL_WG(WIV, false, false); } } while (0)
+    if (Wi == 56) SAL_WG2(56); else SAL_WG2(28);
+#undef SAL_WG2
+#undef SAL_WG
+    return cfn_check_launch("sal_conv_wgrad");
+}
