@@ -90,6 +90,51 @@ ROOFLINE_FAMILIES = {'fine': ('dwconv_fwd',), 'coarse': ('dwconv_fwd', 'gridpool
                      'joint': ('dwconv_fwd', 'gridpool', 'dense_fwd')}
 
 
+def coarse_roofline(dev, B, T, steps=3, warmup=1):
+    """Figure (B) of the headline: depthwise-conv forward family + Grid Pool forward (dense saliency convs,
+    `time_sample_fwd`) of the COARSE stream at the metric's T, timed live by the same HIP events while a few x3d_coarse train
+    steps run.  Carried by the default (fine-stream) line as `roofline_coarse` so that one driver run records both figures."""
+    import cfn_hip
+    import train_coarse_fineFEAT as tc
+    from cfn_hip import dist as cdist
+    net = tc.build_model(dev, pretrained=None)
+    optimizer = optim.SGD(tc.param_groups(net, 0.02), lr=0.02, momentum=0.9, weight_decay=1e-5)
+    x, labels, masks, feat, fm, meta, _, _ = next(iter(tc.SyntheticCoarse(B, 1, T, seed=4321)))
+    x = x[:, 0].contiguous().to(dev)
+    labels, masks, fm, meta = labels.to(dev), masks.to(dev), fm.to(dev), meta.to(dev)
+    feat = {k: v.to(dev) for k, v in feat.items()}
+    net.train(True)
+    reducer = cdist.GradReducer(net.parameters())
+    for _ in range(warmup):
+        tc.train_step(net, reducer, optimizer, x, labels, masks, feat, fm, meta)
+    torch.cuda.synchronize()
+    fams = ROOFLINE_FAMILIES['coarse']
+    for f in fams:
+        cfn_hip.prof_enable(f, True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tc.train_step(net, reducer, optimizer, x, labels, masks, feat, fm, meta)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = {}
+    ms = by = 0.0
+    launches = 0
+    for f in fams:
+        cfn_hip.prof_enable(f, False)
+        m_, n_, b_ = cfn_hip.prof_collect(f)
+        per[f] = {'launches': n_, 'ms': round(m_, 3), 'GB': round(b_ / 1e9, 3)}
+        ms, launches, by = ms + m_, launches + n_, by + b_
+    reducer.close()
+    achieved = (by / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+    return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+            'kernel': 'coarse stream (x3d_coarse train step, %dx3x%dx224x224 + fine features T\'=128): depthwise conv forward family '
+                      '(conv1_t + layer-1 at T, layers 2-4 at K = T/4 + 1 frames) + Grid Pool forward (salconv.hip saliency convs, 1x3x3 '
+                      'conv3, time_sample_fwd)' % (B, T),
+            'family': per, 'launches': launches, 'avg_launch_ms': round(ms / max(launches, 1), 4),
+            'algorithmic_bytes_per_launch': round(by / max(launches, 1)), 'steps': steps,
+            'coarse_ms_per_step': round(dt / steps * 1e3, 3)}
+
+
 def _self_launch(n):
     """`python bench.py --gpus N` outside torchrun: one rank per GPU under torch.distributed.run (as train_fine._spawn)"""
     import socket
@@ -121,6 +166,7 @@ def main():
                          'headline), bf16 = BASELINE configs[1] (bf16 MFMA pointwise, fp32 accumulation and statistics)')
     ap.add_argument('--graph', action='store_true', help='replay the step from captured hipGraphs (one graph on a single GPU; with --gpus > 1: forward+backward graph, eager all-reduce, optimizer graph)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-coarse-roofline', action='store_true', help='skip the coarse-stream roofline leg (figure B) of the default line')
     ap.add_argument('--cpu-sample-frames', type=int, default=128)
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -232,7 +278,7 @@ def main():
         # passes, gfx950 correction applied) is measured offline -- bench.py cannot run under the counter tool -- and
         # committed in profiles/; quoted only for the configuration it was measured on
         traffic = traffic_note = None
-        for name in ('r03_pmc_dwfwd.json', 'r02_pmc_dwfwd.json', 'r01_pmc_dwfwd.json'):
+        for name in ('r04_pmc_dwfwd.json', 'r03_pmc_dwfwd.json', 'r02_pmc_dwfwd.json', 'r01_pmc_dwfwd.json'):
             pmc = os.path.join(ROOT, 'profiles', name)
             if not coarse and args.dtype == 'f32' and os.path.exists(pmc):
                 doc = json.load(open(pmc))
@@ -278,6 +324,11 @@ def main():
                          'launches': launches, 'avg_launch_ms': round(ms / max(launches, 1), 4),
                          'algorithmic_bytes_per_launch': round(by / max(launches, 1))},
         }
+        if world == 1 and args.stream == 'fine' and args.dtype == 'f32' and not args.graph and not args.no_coarse_roofline:
+            del losses
+            net = optimizer = reducer = x = labels = masks = None          # the fine step's tensors go back to the allocator first
+            torch.cuda.empty_cache()
+            out['roofline_coarse'] = coarse_roofline(dev, B, T)
         if world == 1 and not args.no_cpu_baseline and not joint:       # joint: the CPU legs of the two streams are reported by their own runs
             out['cpu_baseline'] = cpu_baseline(T, args.cpu_sample_frames, stream=args.stream)   # joint: none (see below)
         print(json.dumps(out), flush=True)
