@@ -785,3 +785,62 @@ time_resize.register_autograd(lambda ctx, g: (torch.ops.cfn.time_resize_backward
 
 OPERATORS = ('dwconv3d', 'pwconv', 'time_sample', 'dwconv_t5', 'stem_conv', 'conv3d_dense', 'bn_fold', 'bn_add_relu', 'affine_act',
              'pool_hw', 'interp1d', 'grid_cdf', 'gauss_align', 'fusion_gather', 'film', 'time_resize')
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# cfn_hip.ops-shaped facade over the registered operators: the CFN_USE_TORCH_OPS route of the x3d_coarse modules (GridPoolLayer,
+# GridUnpool, Gaussian, RewightLayer, MixingLayer; reference x3d_coarse.py:175-451) calls the SAME function names with the same
+# arguments, and every call goes through the dispatcher (torch.ops.cfn.*) instead of the autograd Functions of cfn_hip.ops.
+# Prologue coefficients arrive as fp64 tensors holding fp32 values (cfn_hip.ops convention); the operators' gradient formulas return
+# fp32, so they are narrowed here (lossless, differentiable).
+# ---------------------------------------------------------------------------------------------------------------------------
+def _f32(t):
+    return t if t is None or t.dtype == torch.float32 else t.float()
+
+
+class TorchOps(object):
+    @staticmethod
+    def pwconv(x, w, A=None, B=None, act=ACT_NONE, stride=1, stats=True, **_unused):
+        y, s, q = torch.ops.cfn.pwconv(x, w, _f32(A), _f32(B), act, stride)
+        return (y, s, q) if stats else (y, None, None)
+
+    @staticmethod
+    def conv3d_dense(x, w, kernel, stride, padding, A=None, B=None, act=ACT_NONE, stats=True):
+        y, s, q = torch.ops.cfn.conv3d_dense(x, w, list(kernel), list(stride), list(padding), _f32(A), _f32(B), act)
+        return (y, s, q) if stats else (y, None, None)
+
+    @staticmethod
+    def affine_act(x, A, B, act=ACT_NONE):
+        return torch.ops.cfn.affine_act(x, _f32(A), _f32(B), act)
+
+    @staticmethod
+    def pool_hw(x, OH, OW, A=None, B=None, act=ACT_NONE):
+        return torch.ops.cfn.pool_hw(x, OH, OW, _f32(A), _f32(B), act)
+
+    @staticmethod
+    def fusion_gather(x, at_raw, at_bias, GX, mask, crops=1):
+        return torch.ops.cfn.fusion_gather(x, at_raw, at_bias, GX, mask, crops)[0]
+
+    @staticmethod
+    def gauss_align(meta, mask, gx, tx, ratio, crops, K):
+        return torch.ops.cfn.gauss_align(meta, mask, gx, 1.0 if tx is None else float(tx), float(ratio), crops, K)
+
+    @staticmethod
+    def grid_cdf(g, bias=None):
+        return torch.ops.cfn.grid_cdf(g, bias)
+
+    @staticmethod
+    def time_sample(x, cdf):
+        return torch.ops.cfn.time_sample(x, cdf)
+
+    @staticmethod
+    def time_resize(x, L, align_corners=True):
+        return torch.ops.cfn.time_resize(x, L, align_corners)
+
+    @staticmethod
+    def film(x, m, c, f):
+        return torch.ops.cfn.film(x, m, c, f)
+
+    @staticmethod
+    def interp1d(x, y, xnew):
+        return torch.ops.cfn.interp1d(x, y, xnew)

@@ -10,6 +10,8 @@ to the CPU reference (tests/test_hip_ops.py::test_interp1d_bit_exact).
 Gradients w.r.t. x, y and xnew are provided by a second kernel with the index held constant -- the
 behaviour the reference gets from plain autograd, since its custom ``backward`` is dead code
 (SURVEY 3.4)."""
+import sys
+
 import torch
 
 from cfn_hip import ops
@@ -33,7 +35,12 @@ class Interp1d(object):
         qshape = Q.shape
         if stacked:
             Q = Q.contiguous().view(1, -1)
-        ynew, ind = ops.interp1d(X.float(), Y.float(), Q.float())
+        o = ops
+        fine = sys.modules.get('x3d_fine')
+        if fine is not None and fine.USE_TORCH_OPS:       # CFN_USE_TORCH_OPS route: the registered dispatcher operator
+            from cfn_hip import torchlib
+            o = torchlib.TorchOps
+        ynew, ind = o.interp1d(X.float(), Y.float(), Q.float())
         if stacked:
             ynew, ind = ynew.view(qshape), ind.view(qshape)
         if out is not None and out.numel() == ynew.numel():

@@ -25,6 +25,16 @@ import x3d_fine
 FUSION_HW = 7     # spatial size of the pre-extracted fine features (extract_fineFEAT / x3d_fine.py:345-363)
 
 
+def _o():
+    """operator namespace of the Grid Pool / Unpool / fusion modules: cfn_hip.ops (autograd Functions over the C ABI, the default)
+    or, with CFN_USE_TORCH_OPS=1 / x3d_fine.USE_TORCH_OPS = True, the registered dispatcher operators torch.ops.cfn.* behind the
+    same function names (cfn_hip.torchlib.TorchOps) -- the same kernels, visible to torch.compile / torch.export"""
+    if x3d_fine.USE_TORCH_OPS:
+        from cfn_hip import torchlib
+        return torchlib.TorchOps
+    return ops
+
+
 def _w5(conv1d):
     """Conv1d (O,I,1) weight as a 1x1x1 conv weight"""
     w = conv1d.weight
@@ -85,13 +95,13 @@ class RewightLayer(nn.Module):
 
     def _mlp(self, z5, first, second):
         n = z5.shape[0]
-        h, _, _ = ops.pwconv(z5, _w5(first), stats=False)
+        h, _, _ = _o().pwconv(z5, _w5(first), stats=False)
         one = _ones(n, h.shape[1], z5.device)
         if self.pool and self.training and self.dropout.p > 0:     # x3d_coarse.py:232-233 (rw6 only)
-            h = self.dropout(ops.affine_act(h, one, _rows(first.bias, n), ACT_RELU))
-            out, _, _ = ops.pwconv(h, _w5(second), stats=False)
+            h = self.dropout(_o().affine_act(h, one, _rows(first.bias, n), ACT_RELU))
+            out, _, _ = _o().pwconv(h, _w5(second), stats=False)
         else:
-            out, _, _ = ops.pwconv(h, _w5(second), one, _rows(first.bias, n), ACT_RELU, stats=False)
+            out, _, _ = _o().pwconv(h, _w5(second), one, _rows(first.bias, n), ACT_RELU, stats=False)
         return out                                                  # raw: the bias of `second` is still to be added
 
     def gather(self, x, b2, mask, GX):
@@ -101,11 +111,11 @@ class RewightLayer(nn.Module):
         if mask.shape[1] != t:
             mask = F.adaptive_max_pool1d(mask.unsqueeze(1), t).squeeze(1)
             GX = F.adaptive_avg_pool2d(GX.unsqueeze(1), (t, None)).squeeze(1)
-        y1, _, _ = ops.pwconv(x, _w5(self.at1), stats=False)
+        y1, _, _ = _o().pwconv(x, _w5(self.at1), stats=False)
         one = _ones(b, c, x.device)
-        y2, _, _ = ops.pwconv(y1, _w5(self.at2), one, _rows(self.at1.bias, b), ACT_RELU, stats=False)
+        y2, _, _ = _o().pwconv(y1, _w5(self.at2), one, _rows(self.at1.bias, b), ACT_RELU, stats=False)
         # sigmoid(at2 + bias), the mask multiply and the per-crop repeat happen inside the gather kernel
-        z = ops.fusion_gather(x.reshape(b, c, t, h * w), y2.view(b, t, h * w), self.at2.bias, GX, mask, b2 // b)
+        z = _o().fusion_gather(x.reshape(b, c, t, h * w), y2.view(b, t, h * w), self.at2.bias, GX, mask, b2 // b)
         return z.view(b2, c, GX.shape[2], h, w)
 
     def forward7(self, x, b2, mask, GX, is_mixing):
@@ -156,8 +166,8 @@ class Gaussian(nn.Module):
         meta, mask, gx, tx = inp
         b, b2 = meta.shape[0], gx.shape[0]
         if tx is not None:
-            return ops.gauss_align(meta, mask, gx, tx, self.ratio, b2 // b, gx.shape[1])
-        return ops.gauss_align(meta, mask, None, None, self.ratio, b2 // b, gx.shape[2])
+            return _o().gauss_align(meta, mask, gx, tx, self.ratio, b2 // b, gx.shape[1])
+        return _o().gauss_align(meta, mask, None, None, self.ratio, b2 // b, gx.shape[2])
 
 
 class MixingLayer(nn.Module):
@@ -183,8 +193,8 @@ class MixingLayer(nn.Module):
         def mix(items, conv, act):
             raw = torch.cat([r for r, _ in items], dim=1)
             b = _rows(torch.cat([bb for _, bb in items]), n)
-            y, _, _ = ops.pwconv(raw, _w5(conv), one, b, ACT_NONE, stats=False)
-            return ops.affine_act(y, _ones(n, y.shape[1], y.device), _rows(conv.bias, n), act)
+            y, _, _ = _o().pwconv(raw, _w5(conv), one, b, ACT_NONE, stats=False)
+            return _o().affine_act(y, _ones(n, y.shape[1], y.device), _rows(conv.bias, n), act)
 
         return mix(bias, self.conv_at, ACT_NONE), mix(scale, self.conv_at2, ACT_SIGMOID)
 
@@ -218,32 +228,32 @@ class GridPoolLayer(nn.Module):
         statistics of y+b follow from those of y."""
         n = x.shape[0]
         st = tuple(conv.stride)
-        y, s, q = ops.conv3d_dense(x, conv.weight, (3, 3, 3), st, (1, 1, 1), A, B, act, stats=self.training)
+        y, s, q = _o().conv3d_dense(x, conv.weight, (3, 3, 3), st, (1, 1, 1), A, B, act, stats=self.training)
         cnt = _count(y)
         bias = conv.bias.double().view(1, -1)
         if self.training:
             q = q + 2.0 * bias * s + cnt * bias * bias
             s = s + cnt * bias
-        A2, B2 = bn.fold(s, q, cnt, n)
+        A2, B2 = (bn.fold_op if x3d_fine.USE_TORCH_OPS else bn.fold)(s, q, cnt, n)
         return y, A2, B2 + A2 * conv.bias.view(1, -1)
 
     def saliency(self, x):
         """(B,C,T,H,W) -> (B, T/4) saliency logits (x3d_coarse.py:379-383)"""
         y1, A1, B1 = self._conv_bn(x, self.conv1, self.bn1, None, None, ACT_NONE)
         y2, A2, B2 = self._conv_bn(y1, self.conv2, self.bn2, A1, B1, ACT_RELU)
-        y3, _, _ = ops.conv3d_dense(y2, self.conv3.weight, (1, 3, 3), (1, 2, 2), (0, 1, 1), A2, B2, ACT_RELU, stats=False)
-        g = ops.pool_hw(y3, 1, 1)
+        y3, _, _ = _o().conv3d_dense(y2, self.conv3.weight, (1, 3, 3), (1, 2, 2), (0, 1, 1), A2, B2, ACT_RELU, stats=False)
+        g = _o().pool_hw(y3, 1, 1)
         return g.view(g.shape[0], g.shape[2])          # conv3's bias is added by the CDF kernel
 
     @staticmethod
     def cdf(g, bias=None):
         """saliency logits (+ bias) -> CDF knots (B, K) (x3d_coarse.py:384-392): one kernel, cumsum accumulated in fp64"""
-        return ops.grid_cdf(g, bias)
+        return _o().grid_cdf(g, bias)
 
     def forward(self, inp):
         x = inp.materialize() if isinstance(inp, Deferred) else inp
         gx_out = self.cdf(self.saliency(x), self.conv3.bias)
-        return ops.time_sample(x, gx_out), gx_out
+        return _o().time_sample(x, gx_out), gx_out
 
 
 def GridUnpool(inp, return_aux=False):
@@ -255,9 +265,9 @@ def GridUnpool(inp, return_aux=False):
     mid = (mid / (k - 1.)).view(1, -1).repeat(b, 1)
     gx_inv, ind = Interp1d().forward(gx, mid, mid, None, return_index=True)
     if is_logit:
-        y = ops.time_sample(x.unsqueeze(3), gx_inv).squeeze(3)
+        y = _o().time_sample(x.unsqueeze(3), gx_inv).squeeze(3)
     else:
-        y = ops.time_resize(ops.time_sample(x, gx_inv), x.shape[2] * ratio)
+        y = _o().time_resize(_o().time_sample(x, gx_inv), x.shape[2] * ratio)
     if return_aux:
         return y, gx_inv, ind
     return y

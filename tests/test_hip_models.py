@@ -182,9 +182,17 @@ def test_fine_eval_mode_backward_vs_oracle():
 
 
 # ---- coarse stream -----------------------------------------------------------------------------------
+@pytest.fixture(params=[False, True], ids=['ops', 'torch_ops'])
+def op_route(request, monkeypatch):
+    """the module under test on cfn_hip.ops (default) and on the registered dispatcher operators torch.ops.cfn.* (CFN_USE_TORCH_OPS)"""
+    import x3d_fine
+    monkeypatch.setattr(x3d_fine, 'USE_TORCH_OPS', request.param)
+    return request.param
+
+
 @pytest.mark.parametrize('tag,depth', [('d4', 4), ('d24', 24)])
 @pytest.mark.parametrize('mode', ['eval', 'train'])
-def test_gridpool_layer_vs_reference(tag, depth, mode):
+def test_gridpool_layer_vs_reference(tag, depth, mode, op_route):
     import x3d_coarse
     from cfn_hip import ops
     from oracle import spec
@@ -210,7 +218,7 @@ def test_gridpool_layer_vs_reference(tag, depth, mode):
         assert maxdiff(m.bn2.split_bn.running_var, z['rv2']) <= 1e-5
 
 
-def test_gridunpool_vs_reference():
+def test_gridunpool_vs_reference(op_route):
     import x3d_coarse
     from cfn_hip import ops
     z = load_golden('gridunpool')
@@ -223,7 +231,7 @@ def test_gridunpool_vs_reference():
 
 
 @pytest.mark.parametrize('name', ['gaussian', 'gaussian_multicrop'])
-def test_gaussian_vs_reference(name):
+def test_gaussian_vs_reference(name, op_route):
     """Gaussian module = one HIP kernel; 'gaussian_multicrop': b2 = 2b, crop j starts at start + step*j (x3d_coarse.py:264-266)"""
     import x3d_coarse
     z = load_golden(name)
@@ -232,7 +240,7 @@ def test_gaussian_vs_reference(name):
 
 
 @pytest.mark.parametrize('mix', [True, False])
-def test_rewight_multicrop_vs_reference(mix):
+def test_rewight_multicrop_vs_reference(mix, op_route):
     """b2 = 2b (validation-time multi-crop, x3d_coarse.py:209-211): fine features / mask of a video are shared by its crops"""
     import x3d_coarse
     z = load_golden('rewight_multicrop_%s' % ('mix' if mix else 'nomix'))
@@ -249,7 +257,7 @@ def test_rewight_multicrop_vs_reference(mix):
                                                ('rewight_h14_mix', 14, True, False),
                                                ('rewight_h14_nomix', 14, False, False),
                                                ('rewight_pool', 7, False, True)])
-def test_rewight_vs_reference(name, hgt, mix, pool):
+def test_rewight_vs_reference(name, hgt, mix, pool, op_route):
     import x3d_coarse
     z = load_golden(name)
     ch = z['bias'].shape[1]
@@ -263,7 +271,7 @@ def test_rewight_vs_reference(name, hgt, mix, pool):
 
 
 @pytest.mark.parametrize('li,h', [(0, 14), (3, 7)])
-def test_mixing_vs_reference(li, h):
+def test_mixing_vs_reference(li, h, op_route):
     import x3d_coarse
     from oracle import spec
     z = load_golden('mixing_l%d' % li)
@@ -305,7 +313,7 @@ def _coarse_model(depth, dropout=0.5):
     return m.to(DEV)
 
 
-def test_coarse_eval_logits_vs_reference():
+def test_coarse_eval_logits_vs_reference(op_route):
     """full Coarse-Fine forward (fineFEAT fusion), north_star tolerance 1e-3 on logits"""
     z = load_golden('coarse_eval')
     x, feat, fm, meta, depth = _coarse_inputs(100, 1, 16, 12)
@@ -325,7 +333,7 @@ def test_coarse_eval_logits_vs_reference():
     assert int((i_own.cpu()[:, -1] - i_ref[:, -1]).abs().max()) <= 1     # last knot: T-2 (w=1) == T-1 (w=0), see test_hip_ops
 
 
-def test_coarse_train_fwd_bwd_vs_reference():
+def test_coarse_train_fwd_bwd_vs_reference(op_route):
     z = load_golden('coarse_train')
     x, feat, fm, meta, depth = _coarse_inputs(110, 2, 16, 12)
     m = _coarse_model(depth, dropout=0.0)
