@@ -297,6 +297,60 @@ __global__ __launch_bounds__(256) void pool_hw_bwd_kernel(const float* __restric
     }
 }
 
+// Global spatial mean (OH = OW = 1) of small planes (H*W <= 64: the head's 7x7, x3d_fine.py:255,366): one WAVE per frame -- lane =
+// plane element, one coalesced load of the frame's contiguous run, prologue, wave reduction -- instead of one thread walking a
+// whole plane (49 serial strided loads per thread: 0.69 ms for 173 MB at 8 clips x 256 frames).  Frames of a (n, c) row are dealt
+// to the four waves of its workgroup, eight frames in flight per wave.
+__global__ __launch_bounds__(256) void pool_hw1_fwd_kernel(const float* __restrict__ x, const double* __restrict__ A,
+                                                           const double* __restrict__ B, int act, float* __restrict__ out,
+                                                           int T, int HW) {
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float a = A ? (float)A[nc] : 1.0f, b = A ? (float)B[nc] : 0.0f;
+    const float inv = 1.0f / (float)HW;
+    const float* p = x + nc * (long)T * HW;
+    for (int t0 = (blockIdx.x * 4 + wv) * 8; t0 < T; t0 += gridDim.x * 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (lane < HW && t0 + u < T) ? p[(long)(t0 + u) * HW + lane] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float s = (lane < HW && t0 + u < T) ? cfn_act_rt(fmaf(v[u], a, b), act) : 0.0f;
+            s = cfn_wave_sum(s);
+            if (lane == 0 && t0 + u < T) out[nc * T + t0 + u] = s * inv;
+        }
+    }
+}
+
+// backward of the same: one workgroup per (n, c) row, element-per-thread (coalesced), ONE block reduction and one pair of fp64
+// atomics per row (the general kernel reduces and commits once per 256 elements)
+__global__ __launch_bounds__(256) void pool_hw1_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x,
+                                                           const double* __restrict__ A, const double* __restrict__ B, int act,
+                                                           float* __restrict__ gx, double* __restrict__ gA,
+                                                           double* __restrict__ gB, int T, int HW) {
+    __shared__ float sh[8];
+    const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;
+    const float a = A ? (float)A[nc] : 1.0f, b = A ? (float)B[nc] : 0.0f;
+    const float inv = 1.0f / (float)HW;
+    const long vol = (long)T * HW;
+    const float* xp = x + nc * vol;
+    const float* gp = gout + nc * T;
+    float* op = gx + nc * vol;
+    float acc[2] = {0.f, 0.f};
+    for (long i = threadIdx.x; i < vol; i += 256) {
+        const int t = (int)(i / HW);
+        const float xv = xp[i];
+        const float dz = gp[t] * inv * cfn_act_grad_rt(fmaf(xv, a, b), act);
+        acc[0] = fmaf(dz, xv, acc[0]);
+        acc[1] += dz;
+        op[i] = dz * a;
+    }
+    if (gA) {
+        block_sum<2>(acc, sh);
+        if (threadIdx.x == 0) { atomicAdd(&gA[nc], (double)acc[0]); atomicAdd(&gB[nc], (double)acc[1]); }
+    }
+}
+
 // ---- FiLM with 7x7 block-constant modulation (x3d_coarse.py:663-679 after the fusion branch has been
 // evaluated at its native 7x7 resolution): out = x * m[h/f, w/f] + c[h/f, w/f] -------------------------
 __global__ __launch_bounds__(256) void film_fwd_kernel(const float* __restrict__ x, const float* __restrict__ m,
@@ -440,6 +494,10 @@ extern "C" int cfn_pool_hw_fwd(const float* x, const double* A, const double* B,
     CFN_NC_CHECK(NC);
     hipStream_t st = (hipStream_t)stream;
     const long ovol = (long)T * OH * OW;
+    if (OH == 1 && OW == 1 && H * W <= 64) {
+        hipLaunchKernelGGL(pool_hw1_fwd_kernel, nc_grid(cfn_cdiv(T, 32) < 16 ? cfn_cdiv(T, 32) : 16, NC), dim3(256), 0, st, x, A, B, act, out, T, H * W);
+        return cfn_check_launch("pool_hw_fwd(global mean)");
+    }
     hipLaunchKernelGGL(pool_hw_fwd_kernel, nc_grid(cfn_cdiv(ovol, 256), NC), dim3(256), 0, st, x, A, B, act, out, T, H, W, OH, OW);
     return cfn_check_launch("pool_hw_fwd");
 }
@@ -453,6 +511,11 @@ extern "C" int cfn_pool_hw_bwd(const float* gout, const float* x, const double* 
     CFN_NC_CHECK(NC);
     hipStream_t st = (hipStream_t)stream;
     const long vol = (long)T * H * W;
+    if (OH == 1 && OW == 1 && H * W <= 64) {
+        hipLaunchKernelGGL(pool_hw1_bwd_kernel, nc_grid(1, NC), dim3(256), 0, st, gout, x, A, B, act, gx,
+                           A ? gA : nullptr, A ? gB : nullptr, T, H * W);
+        return cfn_check_launch("pool_hw_bwd(global mean)");
+    }
     hipLaunchKernelGGL(pool_hw_bwd_kernel, nc_grid(cfn_cdiv(vol, 256), NC), dim3(256), 0, st, gout, x, A, B, act, gx,
                        A ? gA : nullptr, A ? gB : nullptr, T, H, W, OH, OW);
     return cfn_check_launch("pool_hw_bwd");

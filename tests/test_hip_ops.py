@@ -199,6 +199,32 @@ def test_bn_add_relu(shape, affine_res):
         assert relerr(g[k].grad, c[k].grad) <= 2e-5, k
 
 
+@pytest.mark.parametrize('N,Cin,Cout,T,H,W', [(2, 24, 24, 3, 8, 8), (1, 24, 24, 5, 14, 14), (1, 20, 32, 2, 6, 6), (3, 32, 12, 1, 4, 4),
+                                              (1, 24, 24, 37, 28, 28)])
+@pytest.mark.parametrize('two', [True, False])
+def test_pwconv_few_channel_data_gradient(N, Cin, Cout, T, H, W, two):
+    """cfn_pwconv_bwd_data_acc without prologue / epilogue at <= 32 channels on both sides (the compact shortcut gradient of layer 1,
+    ops.ShortcutToken): gx = W^T (gsc gy + gs + 2 gq y) against fp64, bit-repeatable.  (A streaming VALU kernel for this shape was
+    measured in round 4: 0.476 ms against pw_gemm_kernel's ~0.38 ms in the step, same-box A/B +0.1 ms per step -- not kept.)"""
+    import cfn_hip
+    f64 = lambda seed, *shape, scale=1.0: (rnd(seed, *shape) * scale).double().to(DEV)
+    gy, y = rnd(1, N, Cout, T, H, W).to(DEV), rnd(2, N, Cout, T, H, W).to(DEV)
+    w = (0.3 * rnd(4, Cout, Cin)).to(DEV)
+    gs, gq, gsc = f64(5, N, Cout, scale=0.05), (f64(6, N, Cout, scale=0.01) if two else None), 1.0 + f64(7, N, Cout, scale=0.3)
+    outs = []
+    for _ in range(2):
+        gx = torch.empty(N, Cin, T, H, W, device=DEV)
+        cfn_hip.call('cfn_pwconv_bwd_data_acc', gy, y if two else None, gs, gq, w, None, None, None, 0, gx, None, None, N, Cin, Cout, T, H, W, 1,
+                     None, 1, gsc)
+        outs.append(gx)
+    assert torch.equal(outs[0], outs[1])
+    gp = gy.double() * gsc.view(N, Cout, 1, 1, 1) + gs.view(N, Cout, 1, 1, 1)
+    if two:
+        gp = gp + 2.0 * gq.view(N, Cout, 1, 1, 1) * y.double()
+    ref = torch.einsum('nkthw,km->nmthw', gp, w.double())
+    assert relerr(outs[0].double(), ref) <= 2e-6
+
+
 @pytest.mark.parametrize('act', [None, 0, 1, 2])
 @pytest.mark.parametrize('cfg', [(2, 24, 54, 3, 8, 8, 0), (2, 54, 24, 2, 12, 12, 0), (1, 24, 24, 5, 6, 6, 2), (2, 64, 32, 1, 10, 10, 0),
                                  (1, 20, 12, 3, 6, 6, 2), (2, 24, 54, 4, 8, 8, 2), (1, 3, 7, 2, 4, 6, 0)])
@@ -320,9 +346,11 @@ def test_affine_act_and_stats(act):
 
 
 @pytest.mark.parametrize('H,W,OH,OW,pro', [(7, 7, 1, 1, True), (14, 14, 7, 7, False), (16, 16, 7, 7, False),
-                                           (8, 8, 7, 7, True), (7, 7, 7, 7, True), (56, 56, 7, 7, False)])
-def test_pool_hw(H, W, OH, OW, pro):
-    shape = (2, 4, 3, H, W)
+                                           (8, 8, 7, 7, True), (7, 7, 7, 7, True), (56, 56, 7, 7, False),
+                                           (7, 7, 1, 1, False), (8, 8, 1, 1, True), (5, 5, 1, 1, True), (14, 14, 1, 1, True)])
+@pytest.mark.parametrize('T', [3, 41])       # 41 frames: several frame groups per wave of the global-mean kernel, ragged tail
+def test_pool_hw(H, W, OH, OW, pro, T):
+    shape = (2, 4, T, H, W)
     x = rnd(1, *shape)
     A = 1 + 0.2 * rnd(2, 2, 4) if pro else None
     B = 0.2 * rnd(3, 2, 4) if pro else None
