@@ -44,43 +44,60 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(frames_full, sample_frames=128, repeats=2, stream='fine'):
-    """CPU oracle (oracle/x3d_ref.py, stock torch CPU ops) fwd+bwd on a bounded sample of the same workload.
-    fine: `repeats` clips of 3 x sample_frames x 224 x 224; cost is linear in T, so clips/s at T=frames_full =
-    (repeats / t) * sample_frames / frames_full.  coarse: one 64-frame clip with T'=128 fine features (the full unit)."""
+def cpu_baseline(frames_full, sample_frames=64, repeats=3, stream='fine'):
+    """CPU oracle (oracle/x3d_ref.py, stock torch CPU ops) fwd+bwd on a bounded sample of the same workload, SURVEY 8d protocol:
+    one untimed warm-up, then the MEDIAN of `repeats` timed runs.
+    fine: one clip of 3 x sample_frames x 224 x 224 per run; cost is linear in T, so clips/s at T=frames_full =
+    (1 / t_median) * sample_frames / frames_full.  coarse: one clip with T'=128 fine features (the full unit)."""
     from oracle import spec, x3d_ref
     # torch's CPU conv kernels stop scaling (and thrash) far below the hardware threads of the GPU box: 16 threads is near
     # the measured optimum.  `cores` = threads used; the box's logical CPU count and model are stated next to it
     threads = min(os.cpu_count() or 1, int(os.environ.get('CFN_CPU_THREADS', '16')))
     torch.set_num_threads(threads)
     host = {'cores': threads, 'host_logical_cpus': os.cpu_count(), 'cpu_model': _cpu_model(), 'kind': 'port'}
-    if stream == 'coarse':
-        import train_coarse_fineFEAT as tc
-        sd = spec.procedural_fill(spec.coarse_keys('M', 157, 1))
+
+    def leaves(sd):
         for k, v in sd.items():
             if v.is_floating_point() and 'running' not in k:
                 v.requires_grad_(True)
-        x, labels, masks, feat, fm, meta, _, _ = next(iter(tc.SyntheticCoarse(1, 1, frames_full)))
-        t0 = time.time()
-        y = x3d_ref.x3d_coarse_forward(sd, [x[:, 0], feat, fm, 0, meta], 'M', training=True)
-        y.square().mean().backward()
-        dt = time.time() - t0
-        return dict(host, value=round(1.0 / dt, 5), unit='clips/s',
-                    sample='1 clip 3x%dx224x224 + fine features T\'=128, fwd+bwd fp32 (%.1f s)' % (frames_full, dt))
-    sd = spec.procedural_fill(spec.fine_keys('M', 157, 1))
-    for k, v in sd.items():
-        if v.is_floating_point() and 'running' not in k:
-            v.requires_grad_(True)
-    dt = 0.0
-    for r in range(repeats):
-        x = spec.rand_input(r, (1, 3, sample_frames, 224, 224))
+        return sd
+
+    def median(ts):
+        ts = sorted(ts)
+        return ts[len(ts) // 2]
+
+    if stream == 'coarse':
+        import train_coarse_fineFEAT as tc
+        sd = leaves(spec.procedural_fill(spec.coarse_keys('M', 157, 1)))
+        cf = min(frames_full, 64)                         # bounded: a 64-frame clip per run, scaled linearly in T
+        x, labels, masks, feat, fm, meta, _, _ = next(iter(tc.SyntheticCoarse(1, 1, cf)))
+        ts = []
+        for r in range(repeats + 1):                      # run 0 = warm-up
+            for v in sd.values():
+                v.grad = None
+            t0 = time.time()
+            y = x3d_ref.x3d_coarse_forward(sd, [x[:, 0], feat, fm, 0, meta], 'M', training=True)
+            y.square().mean().backward()
+            ts.append(time.time() - t0)
+        dt = median(ts[1:])
+        return dict(host, value=round((1.0 / dt) * cf / frames_full, 5), unit='clips/s',
+                    sample='1 warm-up + median of %d runs of 1 clip 3x%dx224x224 + fine features T\'=128, fwd+bwd fp32 (%.1f s each)%s'
+                           % (repeats, cf, dt, '' if cf == frames_full else ', scaled by %d/%d to T=%d' % (cf, frames_full, frames_full)))
+    sd = leaves(spec.procedural_fill(spec.fine_keys('M', 157, 1)))
+    ts = []
+    for r in range(repeats + 1):                          # run 0 = warm-up (a quarter-length clip: thread pool, allocator, oneDNN primitives)
+        T = max(sample_frames // 4, 8) if r == 0 else sample_frames
+        x = spec.rand_input(r, (1, 3, T, 224, 224))
+        for v in sd.values():
+            v.grad = None
         t0 = time.time()
         y = x3d_ref.x3d_fine_forward(sd, x, 'M', training=True)
         y.square().mean().backward()
-        dt += time.time() - t0
+        ts.append(time.time() - t0)
         del y
-    return dict(host, value=round((repeats / dt) * sample_frames / frames_full, 5), unit='clips/s',
-                sample='%d clips 3x%dx224x224 fwd+bwd fp32 (%.1f s), scaled by %d/%d to T=%d clips'
+    dt = median(ts[1:])
+    return dict(host, value=round((1.0 / dt) * sample_frames / frames_full, 5), unit='clips/s',
+                sample='1 warm-up + median of %d runs of 1 clip 3x%dx224x224 fwd+bwd fp32 (%.1f s each), scaled by %d/%d to T=%d clips'
                        % (repeats, sample_frames, dt, sample_frames, frames_full, frames_full))
 
 
@@ -167,7 +184,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay the step from captured hipGraphs (one graph on a single GPU; with --gpus > 1: forward+backward graph, eager all-reduce, optimizer graph)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-coarse-roofline', action='store_true', help='skip the coarse-stream roofline leg (figure B) of the default line')
-    ap.add_argument('--cpu-sample-frames', type=int, default=128)
+    ap.add_argument('--cpu-sample-frames', type=int, default=64)
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(_self_launch(args.gpus))
@@ -315,7 +332,10 @@ def main():
                            + ('; bf16 stands in for BASELINE configs[4]\'s "fp16 MFMA pointwise" (same MFMA rate on gfx950, no loss-scaling '
                               'needed: the engine has no fp16 path)' if joint else '')),
             'config': {'workload': workload, 'clips_per_gpu': B, 'frames': T, 'parallelism': 'dp%d' % world,
-                       'launch': 'hipGraph replay' if args.graph else 'eager', 'dist': cdist.describe()},
+                       'launch': ('hipGraph replay' if args.graph else 'eager') +
+                                 (' (two graphs around an eager bucketed all-reduce: the all-reduce runs AFTER the replayed backward, not '
+                                  'overlapped with it as in the eager path)' if args.graph and world > 1 else ''),
+                       'dist': cdist.describe()},
             'loss': {'first_step_cls_loc': [round(v, 6) for v in loss_first], 'last_step_cls_loc': [round(v, 6) for v in loss_last]},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
