@@ -492,6 +492,10 @@ static int pwss_try(const void* gy, const void* y, const double* gs, const doubl
         if (tiles <= 24) return pwss_launch<4, 3, 1, 2>(a, blocks, lds, st);
         return pwss_launch<4, 6, 1, 2>(a, blocks, lds, st);
     }
+    // <= 8 tiles (layer 2: 48 x 108): ONE tile per wave -- with two per wave only four of the eight waves multiply while the other four
+    // (staging only) run a phase ahead of them; besides the idle matrix pipes, that is the configuration in which tools/diag_wgrad_race.py
+    // caught the kernel (as compiled in round 3) writing stale operand rows from lanes 48-63 of exactly those waves in 1-3 % of passes
+    if (a.mtg <= 4 && a.ktg <= 4 && tiles <= 8) return NS == 2 ? pwss_launch<2, 1, 2>(a, blocks, lds, st) : pwss_launch<2, 1, 3>(a, blocks, lds, st);
     if (a.mtg <= 4 && a.ktg <= 4) return NS == 2 ? pwss_launch<2, 2, 2>(a, blocks, lds, st) : pwss_launch<2, 2, 3>(a, blocks, lds, st);
     if (tiles <= 24) return NS == 2 ? pwss_launch<4, 3, 2>(a, blocks, lds, st) : pwss_launch<4, 3, 3>(a, blocks, lds, st);
     return NS == 2 ? pwss_launch<4, 6, 2>(a, blocks, lds, st) : pwss_launch<4, 6, 3>(a, blocks, lds, st);

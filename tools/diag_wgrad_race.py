@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Diagnosis of a run-to-run difference in ONE weight gradient of x3d_fine (tools/determinism_scan.py found layer2.4.conv3.weight in
+some processes): every `cfn_pwconv_bwd_weight` call of that shape is bracketed WITHOUT host synchronisation by (a) order-independent
+bit checksums of all its inputs, (b) a copy of the fp64 accumulator before and after the kernel; everything is compared with run 0
+at the end of each pass."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'coarse-fine-networks_amd')):
+    sys.path.insert(0, p)
+import torch                      # noqa: E402
+import cfn_hip                    # noqa: E402
+from cfn_hip import ops           # noqa: E402
+cfn_hip.load()
+from oracle import spec           # noqa: E402
+import x3d_fine                   # noqa: E402
+
+MODE = int(os.environ.get('DIAG_MODE', '3'))      # bit 0: input checksums, bit 1: accumulator snapshots
+RUNS = int(os.environ.get('DIAG_RUNS', '40'))
+net = x3d_fine.generate_model('M', n_classes=157, task='loc', base_bn_splits=1, dropout=0.0)
+spec.fill_module_(net)
+net.to('cuda').train(True)
+x = spec.rand_input(5, (2, 3, 16, 224, 224)).to('cuda')
+orig = ops.call
+rec = []
+NAMES = ('gy', 'y', 'gs', 'gq', 'x', 'A', 'B')
+
+
+def call(name, *args):
+    hit = name == 'cfn_pwconv_bwd_weight' and args[10] == 108 and args[11] == 48
+    if hit:
+        sig, pre = {}, None
+        if MODE & 1:
+            for nm, t in list(zip(NAMES, args[:7])) + [('gsc', args[-1])]:
+                if t is not None:
+                    sig[nm] = t.contiguous().view(torch.int32 if t.dtype == torch.float32 else torch.int64).sum(dtype=torch.int64)
+        if MODE & 2:
+            pre = args[8].clone()
+    r = orig(name, *args)
+    if hit:
+        rec.append((sig, pre, args[8].clone() if MODE & 2 else None))
+    return r
+
+
+ops.call = call
+first = None
+odd = 0
+for run in range(RUNS):
+    rec.clear()
+    for p in net.parameters():
+        p.grad = None
+    y = net([x, None])
+    if run == 0:
+        r = spec.rand_input(777, tuple(y.shape)).to('cuda')
+    (y * r).sum().backward()
+    torch.cuda.synchronize()
+    g = net.layer2[4].conv3.weight.grad.clone()
+    sig, pre, post = rec[0]                       # first call in backward order = layer2.4
+    cur = {k: int(v) for k, v in sig.items()}
+    if first is None:
+        first = (g, cur)
+        continue
+    if not torch.equal(g, first[0]):
+        odd += 1
+        d = (g - first[0]).view(48, 108).abs()
+        thr = 1e-7 * float(first[0].abs().max())
+        rows = sorted(set(torch.nonzero(d > thr)[:, 0].tolist())); cols = sorted(set(torch.nonzero(d > thr)[:, 1].tolist()))
+        print('   pattern: %d elements differ; rows (co) %s; columns (ci) %s; max |d| %.3e at %s'
+              % (int((d > thr).sum()), rows if len(rows) <= 12 else '%d rows %d..%d' % (len(rows), rows[0], rows[-1]),
+                 cols if len(cols) <= 12 else '%d cols %d..%d' % (len(cols), cols[0], cols[-1]), float(d.max()), divmod(int(d.argmax()), 108)))
+        print('run %d DIFFERS (norm-rel %.2e): inputs whose bits differ from run 0: %s; accumulator zero before the kernel: %s; grad == its accumulator: %s'
+              % (run, float((g - first[0]).norm() / first[0].norm()), [k for k in cur if cur[k] != first[1][k]],
+                 None if pre is None else bool((pre == 0).all()), None if post is None else torch.equal(g.view(48, 108), post.float())))
+print('%d of %d runs differ from run 0 (mode %d)' % (odd, RUNS - 1, MODE))

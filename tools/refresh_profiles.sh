@@ -8,8 +8,7 @@ FILT="^RCCL\|^HIP\|^ROCm\|^Host\|^Lib\|amdgpu.ids"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python $R/bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_bf16 -- python $R/bench.py --dtype bf16 > $O/bench_bf16.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_coarse -- python $R/bench.py --stream coarse --no-cpu-baseline > $O/bench_coarse.json 2>> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_coarse_t256 -- python $R/tools/sal_bench.py 2>&1 | grep -v "$FILT" > $O/sal_bench.txt
-python $R/tools/determinism_scan.py --runs 12 2>&1 | grep -v "$FILT" > $O/determinism_scan.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_coarse_t256 -- python $R/bench.py --stream coarse --frames 256 --no-cpu-baseline > $O/bench_coarse_t256.json 2>> $O/bench.err
 python $R/bench.py --stream joint > $O/bench_joint.json 2>> $O/bench.err
 python $R/bench.py --stream joint --dtype bf16 > $O/bench_joint_bf16tower.json 2>> $O/bench.err
 # HBM traffic of the depthwise forward family: separate --pmc passes, kernel trace only
