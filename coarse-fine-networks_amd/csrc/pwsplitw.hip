@@ -311,12 +311,12 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
     const int pbeg = strip * a.per, pend = min(pbeg + a.per, Q);
     const int nh = pend > pbeg ? (pend - pbeg + PWSS_P - 1) / PWSS_P : 0;
 
-    // this wave's tiles: a row-major run of TPW tiles of the group's mtn x ktn
+    // this wave's tiles: tiles wave, wave + 8, ... of the group's mtn x ktn (row major)
     int aoff[TPW], boff[TPW];
     bool live[TPW];
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
-        const int t = wave * TPW + tt;
+        const int t = wave + (PWSS_THREADS / 64) * tt;            // tiles dealt round robin: every wave multiplies (no staging-only waves)
         live[tt] = t < mtn * ktn;                                 // wave uniform
         const int ti = live[tt] ? t / ktn : 0, tj = live[tt] ? t - ti * ktn : 0;
         aoff[tt] = (ti * 32 + r) * PWSS_PITCH + kg * 16;
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
         if (live[tt]) {
-            const int t = wave * TPW + tt, ti = t / ktn, tj = t - ti * ktn;
+            const int t = wave + (PWSS_THREADS / 64) * tt, ti = t / ktn, tj = t - ti * ktn;
             const int k = k0 + tj * 32 + r;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
