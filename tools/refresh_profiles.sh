@@ -5,7 +5,9 @@ O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 FILT="^RCCL\|^HIP\|^ROCm\|^Host\|^Lib\|amdgpu.ids"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python $R/bench.py > $O/bench.json 2> $O/bench.err
+# kernel stats of the FINE step alone (the default line's coarse leg would mix x3d_coarse kernels into the table); then the default line itself
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python $R/bench.py --no-coarse-roofline --no-cpu-baseline > $O/bench_rocprof.json 2> $O/bench.err
+python $R/bench.py > $O/bench.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_bf16 -- python $R/bench.py --dtype bf16 > $O/bench_bf16.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_coarse -- python $R/bench.py --stream coarse --no-cpu-baseline > $O/bench_coarse.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_coarse_t256 -- python $R/bench.py --stream coarse --frames 256 --no-cpu-baseline > $O/bench_coarse_t256.json 2>> $O/bench.err
