@@ -75,6 +75,8 @@ enum { DW_FWD = 0, DW_DGRAD = 1, DW_WGRAD = 2 };
 #ifndef DW_BF16
 int dw_small_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
                      int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);   // dwsmall.hip
+int dw_flat_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
+                    int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);    // dwflat.hip
 #endif
 // column-pair wave kernels (dwcp.hip, dwcpb.hip; compiled for both element types like this file: cp_io.h)
 int DWN(dw_cp_fwd_try)(const dwe_t* x, const double* A, const double* B, int act, const float* w, dwe_t* y, double* sum, double* sumsq,
@@ -1250,6 +1252,13 @@ extern "C" int DWN(cfn_dwconv3d_fwd)(const dwe_t* x, const double* A, const doub
     a.src = x; a.A = A; a.B = B; a.act = act; a.w = w; a.dst = y; a.s1 = sum; a.s2 = sumsq;
     a.N = N; a.C = C; a.T = T; a.Hi = Hi; a.Wi = Wi;
     hipStream_t st = (hipStream_t)stream;
+#ifndef DW_BF16
+    if (dw_flat_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
+        // 56x56 / 28x28 stride 1: flat kernel, every load of a work item up front (dwflat.hip)
+        CfnProfScope prof(CFN_K_DWCONV_FWD, st, (double)DW_ES * N * C * T * 2.0 * Hi * Wi + 4.0 * C * 27);
+        return dw_flat_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, false);
+    }
+#endif
     if (DWN(dw_cp_fwd_try)(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
         // output planes 56x56 / 28x28 / 14x14, stride 1 and 2: column-pair wave kernel (dwcp.hip)
         const double po_ = stride == 1 ? (double)Hi * Wi : ((Hi - 1) / 2 + 1.0) * ((Wi - 1) / 2 + 1.0);
