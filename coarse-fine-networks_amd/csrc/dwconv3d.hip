@@ -1254,8 +1254,9 @@ extern "C" int DWN(cfn_dwconv3d_fwd)(const dwe_t* x, const double* A, const doub
     hipStream_t st = (hipStream_t)stream;
 #ifndef DW_BF16
     if (dw_flat_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
-        // 56x56 / 28x28 stride 1: flat kernel, every load of a work item up front (dwflat.hip)
-        CfnProfScope prof(CFN_K_DWCONV_FWD, st, (double)DW_ES * N * C * T * 2.0 * Hi * Wi + 4.0 * C * 27);
+        // output planes 56x56 / 28x28 / 14x14, stride 1 and 2, fp32: flat kernels, every load of a work item up front (dwflat.hip)
+        const double po_ = stride == 1 ? (double)Hi * Wi : ((Hi - 1) / 2 + 1.0) * ((Wi - 1) / 2 + 1.0);
+        CfnProfScope prof(CFN_K_DWCONV_FWD, st, (double)DW_ES * N * C * T * ((double)Hi * Wi + po_) + 4.0 * C * 27);
         return dw_flat_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, false);
     }
 #endif

@@ -1,4 +1,5 @@
-// Depthwise 3x3x3 forward, stride 1, 56x56 / 28x28 / 14x14 planes (conv2 of layers 1-3 of X3D-M; x3d_fine.py:89-97), fp32 tensors --
+// Depthwise 3x3x3 forward onto 56x56 / 28x28 / 14x14 output planes, stride 1 and 2 (conv2 of layers 1-3 of X3D-M; x3d_fine.py:89-97,171-201),
+// fp32 tensors --
 // FLAT kernels (round 4).
 //
 // dwcp.hip marches a wave along t: per frame step it asks for ONE frame of its band, two frames ahead.  The temporal 5-tap conv (dwt5.hip, 4g)
@@ -253,13 +254,144 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat14_fwd_kernel(const DwFlatArg
     }
 }
 
+// Stride 2 (112 -> 56, 56 -> 28, 28 -> 14: conv2 of the first block of layers 1-3): a workgroup per (sample, channel, chunk of TO output
+// frames, band of RBO output rows).  A band reads 2 RBO + 1 input rows; the LDS image keeps the EVEN and the ODD input columns of a row in
+// separate halves (E[i] = column 2 i, O[i] = column 2 i + 1), so that the taps of two adjacent outputs (j, j + 1) are the natural pairs
+// (O[j-1], O[j]), (E[j], E[j+1]), (O[j], O[j+1]); a loaded float4 is two 8-byte LDS stores.  A compute lane owns 2 adjacent outputs of one
+// row for all TO frames (the compute lanes fill waves 0-1 densely: idle lanes still cost issue slots).
+template <int W, int RBO, int TO>                    // W: OUTPUT width (square planes; the input plane is 2W x 2W)
+__global__ __launch_bounds__(256, 4) void dw3d_flat_s2_fwd_kernel(const DwFlatArgs a) {
+    constexpr int WI = 2 * W, W4 = WI / 4, W2 = W / 2, NB = W / RBO, IR = 2 * RBO + 1, PIT = WI, NF = TO + 2, FR = IR * PIT;
+    constexpr int PI = WI * WI, PO = W * W, OOB = 0x7fff0000;
+    constexpr int NLOAD = IR * W4, NCOMP = RBO * W2;
+    static_assert(NLOAD <= 256 && NCOMP <= 256 && W % RBO == 0 && W % 2 == 0, "geometry");
+    __shared__ __attribute__((aligned(16))) float img[NF * FR];
+    __shared__ float red[8];
+
+    const int tid = threadIdx.x;
+    const unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    const int band = cfn_uni((int)(L % NB));
+    const unsigned rest = cfn_uni(L / NB);
+    const int chunk = cfn_uni((int)(rest % (unsigned)a.nchunks));
+    const long nc = cfn_uni((int)(rest / (unsigned)a.nchunks));
+    const int c = cfn_uni((int)(nc % a.C));
+    const int T = a.T, t0 = chunk * TO;
+
+    const int lr = tid / W4, lc = tid - lr * W4;
+    const int grow = 2 * band * RBO - 1 + lr;                            // input row (never beyond the plane: even input sizes)
+    const bool lvalid = tid < NLOAD && grow >= 0;
+    const int lofs = lvalid ? (grow * WI + lc * 4) * 4 : OOB;
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * PI, (unsigned)((long)T * PI * 4));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * PO, (unsigned)((long)T * PO * 4));
+
+    fl_f4 R[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+        const int t = t0 - 1 + k;
+        const bool tv = t >= 0 && t < T;                                 // workgroup uniform
+        R[k] = __builtin_bit_cast(fl_f4, __builtin_amdgcn_raw_buffer_load_b128(rx, tv ? lofs : OOB, cfn_uni(tv ? t * PI * 4 : 0), 0));
+    }
+    float wr[27];
+#pragma unroll
+    for (int j = 0; j < 27; ++j) wr[j] = cfn_uni(a.w[(long)c * 27 + j]);
+    const float pa = cfn_uni(a.A ? (float)a.A[nc] : 1.0f);
+    const float pb = cfn_uni(a.A ? (float)a.B[nc] : 0.0f);
+    const float act_lo = a.act == CFN_ACT_RELU ? 0.0f : -__builtin_inff();      // none / ReLU only (the planner checks)
+
+    if (tid < NLOAD) {
+        float* dst = img + lr * PIT + 2 * lc;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            const int t = t0 - 1 + k;
+            const float m = (lvalid && t >= 0 && t < T) ? 1.0f : 0.0f;   // zero padding is applied AFTER the prologue
+            const fl_f4 v = R[k];
+            const float x0 = fmaxf(fmaf(v.x, pa, pb), act_lo) * m, x1 = fmaxf(fmaf(v.y, pa, pb), act_lo) * m;
+            const float x2 = fmaxf(fmaf(v.z, pa, pb), act_lo) * m, x3 = fmaxf(fmaf(v.w, pa, pb), act_lo) * m;
+            *reinterpret_cast<fl_p2*>(dst + k * FR) = (fl_p2){x0, x2};
+            *reinterpret_cast<fl_p2*>(dst + k * FR + W) = (fl_p2){x1, x3};
+        }
+    }
+    __syncthreads();
+
+    float st1 = 0.0f, st2 = 0.0f;
+    if (tid < NCOMP) {
+        const int orow = tid / W2, j = 2 * (tid - orow * W2);            // outputs (orow, j), (orow, j + 1) of the band
+        fl_p2 acc[TO];
+#pragma unroll
+        for (int f = 0; f < TO; ++f) acc[f] = (fl_p2){0.0f, 0.0f};
+        const float* base = img + (2 * orow) * PIT + j;                  // output row orow reads image rows 2 orow .. 2 orow + 2
+        const int eL = j == 0 ? W : W - 1;                               // O[j - 1]; the column left of 0 is not stored: valid address x 0
+        const float mL = j == 0 ? 0.0f : 1.0f;
+        const int yo = ((band * RBO + orow) * W + j) * 4;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float* q = base + k * FR + kh * PIT;
+                const float om = q[eL] * mL;
+                const fl_p2 ve = *reinterpret_cast<const fl_p2*>(q), vo = *reinterpret_cast<const fl_p2*>(q + W);
+                const fl_p2 v0 = {om, vo.x};
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) {
+                    const int f = k - kt;                                // output frame t0 + f reads input frames f .. f + 2 (k = f + kt)
+                    if (f >= 0 && f < TO) {
+                        const float w0 = wr[kt * 9 + kh * 3 + 0], w1 = wr[kt * 9 + kh * 3 + 1], w2 = wr[kt * 9 + kh * 3 + 2];
+                        acc[f] = __builtin_elementwise_fma((fl_p2){w0, w0}, v0, __builtin_elementwise_fma((fl_p2){w1, w1}, ve,
+                                 __builtin_elementwise_fma((fl_p2){w2, w2}, vo, acc[f])));
+                    }
+                }
+            }
+            if (k >= 2) {                                                // output frame k - 2 is complete
+                const int f = k - 2, t = t0 + f;
+                const bool emit = t < T;
+                const fl_p2 y = acc[f];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fl_u2, y), ry, emit ? yo : OOB, cfn_uni(emit ? t * PO * 4 : 0), 0);
+                const fl_p2 ym = y * (emit ? 1.0f : 0.0f);
+                st1 += ym.x + ym.y;
+                st2 += ym.x * y.x + ym.y * y.y;
+            }
+        }
+    }
+    if (a.s1) {
+        const int wave = tid >> 6, lane = tid & 63;
+        st1 = cfn_wave_sum(st1); st2 = cfn_wave_sum(st2);
+        if (lane == 0) { red[wave] = st1; red[4 + wave] = st2; }
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd(&a.s1[nc], (double)(red[0] + red[1] + red[2] + red[3]));
+            atomicAdd(&a.s2[nc], (double)(red[4] + red[5] + red[6] + red[7]));
+        }
+    }
+}
+
 // returns -1 when the shape is not handled; probe: 0 = handled, nothing launched; otherwise the launch status
 int dw_flat_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
                     int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe) {
-    // bit mask of the planes served: 1 = 56x56, 2 = 28x28, 4 = 14x14
-    static const int enabled = getenv("CFN_DW_FLAT") ? atoi(getenv("CFN_DW_FLAT")) : 7;
+    // bit mask of the planes served: stride 1: 1 = 56x56, 2 = 28x28, 4 = 14x14; stride 2: 8 = 112 -> 56, 16 = 56 -> 28, 32 = 28 -> 14
+    static const int enabled = getenv("CFN_DW_FLAT") ? atoi(getenv("CFN_DW_FLAT")) : 63;
     static const int to_env = getenv("CFN_DW_FLAT_TO") ? atoi(getenv("CFN_DW_FLAT_TO")) : 0;
-    if (stride != 1 || Hi != Wi || (Hi != 56 && Hi != 28 && Hi != 14)) return -1;
+    if (Hi != Wi) return -1;
+    if (stride == 2) {
+        if (Hi != 112 && Hi != 56 && Hi != 28) return -1;
+        if (!(enabled & (Hi == 112 ? 8 : Hi == 56 ? 16 : 32))) return -1;
+        if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && A != nullptr) return -1;
+        if ((long)T * Hi * Wi * 4 >= 0x7fff0000L || (((uintptr_t)x | (uintptr_t)y) & 15) != 0) return -1;
+        // same-box steady state, 8 clips x T = 256, dwcp.hip / this kernel at TO = 8 / 6 / 4: 112 -> 56 1373 / 1211 / 1260 / 1214 us, 56 -> 28
+        // 686 / 622 / 618 / 623, 28 -> 14 358 / 309 / 302 / 311; 2-row bands on 112 -> 56 (7 workgroups per CU, 1.25 x row re-reads): 1250
+        const int TO = to_env == 4 || to_env == 8 ? to_env : (T >= 12 ? 8 : 4);
+        const int NB = Hi == 112 ? 14 : Hi == 56 ? 4 : 1;
+        const long nch = (T + TO - 1) / TO, blocks = (long)N * C * nch * NB;
+        if (blocks >= 0x7fffffffL) return -1;
+        if (probe) return 0;
+        DwFlatArgs a = {x, A, B, w, y, sum, sumsq, N, C, T, act, (int)nch, blocks};
+#define CFN_FLAT_GO(...) hipLaunchKernelGGL((dw3d_flat_s2_fwd_kernel<__VA_ARGS__>), dim3((unsigned)blocks), dim3(256), 0, st, a)
+        if (Hi == 112) { if (TO == 8) CFN_FLAT_GO(56, 4, 8); else CFN_FLAT_GO(56, 4, 4); }
+        else if (Hi == 56) { if (TO == 8) CFN_FLAT_GO(28, 7, 8); else CFN_FLAT_GO(28, 7, 4); }
+        else { if (TO == 8) CFN_FLAT_GO(14, 14, 8); else CFN_FLAT_GO(14, 14, 4); }
+#undef CFN_FLAT_GO
+        return cfn_check_launch("dwconv3d flat stride-2 forward");
+    }
+    if (stride != 1 || (Hi != 56 && Hi != 28 && Hi != 14)) return -1;
     if (!(enabled & (Hi == 56 ? 1 : Hi == 28 ? 2 : 4))) return -1;
     if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && A != nullptr) return -1;      // branch-free prologue: none / ReLU (every X3D conv2)
     if ((long)T * Hi * Wi * 4 >= 0x7fff0000L) return -1;

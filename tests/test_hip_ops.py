@@ -100,6 +100,8 @@ WAVE_CASES = [
     (2, 3, 1, 56, 1, 1, True), (1, 2, 2, 56, 1, 0, False), (1, 3, 61, 28, 1, 1, True), (2, 2, 7, 14, 1, 0, True),
     (1, 5, 4, 7, 1, 1, True), (1, 3, 3, 7, 1, 0, False),
     (1, 2, 1, 112, 2, 1, True), (2, 3, 5, 56, 2, 0, False), (1, 4, 58, 28, 2, 1, True),
+    # flat kernels (dwflat.hip): 8-frame items with a ragged last item, exactly one item, the 4-frame variant (T < 12)
+    (1, 2, 13, 14, 1, 1, True), (2, 2, 8, 56, 1, 1, True), (1, 2, 11, 28, 1, 0, True), (1, 2, 12, 112, 2, 1, True), (2, 2, 19, 28, 2, 1, True),
 ]
 
 
