@@ -364,13 +364,123 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat_s2_fwd_kernel(const DwFlatAr
     }
 }
 
+// 14 -> 7 (stride 2, first block of layer 4): a WAVE per (sample, channel, chunk of TO frames); the loader and the image of
+// dw3d_flat14_fwd_kernel, a lane per output position (49 of 64 lanes, scalar FMAs).  Same-box steady state, 8 clips x T = 256: band kernel
+// 199 us, this kernel 171.  (The same kernel for the 7x7 stride-1 planes -- the 10 frames of an item are one run of 490 floats, 4-byte loads --
+// was measured at 110 us with 8-frame items and 94 us with 16-frame items against 95 us of dw3d_small_fwd_kernel: not kept.)
+template <int TO>
+__global__ __launch_bounds__(256, 4) void dw3d_flat14to7_fwd_kernel(const DwFlatArgs a) {
+    constexpr int WI = 14, PI = 196, PO = 49, IR = 16, FR = IR * WI, NF = TO + 2, OOB = 0x7fff0000;
+    __shared__ __attribute__((aligned(16))) float smem[4 * NF * FR];
+    const int lane = threadIdx.x & 63, wv = cfn_uni((int)(threadIdx.x >> 6));
+    const unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    const long widx = cfn_uni((long)L * 4 + wv);
+    if (widx >= a.total) return;                                         // whole waves only: no workgroup barrier below
+    const int chunk = cfn_uni((int)(widx % a.nchunks));
+    const long nc = cfn_uni((long)(widx / a.nchunks));
+    const int c = cfn_uni((int)(nc % a.C));
+    const int T = a.T, t0 = chunk * TO;
+    float* img = smem + wv * NF * FR;
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * PI, (unsigned)((long)T * PI * 4));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * PO, (unsigned)((long)T * PO * 4));
+    const bool on = lane < 49;
+
+    fl_f4 R[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+        const int t = t0 - 1 + k;
+        const bool tv = t >= 0 && t < T && on;
+        R[k] = __builtin_bit_cast(fl_f4, __builtin_amdgcn_raw_buffer_load_b128(rx, tv ? lane * 16 : OOB, cfn_uni(tv ? t * PI * 4 : 0), 0));
+    }
+    float wr[27];
+#pragma unroll
+    for (int j = 0; j < 27; ++j) wr[j] = cfn_uni(a.w[(long)c * 27 + j]);
+    const float pa = cfn_uni(a.A ? (float)a.A[nc] : 1.0f);
+    const float pb = cfn_uni(a.A ? (float)a.B[nc] : 0.0f);
+    const float act_lo = a.act == CFN_ACT_RELU ? 0.0f : -__builtin_inff();
+
+    // zero row 0 of every frame (input row -1; row 15 = input row 14 is never read at stride 2)
+    for (int i = lane; i < NF * 7; i += 64) {
+        const int f = i / 7, j = i - f * 7;
+        *reinterpret_cast<fl_p2*>(img + f * FR + 2 * j) = (fl_p2){0.0f, 0.0f};
+    }
+    if (on) {
+        const int e0 = lane * 4, e2 = e0 + 2;
+        float* d0 = img + (e0 / WI + 1) * WI + e0 % WI;
+        float* d1 = img + (e2 / WI + 1) * WI + e2 % WI;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            const int t = t0 - 1 + k;
+            const float mk = (t >= 0 && t < T) ? 1.0f : 0.0f;           // zero padding is applied AFTER the prologue
+            const fl_f4 v = R[k];
+            *reinterpret_cast<fl_p2*>(d0 + k * FR) = (fl_p2){fmaxf(fmaf(v.x, pa, pb), act_lo) * mk, fmaxf(fmaf(v.y, pa, pb), act_lo) * mk};
+            *reinterpret_cast<fl_p2*>(d1 + k * FR) = (fl_p2){fmaxf(fmaf(v.z, pa, pb), act_lo) * mk, fmaxf(fmaf(v.w, pa, pb), act_lo) * mk};
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    float st1 = 0.0f, st2 = 0.0f;
+    if (on) {
+        const int orow = lane / 7, oc = lane - orow * 7;
+        float acc[TO];
+#pragma unroll
+        for (int j = 0; j < TO; ++j) acc[j] = 0.0f;
+        // output (orow, oc) reads image rows 2 orow .. 2 orow + 2 (image row = input row + 1), input columns 2 oc - 1 .. 2 oc + 1
+        const float* base = img + (2 * orow) * WI + 2 * oc;
+        const int eL = oc == 0 ? 0 : -1;                                 // the column left of 0 is not stored: valid address x 0
+        const float mL = oc == 0 ? 0.0f : 1.0f;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float* q = base + k * FR + kh * WI;
+                const float q0 = q[eL] * mL, q1 = q[0], q2 = q[1];
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) {
+                    const int j = k - kt;
+                    if (j >= 0 && j < TO)
+                        acc[j] = fmaf(wr[kt * 9 + kh * 3 + 0], q0, fmaf(wr[kt * 9 + kh * 3 + 1], q1, fmaf(wr[kt * 9 + kh * 3 + 2], q2, acc[j])));
+                }
+            }
+            if (k >= 2) {
+                const int j = k - 2, t = t0 + j;
+                const bool emit = t < T;
+                const float y = acc[j];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), ry, emit ? lane * 4 : OOB, cfn_uni(emit ? t * PO * 4 : 0), 0);
+                const float ym = emit ? y : 0.0f;
+                st1 += ym;
+                st2 = fmaf(ym, y, st2);
+            }
+        }
+    }
+    if (a.s1) {
+        st1 = cfn_wave_sum(st1); st2 = cfn_wave_sum(st2);
+        if (lane == 0) { atomicAdd(&a.s1[nc], (double)st1); atomicAdd(&a.s2[nc], (double)st2); }
+    }
+}
+
 // returns -1 when the shape is not handled; probe: 0 = handled, nothing launched; otherwise the launch status
 int dw_flat_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
                     int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe) {
-    // bit mask of the planes served: stride 1: 1 = 56x56, 2 = 28x28, 4 = 14x14; stride 2: 8 = 112 -> 56, 16 = 56 -> 28, 32 = 28 -> 14
-    static const int enabled = getenv("CFN_DW_FLAT") ? atoi(getenv("CFN_DW_FLAT")) : 63;
+    // bit mask of the planes served: stride 1: 1 = 56x56, 2 = 28x28, 4 = 14x14; stride 2: 8 = 112 -> 56, 16 = 56 -> 28, 32 = 28 -> 14, 64 = 14 -> 7
+    static const int enabled = getenv("CFN_DW_FLAT") ? atoi(getenv("CFN_DW_FLAT")) : 127;
     static const int to_env = getenv("CFN_DW_FLAT_TO") ? atoi(getenv("CFN_DW_FLAT_TO")) : 0;
     if (Hi != Wi) return -1;
+    if (stride == 2 && Hi == 14) {
+        if (!(enabled & 64)) return -1;
+        if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && A != nullptr) return -1;
+        if ((long)T * Hi * Wi * 4 >= 0x7fff0000L || (((uintptr_t)x | (uintptr_t)y) & 15) != 0) return -1;
+        const int TO = to_env == 4 || to_env == 8 ? to_env : (T >= 12 ? 8 : 4);
+        const long nch = (T + TO - 1) / TO, items = (long)N * C * nch, blocks = (items + 3) / 4;
+        if (blocks >= 0x7fffffffL) return -1;
+        if (probe) return 0;
+        DwFlatArgs a = {x, A, B, w, y, sum, sumsq, N, C, T, act, (int)nch, items};
+        if (TO == 8) hipLaunchKernelGGL((dw3d_flat14to7_fwd_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((dw3d_flat14to7_fwd_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        return cfn_check_launch("dwconv3d flat 14->7 forward");
+    }
     if (stride == 2) {
         if (Hi != 112 && Hi != 56 && Hi != 28) return -1;
         if (!(enabled & (Hi == 112 ? 8 : Hi == 56 ? 16 : 32))) return -1;
