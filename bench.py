@@ -316,7 +316,7 @@ def main():
         else:
             metric = 'clips/sec (fwd+bwd+SGD) x3d_fine X3D-M T=%dx224x224' % T
             workload = 'x3d_fine X3D-M train step (fwd+loss+bwd+SGD), %dx3x%dx224x224 clips per GPU, random-init weights' % (B, T)
-            kernel = 'depthwise conv stack forward: dw3d_cp_fwd_kernel (56/28/14 planes, stride 1 and 2), dw3d_small_fwd_kernel (7x7), dw3d_kernel<FWD> (14->7), dwt5_fwd_flat_kernel (conv1_t)'
+            kernel = 'depthwise conv stack forward: dw3d_flat_fwd_kernel / dw3d_flat14_fwd_kernel (56/28/14 planes, stride 1), dw3d_flat_s2_fwd_kernel / dw3d_flat14to7_fwd_kernel (stride 2), dw3d_small_fwd_kernel (7x7), dwt5_fwd_flat_kernel (conv1_t)'
         out = {
             'metric': metric,
             'value': round(world * B * args.steps / dt, 4),

@@ -74,6 +74,7 @@ int pwd_wgrad_try_dense(const float* gy, const float* y, const double* gs, const
 
 // stem.hip: LDS-tiled forward of the 1x3x3 stride-(1,2,2) stem conv (Cimg == 3, Cout <= 32, Wi % 4 == 0, Hi even); -1 = not handled
 int stem_fwd_try_launch(const float* x, const float* w, float* y, int N, int Cimg, int Cout, int T, int Hi, int Wi, hipStream_t st);
+int stem_wgrad_try_launch(const float* gy, const float* x, double* gw, int N, int Cimg, int Cout, int T, int Hi, int Wi, hipStream_t st, bool probe);
 
 // salconv.hip: LDS-tiled fp32-MFMA kernels for the Grid Pool saliency convs (Cin == 24, Cout <= 32, 3x3x3, stride 2, pad 1, input
 // planes 56 or 28 wide, even height); -1 = not handled

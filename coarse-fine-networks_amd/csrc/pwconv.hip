@@ -804,6 +804,15 @@ extern "C" int cfn_stem_conv_fwd(const float* x, const float* w, float* y, int N
 
 extern "C" int cfn_stem_conv_bwd_weight(const float* gy, const float* x, double* gw, int N, int Cimg, int Cout, int T,
                                         int Hi, int Wi, void* stream) {
+    CFN_REQUIRE(gy && x && gw, "cfn_stem_conv_bwd_weight: null tensor");
+    CFN_REQUIRE(N > 0 && Cimg > 0 && Cout > 0 && T > 0 && Hi > 0 && Wi > 0, "cfn_stem_conv_bwd_weight: bad shape");
+    {   // LDS-staged persistent MFMA kernel (stem.hip) for the 224x224 clip; anything else runs as an implicit GEMM
+        hipStream_t st = (hipStream_t)stream;
+        if (stem_wgrad_try_launch(gy, x, gw, N, Cimg, Cout, T, Hi, Wi, st, true) == 0) {
+            CfnProfScope prof(CFN_K_STEM, st, 4.0 * N * T * ((double)Cimg * Hi * Wi + (double)Cout * (Hi / 2) * (Wi / 2)));
+            return stem_wgrad_try_launch(gy, x, gw, N, Cimg, Cout, T, Hi, Wi, st, false);
+        }
+    }
     return cfn_conv3d_dense_bwd_weight(gy, nullptr, nullptr, nullptr, x, nullptr, nullptr, CFN_ACT_NONE, gw, N, Cimg, Cout, T, Hi, Wi,
                                        kStemGeom, stream);
 }

@@ -167,7 +167,7 @@ def test_dwconv_t5(N, C, T, H, W):
 
 
 @pytest.mark.parametrize('N,T,H,W', [(2, 3, 16, 16), (1, 5, 30, 22), (1, 2, 17, 15), (1, 2, 64, 48), (2, 1, 24, 40), (1, 3, 10, 12),
-                                     (1, 1, 224, 224)])
+                                     (1, 1, 224, 224), (2, 3, 224, 224)])
 def test_stem_conv(N, T, H, W):
     x, w = rnd(1, N, 3, T, H, W), rnd(2, 24, 3, 1, 3, 3, scale=0.3)
     wc, wg = w.clone().requires_grad_(True), w.clone().to(DEV).requires_grad_(True)
