@@ -102,6 +102,8 @@ WAVE_CASES = [
     (1, 2, 1, 112, 2, 1, True), (2, 3, 5, 56, 2, 0, False), (1, 4, 58, 28, 2, 1, True),
     # flat kernels (dwflat.hip): 8-frame items with a ragged last item, exactly one item, the 4-frame variant (T < 12)
     (1, 2, 13, 14, 1, 1, True), (2, 2, 8, 56, 1, 1, True), (1, 2, 11, 28, 1, 0, True), (1, 2, 12, 112, 2, 1, True), (2, 2, 19, 28, 2, 1, True),
+    # flat 7x7 backward (dwflatb.hip): 8-frame items, ragged last item; 14 -> 7 flat forward
+    (1, 4, 21, 7, 1, 1, True), (2, 3, 16, 7, 1, 0, True), (1, 3, 13, 14, 2, 1, True),
 ]
 
 
