@@ -189,12 +189,189 @@ __global__ __launch_bounds__(256, 3) void dw3d_flat7_bwd_kernel(const DwFlatBArg
     }
 }
 
+// 14 -> 7 (stride 2, first block of layer 4): a WAVE per item, lane (o, j) < 49 owns output position (o, j) = the 2 x 2 input block rows
+// 2o, 2o + 1, columns 2j, 2j + 1 (x and a stay in registers: two 8-byte loads / stores per frame); g' (7x7, 4-byte loads of the contiguous
+// run) goes into an LDS image [TO + 2][8][8] with a zero row / column at the bottom / right.  Tap parity: of the 27 taps an even input row /
+// column sees only the centre one, an odd one the two outer ones -- 9 (input position, g' element) products per temporal tap, each feeding
+// the data gradient AND the weight gradient (dwcpb2.hip has the formulas):
+//   (2o, 2j): w[1][1] G[o][j]                          (2o, 2j+1): w[1][0] G[o][j+1] + w[1][2] G[o][j]
+//   (2o+1, 2j): w[0][1] G[o+1][j] + w[2][1] G[o][j]    (2o+1, 2j+1): w[0][0] G[o+1][j+1] + w[0][2] G[o+1][j] + w[2][0] G[o][j+1] + w[2][2] G[o][j]
+// Before: dw3d_dgrad_s2_fast_kernel + dw3d_kernel<WGRAD> (x read twice), 431 + 303 us per step.
+template <int TO, bool HASY>
+__global__ __launch_bounds__(256, 3) void dw3d_flat14to7_bwd_kernel(const DwFlatBArgs a) {
+    constexpr int WO = 7, PO = 49, WI = 14, PI = 196, NF = TO + 2, FR = 64, OOB = 0x7fff0000;
+    constexpr int NG = (NF * PO + 63) / 64;                              // 4-byte loads per lane of the g' run
+    constexpr int WSZ = NF * FR;
+    __shared__ float smem[4 * WSZ];
+    const int lane = threadIdx.x & 63, wv = cfn_uni((int)(threadIdx.x >> 6));
+    const unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    const long widx = cfn_uni((long)L * 4 + wv);
+    if (widx >= a.total) return;                                         // whole waves only: no workgroup barrier below
+    const int chunk = cfn_uni((int)(widx % a.nchunks));
+    const long nc = cfn_uni((long)(widx / a.nchunks));
+    const int c = cfn_uni((int)(nc % a.C));
+    const int T = a.T;
+    float* img = smem + wv * WSZ;
+
+    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(a.gy + nc * (long)T * PO, (unsigned)((long)T * PO * 4));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc((HASY ? a.y : a.gy) + nc * (long)T * PO, (unsigned)((long)T * PO * 4));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * PI, (unsigned)((long)T * PI * 4));
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + nc * (long)T * PI, (unsigned)((long)T * PI * 4));
+
+    float w9[3][9];                                                      // w[kt][kh][kw]
+#pragma unroll
+    for (int j = 0; j < 27; ++j) w9[j / 9][j % 9] = cfn_uni(a.w[(long)c * 27 + j]);
+    const bool hasA = a.A != nullptr;
+    const float pa = cfn_uni(hasA ? (float)a.A[nc] : 1.0f);
+    const float pb = cfn_uni(hasA ? (float)a.B[nc] : 0.0f);
+    const float act_lo = (hasA && a.act == CFN_ACT_RELU) ? 0.0f : -__builtin_inff();   // none / ReLU only (the planner checks)
+    const float gsv = cfn_uni(a.gs ? (float)a.gs[nc] : 0.0f);
+    const float gqv = cfn_uni((HASY && a.gq) ? 2.0f * (float)a.gq[nc] : 0.0f);
+    // zero row 7 and column 7 of every g' frame (never overwritten): 15 floats per frame
+    for (int i = lane; i < NF * 15; i += 64) {
+        const int f = i / 15, j = i - f * 15;
+        img[f * FR + (j < 8 ? 56 + j : (j - 8) * 8 + 7)] = 0.0f;
+    }
+    float dwa[27];                                                       // weight-gradient partials: live over all the wave's chunks
+#pragma unroll
+    for (int j = 0; j < 27; ++j) dwa[j] = 0.0f;
+    float st1 = 0.0f, st2 = 0.0f;
+    const bool on = lane < PO;
+    const int o = lane / WO, jj = lane - o * WO;
+    const int xo = on ? ((2 * o) * WI + 2 * jj) * 4 : OOB;               // byte offset of the block's first row in a frame of x / gx
+    const float* gb = img + o * 8 + jj;
+
+    for (int sub = 0; sub < a.subs; ++sub) {
+        const int t0 = (chunk * a.subs + sub) * TO;
+        if (t0 >= T) break;                                              // wave uniform
+        float Rg[NG], Ry[HASY ? NG : 1];
+        fb_p2 X0[TO], X1[TO];                                            // rows 2o / 2o + 1 of the block
+        const int gstart = (t0 - 1) * PO;
+#pragma unroll
+        for (int m = 0; m < NG; ++m) {
+            const int i = lane + 64 * m;
+            const int vo = (i < NF * PO && gstart + i >= 0) ? (gstart + i) * 4 : OOB;
+            Rg[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, vo, 0, 0));
+            if (HASY) Ry[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, vo, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < TO; ++j) {
+            const bool tv = t0 + j < T;
+            const int so = cfn_uni(tv ? (t0 + j) * PI * 4 : 0);
+            X0[j] = __builtin_bit_cast(fb_p2, __builtin_amdgcn_raw_buffer_load_b64(rx, tv ? xo : OOB, so, 0));
+            X1[j] = __builtin_bit_cast(fb_p2, __builtin_amdgcn_raw_buffer_load_b64(rx, tv ? xo + WI * 4 : OOB, so, 0));
+        }
+        __builtin_amdgcn_wave_barrier();                                 // the previous chunk's LDS reads are done (in-order LDS; compiler fence)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int m = 0; m < NG; ++m) {
+            const int i = lane + 64 * m;
+            if (i < NF * PO) {
+                const int f = i / PO, p = i - f * PO, t = t0 - 1 + f;
+                float v = Rg[m] + gsv;
+                if (HASY) v = fmaf(Ry[m], gqv, v);
+                img[f * FR + (p / WO) * 8 + p % WO] = (t >= 0 && t < T) ? v : 0.0f;   // g' is zero outside the clip
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (on) {
+            float acc[TO][4], av[TO][4];                                 // [frame][(2o,2j), (2o,2j+1), (2o+1,2j), (2o+1,2j+1)]
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+                if (k < TO) {                                            // output frame k enters the window
+                    const float m = t0 + k < T ? 1.0f : 0.0f;            // a is zero beyond the clip (act(B) is not)
+                    const float xs[4] = {X0[k].x, X0[k].y, X1[k].x, X1[k].y};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc[k][e] = 0.0f; av[k][e] = fmaxf(fmaf(xs[e], pa, pb), act_lo) * m; }
+                }
+                const float* q = gb + k * FR;
+                const float g00 = q[0], g01 = q[1], g10 = q[8], g11 = q[9];
+#pragma unroll
+                for (int kr = 0; kr < 3; ++kr) {
+                    const int j = k - kr, kt = 2 - kr;                   // da(t0 + j) takes w[kt] g'(t0 + j - kt + 1) = g' frame k
+                    if (j >= 0 && j < TO) {
+                        const float* w = w9[kt];
+                        acc[j][0] = fmaf(w[4], g00, acc[j][0]);
+                        acc[j][1] = fmaf(w[3], g01, fmaf(w[5], g00, acc[j][1]));
+                        acc[j][2] = fmaf(w[1], g10, fmaf(w[7], g00, acc[j][2]));
+                        acc[j][3] = fmaf(w[0], g11, fmaf(w[2], g10, fmaf(w[6], g01, fmaf(w[8], g00, acc[j][3]))));
+                        float* d = dwa + kt * 9;
+                        d[4] = fmaf(av[j][0], g00, d[4]);
+                        d[3] = fmaf(av[j][1], g01, d[3]); d[5] = fmaf(av[j][1], g00, d[5]);
+                        d[1] = fmaf(av[j][2], g10, d[1]); d[7] = fmaf(av[j][2], g00, d[7]);
+                        d[0] = fmaf(av[j][3], g11, d[0]); d[2] = fmaf(av[j][3], g10, d[2]);
+                        d[6] = fmaf(av[j][3], g01, d[6]); d[8] = fmaf(av[j][3], g00, d[8]);
+                    }
+                }
+                if (k >= 2) {                                            // output frame k - 2 is complete
+                    const int j = k - 2, t = t0 + j;
+                    const bool emit = t < T;
+                    float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+                    if (hasA) {                                          // wave uniform
+                        const float xs[4] = {X0[j].x, X0[j].y, X1[j].x, X1[j].y};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float dz = av[j][e] > act_lo ? v[e] : 0.0f;     // act' of none / ReLU: a > 0 <=> z > 0
+                            const float dm = emit ? dz : 0.0f;
+                            st1 = fmaf(dm, xs[e], st1);
+                            st2 += dm;
+                            v[e] = dz * pa;
+                        }
+                    }
+                    const int so = cfn_uni(emit ? t * PI * 4 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fb_u2, (fb_p2){v[0], v[1]}), rd, emit ? xo : OOB, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fb_u2, (fb_p2){v[2], v[3]}), rd, emit ? xo + WI * 4 : OOB, so, 0);
+                }
+            }
+        }
+    }
+    // ---- reductions: gw (27 per channel), then gA / gB ----
+    {
+        float v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = (j < 27 && on) ? dwa[j] : 0.0f;
+        const float tot = fb_transpose_reduce(v, lane);
+        const int idx = lane >> 1;
+        if ((lane & 1) == 0 && idx < 27) atomicAdd(&a.gw[(long)c * 27 + idx], (double)tot);
+    }
+    if (hasA && a.gA) {
+        st1 = cfn_wave_sum(st1); st2 = cfn_wave_sum(st2);
+        if (lane == 0) { atomicAdd(&a.gA[nc], (double)st1); atomicAdd(&a.gB[nc], (double)st2); }
+    }
+}
+
+// stride 2: returns -1 when the shape is not handled (caller goes on to the wave / band kernels); H, W: INPUT plane
+int dw_flatb_s2_try(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
+                    const double* A, const double* B, int act, float* gx, double* gA, double* gB, double* gw,
+                    int N, int C, int T, int H, int W, hipStream_t st, bool probe) {
+    static const int enabled = getenv("CFN_DW_FLATB") ? atoi(getenv("CFN_DW_FLATB")) : 24;      // 16 = 14 -> 7
+    static const int subs_env = getenv("CFN_DW_FLATB_SUBS") ? atoi(getenv("CFN_DW_FLATB_SUBS")) : 0;
+    if (H != 14 || W != 14 || !(enabled & 16)) return -1;
+    if (A != nullptr && act != CFN_ACT_NONE && act != CFN_ACT_RELU) return -1;
+    if ((long)T * H * W * 4 >= 0x7fff0000L) return -1;
+    if ((((uintptr_t)x | (uintptr_t)gx) & 7) != 0) return -1;
+    const int TO = T >= 12 ? 8 : 4;
+    const long nchunks = (T + TO - 1) / TO;
+    const int subs = subs_env > 0 ? subs_env : 8;
+    const long nch = (nchunks + subs - 1) / subs, items = (long)N * C * nch, blocks = (items + 3) / 4;
+    if (blocks >= 0x7fffffffL) return -1;
+    if (probe) return 0;
+    DwFlatBArgs a = {gy, gq ? y : nullptr, gs, gq, w, x, A, B, gx, A ? gA : nullptr, A ? gB : nullptr, gw, N, C, T, act, (int)nch, subs, items};
+#define CFN_FLATB_GO(...) hipLaunchKernelGGL((dw3d_flat14to7_bwd_kernel<__VA_ARGS__>), dim3((unsigned)blocks), dim3(256), 0, st, a)
+    if (a.y) { if (TO == 8) CFN_FLATB_GO(8, true); else CFN_FLATB_GO(4, true); }
+    else { if (TO == 8) CFN_FLATB_GO(8, false); else CFN_FLATB_GO(4, false); }
+#undef CFN_FLATB_GO
+    return cfn_check_launch("dwconv3d flat stride-2 backward");
+}
+
 // returns -1 when the shape is not handled (caller goes on to the wave / band kernels); probe: 0 = handled, nothing launched
 int dw_flatb_try(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
                  const double* A, const double* B, int act, float* gx, double* gA, double* gB, double* gw,
                  int N, int C, int T, int H, int W, hipStream_t st, bool probe) {
-    // bit mask of the planes served: 8 = 7x7
-    static const int enabled = getenv("CFN_DW_FLATB") ? atoi(getenv("CFN_DW_FLATB")) : 8;
+    // bit mask of the planes served: 8 = 7x7 (16 = 14 -> 7: dw_flatb_s2_try)
+    static const int enabled = getenv("CFN_DW_FLATB") ? atoi(getenv("CFN_DW_FLATB")) : 24;
     static const int to_env = getenv("CFN_DW_FLATB_TO") ? atoi(getenv("CFN_DW_FLATB_TO")) : 0;
     if (H != W || H != 7 || !(enabled & 8)) return -1;
     if (A != nullptr && act != CFN_ACT_NONE && act != CFN_ACT_RELU) return -1;
