@@ -47,8 +47,10 @@ __global__ __launch_bounds__(1024) void bn_fold_fwd_kernel(const BnFoldArgs a) {
     const float* w2s = st ? sh + Wd * C : a.w2;
     const int w2p = st ? Wd + 1 : Wd;                  // row pitch of w2s
     if (st) bnf_stage_se(a.w1, a.w2, sh, sh + Wd * C, C, Wd);
-    // (1) statistics per (split group, channel)
-    for (int e = tid; e < S * C; e += nthr) {
+    // (1) statistics per (split group, channel); without a squeeze-excite gate the launch is several small workgroups (one element per thread:
+    // the fp64 divide / sqrt chain of an element is ~2 us, a single workgroup looping over 8 x 432 elements was 10 us on the critical path)
+    const int gtid = Wd > 0 ? tid : (int)(blockIdx.x * blockDim.x) + tid, gn = Wd > 0 ? nthr : (int)(gridDim.x * blockDim.x);
+    for (int e = gtid; e < S * C; e += gn) {
         const int g = e / C, c = e - g * C;
         double mean, var;
         if (a.training) {
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(1024) void bn_fold_fwd_kernel(const BnFoldArgs a) {
             if (Wd > 0) { a.A0[o] = av; a.B0[o] = bv; } else { a.A[o] = av; a.B[o] = bv; }
         }
     }
-    if (a.training && a.nbt && tid == 0) a.nbt[0] += 1;
+    if (a.training && a.nbt && gtid == 0) a.nbt[0] += 1;
     if (Wd <= 0) return;
     __syncthreads();
     // (2) squeeze-excite gate, BNF_NB samples per pass; dot products are wave cooperative (lanes along the long axis)
@@ -205,8 +207,9 @@ __global__ __launch_bounds__(1024) void bn_fold_bwd_kernel(const BnFoldBwdArgs a
     }
     const double* dA = Wd > 0 ? a.tA : a.gA;
     const double* dB = Wd > 0 ? a.tB : a.gB;
-    // (1') batch-norm adjoint per channel
-    for (int c = tid; c < C; c += nthr) {
+    // (1') batch-norm adjoint per channel (no gate: several small workgroups, one channel per thread)
+    const int gtid = Wd > 0 ? tid : (int)(blockIdx.x * blockDim.x) + tid, gn = Wd > 0 ? nthr : (int)(gridDim.x * blockDim.x);
+    for (int c = gtid; c < C; c += gn) {
         double ggam = 0.0, gbet = 0.0;
         for (int g = 0; g < S; ++g) {
             double ga = 0.0, gb = 0.0;
@@ -249,7 +252,8 @@ extern "C" int cfn_bn_fold_fwd(const double* s, const double* q, const float* ga
                     w1, b1, w2, b2, A, B, mean, rstd, A0, B0, gate, hbuf, pooled};
     CFN_REQUIRE(lds <= 150 * 1024, "cfn_bn_fold_fwd: per-sample SE tables (C=%d, width=%d) exceed LDS", C, Wd);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)bn_fold_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3(1), dim3(Wd > 0 ? 1024 : 256), lds, (hipStream_t)stream, a);
+    const int Se = training ? S : 1;
+    hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3(Wd > 0 ? 1 : cfn_cdiv((long)Se * C, 64)), dim3(Wd > 0 ? 1024 : 64), lds, (hipStream_t)stream, a);
     return cfn_check_launch("bn_fold_fwd");
 }
 
@@ -270,6 +274,6 @@ extern "C" int cfn_bn_fold_bwd(const double* gA, const double* gB, const double*
                        pool_count, gs, gq, ggamma, gbeta, gw1, gb1, gw2, gb2, tA, tB};
     CFN_REQUIRE(lds <= 150 * 1024, "cfn_bn_fold_bwd: per-sample SE tables (C=%d, width=%d) exceed LDS", C, Wd);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)bn_fold_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3(1), dim3(Wd > 0 ? 1024 : 256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3(Wd > 0 ? 1 : cfn_cdiv(C, 64)), dim3(Wd > 0 ? 1024 : 64), lds, (hipStream_t)stream, a);
     return cfn_check_launch("bn_fold_bwd");
 }
