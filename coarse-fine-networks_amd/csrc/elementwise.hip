@@ -5,6 +5,7 @@
 // and the squeeze-excite gate) and fp64 per-(n,c) reduction outputs for the backward of that affine.
 // All kernels: grid = (chunks of the (n,c) volume, N*C), float4 when the volume allows it.
 #include "cfn_common.h"
+#include <stdlib.h>
 
 typedef float __attribute__((ext_vector_type(4))) f4v;
 
@@ -106,6 +107,99 @@ __global__ __launch_bounds__(256) void bn_add_relu_bwd_g_kernel(const float* __r
         atomicAdd(&gA[nc], (double)acc[0]);
         atomicAdd(&gB[nc], (double)acc[1]);
         if (gAr) atomicAdd(&gAr[nc], (double)acc[2]);
+    }
+}
+
+// FLAT variants of the two kernels above (float4 tensors; round 4): the loops above are one load -> wait -> store round trip per iteration
+// (hipcc keeps every iteration behind its `break`, and on gfx950 the wait for a load also waits for the store before it: 8 serial HBM round
+// trips per thread, hidden only by occupancy: 5.3-5.5 TB/s).  Here a thread issues ALL its EW_ITEMS loads of every tensor up front (unconditional
+// buffer loads, out-of-range offsets beyond the channel's volume), and the workgroups are dealt in memory order with each XCD walking one
+// contiguous eighth (cfn_xcd_remap) -- the pattern of dwt5_fwd_flat_kernel.  Same mask words, same per-workgroup reduction.
+struct EwFlatArgs {
+    const float* y; const double* A; const double* B; const float* res; const double* Ar; const double* Br; float* out; unsigned* mask;
+    const float* gout; const float* gout2; const float* outr; const unsigned* maskr; float* g; double* gA; double* gB; double* gAr;
+    long vol; unsigned nchunks;
+};
+
+__global__ __launch_bounds__(256) void bn_add_relu_fwd_flat_kernel(const EwFlatArgs a) {
+    constexpr int OOB = 0x7ffffff0;
+    const unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    const long nc = cfn_uni((int)(L / a.nchunks));
+    const unsigned chunk = cfn_uni(L - (unsigned)nc * a.nchunks);
+    const float ca = a.A[nc], cb = a.B[nc] + (a.Br ? a.Br[nc] : 0.0f), car = a.Ar ? a.Ar[nc] : 1.0f;
+    const unsigned bytes = (unsigned)(a.vol * 4);
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * a.vol, bytes), rr = cfn_rsrc(a.res + nc * a.vol, bytes), ro = cfn_rsrc(a.out + nc * a.vol, bytes);
+    const long i0 = ((long)chunk * 256 * EW_ITEMS + threadIdx.x) * 4;
+    f4v yv[EW_ITEMS], rv[EW_ITEMS];
+    int off[EW_ITEMS];
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k) {
+        const long i = i0 + (long)k * 1024;
+        off[k] = i < a.vol ? (int)(i * 4) : OOB;
+        yv[k] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(ry, off[k], 0, 0));
+        rv[k] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rr, off[k], 0, 0));
+    }
+    unsigned mw = 0;
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k) {
+        f4v o;
+        o.x = fmaxf(fmaf(yv[k].x, ca, fmaf(rv[k].x, car, cb)), 0.f); o.y = fmaxf(fmaf(yv[k].y, ca, fmaf(rv[k].y, car, cb)), 0.f);
+        o.z = fmaxf(fmaf(yv[k].z, ca, fmaf(rv[k].z, car, cb)), 0.f); o.w = fmaxf(fmaf(yv[k].w, ca, fmaf(rv[k].w, car, cb)), 0.f);
+        cfn_bst128(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(4))), o), ro, off[k], 0);
+        if (off[k] != OOB) mw |= ((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u)) << (4 * k);
+    }
+    if (a.mask) a.mask[((unsigned long)nc * a.nchunks + chunk) * 256 + threadIdx.x] = mw;
+}
+
+__global__ __launch_bounds__(256) void bn_add_relu_bwd_g_flat_kernel(const EwFlatArgs a) {
+    constexpr int OOB = 0x7ffffff0;
+    __shared__ float sh[12];
+    const unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    const long nc = cfn_uni((int)(L / a.nchunks));
+    const unsigned chunk = cfn_uni(L - (unsigned)nc * a.nchunks);
+    const unsigned bytes = (unsigned)(a.vol * 4);
+    const bool has2 = a.gout2 != nullptr, hasm = a.maskr != nullptr, hasr = a.gAr != nullptr;     // workgroup uniform
+    // (an absent second gradient gets a descriptor of 0 bytes: its loads return zeros without touching memory)
+    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(a.gout + nc * a.vol, bytes), rg2 = cfn_rsrc((has2 ? a.gout2 : a.gout) + nc * a.vol, has2 ? bytes : 0u);
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * a.vol, bytes), ro = cfn_rsrc((hasm ? a.gout : a.outr) + nc * a.vol, bytes);
+    __amdgpu_buffer_rsrc_t rr = cfn_rsrc((hasr ? a.res : a.gout) + nc * a.vol, bytes), rd = cfn_rsrc(a.g + nc * a.vol, bytes);
+    const long i0 = ((long)chunk * 256 * EW_ITEMS + threadIdx.x) * 4;
+    const unsigned mw = hasm ? a.maskr[((unsigned long)nc * a.nchunks + chunk) * 256 + threadIdx.x] : 0u;
+    f4v go[EW_ITEMS], g2v[EW_ITEMS], yv[EW_ITEMS];
+    int off[EW_ITEMS];
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k) {
+        const long i = i0 + (long)k * 1024;
+        off[k] = i < a.vol ? (int)(i * 4) : OOB;
+        go[k] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rg, off[k], 0, 0));
+        g2v[k] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rg2, off[k], 0, 0));
+        yv[k] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(ry, off[k], 0, 0));
+    }
+    float acc[3] = {0.f, 0.f, 0.f};
+    // the rare tensors in a second round (registers): `out` when there is no bit mask, the residual for gAr (conv shortcut: first block of a layer)
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k) {
+        f4v ov, rv;
+        const f4v g2 = g2v[k];
+        if (!hasm) ov = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(ro, off[k], 0, 0));
+        if (hasr) rv = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rr, off[k], 0, 0));
+        const f4v gs = go[k] + g2;
+        unsigned m4;
+        if (hasm) m4 = (mw >> (4 * k)) & 15u;
+        else m4 = (ov.x > 0.f ? 1u : 0u) | (ov.y > 0.f ? 2u : 0u) | (ov.z > 0.f ? 4u : 0u) | (ov.w > 0.f ? 8u : 0u);
+        f4v g;
+        g.x = (m4 & 1u) ? gs.x : 0.f; g.y = (m4 & 2u) ? gs.y : 0.f;
+        g.z = (m4 & 4u) ? gs.z : 0.f; g.w = (m4 & 8u) ? gs.w : 0.f;
+        acc[0] += g.x * yv[k].x + g.y * yv[k].y + g.z * yv[k].z + g.w * yv[k].w;     // (out-of-range items: every operand is 0)
+        acc[1] += g.x + g.y + g.z + g.w;
+        if (hasr) acc[2] += g.x * rv.x + g.y * rv.y + g.z * rv.z + g.w * rv.w;
+        cfn_bst128(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(4))), g), rd, off[k], 0);
+    }
+    block_sum<3>(acc, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(&a.gA[nc], (double)acc[0]);
+        atomicAdd(&a.gB[nc], (double)acc[1]);
+        if (hasr) atomicAdd(&a.gAr[nc], (double)acc[2]);
     }
 }
 
@@ -399,6 +493,11 @@ static inline bool ew_vec4(long vol, const void* p0, const void* p1 = nullptr, c
     auto al = [](const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; };
     return vol % 4 == 0 && al(p0) && al(p1) && al(p2) && al(p3) && al(p4) && al(p5);
 }
+// flat elementwise kernels: one buffer descriptor per channel (< 2 GB), a 1-D grid
+static inline bool ew_flat_ok(long vol, long NC) {
+    static const int on = getenv("CFN_EW_FLAT") ? atoi(getenv("CFN_EW_FLAT")) : 1;
+    return on && vol * 4 < 0x7ffffff0L && NC * (long)cfn_cdiv(vol, 256L * EW_ITEMS * 4) < 0x7fffffffL && NC < 0x7fffffffL;
+}
 #define CFN_NC_CHECK(NC) CFN_REQUIRE((NC) > 0 && cfn_split_nc_ok(NC), "N*C = %ld has no grid factorisation", (long)(NC))
 
 // words of the ReLU bit mask cfn_bn_add_relu_fwd can emit for (NC, vol); 0 = no mask for this shape (vol % 4 != 0)
@@ -416,7 +515,12 @@ extern "C" int cfn_bn_add_relu_fwd(const float* y, const double* A, const double
     CfnProfScope prof(CFN_K_ELEMWISE, st, 12.0 * NC * vol);
     const bool v4 = ew_vec4(vol, y, res, out);
     CFN_REQUIRE(mask == nullptr || v4, "cfn_bn_add_relu_fwd: the bit mask needs vol %% 4 == 0 and 16-byte aligned tensors");
-    if (v4) hipLaunchKernelGGL(bn_add_relu_fwd_kernel<4>, ew_grid(vol, NC, 4), dim3(256), 0, st, y, A, B, res, Ar, Br, out, (unsigned*)mask, vol);
+    if (v4 && ew_flat_ok(vol, NC)) {
+        EwFlatArgs a = {};
+        a.y = y; a.A = A; a.B = B; a.res = res; a.Ar = Ar; a.Br = Br; a.out = out; a.mask = (unsigned*)mask; a.vol = vol;
+        a.nchunks = (unsigned)cfn_cdiv(vol, 256L * EW_ITEMS * 4);
+        hipLaunchKernelGGL(bn_add_relu_fwd_flat_kernel, dim3((unsigned)(NC * a.nchunks)), dim3(256), 0, st, a);
+    } else if (v4) hipLaunchKernelGGL(bn_add_relu_fwd_kernel<4>, ew_grid(vol, NC, 4), dim3(256), 0, st, y, A, B, res, Ar, Br, out, (unsigned*)mask, vol);
     else hipLaunchKernelGGL(bn_add_relu_fwd_kernel<1>, ew_grid(vol, NC, 1), dim3(256), 0, st, y, A, B, res, Ar, Br, out, (unsigned*)nullptr, vol);
     return cfn_check_launch("bn_add_relu_fwd");
 }
@@ -432,7 +536,12 @@ extern "C" int cfn_bn_add_relu_bwd_g(const float* gout, const float* gout2, cons
     CfnProfScope prof(CFN_K_ELEMWISE, st, (12.0 + (gout2 ? 4.0 : 0.0) + (out ? 4.0 : 0.125) + (gAr ? 4.0 : 0.0)) * NC * vol);
     const bool v4 = ew_vec4(vol, gout, out, y, gAr ? res : nullptr, g) && (((uintptr_t)gout2) & 15) == 0;
     CFN_REQUIRE(mask == nullptr || v4, "cfn_bn_add_relu_bwd_g: the bit mask needs vol %% 4 == 0 and 16-byte aligned tensors");
-    if (v4)
+    if (v4 && ew_flat_ok(vol, NC)) {
+        EwFlatArgs a = {};
+        a.gout = gout; a.gout2 = gout2; a.outr = out; a.maskr = (const unsigned*)mask; a.y = y; a.res = res; a.g = g; a.gA = gA; a.gB = gB; a.gAr = gAr;
+        a.vol = vol; a.nchunks = (unsigned)cfn_cdiv(vol, 256L * EW_ITEMS * 4);
+        hipLaunchKernelGGL(bn_add_relu_bwd_g_flat_kernel, dim3((unsigned)(NC * a.nchunks)), dim3(256), 0, st, a);
+    } else if (v4)
         hipLaunchKernelGGL(bn_add_relu_bwd_g_kernel<4>, ew_grid(vol, NC, 4), dim3(256), 0, st, gout, gout2, out, (const unsigned*)mask, y, res, g, gA, gB, gAr, vol);
     else
         hipLaunchKernelGGL(bn_add_relu_bwd_g_kernel<1>, ew_grid(vol, NC, 1), dim3(256), 0, st, gout, gout2, out, (const unsigned*)nullptr, y, res, g, gA, gB, gAr, vol);

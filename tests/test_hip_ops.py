@@ -183,7 +183,7 @@ def test_stem_conv(N, T, H, W):
 
 
 @pytest.mark.parametrize('affine_res', [False, True])
-@pytest.mark.parametrize('shape', [(2, 6, 3, 8, 8), (1, 5, 2, 7, 7)])
+@pytest.mark.parametrize('shape', [(2, 6, 3, 8, 8), (1, 5, 2, 7, 7), (2, 3, 5, 48, 48)])     # the last: two 8192-element chunks per channel, the second ragged
 def test_bn_add_relu(shape, affine_res):
     N, C = shape[:2]
     vals = dict(y=rnd(1, *shape), A=1 + 0.2 * rnd(2, N, C), B=0.2 * rnd(3, N, C), res=rnd(4, *shape))
