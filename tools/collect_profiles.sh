@@ -14,6 +14,7 @@ cp $(latest "$R/bench_coarse/runc/*kernel_stats.csv") $P/${TAG}_coarse_kernel_st
 cp $(latest "$R/bench_coarse_t256/runc/*kernel_stats.csv") $P/${TAG}_coarse_t256_kernel_stats.csv
 cp $R/sal_bench.txt $P/${TAG}_sal_bench.txt
 cp $R/determinism_scan.txt $P/${TAG}_determinism_scan.txt
+cp $R/power_clock.txt $P/${TAG}_power_clock.txt
 cp $R/microbench_b8.txt $P/${TAG}_microbench_b8.txt
 cp $R/microbench_bf16_b8.txt $P/${TAG}_microbench_bf16_b8.txt
 cp $R/stream_probe.txt $P/${TAG}_stream_probe.txt

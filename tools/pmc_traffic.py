@@ -23,7 +23,7 @@ def per_kernel(path, counter):
     for r in rows:
         name = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')
         if not (name.startswith('dw3d_kernel<0') or name.startswith('dwt5_kernel<0') or name.startswith('dw3d_small_fwd_kernel')
-                or name.startswith('dw3d_cp_fwd_kernel') or name.startswith('dwt5_fwd_stream_kernel')
+                or name.startswith('dw3d_cp_fwd_kernel') or name.startswith('dwt5_fwd_stream_kernel') or name.startswith('dw3d_flat')
                 or name.startswith('dwt5_fwd_flat_kernel')):
             continue
         v = float(r['Counter_Value']) * 1024.0
@@ -54,7 +54,7 @@ def main():
                   'MI355X, T=%d, B=%d' % (T, B),
         'correction': 'counter values are KiB; FETCH_SIZE doubled (gfx950 counts wide coalesced reads at 1/2, '
                       'MI355X_MICROARCH.md HBM section); WRITE_SIZE as is',
-        'kernels': 'dwt5_fwd_flat_kernel (conv1_t) + dw3d_cp_fwd_kernel / dw3d_small_fwd_kernel / dw3d_kernel<FWD> (26 conv2 launches) per x3d_fine forward',
+        'kernels': 'dwt5_fwd_flat_kernel (conv1_t) + dw3d_flat*_fwd_kernel / dw3d_small_fwd_kernel (26 conv2 launches) per x3d_fine forward',
         'batch': B, 'frames': T, 'layers': layers, 'launches_per_step': launches,
         'traffic_bytes_per_step': tot, 'traffic_bytes_per_launch': tot / max(launches, 1),
     }

@@ -29,6 +29,14 @@ python $R/tools/determinism_scan.py --runs 12 2>&1 | grep -v "$FILT" > $O/determ
 python $R/tools/microbench.py pw --bwd --batch 8 2>&1 | grep -v "$FILT" > $O/microbench_b8.txt
 python $R/tools/microbench.py dw --bwd --batch 8 2>&1 | grep -v "$FILT" >> $O/microbench_b8.txt
 python $R/tools/microbench_bf16.py 2>&1 | grep -v "$FILT" > $O/microbench_bf16_b8.txt
+# sustained single-kernel runs with rocm-smi sampled alongside (clock / power): the evidence behind DESIGN 4j
+{ for w in copy t5 dw56s1 dw28s1 dw14s1 dw7s1 dw112s2 dw56s2 dw28s2 dw14s2; do $R/tools/clk_watch.sh $w python $R/tools/busy.py $w --secs 3; done
+  for w in dw56s1 dw28s1 dw14s1 dw112s2 dw56s2 dw28s2 dw14s2; do CFN_DW_FLAT=0 $R/tools/clk_watch.sh marching_$w python $R/tools/busy.py $w --secs 3; done
+  for h in 7 14 28 56; do python $R/tools/dwbwd_busy.py $h; done
+  CFN_DW_FLATB=0 python $R/tools/dwbwd_busy.py 7
+  python $R/tools/stem_wg_bench.py; CFN_STEM_WG_OFF=1 python $R/tools/stem_wg_bench.py
+  python $R/tools/dwbwd_s2_time.py; CFN_DW_FLATB=8 python $R/tools/dwbwd_s2_time.py
+} 2>&1 | grep -v "$FILT" > $O/power_clock.txt
 $R/tools/probe/stream_probe > $O/stream_probe.txt 2>&1
 $R/tools/probe/mfma_rate_probe > $O/mfma_rate_probe.txt 2>&1
 find $O -name "*kernel_trace.csv" -size +4M -delete
