@@ -350,8 +350,19 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
     __syncthreads();
 
     // fast path: contiguous positions, float4 rows, next stage's global loads in flight during the MFMAs
-    const bool fast = (Q % 4 == 0) && a.stride == 1 && !a.stem;
+    // (any Q: rows of an odd-sized volume -- 65 x 7 x 7 in the coarse stream -- start on 4-byte boundaries only; gfx950 takes 16-byte global
+    // loads at any dword address, and the one float4 that straddles the end of a row is fetched element by element)
+    const bool fast = a.stride == 1 && !a.stem;
     const int lrow = tid >> 4, c4 = (tid & 15) * 4;          // 16 lanes cover one 64-position row segment
+    struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
+    auto ld4 = [&](const float* p, int q) -> f4v {             // positions q .. q+3 of a row that ends at Q
+        if (q + 3 < Q) { const f4u t = *reinterpret_cast<const f4u*>(p); return (f4v){t.v[0], t.v[1], t.v[2], t.v[3]}; }
+        f4v r = {0.f, 0.f, 0.f, 0.f};
+        if (q < Q) r.x = p[0];
+        if (q + 1 < Q) r.y = p[1];
+        if (q + 2 < Q) r.z = p[2];
+        return r;
+    };
     f4v pg[NG], py[NG], px[NX];
     auto prefetch = [&](int q0) {
 #pragma unroll
@@ -361,40 +372,40 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
             py[it] = (f4v){0.f, 0.f, 0.f, 0.f};
             if (ch < M && q0 + c4 < Q) {
                 const long base = ((long)n * M + ch) * Q + q0 + c4;
-                pg[it] = *reinterpret_cast<const f4v*>(a.gy + base);
-                if (a.y) py[it] = *reinterpret_cast<const f4v*>(a.y + base);
+                pg[it] = ld4(a.gy + base, q0 + c4);
+                if (a.y) py[it] = ld4(a.y + base, q0 + c4);
             }
         }
 #pragma unroll
         for (int it = 0; it < NX; ++it) {
             const int ch = k0 + it * 16 + lrow;
             px[it] = (f4v){0.f, 0.f, 0.f, 0.f};
-            if (ch < K && q0 + c4 < Q) px[it] = *reinterpret_cast<const f4v*>(a.x + ((long)n * K + ch) * a.Pin + q0 + c4);
+            if (ch < K && q0 + c4 < Q) px[it] = ld4(a.x + ((long)n * K + ch) * a.Pin + q0 + c4, q0 + c4);
         }
     };
     auto stage_fast = [&](int q0, float* sG, float* sX) {
-        const bool inq = q0 + c4 < Q;
+        const int qa = q0 + c4;                                  // element u is inside the row when qa + u < Q (the constant terms must not leak past it)
 #pragma unroll
         for (int it = 0; it < NG; ++it) {
             const int row = it * 16 + lrow;
             const float cs = sCg[2 * row], cq = sCg[2 * row + 1], cz = sCz[row];
-            const bool ok = inq && (m0 + row < M);
+            const bool ok = m0 + row < M;
             float* d = sG + row * WG_PITCH + c4;
-            d[0] = ok ? fmaf(py[it].x, cq, fmaf(pg[it].x, cz, cs)) : 0.0f;
-            d[1] = ok ? fmaf(py[it].y, cq, fmaf(pg[it].y, cz, cs)) : 0.0f;
-            d[2] = ok ? fmaf(py[it].z, cq, fmaf(pg[it].z, cz, cs)) : 0.0f;
-            d[3] = ok ? fmaf(py[it].w, cq, fmaf(pg[it].w, cz, cs)) : 0.0f;
+            d[0] = (ok && qa < Q) ? fmaf(py[it].x, cq, fmaf(pg[it].x, cz, cs)) : 0.0f;
+            d[1] = (ok && qa + 1 < Q) ? fmaf(py[it].y, cq, fmaf(pg[it].y, cz, cs)) : 0.0f;
+            d[2] = (ok && qa + 2 < Q) ? fmaf(py[it].z, cq, fmaf(pg[it].z, cz, cs)) : 0.0f;
+            d[3] = (ok && qa + 3 < Q) ? fmaf(py[it].w, cq, fmaf(pg[it].w, cz, cs)) : 0.0f;
         }
 #pragma unroll
         for (int it = 0; it < NX; ++it) {
             const int row = it * 16 + lrow;
             const float ca = sCx[2 * row], cb = sCx[2 * row + 1];
-            const bool ok = inq && (k0 + row < K);
+            const bool ok = k0 + row < K;
             float* d = sX + row * WG_PITCH + c4;
-            d[0] = ok ? cfn_act_rt(fmaf(px[it].x, ca, cb), a.act) : 0.0f;
-            d[1] = ok ? cfn_act_rt(fmaf(px[it].y, ca, cb), a.act) : 0.0f;
-            d[2] = ok ? cfn_act_rt(fmaf(px[it].z, ca, cb), a.act) : 0.0f;
-            d[3] = ok ? cfn_act_rt(fmaf(px[it].w, ca, cb), a.act) : 0.0f;
+            d[0] = (ok && qa < Q) ? cfn_act_rt(fmaf(px[it].x, ca, cb), a.act) : 0.0f;
+            d[1] = (ok && qa + 1 < Q) ? cfn_act_rt(fmaf(px[it].y, ca, cb), a.act) : 0.0f;
+            d[2] = (ok && qa + 2 < Q) ? cfn_act_rt(fmaf(px[it].z, ca, cb), a.act) : 0.0f;
+            d[3] = (ok && qa + 3 < Q) ? cfn_act_rt(fmaf(px[it].w, ca, cb), a.act) : 0.0f;
         }
     };
     auto stage_slow = [&](int q0, float* sG, float* sX) {          // strided / im2col / ragged positions: element-wise gather
