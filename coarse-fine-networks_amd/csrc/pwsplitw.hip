@@ -340,7 +340,7 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
     auto issue = [&](int h, f4v (&g)[SM], f4v (&yy)[SM], f4v (&xx)[SM]) {
         const int p0 = pbeg + h * PWSS_P;
         const bool hv = h < nh;                                   // uniform; beyond the strip: nothing is fetched
-        const bool pv = hv && p0 + c4 * 4 < pend;                 // Q % 4 == 0 and per % 32 == 0: a float4 is all inside or all outside
+        const bool pv = hv && p0 + c4 * 4 < pend;                 // a float4 whose first element is inside the strip is fetched (fp32: any dword address)
         const int so = hv ? p0 * ES : 0;
 #pragma unroll
         for (int i = 0; i < SM; ++i) {
@@ -350,17 +350,22 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
         }
     };
     auto convert = [&](int h, unsigned char* buf, const f4v (&g)[SM], const f4v (&yy)[SM], const f4v (&xx)[SM]) {
-        const float vm = (h < nh && pbeg + h * PWSS_P + c4 * 4 < pend) ? 1.0f : 0.0f;   // masks the constant term beyond the strip
+        // element e of this thread's float4 is inside the strip (odd volumes -- 65 x 7 x 7 in the coarse stream: the float4 that straddles the
+        // end of a row carries the head of the next row; whole float4s beyond the strip were not fetched)
+        const int pe = pbeg + h * PWSS_P + c4 * 4;
+        float vm[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vm[e] = (h < nh && pe + e < pend) ? 1.0f : 0.0f;
 #pragma unroll
         for (int i = 0; i < SM; ++i) {
             if (ldsG[i] >= 0) {
                 const float4 c = cG[(tid + PWSS_THREADS * i) >> 3];
-                const float c0 = c.x * vm;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = fmaf(g[i][e], c.z, c0);
+                    v[e] = fmaf(g[i][e], c.z, c.x);
                     if (HASY) v[e] = fmaf(yy[i][e], c.y, v[e]);
+                    v[e] = vm[e] != 0.0f ? v[e] : 0.0f;
                 }
                 unsigned p0[NS], p1[NS];
                 pwsw_split<NS>(v[0], v[1], p0);
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
                 const float2 c = cX[(tid + PWSS_THREADS * i) >> 3];
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = cfn_act<ACT>(fmaf(xx[i][e], c.x, c.y));
+                for (int e = 0; e < 4; ++e) v[e] = vm[e] != 0.0f ? cfn_act<ACT>(fmaf(xx[i][e], c.x, c.y)) : 0.0f;
                 unsigned p0[NS], p1[NS];
                 pwsw_split<NS>(v[0], v[1], p0);
                 pwsw_split<NS>(v[2], v[3], p1);
@@ -507,15 +512,17 @@ extern "C" int cfn_pw_split_terms(int terms);
 int pws_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const double* gsc, const float* x,
                          const double* pa, const double* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st) {
     const int terms = cfn_pw_split_terms(-1);
-    if (terms == 0 || M < 48 || K < 48 || Q % 4 != 0) return -1;
+    if (terms == 0 || M < 48 || K < 48) return -1;
+    const bool ragged = Q % 4 != 0;                               // rows on 4-byte boundaries: the staged kernel only (per-element strip masks)
     if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && act != CFN_ACT_SWISH) return -1;
     if (((uintptr_t)gy | (uintptr_t)(y ? y : gy) | (uintptr_t)x) & 15) return -1;
     if ((long)M * Q * 4 >= (1L << 31) - 64 || (long)K * Q * 4 >= (1L << 31) - 64) return -1;
     static const int direct_env = getenv("CFN_PWSW_DIRECT") ? atoi(getenv("CFN_PWSW_DIRECT")) : 0;
-    if (!direct_env) {
+    if (!direct_env || ragged) {
         const int rc = pwss_try(gy, y, gs, gq, gsc, x, pa, pb, act, gw, N, M, K, Q, terms, st);
         if (rc >= 0) return rc;
     }
+    if (ragged) return -1;
     WsArgs a = {gy, gq ? y : nullptr, gs, gq, gsc, x, pa, pb, gw, N, M, K, Q, act};
     // tile group per wave: the candidate with the least operand traffic  kgroups * M rows (x2 with y) + mgroups * K rows
     const int mt = cfn_cdiv(M, 32), kt = cfn_cdiv(K, 32);

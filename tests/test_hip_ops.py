@@ -148,6 +148,8 @@ PW_CASES = [
     (1, 432, 2048, 5, 1, 1, 1, 0, False),  # fc1
     (2, 2048, 157, 3, 1, 1, 1, 1, True),   # fc2 as pointwise
     (1, 3, 5, 40, 13, 11, 1, 1, True),     # odd everything, many position tiles
+    (2, 192, 432, 5, 7, 7, 1, 1, True),    # odd volume (245 positions: rows start on 4-byte boundaries), the coarse stream's layer 4
+    (2, 432, 192, 13, 7, 7, 1, 2, True),
 ]
 
 
