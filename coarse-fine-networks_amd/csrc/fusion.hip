@@ -6,6 +6,7 @@
 //     (B,C,T',K,h,w) product; every quantity is constant over the (h/7 x w/7) blocks, so the 7x7
 //     result up-sampled is identical (measured 3e-8).
 #include "cfn_common.h"
+#include <stdlib.h>
 
 // salconv.hip
 int sal_dgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
@@ -356,6 +357,113 @@ __global__ __launch_bounds__(256) void fusion_gather_fwd_kernel(const float* __r
     if (c == 0) den[(r * K + k) * (long)P + p] = d;
 }
 
+// REGISTER-TILED forward (round 4).  The kernel above gives a thread ONE output and walks Tf with three loads and an expf per step: the
+// sigmoid of at is recomputed C x K times, the step of x3d_coarse at T = 256 spent 2.5 ms here (0.1 TB/s of 240 MB).  Per (row r, position p)
+// the op is a small matrix product  Z_p (C x K) = X_p (C x Tf) . W_p (Tf x K),  W_p[t][k] = at[b,t,p] GX[r,t,k] mask[b,t]:  here a thread owns
+// position p (the lane dimension: every load is a contiguous run over p) and a CT x KT block of (c, k): per t one sigmoid, KT broadcast
+// loads of GX, CT loads of x, CT x KT FMAs.  The sum over t runs in the same order with the same roundings as above (bit-identical z / den).
+template <int CT, int KT>
+__global__ __launch_bounds__(256) void fusion_gather_fwd_tiled_kernel(const float* __restrict__ x, const float* __restrict__ at_raw,
+                                                                      const float* __restrict__ at_bias, const float* __restrict__ GX,
+                                                                      const float* __restrict__ mask, float* __restrict__ z,
+                                                                      float* __restrict__ den, int crops, int C, int Tf, int K, int P,
+                                                                      int kgroups, int cblocks) {
+    const int G = 256 / P;                                             // channel groups per workgroup
+    const int cg = threadIdx.x / P, p = threadIdx.x - cg * P;
+    if (cg >= G) return;
+    unsigned L = blockIdx.x;
+    const int cb = L % cblocks; L /= cblocks;
+    const int kg = L % kgroups;
+    const long r = L / kgroups, b = r / crops;
+    const int c0 = (cb * G + cg) * CT, k0 = kg * KT;
+    if (c0 >= C) return;
+    const float ab = at_bias ? at_bias[0] : 0.0f;
+    const float* ap = at_raw + b * Tf * (long)P + p;
+    const float* gp = GX + r * Tf * (long)K + k0;
+    const float* mp = mask + b * Tf;
+    const float* xp[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) xp[i] = x + ((b * C + min(c0 + i, C - 1)) * Tf) * (long)P + p;
+    float num[CT][KT], d[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        d[j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) num[i][j] = 0.0f;
+    }
+    for (int t = 0; t < Tf; ++t) {
+        const float a = 1.0f / (1.0f + expf(-(ap[(long)t * P] + ab)));
+        const float m = mp[t];
+        float w[KT], xv[CT];
+#pragma unroll
+        for (int j = 0; j < KT; ++j) w[j] = a * ((k0 + j < K ? gp[(long)t * K + j] : 0.0f) * m);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) xv[i] = xp[i][(long)t * P];
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            d[j] += w[j];
+#pragma unroll
+            for (int i = 0; i < CT; ++i) num[i][j] = fmaf(xv[i], w[j], num[i][j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        if (k0 + j < K) {
+            const float dd = d[j] + 1e-6f;
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+                if (c0 + i < C) z[((r * C + c0 + i) * K + k0 + j) * (long)P + p] = num[i][j] / dd;
+            if (c0 == 0) den[(r * K + k0 + j) * (long)P + p] = dd;
+        }
+    }
+}
+
+// REGISTER-TILED dw (see the one-output kernel below for the formula): a thread owns position p and a TT x KT block of (t, k) and walks the
+// channels: per c KT loads of gz and z, TT loads of x, TT x KT (subtract, FMA) pairs -- the same order and roundings per output.
+template <int TT, int KT>
+__global__ __launch_bounds__(256) void fusion_gather_bwd_w_tiled_kernel(const float* __restrict__ gz, const float* __restrict__ z,
+                                                                        const float* __restrict__ den, const float* __restrict__ x,
+                                                                        float* __restrict__ dw, int crops, int C, int Tf, int K, int P,
+                                                                        int kgroups, int tgroups, int rows) {
+    const int G = 256 / P;
+    const int g = threadIdx.x / P, p = threadIdx.x - g * P;
+    if (g >= G) return;
+    const long tiles = (long)kgroups * tgroups;
+    const long tile = (long)blockIdx.x * G + g;                        // over (r, tg, kg)
+    const long r = tile / tiles, b = r / crops;
+    if (r >= rows) return;
+    const int tg = (int)((tile - r * tiles) / kgroups), kg = (int)((tile - r * tiles) % kgroups);
+    const int t0 = tg * TT, k0 = kg * KT;
+    float acc[TT][KT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < KT; ++j) acc[i][j] = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const float* gzp = gz + ((r * C + c) * K + k0) * (long)P + p;
+        const float* zp = z + ((r * C + c) * K + k0) * (long)P + p;
+        const float* xq = x + ((b * C + c) * Tf + t0) * (long)P + p;
+        float gv[KT], zv[KT], xv[TT];
+#pragma unroll
+        for (int j = 0; j < KT; ++j) { const bool ok = k0 + j < K; gv[j] = ok ? gzp[(long)j * P] : 0.0f; zv[j] = ok ? zp[(long)j * P] : 0.0f; }
+#pragma unroll
+        for (int i = 0; i < TT; ++i) xv[i] = t0 + i < Tf ? xq[(long)i * P] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TT; ++i)
+#pragma unroll
+            for (int j = 0; j < KT; ++j) acc[i][j] = fmaf(gv[j], xv[i] - zv[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        if (k0 + j < K) {
+            const float id = 1.0f / den[(r * K + k0 + j) * (long)P + p];
+#pragma unroll
+            for (int i = 0; i < TT; ++i)
+                if (t0 + i < Tf) dw[((r * Tf + t0 + i) * (long)K + k0 + j) * P + p] = acc[i][j] * id;
+        }
+    }
+}
+
 // gx[b,c,t,p] = at[b,t,p] mask[b,t] sum_{crop} sum_k (gz/den)[r,c,k,p] * GX[r,t,k]
 __global__ __launch_bounds__(256) void fusion_gather_bwd_x_kernel(const float* __restrict__ gz, const float* __restrict__ den,
                                                                   const float* __restrict__ at_raw, const float* __restrict__ at_bias,
@@ -443,6 +551,21 @@ extern "C" int cfn_fusion_gather_fwd(const float* x, const float* at_raw, const 
     const long total = (long)B * crops * C * K * P;
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_FUSION, st, 4.0 * B * ((double)C * Tf * P + (double)crops * C * K * P));
+    static const int tiled = getenv("CFN_FUSION_TILED") ? atoi(getenv("CFN_FUSION_TILED")) : 1;
+    if (tiled && P <= 256) {
+        // k tile: 13 (K = 65: T = 256), 9 (K = 17: T = 64) or 8 -- the one that wastes the fewest slots
+        const int G = 256 / P, CT = 4;
+        const int w13 = cfn_cdiv(K, 13) * 13 - K, w9 = cfn_cdiv(K, 9) * 9 - K, w8 = cfn_cdiv(K, 8) * 8 - K;
+        const int KT = (w13 <= w9 && w13 <= w8) ? 13 : (w9 <= w8 ? 9 : 8);
+        const int kgroups = cfn_cdiv(K, KT), cblocks = cfn_cdiv(C, G * CT);
+        const long blocks = (long)B * crops * kgroups * cblocks;
+        if (blocks < 0x7fffffffL) {
+            if (KT == 13) hipLaunchKernelGGL((fusion_gather_fwd_tiled_kernel<4, 13>), dim3((unsigned)blocks), dim3(256), 0, st, x, at_raw, at_bias, GX, mask, z, den, crops, C, Tf, K, P, kgroups, cblocks);
+            else if (KT == 9) hipLaunchKernelGGL((fusion_gather_fwd_tiled_kernel<4, 9>), dim3((unsigned)blocks), dim3(256), 0, st, x, at_raw, at_bias, GX, mask, z, den, crops, C, Tf, K, P, kgroups, cblocks);
+            else hipLaunchKernelGGL((fusion_gather_fwd_tiled_kernel<4, 8>), dim3((unsigned)blocks), dim3(256), 0, st, x, at_raw, at_bias, GX, mask, z, den, crops, C, Tf, K, P, kgroups, cblocks);
+            return cfn_check_launch("fusion_gather_fwd");
+        }
+    }
     hipLaunchKernelGGL(fusion_gather_fwd_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, st, x, at_raw, at_bias, GX, mask, z, den,
                        crops, C, Tf, K, P, total);
     return cfn_check_launch("fusion_gather_fwd");
@@ -461,6 +584,14 @@ extern "C" int cfn_fusion_gather_bwd(const float* gz, const float* z, const floa
     }
     if (gat || gGX) {
         const long total = (long)B * crops * Tf * K * P;
+        static const int tiled = getenv("CFN_FUSION_TILED") ? atoi(getenv("CFN_FUSION_TILED")) : 1;
+        const int G = P <= 256 ? 256 / P : 0;
+        const int kgroups = cfn_cdiv(K, 8), tgroups = cfn_cdiv(Tf, 8);
+        const long nblk = G ? cfn_cdiv((long)B * crops * kgroups * tgroups, G) : 0;
+        if (tiled && G && nblk < 0x7fffffffL)
+            hipLaunchKernelGGL((fusion_gather_bwd_w_tiled_kernel<8, 8>), dim3((unsigned)nblk), dim3(256), 0, st, gz, z, den, x, dw,
+                               crops, C, Tf, K, P, kgroups, tgroups, B * crops);
+        else
         hipLaunchKernelGGL(fusion_gather_bwd_w_kernel, dim3(cfn_cdiv(total, 256)), dim3(256), 0, st, gz, z, den, x, dw, crops, C, Tf, K,
                            P, total);
         hipLaunchKernelGGL(fusion_gather_bwd_reduce_kernel, dim3(B * Tf), dim3(256), P * sizeof(float), st, dw, at_raw, at_bias, GX,
