@@ -10,6 +10,7 @@
 // One workgroup; all arithmetic that feeds the normalisation is fp64.  The SE matrices are staged in LDS and the
 // matrix-vector products are wave cooperative, so the kernel is a handful of dependent memory latencies long.
 #include "cfn_common.h"
+#include <stdlib.h>
 
 struct BnFoldArgs {
     const double* s; const double* q;       // (N,C) sums of y, y*y over `count` positions (training; SE needs s too)
@@ -49,8 +50,13 @@ __global__ __launch_bounds__(1024) void bn_fold_fwd_kernel(const BnFoldArgs a) {
     if (st) bnf_stage_se(a.w1, a.w2, sh, sh + Wd * C, C, Wd);
     // (1) statistics per (split group, channel); without a squeeze-excite gate the launch is several small workgroups (one element per thread:
     // the fp64 divide / sqrt chain of an element is ~2 us, a single workgroup looping over 8 x 432 elements was 10 us on the critical path)
+    // With a gate and several workgroups (one per SAMPLE: the gate of a sample depends on nothing but its own statistics row) a workgroup
+    // computes the statistics of its sample's split group only; the group's first sample writes them.
+    const bool ps = Wd > 0 && gridDim.x > 1;
+    const int gown = ps ? (int)(blockIdx.x % S) : 0;
     const int gtid = Wd > 0 ? tid : (int)(blockIdx.x * blockDim.x) + tid, gn = Wd > 0 ? nthr : (int)(gridDim.x * blockDim.x);
-    for (int e = gtid; e < S * C; e += gn) {
+    for (int e = ps ? gown * C + tid : gtid; e < (ps ? (gown + 1) * C : S * C); e += gn) {
+        const bool wr = !ps || (int)blockIdx.x == gown;
         const int g = e / C, c = e - g * C;
         double mean, var;
         if (a.training) {
@@ -61,29 +67,31 @@ __global__ __launch_bounds__(1024) void bn_fold_fwd_kernel(const BnFoldArgs a) {
             var = qq / cnt - mean * mean;
             if (var < 0.0) var = 0.0;
             const double unb = var * (cnt / (cnt > 1.0 ? cnt - 1.0 : 1.0));
-            a.run_mean[e] = (float)((1.0 - a.momentum) * (double)a.run_mean[e] + a.momentum * mean);
-            a.run_var[e] = (float)((1.0 - a.momentum) * (double)a.run_var[e] + a.momentum * unb);
+            if (wr) {
+                a.run_mean[e] = (float)((1.0 - a.momentum) * (double)a.run_mean[e] + a.momentum * mean);
+                a.run_var[e] = (float)((1.0 - a.momentum) * (double)a.run_var[e] + a.momentum * unb);
+            }
         } else {
             mean = (double)a.run_mean[c];
             var = (double)a.run_var[c];
         }
         const double rstd = 1.0 / sqrt(var + a.eps);
-        a.mean[e] = mean;
-        a.rstd[e] = rstd;
+        if (wr) { a.mean[e] = mean; a.rstd[e] = rstd; }
         const double ga = a.gamma ? (double)a.gamma[c] : 1.0, be = a.beta ? (double)a.beta[c] : 0.0;
         const float av = (float)(ga * rstd), bv = (float)(be - mean * ga * rstd);
         for (int i = 0; i < G; ++i) {
+            if (ps && i * S + g != (int)blockIdx.x) continue;            // this workgroup's sample only
             const long o = (long)(i * S + g) * C + c;
             if (Wd > 0) { a.A0[o] = av; a.B0[o] = bv; } else { a.A[o] = av; a.B[o] = bv; }
         }
     }
-    if (a.training && a.nbt && gtid == 0) a.nbt[0] += 1;
+    if (a.training && a.nbt && gtid == 0 && (!ps || blockIdx.x == 0)) a.nbt[0] += 1;
     if (Wd <= 0) return;
     __syncthreads();
     // (2) squeeze-excite gate, BNF_NB samples per pass; dot products are wave cooperative (lanes along the long axis)
     const int wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
-    for (int n0 = 0; n0 < N; n0 += BNF_NB) {
-        const int nb = min(BNF_NB, N - n0);
+    for (int n0 = ps ? (int)blockIdx.x : 0; n0 < (ps ? (int)blockIdx.x + 1 : N); n0 += BNF_NB) {
+        const int nb = ps ? 1 : min(BNF_NB, N - n0);
         for (int e = tid; e < nb * C; e += nthr) {
             const long o = (long)n0 * C + e;
             const float pv = (float)(a.s[o] / a.pool_count) * a.A0[o] + a.B0[o];
@@ -253,7 +261,8 @@ extern "C" int cfn_bn_fold_fwd(const double* s, const double* q, const float* ga
     CFN_REQUIRE(lds <= 150 * 1024, "cfn_bn_fold_fwd: per-sample SE tables (C=%d, width=%d) exceed LDS", C, Wd);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)bn_fold_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int Se = training ? S : 1;
-    hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3(Wd > 0 ? 1 : cfn_cdiv((long)Se * C, 64)), dim3(Wd > 0 ? 1024 : 64), lds, (hipStream_t)stream, a);
+    static const int per_sample = getenv("CFN_BNFOLD_PS") ? atoi(getenv("CFN_BNFOLD_PS")) : 1;     // gate: one workgroup per sample (0: one for all)
+    hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3(Wd > 0 ? (per_sample ? N : 1) : cfn_cdiv((long)Se * C, 64)), dim3(Wd > 0 ? 1024 : 64), lds, (hipStream_t)stream, a);
     return cfn_check_launch("bn_fold_fwd");
 }
 
