@@ -352,35 +352,30 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
     // fast path: contiguous positions, float4 rows, next stage's global loads in flight during the MFMAs
     // (any Q: rows of an odd-sized volume -- 65 x 7 x 7 in the coarse stream -- start on 4-byte boundaries only; gfx950 takes 16-byte global
     // loads at any dword address, and the one float4 that straddles the end of a row is fetched element by element)
-    const bool fast = a.stride == 1 && !a.stem;
+    const bool fast0 = a.stride == 1 && !a.stem;
     const int lrow = tid >> 4, c4 = (tid & 15) * 4;          // 16 lanes cover one 64-position row segment
-    struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
-    auto ld4 = [&](const float* p, int q) -> f4v {             // positions q .. q+3 of a row that ends at Q
-        if (q + 3 < Q) { const f4u t = *reinterpret_cast<const f4u*>(p); return (f4v){t.v[0], t.v[1], t.v[2], t.v[3]}; }
-        f4v r = {0.f, 0.f, 0.f, 0.f};
-        if (q < Q) r.x = p[0];
-        if (q + 1 < Q) r.y = p[1];
-        if (q + 2 < Q) r.z = p[2];
-        return r;
-    };
+    // unconditional raw buffer loads over the sample's block (range checked per dword: what lies beyond the block reads 0; the elements of a
+    // straddling float4 that belong to the next row are masked when the stage is written)
+    const bool big = (long)M * Q * 4 >= 0x7fff0000L || (long)K * Q * 4 >= 0x7fff0000L;      // (then: the gather path)
+    __amdgpu_buffer_rsrc_t rbg = cfn_rsrc(a.gy + (long)n * M * Q, (unsigned)((long)M * Q * 4));
+    __amdgpu_buffer_rsrc_t rby = cfn_rsrc((a.y ? a.y : a.gy) + (long)n * M * Q, a.y ? (unsigned)((long)M * Q * 4) : 0u);
+    __amdgpu_buffer_rsrc_t rbx = cfn_rsrc(a.x + (long)n * K * a.Pin, (unsigned)((long)K * Q * 4));
+    const bool fast = fast0 && !big;
     f4v pg[NG], py[NG], px[NX];
     auto prefetch = [&](int q0) {
+        constexpr int OOBW = 0x7fffff00;
+        const bool inq = q0 + c4 < Q;
 #pragma unroll
         for (int it = 0; it < NG; ++it) {
             const int ch = m0 + it * 16 + lrow;
-            pg[it] = (f4v){0.f, 0.f, 0.f, 0.f};
-            py[it] = (f4v){0.f, 0.f, 0.f, 0.f};
-            if (ch < M && q0 + c4 < Q) {
-                const long base = ((long)n * M + ch) * Q + q0 + c4;
-                pg[it] = ld4(a.gy + base, q0 + c4);
-                if (a.y) py[it] = ld4(a.y + base, q0 + c4);
-            }
+            const int vo = (ch < M && inq) ? (ch * Q + q0 + c4) * 4 : OOBW;
+            pg[it] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rbg, vo, 0, 0));
+            py[it] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rby, vo, 0, 0));
         }
 #pragma unroll
         for (int it = 0; it < NX; ++it) {
             const int ch = k0 + it * 16 + lrow;
-            px[it] = (f4v){0.f, 0.f, 0.f, 0.f};
-            if (ch < K && q0 + c4 < Q) px[it] = ld4(a.x + ((long)n * K + ch) * a.Pin + q0 + c4, q0 + c4);
+            px[it] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rbx, (ch < K && inq) ? (ch * Q + q0 + c4) * 4 : OOBW, 0, 0));
         }
     };
     auto stage_fast = [&](int q0, float* sG, float* sX) {
