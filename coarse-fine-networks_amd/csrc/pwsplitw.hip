@@ -352,7 +352,11 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
     auto convert = [&](int h, unsigned char* buf, const f4v (&g)[SM], const f4v (&yy)[SM], const f4v (&xx)[SM]) {
         // element e of this thread's float4 is inside the strip (odd volumes -- 65 x 7 x 7 in the coarse stream: the float4 that straddles the
         // end of a row carries the head of the next row; whole float4s beyond the strip were not fetched)
+        // Q % 4 == 0 (every fine-stream shape): a float4 is inside or outside as a whole, masking the constant term of the g' operand is enough
+        // (loads beyond the strip returned zeros, a zero g' row kills whatever act(B) the x operand holds there)
         const int pe = pbeg + h * PWSS_P + c4 * 4;
+        const bool ragged = (Q & 3) != 0;                           // uniform
+        const float vm0 = (h < nh && pe < pend) ? 1.0f : 0.0f;
         float vm[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) vm[e] = (h < nh && pe + e < pend) ? 1.0f : 0.0f;
@@ -360,12 +364,16 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
         for (int i = 0; i < SM; ++i) {
             if (ldsG[i] >= 0) {
                 const float4 c = cG[(tid + PWSS_THREADS * i) >> 3];
+                const float c0 = c.x * vm0;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = fmaf(g[i][e], c.z, c.x);
+                    v[e] = fmaf(g[i][e], c.z, c0);
                     if (HASY) v[e] = fmaf(yy[i][e], c.y, v[e]);
-                    v[e] = vm[e] != 0.0f ? v[e] : 0.0f;
+                }
+                if (ragged) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = vm[e] != 0.0f ? v[e] : 0.0f;
                 }
                 unsigned p0[NS], p1[NS];
                 pwsw_split<NS>(v[0], v[1], p0);
@@ -378,7 +386,11 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
                 const float2 c = cX[(tid + PWSS_THREADS * i) >> 3];
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = vm[e] != 0.0f ? cfn_act<ACT>(fmaf(xx[i][e], c.x, c.y)) : 0.0f;
+                for (int e = 0; e < 4; ++e) v[e] = cfn_act<ACT>(fmaf(xx[i][e], c.x, c.y));
+                if (ragged) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = vm[e] != 0.0f ? v[e] : 0.0f;
+                }
                 unsigned p0[NS], p1[NS];
                 pwsw_split<NS>(v[0], v[1], p0);
                 pwsw_split<NS>(v[2], v[3], p1);
