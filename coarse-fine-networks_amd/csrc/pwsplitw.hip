@@ -11,6 +11,9 @@
 // combined through LDS into one fp64 atomic per element per workgroup.
 #include "pw_common.h"
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <utility>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -249,6 +252,7 @@ struct WssArgs {      // gy, y, x: fp32 (ES = 4) or bf16 (ES = 2) tensors
     int N, M, K, Q, act;
     int mgroups, kgroups, nstrips, mt32, kt32;
     int mtg, ktg, per;      // row / column tiles per group (LDS images are 32*mtg / 32*ktg rows), positions per strip (multiple of 32)
+    float* ws;              // null: one fp64 atomic per element and workgroup; else the workgroup's fp32 tiles go to ws (pws_wgrad_reduce_kernel adds them)
 };
 
 // ES = 2: bf16 tensors (the bf16 activation path, section 4b of DESIGN.md): the same staging with 8-byte loads of 4 positions and
@@ -436,6 +440,19 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
         mfma(buf1);
     }
 
+    if (a.ws) {     // partial tiles of this workgroup: [group][n * nstrips + strip][tile][element e][lane]
+        const int S = a.N * a.nstrips, TPG = a.mtg * a.ktg;
+        float* wb = a.ws + (((size_t)(mgi * a.kgroups + kgi) * S + (size_t)n * a.nstrips + strip) * TPG) * 1024 + lane;
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            if (live[tt]) {
+                const int t = wave + (PWSS_THREADS / 64) * tt;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) wb[(size_t)t * 1024 + e * 64] = acc[tt][e];
+            }
+        }
+        return;
+    }
     // tile element e of lane (r, kg): row (e & 3) + 8 (e >> 2) + 4 kg, column r
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
@@ -449,6 +466,58 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
             }
         }
     }
+}
+
+// Second phase of the staged weight gradient when the workgroups' tiles went to the workspace: gW[m][k] += sum over the S = N x nstrips
+// partial tiles in a FIXED order (fp64).  A workgroup = one 64-element row of a tile (element e, all lanes) x 4 slices of S; the fp64 atomics
+// this replaces were 12-15 % of the first phase (6-11 M per launch, 256 workgroups onto the same M x K addresses), and the result no longer
+// depends on the order in which workgroups finish.
+__global__ __launch_bounds__(256) void pws_wgrad_reduce_kernel(const WssArgs a) {
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6, kg = lane >> 5, r = lane & 31;
+    const int TPG = a.mtg * a.ktg, S = a.N * a.nstrips;
+    unsigned L = blockIdx.x;
+    const int e = L & 15; L >>= 4;
+    const int t = L % TPG; L /= TPG;
+    const int kgi = L % a.kgroups, mgi = L / a.kgroups;
+    int mt0, mtn, kt0, ktn;
+    pwsw_run(a.mt32, a.mgroups, mgi, mt0, mtn);
+    pwsw_run(a.kt32, a.kgroups, kgi, kt0, ktn);
+    if (t >= mtn * ktn) return;                                       // (whole workgroup)
+    const float* wb = a.ws + (((size_t)(mgi * a.kgroups + kgi) * S) * TPG + t) * 1024 + e * 64 + lane;
+    const size_t sstride = (size_t)TPG * 1024;
+    double acc = 0.0;
+    for (int s0 = sg; s0 < S; s0 += 32) {                              // 8 loads in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = s0 + 4 * u < S ? wb[(size_t)(s0 + 4 * u) * sstride] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    part[sg][lane] = acc;
+    __syncthreads();
+    if (sg == 0) {
+        const int ti = t / ktn, tj = t - ti * ktn;
+        const int m = (mt0 + ti) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg, k = (kt0 + tj) * 32 + r;
+        if (m < a.M && k < a.K) a.gw[(long)m * a.K + k] += ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    }
+}
+
+// workspace of the two-phase weight gradient: one grow-only device buffer per stream (the engine runs one stream per process; a second stream
+// gets its own buffer).  No allocation while the stream is being captured into a graph: the launch then keeps the atomics.
+static float* pwss_workspace(size_t bytes, hipStream_t st) {
+    static std::mutex mu;
+    static std::map<hipStream_t, std::pair<float*, size_t>> bufs;
+    std::lock_guard<std::mutex> lk(mu);
+    auto& b = bufs[st];
+    if (b.second >= bytes) return b.first;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    float* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (b.first) { (void)hipStreamSynchronize(st); (void)hipFree(b.first); }
+    b = {p, bytes};
+    return p;
 }
 
 static size_t pwss_lds(int mtg, int ktg, int NS) {
@@ -474,6 +543,8 @@ static int pwss_launch(const WssArgs& a, unsigned blocks, size_t lds, hipStream_
 #undef PWSS_GO
     return cfn_check_launch("pwconv_bwd_weight(split bf16, staged)");
 }
+
+static int pwss_launch_any(const WssArgs& a, unsigned blocks, size_t lds, int tiles, int NS, hipStream_t st);
 
 // -1 = shape not handled
 // terms: 3 / 6 (fp32 tensors, split), 1 (bf16 tensors)
@@ -504,6 +575,15 @@ static int pwss_try(const void* gy, const void* y, const double* gs, const doubl
     const unsigned blocks = (unsigned)(groups * a.nstrips);
     const size_t lds = pwss_lds(a.mtg, a.ktg, NS);
     const int tiles = a.mtg * a.ktg;
+    static const int ws_env = getenv("CFN_PWSS_WS") ? atoi(getenv("CFN_PWSS_WS")) : 1;     // 0: fp64 atomics from every workgroup
+    a.ws = (ws_env && N * a.nstrips >= 8) ? pwss_workspace((size_t)blocks * tiles * 4096, st) : nullptr;
+    const int rc1 = pwss_launch_any(a, blocks, lds, tiles, NS, st);
+    if (rc1 != 0 || !a.ws) return rc1;
+    hipLaunchKernelGGL(pws_wgrad_reduce_kernel, dim3((unsigned)(a.mgroups * a.kgroups * tiles * 16)), dim3(256), 0, st, a);
+    return cfn_check_launch("pwconv_bwd_weight(split bf16, staged) reduce");
+}
+
+static int pwss_launch_any(const WssArgs& a, unsigned blocks, size_t lds, int tiles, int NS, hipStream_t st) {
     if (NS == 1) {
         if (a.mtg <= 4 && a.ktg <= 4) return pwss_launch<2, 2, 1, 2>(a, blocks, lds, st);
         if (tiles <= 24) return pwss_launch<4, 3, 1, 2>(a, blocks, lds, st);
