@@ -307,12 +307,12 @@ def main():
             metric = 'clips/sec (fwd+bwd+SGD) joint Coarse-Fine two-stream, fine T=%d + coarse T=%d, 224x224' % (T, T // 2)
             workload = ('joint two-stream train step: x3d_fine tower (global_tower) on %dx3x%dx224x224 -> 5 feature maps -> x3d_coarse '
                         '(Grid Pool + learned fusion) on the centre %d frames, one backward through both, random-init weights' % (B, T, T // 2))
-            kernel = 'depthwise conv forward family of both streams (dw3d_cp_fwd / dw3d_small_fwd / dw3d<FWD> / dwt5_fwd_stream) + Grid Pool forward'
+            kernel = 'depthwise conv forward family of both streams (dw3d_flat*_fwd (fp32) / dw3d_cp_fwd (bf16) / dw3d_small_fwd / dwt5_fwd_flat) + Grid Pool forward'
         elif coarse:
             metric = 'clips/sec (fwd+bwd+SGD) x3d_coarse fineFEAT fusion T=%dx224x224, T\'=128' % T
             workload = ('x3d_coarse X3D-M (Grid Pool + learned Multi-stage Fusion) train step, %dx3x%dx224x224 clips + fine features '
                         '(T\'=128, 7x7) per GPU, random-init weights' % (B, T))
-            kernel = 'depthwise conv forward family (dw3d_cp_fwd / dw3d_small_fwd / dw3d<FWD> / dwt5_fwd_stream) + Grid Pool forward (dense saliency convs, time_sample_fwd)'
+            kernel = 'depthwise conv forward family (dw3d_flat*_fwd / dw3d_small_fwd / dwt5_fwd_flat) + Grid Pool forward (dense saliency convs, time_sample_fwd)'
         else:
             metric = 'clips/sec (fwd+bwd+SGD) x3d_fine X3D-M T=%dx224x224' % T
             workload = 'x3d_fine X3D-M train step (fwd+loss+bwd+SGD), %dx3x%dx224x224 clips per GPU, random-init weights' % (B, T)
