@@ -26,6 +26,15 @@ import torch
 from . import ops
 
 
+def _capture_mode():
+    """Stream-capture error mode.  With a process group alive, ProcessGroupNCCL's watchdog THREAD polls the events of earlier collectives
+    (hipEventQuery); under the default 'global' mode that call is illegal while any thread captures and the watchdog aborts the process
+    ("operation not permitted when stream is capturing": tests/test_hip_train.py failed that way in about half of the runs).  'thread_local'
+    restricts the check to the capturing thread, which is the one that matters here."""
+    import torch.distributed as dist
+    return 'thread_local' if (dist.is_available() and dist.is_initialized()) else 'global'
+
+
 def _lr_signature(optimizer):
     return tuple((g.get('lr'), g.get('momentum'), g.get('weight_decay')) for g in optimizer.param_groups) if optimizer else ()
 
@@ -84,7 +93,7 @@ class GraphedStep(object):
         torch.cuda.synchronize()
         ops.reset_scratch()                    # the zero-filled scratch must be allocated (and zeroed) INSIDE the graph
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, pool=self.pool, stream=self._side_stream(args)):
+        with torch.cuda.graph(graph, pool=self.pool, stream=self._side_stream(args), capture_error_mode=_capture_mode()):
             static_out = self.fn(*static_in)
         ops.reset_scratch()                    # ... and must not leak into later eager calls
         return graph, static_in, static_out, _lr_signature(self.optimizer)
@@ -171,7 +180,7 @@ class GraphedDPStep(GraphedStep):
         if og is None or og[1] != lr:              # the learning rate is baked into the optimizer kernels
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.pool, stream=self._side_stream(full)):
+            with torch.cuda.graph(g, pool=self.pool, stream=self._side_stream(full), capture_error_mode=_capture_mode()):
                 self.optimizer.step()
             og = (g, lr)
             self._opt_graphs[sig] = og
