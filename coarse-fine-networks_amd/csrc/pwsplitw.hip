@@ -472,34 +472,45 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
 // partial tiles in a FIXED order (fp64).  A workgroup = one 64-element row of a tile (element e, all lanes) x 4 slices of S; the fp64 atomics
 // this replaces were 12-15 % of the first phase (6-11 M per launch, 256 workgroups onto the same M x K addresses), and the result no longer
 // depends on the order in which workgroups finish.
-__global__ __launch_bounds__(256) void pws_wgrad_reduce_kernel(const WssArgs a) {
-    __shared__ double part[4][64];
-    const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6, kg = lane >> 5, r = lane & 31;
+__global__ __launch_bounds__(1024) void pws_wgrad_reduce_kernel(const WssArgs a) {
+    // a workgroup = a quarter of a tile (256 floats = 64 float4) x 16 slices of S: every thread has ALL its (<= 16) 16-byte loads in flight at
+    // once (the first version -- 64 floats x 4 slices per workgroup, 8 four-byte loads in flight -- took 16 us per launch, 0.8 ms per step)
+    __shared__ double part[16][64][4];
+    typedef float __attribute__((ext_vector_type(4))) rf4;
+    const int l4 = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const int TPG = a.mtg * a.ktg, S = a.N * a.nstrips;
     unsigned L = blockIdx.x;
-    const int e = L & 15; L >>= 4;
+    const int qt = L & 3; L >>= 2;
     const int t = L % TPG; L /= TPG;
     const int kgi = L % a.kgroups, mgi = L / a.kgroups;
     int mt0, mtn, kt0, ktn;
     pwsw_run(a.mt32, a.mgroups, mgi, mt0, mtn);
     pwsw_run(a.kt32, a.kgroups, kgi, kt0, ktn);
     if (t >= mtn * ktn) return;                                       // (whole workgroup)
-    const float* wb = a.ws + (((size_t)(mgi * a.kgroups + kgi) * S) * TPG + t) * 1024 + e * 64 + lane;
+    const float* wb = a.ws + (((size_t)(mgi * a.kgroups + kgi) * S) * TPG + t) * 1024 + qt * 256 + l4 * 4;
     const size_t sstride = (size_t)TPG * 1024;
-    double acc = 0.0;
-    for (int s0 = sg; s0 < S; s0 += 32) {                              // 8 loads in flight
-        float v[8];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int s0 = sg; s0 < S; s0 += 256) {                             // S <= 256 in practice: one trip
+        rf4 v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = s0 + 4 * u < S ? wb[(size_t)(s0 + 4 * u) * sstride] : 0.0f;
+        for (int u = 0; u < 16; ++u) v[u] = s0 + 16 * u < S ? *reinterpret_cast<const rf4*>(wb + (size_t)(s0 + 16 * u) * sstride) : (rf4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += (double)v[u];
+        for (int u = 0; u < 16; ++u) { acc[0] += (double)v[u].x; acc[1] += (double)v[u].y; acc[2] += (double)v[u].z; acc[3] += (double)v[u].w; }
     }
-    part[sg][lane] = acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[sg][l4][i] = acc[i];
     __syncthreads();
     if (sg == 0) {
         const int ti = t / ktn, tj = t - ti * ktn;
-        const int m = (mt0 + ti) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg, k = (kt0 + tj) * 32 + r;
-        if (m < a.M && k < a.K) a.gw[(long)m * a.K + k] += ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = qt * 256 + l4 * 4 + i, e = f >> 6, lane = f & 63, kg = lane >> 5, r = lane & 31;
+            const int m = (mt0 + ti) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg, k = (kt0 + tj) * 32 + r;
+            double sum = 0.0;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sum += part[g][l4][i];
+            if (m < a.M && k < a.K) a.gw[(long)m * a.K + k] += sum;
+        }
     }
 }
 
@@ -579,7 +590,7 @@ static int pwss_try(const void* gy, const void* y, const double* gs, const doubl
     a.ws = (ws_env && N * a.nstrips >= 8) ? pwss_workspace((size_t)blocks * tiles * 4096, st) : nullptr;
     const int rc1 = pwss_launch_any(a, blocks, lds, tiles, NS, st);
     if (rc1 != 0 || !a.ws) return rc1;
-    hipLaunchKernelGGL(pws_wgrad_reduce_kernel, dim3((unsigned)(a.mgroups * a.kgroups * tiles * 16)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(pws_wgrad_reduce_kernel, dim3((unsigned)(a.mgroups * a.kgroups * tiles * 4)), dim3(1024), 0, st, a);
     return cfn_check_launch("pwconv_bwd_weight(split bf16, staged) reduce");
 }
 
