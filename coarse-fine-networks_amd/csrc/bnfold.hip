@@ -26,7 +26,7 @@ struct BnFoldArgs {
     float* A0; float* B0; float* gate; float* hbuf; float* pooled;   // SE saved: (N,C),(N,C),(N,C),(N,Wd),(N,C)
 };
 
-#define BNF_NB 4   // samples per squeeze-excite pass (LDS tables are sized for this many)
+#define BNF_NB 8   // samples per squeeze-excite pass (LDS tables are sized for this many; 8: a batch of 8 clips is ONE pass of the backward)
 
 // stage the two SE matrices in LDS: w1s[j*C + c] (rows contiguous), w2s[c*(Wd+1) + j] (odd pitch => lanes along c
 // hit distinct banks)
