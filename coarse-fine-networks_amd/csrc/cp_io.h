@@ -31,6 +31,7 @@ __device__ __forceinline__ void cp_st4(cp_f4 v, __amdgpu_buffer_rsrc_t r, int vo
 }
 // value as the consumer will read it back (forward statistics are taken over the stored values)
 __device__ __forceinline__ cp_f2 cp_rt2(cp_f2 v) { const unsigned u = cp_pk(v.x, v.y); return (cp_f2){cp_lo(u), cp_hi(u)}; }
+__device__ __forceinline__ float cp_rt1(float v) { return cp_lo(cp_pk(v, 0.0f)); }
 #else
 typedef float cpe_t;
 #define CP_ES 4
@@ -41,4 +42,5 @@ __device__ __forceinline__ void cp_st1(float v, __amdgpu_buffer_rsrc_t r, int vo
 __device__ __forceinline__ void cp_st2(cp_f2 v, __amdgpu_buffer_rsrc_t r, int vo, int so) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cp_u2, v), r, vo, so, 0); }
 __device__ __forceinline__ void cp_st4(cp_f4 v, __amdgpu_buffer_rsrc_t r, int vo, int so) { cfn_bst128(__builtin_bit_cast(cp_u4, v), r, vo, so); }
 __device__ __forceinline__ cp_f2 cp_rt2(cp_f2 v) { return v; }
+__device__ __forceinline__ float cp_rt1(float v) { return v; }
 #endif

@@ -72,9 +72,9 @@ __device__ __forceinline__ float dw_rt(float v) { return v; }
 #endif
 
 enum { DW_FWD = 0, DW_DGRAD = 1, DW_WGRAD = 2 };
+int DWN(dw_small_fwd_try)(const dwe_t* x, const double* A, const double* B, int act, const float* w, dwe_t* y, double* sum, double* sumsq,
+                          int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);   // dwsmall.hip (both element types)
 #ifndef DW_BF16
-int dw_small_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
-                     int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);   // dwsmall.hip
 int dw_cpbx_try(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
                 const double* A, const double* B, int act, float* gx, double* gA, double* gB, double* gw,
                 int N, int C, int T, int H, int W, hipStream_t st, bool probe);                        // dwcpbx.hip
@@ -1272,13 +1272,11 @@ extern "C" int DWN(cfn_dwconv3d_fwd)(const dwe_t* x, const double* A, const doub
         CfnProfScope prof(CFN_K_DWCONV_FWD, st, (double)DW_ES * N * C * T * ((double)Hi * Wi + po_) + 4.0 * C * 27);
         return DWN(dw_cp_fwd_try)(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, false);
     }
-#ifndef DW_BF16
-    if (dw_small_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
+    if (DWN(dw_small_fwd_try)(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
         // 14x14 / 7x7 stride 1: wave-per-channel kernel (dwsmall.hip)
         CfnProfScope prof(CFN_K_DWCONV_FWD, st, (double)DW_ES * N * C * T * 2.0 * Hi * Wi + 4.0 * C * 27);
-        return dw_small_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, false);
+        return DWN(dw_small_fwd_try)(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, false);
     }
-#endif
     DwPlan pl;
     int rc = dw_plan(a, stride, DW_FWD, pl);
     if (rc) return rc;

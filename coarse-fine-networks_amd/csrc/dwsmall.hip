@@ -16,11 +16,15 @@
 // instructions against 27 FMAs per lane) was the limit, hence the frame groups; 14x14 is ~70 % VALU bound (lane waste of
 // the 14-wide rows, 4.5 LDS reads per output).  LDS accesses of one wave execute in order, so the staged frame is visible to the wave's later reads
 // without a barrier (a wave-level fence keeps the compiler from reordering them).
-#include "cfn_common.h"
+// fp32 or bf16 tensors (cp_io.h: compiled a second time through dwsmall_bf16.hip; LDS image, accumulators and statistics stay fp32).
+#include "cp_io.h"
 #include <stdlib.h>
 
+#ifdef DW_BF16
+#define DwSmallArgs DwSmallArgsBf16
+#endif
 struct DwSmallArgs {
-    const float* x; const double* A; const double* B; const float* w; float* y; double* s1; double* s2;
+    const cpe_t* x; const double* A; const double* B; const float* w; cpe_t* y; double* s1; double* s2;
     int N, C, T, act, TT, nchunks;
     long total_waves;
 };
@@ -80,15 +84,15 @@ __global__ __launch_bounds__(256, 4) void dw3d_small_fwd_kernel(const DwSmallArg
     // offset: loads return 0, stores are dropped): with no vector-memory instruction under a branch the compiler counts
     // them and waits with vmcnt(N) for exactly the frame it needs, so the DEPTH prefetched frames really stay in flight
     // (with predicated loads it waits with vmcnt(0) and every frame costs a full HBM round trip).
-    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<float*>(a.x + nc * (long)T * P), (unsigned)((long)T * P * 4));
-    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * P, (unsigned)((long)T * P * 4));
-    const int ldo = ld_on ? e0 * 4 : OOB;
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<cpe_t*>(a.x + nc * (long)T * P), (unsigned)((long)T * P * CP_ES));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
+    const int ldo = ld_on ? e0 * CP_ES : OOB;
     auto fetch = [&](int f) -> f4 {
         const bool want = f >= 0 && f < T && f <= t1;
-        const int vo = want ? ldo : OOB, so = cfn_uni(want ? f * P * 4 : 0);
+        const int vo = want ? ldo : OOB, so = cfn_uni(want ? f * P * CP_ES : 0);
         f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (LV == 4) v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, so, 0));
-        else v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, so, 0));
+        if (LV == 4) v = cp_ld4(rx, vo, so);
+        else v.x = cp_ld1(rx, vo, so);
         return v;
     };
     auto stage = [&](int f, f4 v, float* im) {       // frames outside the clip are zero AFTER the prologue
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256, 4) void dw3d_small_fwd_kernel(const DwSmallArg
 #pragma unroll
     for (int j = 0; j < 6; ++j) w2p[j] = (p2){wr[18 + 3 + j], wr[18 + j]};      // (kh = 1 + j/3, kh - 1) at kw = j % 3
     float st1 = 0.0f, st2 = 0.0f;
-    const int yo = act_lane ? (row0 * PH + cc) * 4 : OOB;
+    const int yo = act_lane ? (row0 * PH + cc) * CP_ES : OOB;
 
     // input frames t0-1 .. t1; frame f finishes output frame f-1.  Frames are fetched in GROUPS of G consecutive frames of the
     // channel (G back-to-back loads of one contiguous G*P*4-byte run: the DRAM page is still open for the next one) one
@@ -165,12 +169,12 @@ __global__ __launch_bounds__(256, 4) void dw3d_small_fwd_kernel(const DwSmallArg
         }
         const int to = f - 1;
         const bool emit = to >= t0 && to < t1 && f <= f_last;
-        const int so = cfn_uni(emit ? to * P * 4 : 0);
+        const int so = cfn_uni(emit ? to * P * CP_ES : 0);
 #pragma unroll
         for (int i = 0; i < HS; ++i) {
             const bool ok = emit && act_lane && row0 + i < PH;
-            const float v = ok ? ((i & 1) ? a2[i >> 1].y : a2[i >> 1].x) : 0.0f;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, ok ? yo + i * PH * 4 : OOB, so, 0);
+            const float v = cp_rt1(ok ? ((i & 1) ? a2[i >> 1].y : a2[i >> 1].x) : 0.0f);      // (bf16: statistics over the stored values)
+            cp_st1(v, ry, ok ? yo + i * PH * CP_ES : OOB, so);
             st1 += v;
             st2 = fmaf(v, v, st2);
         }
@@ -209,13 +213,13 @@ __global__ __launch_bounds__(256, 4) void dw3d_small_fwd_kernel(const DwSmallArg
 
 // returns -1 when the shape is not handled (caller uses the band kernel); probe: 0 = handled, nothing launched; otherwise the
 // launch status
-int dw_small_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
+int CPN(dw_small_fwd_try)(const cpe_t* x, const double* A, const double* B, int act, const float* w, cpe_t* y, double* sum, double* sumsq,
                      int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe) {
     static const int enabled = getenv("CFN_DW_SMALL") ? atoi(getenv("CFN_DW_SMALL")) : 1;
     if (!enabled || stride != 1 || Hi != Wi || (Hi != 14 && Hi != 7)) return -1;
     if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && A != nullptr) return -1;      // branch-free prologue: none / ReLU (every X3D conv2)
-    if ((long)T * Hi * Wi * 4 >= 0x7ffffff0L) return -1;
-    if (Hi == 14 && (((uintptr_t)x & 15) != 0)) return -1;
+    if ((long)T * Hi * Wi * CP_ES >= 0x7ffffff0L) return -1;
+    if (Hi == 14 && (((uintptr_t)x & (4 * CP_ES - 1)) != 0)) return -1;
     if (probe) return 0;
     DwSmallArgs a = {x, A, B, w, y, sum, sumsq, N, C, T, act, 0, 0, 0};
     // t-chunks: ~2 rounds of the chip at 24 resident waves per CU (6 per SIMD), at least 8 frames per chunk (halo re-reads)
