@@ -24,6 +24,7 @@ __device__ __forceinline__ cp_f4 cp_ld4(__amdgpu_buffer_rsrc_t r, int vo, int so
     return (cp_f4){cp_lo(u.x), cp_hi(u.x), cp_lo(u.y), cp_hi(u.y)};
 }
 __device__ __forceinline__ float cp_ld1(__amdgpu_buffer_rsrc_t r, int vo, int so) { return cp_lo((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, vo, so, 0)); }
+__device__ __forceinline__ cp_f2 cp_ld2(__amdgpu_buffer_rsrc_t r, int vo, int so) { const unsigned u = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0); return (cp_f2){cp_lo(u), cp_hi(u)}; }
 __device__ __forceinline__ void cp_st1(float v, __amdgpu_buffer_rsrc_t r, int vo, int so) { __builtin_amdgcn_raw_buffer_store_b16((short)(cp_pk(v, 0.0f) & 0xffffu), r, vo, so, 0); }
 __device__ __forceinline__ void cp_st2(cp_f2 v, __amdgpu_buffer_rsrc_t r, int vo, int so) { __builtin_amdgcn_raw_buffer_store_b32(cp_pk(v.x, v.y), r, vo, so, 0); }
 __device__ __forceinline__ void cp_st4(cp_f4 v, __amdgpu_buffer_rsrc_t r, int vo, int so) {
@@ -38,6 +39,7 @@ typedef float cpe_t;
 #define CPN(name) name
 __device__ __forceinline__ cp_f4 cp_ld4(__amdgpu_buffer_rsrc_t r, int vo, int so) { return __builtin_bit_cast(cp_f4, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0)); }
 __device__ __forceinline__ float cp_ld1(__amdgpu_buffer_rsrc_t r, int vo, int so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0)); }
+__device__ __forceinline__ cp_f2 cp_ld2(__amdgpu_buffer_rsrc_t r, int vo, int so) { return __builtin_bit_cast(cp_f2, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0)); }
 __device__ __forceinline__ void cp_st1(float v, __amdgpu_buffer_rsrc_t r, int vo, int so) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, so, 0); }
 __device__ __forceinline__ void cp_st2(cp_f2 v, __amdgpu_buffer_rsrc_t r, int vo, int so) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cp_u2, v), r, vo, so, 0); }
 __device__ __forceinline__ void cp_st4(cp_f4 v, __amdgpu_buffer_rsrc_t r, int vo, int so) { cfn_bst128(__builtin_bit_cast(cp_u4, v), r, vo, so); }

@@ -14,13 +14,17 @@
 // not start on a 16-byte boundary: 4-byte loads, lane l takes floats l, l + 64, ...; g' AND x go through LDS (a lane's loads are not its
 // position).
 // hipcc-flags: -fno-slp-vectorize
-#include "cfn_common.h"
+// fp32 or bf16 tensors (cp_io.h: compiled a second time through dwflatb_bf16.hip; LDS images, accumulators and every reduction stay fp32 / fp64).
+#include "cp_io.h"
 #include <stdint.h>
 #include <stdlib.h>
 
+#ifdef DW_BF16
+#define DwFlatBArgs DwFlatBArgsBf16
+#endif
 struct DwFlatBArgs {
-    const float* gy; const float* y; const double* gs; const double* gq; const float* w; const float* x;
-    const double* A; const double* B; float* gx; double* gA; double* gB; double* gw;
+    const cpe_t* gy; const cpe_t* y; const double* gs; const double* gq; const float* w; const cpe_t* x;
+    const double* A; const double* B; cpe_t* gx; double* gA; double* gB; double* gw;
     int N, C, T, act, nchunks, subs;     // nchunks: wave items per (sample, channel); a wave item = subs consecutive chunks of TO frames
     long total;
 };
@@ -62,10 +66,10 @@ __global__ __launch_bounds__(256, 3) void dw3d_flat7_bwd_kernel(const DwFlatBArg
     float* img = smem + wv * WSZ;
     float* ximg = img + NF * FR;
 
-    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(a.gy + nc * (long)T * P, (unsigned)((long)T * P * 4));
-    __amdgpu_buffer_rsrc_t ry = cfn_rsrc((HASY ? a.y : a.gy) + nc * (long)T * P, (unsigned)((long)T * P * 4));
-    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * P, (unsigned)((long)T * P * 4));
-    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + nc * (long)T * P, (unsigned)((long)T * P * 4));
+    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(a.gy + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc((HASY ? a.y : a.gy) + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
 
     float wr[27];                                                        // flipped taps for the data gradient
 #pragma unroll
@@ -96,14 +100,14 @@ __global__ __launch_bounds__(256, 3) void dw3d_flat7_bwd_kernel(const DwFlatBArg
 #pragma unroll
     for (int m = 0; m < NG; ++m) {
         const int i = lane + 64 * m;
-        const int vo = (i < NF * P && gstart + i >= 0) ? (gstart + i) * 4 : OOB;
-        Rg[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, vo, 0, 0));
-        if (HASY) Ry[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, vo, 0, 0));
+        const int vo = (i < NF * P && gstart + i >= 0) ? (gstart + i) * CP_ES : OOB;
+        Rg[m] = cp_ld1(rg, vo, 0);
+        if (HASY) Ry[m] = cp_ld1(ry, vo, 0);
     }
 #pragma unroll
     for (int m = 0; m < NX; ++m) {
         const int i = lane + 64 * m;
-        Rx[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, i < TO * P ? (xstart + i) * 4 : OOB, 0, 0));
+        Rx[m] = cp_ld1(rx, i < TO * P ? (xstart + i) * CP_ES : OOB, 0);
     }
     __builtin_amdgcn_wave_barrier();                                     // the previous chunk's LDS reads are done (in-order LDS; compiler fence)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256, 3) void dw3d_flat7_bwd_kernel(const DwFlatBArg
                     st2 += dm;
                     v = dz * pa;
                 }
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, emit ? lane * 4 : OOB, cfn_uni(emit ? t * P * 4 : 0), 0);
+                cp_st1(v, rd, emit ? lane * CP_ES : OOB, cfn_uni(emit ? t * P * CP_ES : 0));
             }
         }
     }
@@ -213,10 +217,10 @@ __global__ __launch_bounds__(256, 3) void dw3d_flat14to7_bwd_kernel(const DwFlat
     const int T = a.T;
     float* img = smem + wv * WSZ;
 
-    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(a.gy + nc * (long)T * PO, (unsigned)((long)T * PO * 4));
-    __amdgpu_buffer_rsrc_t ry = cfn_rsrc((HASY ? a.y : a.gy) + nc * (long)T * PO, (unsigned)((long)T * PO * 4));
-    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * PI, (unsigned)((long)T * PI * 4));
-    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + nc * (long)T * PI, (unsigned)((long)T * PI * 4));
+    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(a.gy + nc * (long)T * PO, (unsigned)((long)T * PO * CP_ES));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc((HASY ? a.y : a.gy) + nc * (long)T * PO, (unsigned)((long)T * PO * CP_ES));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * PI, (unsigned)((long)T * PI * CP_ES));
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + nc * (long)T * PI, (unsigned)((long)T * PI * CP_ES));
 
     float w9[3][9];                                                      // w[kt][kh][kw]
 #pragma unroll
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256, 3) void dw3d_flat14to7_bwd_kernel(const DwFlat
     float st1 = 0.0f, st2 = 0.0f;
     const bool on = lane < PO;
     const int o = lane / WO, jj = lane - o * WO;
-    const int xo = on ? ((2 * o) * WI + 2 * jj) * 4 : OOB;               // byte offset of the block's first row in a frame of x / gx
+    const int xo = on ? ((2 * o) * WI + 2 * jj) * CP_ES : OOB;               // byte offset of the block's first row in a frame of x / gx
     const float* gb = img + o * 8 + jj;
 
     for (int sub = 0; sub < a.subs; ++sub) {
@@ -250,16 +254,16 @@ __global__ __launch_bounds__(256, 3) void dw3d_flat14to7_bwd_kernel(const DwFlat
 #pragma unroll
         for (int m = 0; m < NG; ++m) {
             const int i = lane + 64 * m;
-            const int vo = (i < NF * PO && gstart + i >= 0) ? (gstart + i) * 4 : OOB;
-            Rg[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, vo, 0, 0));
-            if (HASY) Ry[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, vo, 0, 0));
+            const int vo = (i < NF * PO && gstart + i >= 0) ? (gstart + i) * CP_ES : OOB;
+            Rg[m] = cp_ld1(rg, vo, 0);
+            if (HASY) Ry[m] = cp_ld1(ry, vo, 0);
         }
 #pragma unroll
         for (int j = 0; j < TO; ++j) {
             const bool tv = t0 + j < T;
-            const int so = cfn_uni(tv ? (t0 + j) * PI * 4 : 0);
-            X0[j] = __builtin_bit_cast(fb_p2, __builtin_amdgcn_raw_buffer_load_b64(rx, tv ? xo : OOB, so, 0));
-            X1[j] = __builtin_bit_cast(fb_p2, __builtin_amdgcn_raw_buffer_load_b64(rx, tv ? xo + WI * 4 : OOB, so, 0));
+            const int so = cfn_uni(tv ? (t0 + j) * PI * CP_ES : 0);
+            X0[j] = cp_ld2(rx, tv ? xo : OOB, so);
+            X1[j] = cp_ld2(rx, tv ? xo + WI * CP_ES : OOB, so);
         }
         __builtin_amdgcn_wave_barrier();                                 // the previous chunk's LDS reads are done (in-order LDS; compiler fence)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -320,9 +324,9 @@ __global__ __launch_bounds__(256, 3) void dw3d_flat14to7_bwd_kernel(const DwFlat
                             v[e] = dz * pa;
                         }
                     }
-                    const int so = cfn_uni(emit ? t * PI * 4 : 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fb_u2, (fb_p2){v[0], v[1]}), rd, emit ? xo : OOB, so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fb_u2, (fb_p2){v[2], v[3]}), rd, emit ? xo + WI * 4 : OOB, so, 0);
+                    const int so = cfn_uni(emit ? t * PI * CP_ES : 0);
+                    cp_st2((fb_p2){v[0], v[1]}, rd, emit ? xo : OOB, so);
+                    cp_st2((fb_p2){v[2], v[3]}, rd, emit ? xo + WI * CP_ES : OOB, so);
                 }
             }
         }
@@ -343,15 +347,15 @@ __global__ __launch_bounds__(256, 3) void dw3d_flat14to7_bwd_kernel(const DwFlat
 }
 
 // stride 2: returns -1 when the shape is not handled (caller goes on to the wave / band kernels); H, W: INPUT plane
-int dw_flatb_s2_try(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
-                    const double* A, const double* B, int act, float* gx, double* gA, double* gB, double* gw,
+int CPN(dw_flatb_s2_try)(const cpe_t* gy, const cpe_t* y, const double* gs, const double* gq, const float* w, const cpe_t* x,
+                    const double* A, const double* B, int act, cpe_t* gx, double* gA, double* gB, double* gw,
                     int N, int C, int T, int H, int W, hipStream_t st, bool probe) {
     static const int enabled = getenv("CFN_DW_FLATB") ? atoi(getenv("CFN_DW_FLATB")) : 24;      // 16 = 14 -> 7
     static const int subs_env = getenv("CFN_DW_FLATB_SUBS") ? atoi(getenv("CFN_DW_FLATB_SUBS")) : 0;
     if (H != 14 || W != 14 || !(enabled & 16)) return -1;
     if (A != nullptr && act != CFN_ACT_NONE && act != CFN_ACT_RELU) return -1;
-    if ((long)T * H * W * 4 >= 0x7fff0000L) return -1;
-    if ((((uintptr_t)x | (uintptr_t)gx) & 7) != 0) return -1;
+    if ((long)T * H * W * CP_ES >= 0x7fff0000L) return -1;
+    if ((((uintptr_t)x | (uintptr_t)gx) & (2 * CP_ES - 1)) != 0) return -1;
     const int TO = T >= 12 ? 8 : 4;
     const long nchunks = (T + TO - 1) / TO;
     const int subs = subs_env > 0 ? subs_env : 8;
@@ -367,15 +371,15 @@ int dw_flatb_s2_try(const float* gy, const float* y, const double* gs, const dou
 }
 
 // returns -1 when the shape is not handled (caller goes on to the wave / band kernels); probe: 0 = handled, nothing launched
-int dw_flatb_try(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
-                 const double* A, const double* B, int act, float* gx, double* gA, double* gB, double* gw,
+int CPN(dw_flatb_try)(const cpe_t* gy, const cpe_t* y, const double* gs, const double* gq, const float* w, const cpe_t* x,
+                 const double* A, const double* B, int act, cpe_t* gx, double* gA, double* gB, double* gw,
                  int N, int C, int T, int H, int W, hipStream_t st, bool probe) {
     // bit mask of the planes served: 8 = 7x7 (16 = 14 -> 7: dw_flatb_s2_try)
     static const int enabled = getenv("CFN_DW_FLATB") ? atoi(getenv("CFN_DW_FLATB")) : 24;
     static const int to_env = getenv("CFN_DW_FLATB_TO") ? atoi(getenv("CFN_DW_FLATB_TO")) : 0;
     if (H != W || H != 7 || !(enabled & 8)) return -1;
     if (A != nullptr && act != CFN_ACT_NONE && act != CFN_ACT_RELU) return -1;
-    if ((long)T * H * W * 4 >= 0x7fff0000L) return -1;
+    if ((long)T * H * W * CP_ES >= 0x7fff0000L) return -1;
     const int TO = to_env == 4 || to_env == 8 ? to_env : (T >= 12 ? 8 : 4);        // (16-frame items: 128 VGPRs + 670 spilled)
     // a wave takes `subs` consecutive chunks and reduces its 27 weight-gradient partials once (one chunk per wave: 55 k waves x 27 fp64 atomics per
     // launch made the kernel 2.6 x slower than the one it replaces)
