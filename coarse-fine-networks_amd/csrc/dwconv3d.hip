@@ -77,10 +77,10 @@ int DWN(dw_small_fwd_try)(const dwe_t* x, const double* A, const double* B, int 
 int DWN(dw_flatb_try)(const dwe_t* gy, const dwe_t* y, const double* gs, const double* gq, const float* w, const dwe_t* x,
                       const double* A, const double* B, int act, dwe_t* gx, double* gA, double* gB, double* gw,
                       int N, int C, int T, int H, int W, hipStream_t st, bool probe);                  // dwflatb.hip (both element types)
+int DWN(dw_cpbx_try)(const dwe_t* gy, const dwe_t* y, const double* gs, const double* gq, const float* w, const dwe_t* x,
+                     const double* A, const double* B, int act, dwe_t* gx, double* gA, double* gB, double* gw,
+                     int N, int C, int T, int H, int W, hipStream_t st, bool probe);                   // dwcpbx.hip (both element types)
 #ifndef DW_BF16
-int dw_cpbx_try(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
-                const double* A, const double* B, int act, float* gx, double* gA, double* gB, double* gw,
-                int N, int C, int T, int H, int W, hipStream_t st, bool probe);                        // dwcpbx.hip
 int dw_flat_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
                     int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);    // dwflat.hip
 #endif
@@ -1377,13 +1377,11 @@ extern "C" int DWN(cfn_dwconv3d_bwd_fused)(const dwe_t* gy, const dwe_t* y, cons
         CfnProfScope prof(CFN_K_DWCONV_BWD, (hipStream_t)stream, (double)DW_ES * N * C * T * (double)H * W * (y ? 4 : 3));
         return DWN(dw_flatb_try)(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, (hipStream_t)stream, false);
     }
-#ifndef DW_BF16
-    if (dw_cpbx_try(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, (hipStream_t)stream, true) == 0) {
-        // 56x56 / 28x28 / 14x14, fp32: column-pair wave kernel with one LDS image, x / a in registers (dwcpbx.hip)
+    if (DWN(dw_cpbx_try)(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, (hipStream_t)stream, true) == 0) {
+        // 56x56 / 28x28 / 14x14: column-pair wave kernel with one LDS image, x / a in registers (dwcpbx.hip)
         CfnProfScope prof(CFN_K_DWCONV_BWD, (hipStream_t)stream, (double)DW_ES * N * C * T * (double)H * W * (y ? 4 : 3));
-        return dw_cpbx_try(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, (hipStream_t)stream, false);
+        return DWN(dw_cpbx_try)(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, (hipStream_t)stream, false);
     }
-#endif
     if (DWN(dw_cpb_try)(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, (hipStream_t)stream, true) == 0) {
         // 56x56 / 28x28 / 14x14: column-pair wave kernel (dwcpb.hip)
         CfnProfScope prof(CFN_K_DWCONV_BWD, (hipStream_t)stream, (double)DW_ES * N * C * T * (double)H * W * (y ? 4 : 3));

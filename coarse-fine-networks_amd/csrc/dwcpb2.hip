@@ -344,11 +344,9 @@ int CPN(dw_cpb2_try)(const cpe_t* gy, const cpe_t* y, const double* gs, const do
 int CPN(dw_flatb_s2_try)(const cpe_t* gy, const cpe_t* y, const double* gs, const double* gq, const float* w, const cpe_t* x,
                          const double* A, const double* B, int act, cpe_t* gx, double* gA, double* gB, double* gw,
                          int N, int C, int T, int H, int W, hipStream_t st, bool probe);              // dwflatb.hip (both element types)
-#ifndef DW_BF16
-int dw_cpb2x_try(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
-                 const double* A, const double* B, int act, float* gx, double* gA, double* gB, double* gw,
-                 int N, int C, int T, int H, int W, hipStream_t st, bool probe);                      // dwcpb2x.hip
-#endif
+int CPN(dw_cpb2x_try)(const cpe_t* gy, const cpe_t* y, const double* gs, const double* gq, const float* w, const cpe_t* x,
+                      const double* A, const double* B, int act, cpe_t* gx, double* gA, double* gB, double* gw,
+                      int N, int C, int T, int H, int W, hipStream_t st, bool probe);                 // dwcpb2x.hip (both element types)
 // C ABI (include/cfn_hip.h): data AND weight gradient of the stride-2 conv in one pass; -1 = not handled, call the two kernels
 extern "C" int CPN(cfn_dwconv3d_bwd_fused_s2)(const cpe_t* gy, const cpe_t* y, const double* gsum, const double* gsumsq, const float* w,
                                          const cpe_t* x, const double* A, const double* B, int act, cpe_t* gx, double* gA, double* gB,
@@ -364,13 +362,11 @@ extern "C" int CPN(cfn_dwconv3d_bwd_fused_s2)(const cpe_t* gy, const cpe_t* y, c
         CfnProfScope prof(CFN_K_DWCONV_BWD, st, (double)CP_ES * N * C * T * (2.0 * H * W + 49.0 * (y ? 2 : 1)));
         return CPN(dw_flatb_s2_try)(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, st, false);
     }
-#ifndef DW_BF16
-    if (dw_cpb2x_try(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, st, true) == 0) {
-        // 112 -> 56, 56 -> 28, 28 -> 14, fp32: one LDS image, x / a in registers (dwcpb2x.hip)
+    if (CPN(dw_cpb2x_try)(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, st, true) == 0) {
+        // 112 -> 56, 56 -> 28, 28 -> 14: one LDS image, x / a in registers (dwcpb2x.hip)
         CfnProfScope prof(CFN_K_DWCONV_BWD, st, (double)CP_ES * N * C * T * (2.0 * H * W + (double)(H / 2) * (W / 2) * (y ? 2 : 1)));
-        return dw_cpb2x_try(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, st, false);
+        return CPN(dw_cpb2x_try)(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, C, T, H, W, st, false);
     }
-#endif
     if (H != W || (H != 112 && H != 56 && H != 28)) return -1;
     const double po = (double)(H / 2) * (W / 2);
     CfnProfScope prof(CFN_K_DWCONV_BWD, st, (double)CP_ES * N * C * T * (2.0 * H * W + po * (y ? 2 : 1)));

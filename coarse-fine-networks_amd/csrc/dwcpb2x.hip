@@ -11,13 +11,18 @@
 // Step f: G(f) is in the image; output frame f + 1 - s (set s) takes the taps kt = 2 - s; frame f - 1 is complete afterwards.  A wave owns the
 // weight-gradient terms of the a positions of ITS chunk (a is zero outside it).
 // hipcc-flags: -fno-slp-vectorize
-#include "cfn_common.h"
+// fp32 or bf16 tensors (cp_io.h: compiled a second time through dwcpb2x_bf16.hip; the LDS image, accumulators and every reduction stay fp32 / fp64).
+#include "cp_io.h"
 #include <stdint.h>
 #include <stdlib.h>
 
+#ifdef DW_BF16
+#define DwCpb2xArgs DwCpb2xArgsBf16
+#endif
+
 struct DwCpb2xArgs {
-    const float* gy; const float* y; const double* gs; const double* gq; const float* w; const float* x;
-    const double* A; const double* B; float* gx; double* gA; double* gB; double* gw;
+    const cpe_t* gy; const cpe_t* y; const double* gs; const double* gq; const float* w; const cpe_t* x;
+    const double* A; const double* B; cpe_t* gx; double* gA; double* gB; double* gw;
     int N, C, T, act, TT, nchunks;
     long total_waves;
 };
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cpx_bwd_s2_kernel(const DwCpb2x
     for (int k = 0; k < NLG; ++k) {
         const int e0 = eb + (k * 64 + lane) * 4;
         const bool on = e0 < gr_hi * WO;
-        ldg[k] = on ? e0 * 4 : OOB;
+        ldg[k] = on ? e0 * CP_ES : OOB;
         const int r0 = e0 / WO - gr_lo, r2 = (e0 + 2) / WO - gr_lo;
         lg0[k] = (on && e0 >= gr_lo * WO) ? r0 * GP + e0 % WO : -1;
         if (!GROW4) lg1[k] = (on && e0 + 2 < gr_hi * WO) ? r2 * GP + (e0 + 2) % WO : -1;
@@ -82,24 +87,24 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cpx_bwd_s2_kernel(const DwCpb2x
     const int g = lane / CP, cp = lane - g * CP;
     const bool act_lane = g < RG && band * BR + g < HO;
     const int gofs = act_lane ? g * GP + 2 * cp : 0;                       // G image: g'[o][2cp]
-    const int xo = act_lane ? ((2 * (band * BR + g)) * WI + 4 * cp) * 4 : OOB;   // x / gx: row 2o, column 4cp
+    const int xo = act_lane ? ((2 * (band * BR + g)) * WI + 4 * cp) * CP_ES : OOB;   // x / gx: row 2o, column 4cp
 
-    __amdgpu_buffer_rsrc_t rgy = cfn_rsrc(a.gy + nc * (long)T * PO, (unsigned)((long)T * PO * 4));
-    __amdgpu_buffer_rsrc_t ryy = cfn_rsrc((HASY ? a.y : a.gy) + nc * (long)T * PO, (unsigned)((long)T * PO * 4));
-    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * PI, (unsigned)((long)T * PI * 4));
-    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + nc * (long)T * PI, (unsigned)((long)T * PI * 4));
+    __amdgpu_buffer_rsrc_t rgy = cfn_rsrc(a.gy + nc * (long)T * PO, (unsigned)((long)T * PO * CP_ES));
+    __amdgpu_buffer_rsrc_t ryy = cfn_rsrc((HASY ? a.y : a.gy) + nc * (long)T * PO, (unsigned)((long)T * PO * CP_ES));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * PI, (unsigned)((long)T * PI * CP_ES));
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + nc * (long)T * PI, (unsigned)((long)T * PI * CP_ES));
 
     auto fetchG = [&](__amdgpu_buffer_rsrc_t r, int f, f4 (&dst)[NLG]) {     // unconditional: an unwanted frame reads zeros
         const bool want = f >= 0 && f < T && f <= t1;
-        const int so = cfn_uni(want ? f * PO * 4 : 0);
+        const int so = cfn_uni(want ? f * PO * CP_ES : 0);
 #pragma unroll
-        for (int k = 0; k < NLG; ++k) dst[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, want ? ldg[k] : OOB, so, 0));
+        for (int k = 0; k < NLG; ++k) dst[k] = cp_ld4(r, want ? ldg[k] : OOB, so);
     };
     auto fetchX = [&](int f, f4 (&dst)[2]) {           // the lane's own 2 x 4 block of x(f); frames outside the chunk read zeros
         const bool want = f >= t0 && f < t1;
-        const int so = cfn_uni(want ? f * PI * 4 : 0);
-        dst[0] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, want ? xo : OOB, so, 0));
-        dst[1] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, want ? xo + WI * 4 : OOB, so, 0));
+        const int so = cfn_uni(want ? f * PI * CP_ES : 0);
+        dst[0] = cp_ld4(rx, want ? xo : OOB, so);
+        dst[1] = cp_ld4(rx, want ? xo + WI * CP_ES : OOB, so);
     };
     auto stageG = [&](int f, const f4 (&sg)[NLG], const f4 (&sy)[NLG], float* im) {   // g' = gy + gs + 2 y gq, zero outside
         const float m = (f >= 0 && f < T && f <= t1) ? 1.0f : 0.0f;
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cpx_bwd_s2_kernel(const DwCpb2x
             // ---- emit gx(f-1): complete in set 2 ----
             const int to = f - 1;
             const bool emit = to >= t0 && to < t1;                         // wave uniform
-            const int so = cfn_uni(emit ? to * PI * 4 : 0);
+            const int so = cfn_uni(emit ? to * PI * CP_ES : 0);
             const float mf = emit ? lane_m : 0.0f;
             const int vo = emit ? xo : OOB;
 #pragma unroll
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cpx_bwd_s2_kernel(const DwCpb2x
                         v[e] = dz * pa;
                     }
                 }
-                cfn_bst128(__builtin_bit_cast(u4, v), rd, vo + rr * WI * 4, so);
+                cp_st4(v, rd, vo + rr * WI * CP_ES, so);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {                                  // rotate: frame f+1 becomes frame f of the next step
@@ -257,8 +262,8 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cpx_bwd_s2_kernel(const DwCpb2x
 }
 
 // returns -1 when the shape is not handled (caller goes on to dwcpb2.hip); probe: 0 = handled, nothing launched.  H, W: input size.
-int dw_cpb2x_try(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
-                 const double* A, const double* B, int act, float* gx, double* gA, double* gB, double* gw,
+int CPN(dw_cpb2x_try)(const cpe_t* gy, const cpe_t* y, const double* gs, const double* gq, const float* w, const cpe_t* x,
+                 const double* A, const double* B, int act, cpe_t* gx, double* gA, double* gB, double* gw,
                  int N, int C, int T, int H, int W, hipStream_t st, bool probe) {
     // bit mask of the shapes served: 1 = 112->56, 2 = 56->28, 4 = 28->14
     static const int enabled = getenv("CFN_DW_CPB2X") ? atoi(getenv("CFN_DW_CPB2X")) : 7;
@@ -266,8 +271,8 @@ int dw_cpb2x_try(const float* gy, const float* y, const double* gs, const double
     if (H != W || (H != 112 && H != 56 && H != 28)) return -1;
     if (!(enabled & (H == 112 ? 1 : H == 56 ? 2 : 4))) return -1;
     if (A != nullptr && act != CFN_ACT_NONE && act != CFN_ACT_RELU) return -1;      // act' from the sign of a: none / ReLU (every X3D conv2)
-    if ((long)T * H * W * 4 >= 0x7fff0000L) return -1;
-    if ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)(y ? y : gy)) & 15) != 0) return -1;
+    if ((long)T * H * W * CP_ES >= 0x7fff0000L) return -1;
+    if ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)(y ? y : gy)) & (4 * CP_ES - 1)) != 0) return -1;
     if (probe) return 0;
     const bool hasy = y != nullptr && gq != nullptr;
     DwCpb2xArgs a = {gy, hasy ? y : nullptr, gs, hasy ? gq : nullptr, w, x, A, B, gx, A ? gA : nullptr, A ? gB : nullptr, gw, N, C, T, act, 0, 0, 0};

@@ -13,13 +13,18 @@
 // f - 1, f, f + 1 and the three accumulator sets rotate in registers.  A wave owns the weight-gradient terms of the a positions of ITS chunk
 // (a is zero outside it).
 // hipcc-flags: -fno-slp-vectorize
-#include "cfn_common.h"
+// fp32 or bf16 tensors (cp_io.h: compiled a second time through dwcpbx_bf16.hip; the LDS image, accumulators and every reduction stay fp32 / fp64).
+#include "cp_io.h"
 #include <stdint.h>
 #include <stdlib.h>
 
+#ifdef DW_BF16
+#define DwCpbxArgs DwCpbxArgsBf16
+#endif
+
 struct DwCpbxArgs {
-    const float* gy; const float* y; const double* gs; const double* gq; const float* w; const float* x;
-    const double* A; const double* B; float* gx; double* gA; double* gB; double* gw;
+    const cpe_t* gy; const cpe_t* y; const double* gs; const double* gq; const float* w; const cpe_t* x;
+    const double* A; const double* B; cpe_t* gx; double* gA; double* gB; double* gw;
     int N, C, T, act, TT, nchunks;
     long total_waves;
 };
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cpx_bwd_kernel(const DwCpbxArgs
         const int e0 = (k * 64 + lane) * 4;
         const bool on = e0 < nel;
         const int r0 = row_lo + e0 / W - (band * BR - 1), c0 = e0 % W;
-        ldo[k] = on ? (row_lo * W + e0) * 4 : OOB;
+        ldo[k] = on ? (row_lo * W + e0) * CP_ES : OOB;
         lo0[k] = on ? r0 * PIT + XO + c0 : -1;
         if (!ROW4) {
             const int r2 = row_lo + (e0 + 2) / W - (band * BR - 1), c2 = (e0 + 2) % W;
@@ -86,24 +91,24 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cpx_bwd_kernel(const DwCpbxArgs
     const int g = lane / CP, cp = lane - g * CP;
     const bool act_lane = g < RG && band * BR + g * HS < H;        // H % HS == 0: a row group is valid as a whole
     const int tofs = act_lane ? (g * HS) * PIT + (XO - 1) + 2 * cp : 0;
-    const int yo = act_lane ? ((band * BR + g * HS) * W + 2 * cp) * 4 : OOB;
+    const int yo = act_lane ? ((band * BR + g * HS) * W + 2 * cp) * CP_ES : OOB;
 
-    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(a.gy + nc * (long)T * P, (unsigned)((long)T * P * 4));
-    __amdgpu_buffer_rsrc_t ry = cfn_rsrc((HASY ? a.y : a.gy) + nc * (long)T * P, (unsigned)((long)T * P * 4));
-    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * P, (unsigned)((long)T * P * 4));
-    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + nc * (long)T * P, (unsigned)((long)T * P * 4));
+    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(a.gy + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc((HASY ? a.y : a.gy) + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
 
     auto fetch1 = [&](__amdgpu_buffer_rsrc_t r, int f, f4 (&dst)[NLD]) {     // unconditional: an unwanted frame reads zeros
         const bool want = f >= 0 && f < T && f <= t1;
-        const int so = cfn_uni(want ? f * P * 4 : 0);
+        const int so = cfn_uni(want ? f * P * CP_ES : 0);
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) dst[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, want ? ldo[k] : OOB, so, 0));
+        for (int k = 0; k < NLD; ++k) dst[k] = cp_ld4(r, want ? ldo[k] : OOB, so);
     };
     auto fetchx = [&](int f, p2 (&dst)[HS]) {         // the lane's own column pair of x(f), HS rows; frames outside the chunk read zeros
         const bool want = f >= t0 && f < t1;
-        const int so = cfn_uni(want ? f * P * 4 : 0);
+        const int so = cfn_uni(want ? f * P * CP_ES : 0);
 #pragma unroll
-        for (int i = 0; i < HS; ++i) dst[i] = __builtin_bit_cast(p2, __builtin_amdgcn_raw_buffer_load_b64(rx, want ? yo + i * W * 4 : OOB, so, 0));
+        for (int i = 0; i < HS; ++i) dst[i] = cp_ld2(rx, want ? yo + i * W * CP_ES : OOB, so);
     };
     // branch-free staging: a loader lane without an element writes into the wave's dump slot
     float* dump = imG + 2 * IMG;
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cpx_bwd_kernel(const DwCpbxArgs
             // ---- emit gx(f-1): complete in set 2 ----
             const int to = f - 1;
             const bool emit = to >= t0 && to < t1;                         // wave uniform
-            const int so = cfn_uni(emit ? to * P * 4 : 0);
+            const int so = cfn_uni(emit ? to * P * CP_ES : 0);
             const float mf = emit ? lane_m : 0.0f;
             const int vo = emit ? yo : OOB;
 #pragma unroll
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cpx_bwd_kernel(const DwCpbxArgs
                     s2p += dm;
                     v = dz * pa;
                 }
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rd, vo + i * W * 4, so, 0);
+                cp_st2(v, rd, vo + i * W * CP_ES, so);
             }
 #pragma unroll
             for (int i = 0; i < HS; ++i) {                                 // rotate: frame f+1 becomes frame f of the next step
@@ -257,8 +262,8 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cpx_bwd_kernel(const DwCpbxArgs
 }
 
 // returns -1 when the shape is not handled (caller goes on to dwcpb.hip / the band kernels); probe: 0 = handled, nothing launched
-int dw_cpbx_try(const float* gy, const float* y, const double* gs, const double* gq, const float* w, const float* x,
-                const double* A, const double* B, int act, float* gx, double* gA, double* gB, double* gw,
+int CPN(dw_cpbx_try)(const cpe_t* gy, const cpe_t* y, const double* gs, const double* gq, const float* w, const cpe_t* x,
+                const double* A, const double* B, int act, cpe_t* gx, double* gA, double* gB, double* gw,
                 int N, int C, int T, int H, int W, hipStream_t st, bool probe) {
     // bit mask of the planes served: 1 = 56x56, 2 = 28x28, 4 = 14x14
     static const int enabled = getenv("CFN_DW_CPBX") ? atoi(getenv("CFN_DW_CPBX")) : 7;
@@ -266,8 +271,8 @@ int dw_cpbx_try(const float* gy, const float* y, const double* gs, const double*
     if (H != W || (H != 56 && H != 28 && H != 14)) return -1;
     if (!(enabled & (H == 56 ? 1 : H == 28 ? 2 : 4))) return -1;
     if (A != nullptr && act != CFN_ACT_NONE && act != CFN_ACT_RELU) return -1;      // act' from the sign of a: none / ReLU (every X3D conv2)
-    if ((long)T * H * W * 4 >= 0x7fff0000L) return -1;
-    if ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)(y ? y : gy)) & 15) != 0) return -1;
+    if ((long)T * H * W * CP_ES >= 0x7fff0000L) return -1;
+    if ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)(y ? y : gy)) & (4 * CP_ES - 1)) != 0) return -1;
     if (probe) return 0;
     const bool hasy = y != nullptr && gq != nullptr;
     DwCpbxArgs a = {gy, hasy ? y : nullptr, gs, hasy ? gq : nullptr, w, x, A, B, gx, A ? gA : nullptr, A ? gB : nullptr, gw, N, C, T, act, 0, 0, 0};
