@@ -320,7 +320,7 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
     bool live[TPW];
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
-        const int t = wave + (PWSS_THREADS / 64) * tt;            // tiles dealt round robin: every wave multiplies (no staging-only waves)
+        const int t = wave + (PWSS_THREADS / 64) * tt;            // tiles dealt round robin (groups of < 8 tiles still leave waves without one: `uneven` below)
         live[tt] = t < mtn * ktn;                                 // wave uniform
         const int ti = live[tt] ? t / ktn : 0, tj = live[tt] ? t - ti * ktn : 0;
         aoff[tt] = (ti * 32 + r) * PWSS_PITCH + kg * 16;
@@ -330,6 +330,23 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) acc[tt] = (f16v)0.0f;
 
+    // prologue coefficients of this thread's slots, in REGISTERS for the whole strip.  Round 3 re-read them from the LDS tables inside every
+    // conversion step; the ISA-level bisection of the round-3 race (profiles/r05_race_bisect.txt) ended at exactly that pattern: in a
+    // wave that converts while the other wave of its SIMD multiplies, the packed FMA behind `ds_read_b64/b96 coefficient; s_waitcnt lgkmcnt(0)` saw
+    // the high register of the returned pair as zero in lanes 48-63 (a = swish(A x) instead of swish(A x + B), g' without its 2 gq y term).
+    // (SM = 4 variants -- 96 accumulator + 96 operand registers -- would spill 40-126 registers with 20 more live ones: they keep the table reads;
+    // all their waves own tiles and convert in the same phase, see `uneven` below)
+    constexpr bool KREG = SM <= 2;
+    float4 kG[KREG ? SM : 1];
+    float2 kX[KREG ? SM : 1];
+    if constexpr (KREG) {
+#pragma unroll
+        for (int i = 0; i < SM; ++i) {
+            const int row = (tid + PWSS_THREADS * i) >> 3;
+            kG[i] = row < GR ? cG[row] : float4{0.f, 0.f, 1.f, 0.f};
+            kX[i] = row < XR ? cX[row] : float2{1.f, 0.f};
+        }
+    }
     f4v rG[2][SM], rY[2][SM], rX[2][SM];
     auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, int vo, int so) -> f4v {
         if constexpr (ES == 4) {
@@ -367,7 +384,7 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
 #pragma unroll
         for (int i = 0; i < SM; ++i) {
             if (ldsG[i] >= 0) {
-                const float4 c = cG[(tid + PWSS_THREADS * i) >> 3];
+                const float4 c = KREG ? kG[KREG ? i : 0] : cG[(tid + PWSS_THREADS * i) >> 3];
                 const float c0 = c.x * vm0;
                 float v[4];
 #pragma unroll
@@ -387,7 +404,7 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
                     *reinterpret_cast<uint2*>(buf + sp * gimg + ldsG[i]) = uint2{p0[sp], p1[sp]};
             }
             if (ldsX[i] >= 0) {
-                const float2 c = cX[(tid + PWSS_THREADS * i) >> 3];
+                const float2 c = KREG ? kX[KREG ? i : 0] : cX[(tid + PWSS_THREADS * i) >> 3];
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = cfn_act<ACT>(fmaf(xx[i][e], c.x, c.y));
@@ -427,6 +444,11 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
     };
 
     unsigned char* buf1 = buf0 + bufb;
+    // uneven: the tile count of the group is not a multiple of the wave count, i.e. in the last tile slot some waves multiply and some do not.  The
+    // round-3 failure needed waves that convert while others multiply (with an extra barrier behind every multiply phase: 0 of 1,200 passes, same
+    // binary otherwise); such groups (layer 2's 48 x 108 = 8 tiles is even; 48 x 96 = 6 tiles, the coarse stream's fusion convs) pay two more
+    // barriers per pair of half-stages and keep every wave in the same phase.
+    const bool uneven = (mtn * ktn) % (PWSS_THREADS / 64) != 0;   // workgroup uniform
     issue(0, rG[0], rY[0], rX[0]);
     issue(1, rG[1], rY[1], rX[1]);
     for (int h = 0; h < nh; h += 2) {
@@ -434,10 +456,12 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
         __syncthreads();
         issue(h + 2, rG[0], rY[0], rX[0]);
         mfma(buf0);
+        if (uneven) __syncthreads();
         convert(h + 1, buf1, rG[1], rY[1], rX[1]);                // h + 1 == nh: zeros (masked loads, masked constant term)
         __syncthreads();
         issue(h + 3, rG[1], rY[1], rX[1]);
         mfma(buf1);
+        if (uneven) __syncthreads();
     }
 
     if (a.ws) {     // partial tiles of this workgroup: [group][n * nstrips + strip][tile][element e][lane]
@@ -514,20 +538,24 @@ __global__ __launch_bounds__(1024) void pws_wgrad_reduce_kernel(const WssArgs a)
     }
 }
 
-// workspace of the two-phase weight gradient: one grow-only device buffer per stream (the engine runs one stream per process; a second stream
-// gets its own buffer).  No allocation while the stream is being captured into a graph: the launch then keeps the atomics.
+// workspace of the two-phase weight gradient: one grow-only device buffer per (device, stream) (the engine runs one stream per process; a second
+// stream or a second device gets its own buffer).  No allocation while the stream is being captured into a graph: the launch then keeps the
+// atomics.  A buffer that has been handed out is NEVER freed: a captured graph may have its address baked in; growing allocates a new
+// buffer of at least twice the size and retires the old one (geometric growth bounds the retired bytes by the live buffer's size).
 static float* pwss_workspace(size_t bytes, hipStream_t st) {
     static std::mutex mu;
-    static std::map<hipStream_t, std::pair<float*, size_t>> bufs;
+    static std::map<std::pair<int, hipStream_t>, std::pair<float*, size_t>> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     std::lock_guard<std::mutex> lk(mu);
-    auto& b = bufs[st];
+    auto& b = bufs[std::make_pair(dev, st)];
     if (b.second >= bytes) return b.first;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    const size_t want = bytes > 2 * b.second ? bytes : 2 * b.second;
     float* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (b.first) { (void)hipStreamSynchronize(st); (void)hipFree(b.first); }
-    b = {p, bytes};
+    if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    b = {p, want};                                  // (the previous buffer, if any, stays allocated)
     return p;
 }
 
@@ -600,9 +628,9 @@ static int pwss_launch_any(const WssArgs& a, unsigned blocks, size_t lds, int ti
         if (tiles <= 24) return pwss_launch<4, 3, 1, 2>(a, blocks, lds, st);
         return pwss_launch<4, 6, 1, 2>(a, blocks, lds, st);
     }
-    // <= 8 tiles (layer 2: 48 x 108): ONE tile per wave -- with two per wave only four of the eight waves multiply while the other four
-    // (staging only) run a phase ahead of them; besides the idle matrix pipes, that is the configuration in which tools/diag_wgrad_race.py
-    // caught the kernel (as compiled in round 3) writing stale operand rows from lanes 48-63 of exactly those waves in 1-3 % of passes
+    // <= 8 tiles (layer 2: 48 x 108): ONE tile per wave -- with two per wave only four of the eight waves multiply while the other four only stage
+    // operands a phase ahead of them: idle matrix pipes, and the configuration of the round-3 race (a staging-only wave's packed FMA read
+    // a just-returned LDS coefficient as zero in lanes 48-63; the coefficients are registers now and uneven groups keep every wave in one phase)
     if (a.mtg <= 4 && a.ktg <= 4 && tiles <= 8) return NS == 2 ? pwss_launch<2, 1, 2>(a, blocks, lds, st) : pwss_launch<2, 1, 3>(a, blocks, lds, st);
     if (a.mtg <= 4 && a.ktg <= 4) return NS == 2 ? pwss_launch<2, 2, 2>(a, blocks, lds, st) : pwss_launch<2, 2, 3>(a, blocks, lds, st);
     if (tiles <= 24) return NS == 2 ? pwss_launch<4, 3, 2>(a, blocks, lds, st) : pwss_launch<4, 3, 3>(a, blocks, lds, st);

@@ -363,9 +363,10 @@ def test_coarse_train_fwd_bwd_vs_reference(op_route):
 
 
 def test_coarse_run_to_run_reproducibility():
-    """two identical train-mode passes of the full Coarse-Fine net: every reduction has a fixed order inside a workgroup and
-    fp64 accumulation of fp32 partials across workgroups, so logits and gradients normally repeat bit for bit (the loose
-    bounds only allow for a rare inexact fp64 sum, which train-mode BN would amplify)."""
+    """60 identical train-mode passes of the full Coarse-Fine net (2 clips x 16 frames + fine features): logits and EVERY parameter gradient
+    bit-identical to the first pass (two passes with a tolerance do not catch a kernel that is wrong in 1-3 % of passes).
+    Every reduction has a fixed order inside a workgroup; across workgroups fp32 partials meet in fp64 atomics (exact unless an addend is
+    below 2^-29 of the running sum) or in the fixed-order reduce kernels."""
     x, feat, fm, meta, depth = _coarse_inputs(130, 2, 16, 12)
     m = _coarse_model(depth, dropout=0.0)
     m.train(True)
@@ -373,24 +374,21 @@ def test_coarse_run_to_run_reproducibility():
     from oracle import spec
     r = spec.rand_input(131, (2, 157, 16)).to(DEV)
     inp = [x.to(DEV), {k: v.to(DEV) for k, v in feat.items()}, fm.to(DEV), 0, meta.to(DEV)]
-    outs, grads = [], []
-    for _ in range(2):
+    ref, bad = None, {}
+    for _ in range(60):
         for p in m.parameters():
             p.grad = None
         y = m(inp)
         (y * r).sum().backward()
-        outs.append(y.detach().clone())
-        grads.append({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
-    d_out = float((outs[0] - outs[1]).abs().max() / outs[0].abs().max())
-    worst, where = 0.0, None
-    for k in grads[0]:
-        d = float((grads[0][k] - grads[1][k]).norm() / (grads[0][k].norm() + 1e-30))
-        if d > worst:
-            worst, where = d, k
-    print('coarse run-to-run: logits rel %.2e, worst gradient norm-rel %.2e (%s)' % (d_out, worst, where))
-    # round 4: with the saliency convs on csrc/salconv.hip (no atomics on gx, fixed-order in-workgroup sums) the two passes are bit-identical
-    # in practice (tools/determinism_scan.py: 0 of 403 tensors over 12 passes); the bound only leaves room for a rare inexact fp64 sum
-    assert d_out <= 1e-6 and worst <= 1e-6
+        cur = {'<logits>': y.detach().clone()}
+        cur.update({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+        if ref is None:
+            ref = cur
+            continue
+        for k, v in cur.items():
+            if not torch.equal(v, ref[k]):
+                bad[k] = bad.get(k, 0) + 1
+    assert not bad, bad
 
 
 def test_fine_run_to_run_bit_reproducibility():

@@ -277,3 +277,76 @@ def test_pwk_is_the_kernel_that_runs():
     finally:
         cfn_hip.query('cfn_pw_split_terms', prev)
     assert relerr(y6, y0) <= 3e-6 and not torch.equal(y6, y0)
+
+
+# ---- staged split-bf16 weight gradient (csrc/pwsplitw.hip pws_wgrad_staged_kernel): bit-repeat stress in a launch sequence that looks
+# like a backward pass.  Round 3 shipped a build of this kernel whose layer-2 conv3 weight gradient was wrong in 1-3 % of backward passes
+# (in a wave that only staged operands while the other wave of its SIMD multiplied, ONE packed FMA behind an LDS coefficient read
+# lost a term in lanes 48-63); two-run repeatability checks and 2,400 isolated launches never saw it.  These cases cover what
+# VERDICT r4 #2 listed as uncovered: the benchmark's own layer-2/3/4 shapes at 8 clips x 256 frames, tile counts that leave waves
+# without a tile (4 and 6 tiles: the `uneven` barrier path), the coarse stream's odd volume 65 x 7 x 7 (per-element strip masks),
+# and the bf16 instantiation.  Between launches other kernels run on changing data (the data gradient of the same conv, a second
+# conv shape, an L2-sized elementwise pass), so the kernel under test starts cold every time as it does inside a model.
+WGRAD_STRESS = [
+    # N, Cin, Cout, T, H, W, act, launches
+    (8, 108, 48, 256, 28, 28, 2, 200),      # layer-2 conv3 at the benchmark's size (8 tiles: one per wave)
+    (8, 48, 108, 256, 28, 28, 0, 200),      # layer-2 conv1
+    (8, 216, 96, 256, 14, 14, 2, 200),      # layer-3 conv3 (21 tiles)
+    (8, 96, 216, 256, 14, 14, 0, 200),      # layer-3 conv1
+    (8, 432, 192, 256, 7, 7, 2, 200),       # layer-4 conv3 (84 tiles in groups)
+    (8, 192, 432, 256, 7, 7, 0, 200),       # layer-4 conv1
+    (2, 96, 48, 16, 28, 28, 2, 300),        # 2 x 3 = 6 tiles on 8 waves: two waves without a tile
+    (2, 64, 64, 16, 28, 28, 1, 300),        # 2 x 2 = 4 tiles: four waves without a tile
+    (2, 48, 48, 16, 14, 14, 2, 300),        # 4 tiles, short strips
+    (2, 160, 96, 8, 14, 14, 2, 300),        # 3 x 5 = 15 tiles: the second tile slot is uneven
+    (2, 432, 192, 65, 7, 7, 2, 300),        # coarse stream layer 4: odd volume 65 x 7 x 7 (rows start on 4-byte boundaries)
+    (2, 192, 432, 65, 7, 7, 0, 300),
+    (3, 216, 96, 17, 7, 7, 1, 300),         # odd volume, T = 17 (the reference's T = 64 coarse clip)
+]
+
+
+def _wgrad_stress(N, Cin, Cout, T, H, W, act, launches, dtype):
+    o = ops()
+    x = rnd(1, N, Cin, T, H, W).to(DEV).to(dtype).requires_grad_(True)
+    w = rnd(2, Cout, Cin, 1, 1, 1, scale=(2.0 / Cin) ** 0.5).to(DEV).requires_grad_(True)
+    A = (1 + 0.2 * rnd(3, N, Cin)).to(DEV).requires_grad_(True)
+    B = (0.3 * rnd(4, N, Cin)).to(DEV).requires_grad_(True)
+    y, s, q = o.pwconv(x, w, A, B, act, 1, True)
+    gy = rnd(5, *y.shape).to(DEV).to(dtype)
+    gs, gq = (0.01 * rnd(6, *s.shape)).to(DEV).to(s.dtype), (0.001 * rnd(7, *q.shape)).to(DEV).to(q.dtype)
+    # a second conv (another kernel variant) and an L2-sized buffer to run in between
+    x2 = rnd(8, 2, 54, 4, 28, 28).to(DEV).to(dtype).requires_grad_(True)
+    w2 = rnd(9, 24, 54, 1, 1, 1, scale=0.2).to(DEV).requires_grad_(True)
+    y2, s2, q2 = o.pwconv(x2, w2, None, None, 0, 1, True)
+    junk = torch.zeros(48 << 20, device=DEV)
+    ref = torch.autograd.grad((y, s, q), (w,), (gy, gs, gq), retain_graph=True)[0].clone()
+    # the thing that repeats must also be right (fp64 reference of the weight gradient on a subsample of rows)
+    if dtype == torch.float32:
+        xd = x.detach().double()
+        z = xd * A.detach().double().view(N, Cin, 1, 1, 1) + B.detach().double().view(N, Cin, 1, 1, 1)
+        a = z * torch.sigmoid(z) if act == 2 else (z.clamp(min=0) if act == 1 else z)
+        rows = torch.arange(0, Cout, max(Cout // 6, 1), device=DEV)
+        yd = torch.einsum('ncthw,kc->nkthw', a, w.detach().double().view(Cout, Cin)[rows])
+        gp = gy.double()[:, rows] + gs.double()[:, rows].view(N, -1, 1, 1, 1) + 2.0 * yd * gq.double()[:, rows].view(N, -1, 1, 1, 1)
+        gw = torch.einsum('nkthw,ncthw->kc', gp, a)
+        assert relerr(ref.view(Cout, Cin)[rows].double(), gw) <= 3e-6
+        del xd, z, a, yd, gp
+    bad = 0
+    for i in range(launches):
+        junk.add_(1.0)
+        torch.autograd.grad((y2, s2, q2), (x2, w2), (y2.detach(), s2.detach(), q2.detach()), retain_graph=True)
+        g = torch.autograd.grad((y, s, q), (w, x) if i % 4 == 0 else (w,), (gy, gs, gq), retain_graph=True)[0]
+        bad += int(not torch.equal(g, ref))
+    assert bad == 0, '%d of %d launches differ' % (bad, launches)
+
+
+@pytest.mark.parametrize('N,Cin,Cout,T,H,W,act,launches', WGRAD_STRESS)
+def test_staged_wgrad_stress_bit_repeatable(split, N, Cin, Cout, T, H, W, act, launches):
+    split(6)
+    _wgrad_stress(N, Cin, Cout, T, H, W, act, launches, torch.float32)
+
+
+@pytest.mark.parametrize('N,Cin,Cout,T,H,W,act,launches', [c for c in WGRAD_STRESS if (c[3] * c[4] * c[5]) % 4 == 0 and c[0] < 8]
+                         + [(4, 108, 48, 64, 28, 28, 2, 200), (4, 216, 96, 64, 14, 14, 2, 200), (4, 432, 192, 64, 7, 7, 2, 200)])
+def test_staged_wgrad_stress_bit_repeatable_bf16(N, Cin, Cout, T, H, W, act, launches):
+    _wgrad_stress(N, Cin, Cout, T, H, W, act, launches, torch.bfloat16)

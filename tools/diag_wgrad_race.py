@@ -11,6 +11,8 @@ for p in (ROOT, os.path.join(ROOT, 'coarse-fine-networks_amd')):
 import torch                      # noqa: E402
 import cfn_hip                    # noqa: E402
 from cfn_hip import ops           # noqa: E402
+if os.environ.get('CFN_LIB'):
+    cfn_hip.LIB_PATH = os.environ['CFN_LIB']
 cfn_hip.load()
 from oracle import spec           # noqa: E402
 import x3d_fine                   # noqa: E402
@@ -36,6 +38,9 @@ def call(name, *args):
                     sig[nm] = t.contiguous().view(torch.int32 if t.dtype == torch.float32 else torch.int64).sum(dtype=torch.int64)
         if MODE & 2:
             pre = args[8].clone()
+    if hit and os.environ.get('DIAG_SAVE') and not os.path.exists(os.environ['DIAG_SAVE'] + '/inputs.pt') and not rec:
+        torch.save({k: (None if t is None else t.detach().cpu()) for k, t in list(zip(NAMES, args[:7])) + [('gsc', args[-1])]} | {'act': args[7], 'dims': args[9:16]},
+                   os.environ['DIAG_SAVE'] + '/inputs.pt')
     r = orig(name, *args)
     if hit:
         rec.append((sig, pre, args[8].clone() if MODE & 2 else None))
@@ -62,6 +67,8 @@ for run in range(RUNS):
         continue
     if not torch.equal(g, first[0]):
         odd += 1
+        if os.environ.get('DIAG_SAVE') and odd <= 12:
+            torch.save({'g0': first[0].cpu(), 'g': g.cpu()}, os.environ['DIAG_SAVE'] + '/bad_%d.pt' % run)
         d = (g - first[0]).view(48, 108).abs()
         thr = 1e-7 * float(first[0].abs().max())
         rows = sorted(set(torch.nonzero(d > thr)[:, 0].tolist())); cols = sorted(set(torch.nonzero(d > thr)[:, 1].tolist()))
