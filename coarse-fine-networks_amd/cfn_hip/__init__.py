@@ -70,7 +70,18 @@ def load():
         fn.restype = ret
         fn.argtypes = at
     _lib, _protos = lib, protos
+    if os.environ.get('CFN_DETERMINISTIC', '0') not in ('', '0') and torch.cuda.is_available():
+        if lib.cfn_deterministic(1) < 0:                  # include/cfn_hip.h: order-independent commits of every cross-workgroup accumulation
+            raise RuntimeError(lib.cfn_last_error().decode())
     return lib
+
+
+def deterministic(on=None):
+    """switch / query the library's deterministic mode (include/cfn_hip.h cfn_deterministic); returns the previous setting"""
+    rc = load().cfn_deterministic(-1 if on is None else (1 if on else 0))
+    if rc < 0:
+        raise RuntimeError(last_error())
+    return bool(rc)
 
 
 def last_error():

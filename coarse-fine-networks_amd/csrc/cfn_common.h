@@ -30,6 +30,31 @@ struct CfnProfScope {
     ~CfnProfScope();
 };
 
+// ---------------------------------------------------------------------------------------------
+// Deterministic mode (cfn_deterministic(1); SURVEY 8(b): "deterministic reductions preferred for parity tests (atomics order) -- offer a
+// deterministic mode").  Every cross-workgroup fp64 accumulation of the library goes through cfn_add64().  Normally that is one fp64 atomic
+// (the order in which workgroups arrive decides the rounding of the running sum -- exact unless an addend is below 2^-29 of it).  In
+// deterministic mode the (address, addend) pair is appended to a record buffer instead, and after the entry point's launches capi.hip sorts
+// the records by (address, addend bits) and adds every address's addends to it in that order: the result no longer depends on the order of
+// arrival, by construction.  The state lives in one __device__ variable per translation unit (no relocatable device code in this build);
+// each unit registers a setter with capi.hip.
+struct CfnDetState { unsigned long long* keys; unsigned long long* vals; unsigned long long* count; unsigned long long cap; };
+static __device__ CfnDetState cfn_det_dev;
+int cfn_det_register(void (*set)(const CfnDetState*));
+static void cfn_det_tu_set(const CfnDetState* st) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(cfn_det_dev), st, sizeof(*st)) != hipSuccess) (void)hipGetLastError();   // (a unit without accumulations has no symbol)
+}
+static const int cfn_det_tu_registered = cfn_det_register(&cfn_det_tu_set);
+__device__ __forceinline__ void cfn_add64(double* p, double v) {
+    unsigned long long* const keys = cfn_det_dev.keys;
+    if (__builtin_expect(keys != nullptr, 0)) {
+        const unsigned long long i = atomicAdd(cfn_det_dev.count, 1ull);
+        if (i < cfn_det_dev.cap) { keys[i] = (unsigned long long)(uintptr_t)p; cfn_det_dev.vals[i] = __builtin_bit_cast(unsigned long long, v); }
+    } else {
+        atomicAdd(p, v);
+    }
+}
+
 static inline int cfn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // grid.y is limited to 65535: kernels indexed by (n, c) = blockIdx.y + blockIdx.z * gridDim.y get an EXACT factorisation
@@ -120,5 +145,9 @@ __device__ __forceinline__ double cfn_wave_sum_d(double v) {
 __device__ __forceinline__ unsigned cfn_xcd_remap(unsigned b, unsigned total) {
     const unsigned q = total >> 3, r = total & 7u;
     const unsigned xcd = b & 7u, i = b >> 3;
+#ifdef CFN_XCD_REVERSE      // experiment (tools/mall_probe.py): every XCD walks its eighth from the END (what the producer wrote last is read first)
+    return total - 1u - (xcd * q + (xcd < r ? xcd : r) + i);
+#else
     return xcd * q + (xcd < r ? xcd : r) + i;
+#endif
 }

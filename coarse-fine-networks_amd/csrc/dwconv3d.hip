@@ -485,7 +485,7 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
         for (int i = tid; i < ncg * 27; i += nthr) {
             float v = 0.0f;
             for (int w = 0; w < nwv; ++w) v += sR[w * a.CG * 27 + i];
-            atomicAdd(&a.s1[(long)c0 * 27 + i], (double)v);
+            cfn_add64(&a.s1[(long)c0 * 27 + i], (double)v);
         }
     } else if (a.s1 != nullptr) {
         const float r1 = seg_wave_sum(st1, key, lane);
@@ -495,8 +495,8 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, UNIW ? (MAXLD == 2 ? (MODE == DW_
         if (tid < ncg) {
             float v1 = 0.0f, v2 = 0.0f;
             for (int w = 0; w < nwv; ++w) { v1 += sR[(w * a.CG + tid) * KJ]; v2 += sR[(w * a.CG + tid) * KJ + 1]; }
-            atomicAdd(&a.s1[(long)n * C + c0 + tid], (double)v1);
-            atomicAdd(&a.s2[(long)n * C + c0 + tid], (double)v2);
+            cfn_add64(&a.s1[(long)n * C + c0 + tid], (double)v1);
+            cfn_add64(&a.s2[(long)n * C + c0 + tid], (double)v2);
         }
     }
 }
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, 2) void dw3d_bwd_fused_kernel(con
     for (int i = tid; i < ncg * 27; i += nthr) {
         float v = 0.0f;
         for (int w = 0; w < nwv; ++w) v += sR[w * a.CG * 27 + i];
-        atomicAdd(&a.gw[(long)c0 * 27 + i], (double)v);
+        cfn_add64(&a.gw[(long)c0 * 27 + i], (double)v);
     }
     if (a.A && a.gA) {
         __syncthreads();
@@ -787,8 +787,8 @@ __global__ __launch_bounds__(UNIW ? 256 : 512, 2) void dw3d_bwd_fused_kernel(con
         if (tid < ncg) {
             float v1 = 0.0f, v2 = 0.0f;
             for (int w = 0; w < nwv; ++w) { v1 += sR[(w * a.CG + tid) * 27]; v2 += sR[(w * a.CG + tid) * 27 + 1]; }
-            atomicAdd(&a.gA[(long)n * C + c0 + tid], (double)v1);
-            atomicAdd(&a.gB[(long)n * C + c0 + tid], (double)v2);
+            cfn_add64(&a.gA[(long)n * C + c0 + tid], (double)v1);
+            cfn_add64(&a.gB[(long)n * C + c0 + tid], (double)v2);
         }
     }
 }
@@ -944,16 +944,16 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_kernel(const DwS2Args a) {
             const float q1 = seg_wave_sum(s1, key, lane);
             const float q2 = seg_wave_sum(s2, key, lane);
             if (head) {
-                atomicAdd(&a.gA[nc], (double)q1);
-                atomicAdd(&a.gB[nc], (double)q2);
+                cfn_add64(&a.gA[nc], (double)q1);
+                cfn_add64(&a.gB[nc], (double)q2);
             }
         } else {           // one channel per workgroup: ONE atomic pair per workgroup (same-address fp64 atomics serialise)
             s1 = cfn_wave_sum(s1); s2 = cfn_wave_sum(s2);
             if (lane == 0) { sh[threadIdx.x >> 6] = s1; sh[4 + (threadIdx.x >> 6)] = s2; }
             __syncthreads();
             if (threadIdx.x == 0) {
-                atomicAdd(&a.gA[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
-                atomicAdd(&a.gB[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
+                cfn_add64(&a.gA[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
+                cfn_add64(&a.gB[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
             }
         }
     }
@@ -1069,16 +1069,16 @@ __global__ __launch_bounds__(256) void dw3d_dgrad_s2_fast_kernel(const DwS2Args 
             const float q1 = seg_wave_sum(s1, key, lane);
             const float q2 = seg_wave_sum(s2, key, lane);
             if (head) {
-                atomicAdd(&a.gA[nc], (double)q1);
-                atomicAdd(&a.gB[nc], (double)q2);
+                cfn_add64(&a.gA[nc], (double)q1);
+                cfn_add64(&a.gB[nc], (double)q2);
             }
         } else {
             s1 = cfn_wave_sum(s1); s2 = cfn_wave_sum(s2);
             if (lane == 0) { sh[threadIdx.x >> 6] = s1; sh[4 + (threadIdx.x >> 6)] = s2; }
             __syncthreads();
             if (threadIdx.x == 0) {
-                atomicAdd(&a.gA[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
-                atomicAdd(&a.gB[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
+                cfn_add64(&a.gA[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
+                cfn_add64(&a.gB[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
             }
         }
     }

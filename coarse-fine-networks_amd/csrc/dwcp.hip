@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_fwd_kernel(const DwCpArgs a)
     }
     if (a.s1) {
         const float st1 = cfn_wave_sum(s1p.x + s1p.y), st2 = cfn_wave_sum(s2p.x + s2p.y);
-        if (lane == 0) { atomicAdd(&a.s1[nc], (double)st1); atomicAdd(&a.s2[nc], (double)st2); }
+        if (lane == 0) { cfn_add64(&a.s1[nc], (double)st1); cfn_add64(&a.s2[nc], (double)st2); }
     }
 }
 

@@ -311,11 +311,11 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_kernel(const DwCpbArgs a
         }
         const float tot = v[0] + __shfl_xor(v[0], 1, 64);
         const int idx = lane >> 1;                                         // value index: bits 5..1 of the lane, MSB first
-        if ((lane & 1) == 0 && idx < 27) atomicAdd(&a.gw[(long)c * 27 + idx], (double)tot);
+        if ((lane & 1) == 0 && idx < 27) cfn_add64(&a.gw[(long)c * 27 + idx], (double)tot);
     }
     if (hasA && a.gA) {
         const float st1 = cfn_wave_sum(s1p.x + s1p.y), st2 = cfn_wave_sum(s2p.x + s2p.y);
-        if (lane == 0) { atomicAdd(&a.gA[nc], (double)st1); atomicAdd(&a.gB[nc], (double)st2); }
+        if (lane == 0) { cfn_add64(&a.gA[nc], (double)st1); cfn_add64(&a.gB[nc], (double)st2); }
     }
 }
 

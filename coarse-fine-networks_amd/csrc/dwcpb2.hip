@@ -293,11 +293,11 @@ __global__ __launch_bounds__(256, OCC) void dw3d_cp_bwd_s2_kernel(const DwCpb2Ar
         }
         const float tot = v[0] + __shfl_xor(v[0], 1, 64);
         const int idx = lane >> 1;
-        if ((lane & 1) == 0 && idx < 27) atomicAdd(&a.gw[(long)c * 27 + idx], (double)tot);
+        if ((lane & 1) == 0 && idx < 27) cfn_add64(&a.gw[(long)c * 27 + idx], (double)tot);
     }
     if (hasA && a.gA) {
         st1 = cfn_wave_sum(st1); st2 = cfn_wave_sum(st2);
-        if (lane == 0) { atomicAdd(&a.gA[nc], (double)st1); atomicAdd(&a.gB[nc], (double)st2); }
+        if (lane == 0) { cfn_add64(&a.gA[nc], (double)st1); cfn_add64(&a.gB[nc], (double)st2); }
     }
 }
 

@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat_fwd_kernel(const DwFlatArgs 
         if (lane == 0) { red[wave] = st1; red[4 + wave] = st2; }
         __syncthreads();
         if (tid == 0) {
-            atomicAdd(&a.s1[nc], (double)(red[0] + red[1] + red[2] + red[3]));
-            atomicAdd(&a.s2[nc], (double)(red[4] + red[5] + red[6] + red[7]));
+            cfn_add64(&a.s1[nc], (double)(red[0] + red[1] + red[2] + red[3]));
+            cfn_add64(&a.s2[nc], (double)(red[4] + red[5] + red[6] + red[7]));
         }
     }
 }
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat14_fwd_kernel(const DwFlatArg
     }
     if (a.s1) {
         st1 = cfn_wave_sum(st1); st2 = cfn_wave_sum(st2);
-        if (lane == 0) { atomicAdd(&a.s1[nc], (double)st1); atomicAdd(&a.s2[nc], (double)st2); }
+        if (lane == 0) { cfn_add64(&a.s1[nc], (double)st1); cfn_add64(&a.s2[nc], (double)st2); }
     }
 }
 
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat_s2_fwd_kernel(const DwFlatAr
         if (lane == 0) { red[wave] = st1; red[4 + wave] = st2; }
         __syncthreads();
         if (tid == 0) {
-            atomicAdd(&a.s1[nc], (double)(red[0] + red[1] + red[2] + red[3]));
-            atomicAdd(&a.s2[nc], (double)(red[4] + red[5] + red[6] + red[7]));
+            cfn_add64(&a.s1[nc], (double)(red[0] + red[1] + red[2] + red[3]));
+            cfn_add64(&a.s2[nc], (double)(red[4] + red[5] + red[6] + red[7]));
         }
     }
 }
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat14to7_fwd_kernel(const DwFlat
     }
     if (a.s1) {
         st1 = cfn_wave_sum(st1); st2 = cfn_wave_sum(st2);
-        if (lane == 0) { atomicAdd(&a.s1[nc], (double)st1); atomicAdd(&a.s2[nc], (double)st2); }
+        if (lane == 0) { cfn_add64(&a.s1[nc], (double)st1); cfn_add64(&a.s2[nc], (double)st2); }
     }
 }
 

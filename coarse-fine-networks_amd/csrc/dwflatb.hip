@@ -185,11 +185,11 @@ __global__ __launch_bounds__(256, 3) void dw3d_flat7_bwd_kernel(const DwFlatBArg
         for (int j = 0; j < 32; ++j) v[j] = j < 27 ? dwa[j] : 0.0f;
         const float tot = fb_transpose_reduce(v, lane);
         const int idx = lane >> 1;
-        if ((lane & 1) == 0 && idx < 27) atomicAdd(&a.gw[(long)c * 27 + idx], (double)tot);
+        if ((lane & 1) == 0 && idx < 27) cfn_add64(&a.gw[(long)c * 27 + idx], (double)tot);
     }
     if (hasA && a.gA) {
         st1 = cfn_wave_sum(st1); st2 = cfn_wave_sum(st2);
-        if (lane == 0) { atomicAdd(&a.gA[nc], (double)st1); atomicAdd(&a.gB[nc], (double)st2); }
+        if (lane == 0) { cfn_add64(&a.gA[nc], (double)st1); cfn_add64(&a.gB[nc], (double)st2); }
     }
 }
 
@@ -338,11 +338,11 @@ __global__ __launch_bounds__(256, 3) void dw3d_flat14to7_bwd_kernel(const DwFlat
         for (int j = 0; j < 32; ++j) v[j] = (j < 27 && on) ? dwa[j] : 0.0f;
         const float tot = fb_transpose_reduce(v, lane);
         const int idx = lane >> 1;
-        if ((lane & 1) == 0 && idx < 27) atomicAdd(&a.gw[(long)c * 27 + idx], (double)tot);
+        if ((lane & 1) == 0 && idx < 27) cfn_add64(&a.gw[(long)c * 27 + idx], (double)tot);
     }
     if (hasA && a.gA) {
         st1 = cfn_wave_sum(st1); st2 = cfn_wave_sum(st2);
-        if (lane == 0) { atomicAdd(&a.gA[nc], (double)st1); atomicAdd(&a.gB[nc], (double)st2); }
+        if (lane == 0) { cfn_add64(&a.gA[nc], (double)st1); cfn_add64(&a.gB[nc], (double)st2); }
     }
 }
 

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 4) void dw3d_small_fwd_kernel(const DwSmallArg
     if (a.s1) {
         st1 = cfn_wave_sum(st1);
         st2 = cfn_wave_sum(st2);
-        if (lane == 0) { atomicAdd(&a.s1[nc], (double)st1); atomicAdd(&a.s2[nc], (double)st2); }
+        if (lane == 0) { cfn_add64(&a.s1[nc], (double)st1); cfn_add64(&a.s2[nc], (double)st2); }
     }
 }
 

@@ -158,15 +158,15 @@ __global__ __launch_bounds__(256) void dwt5_kernel(const T5Args a) {
         for (int k = 0; k < 5; ++k) { acc[k] = cfn_wave_sum(acc[k]); if (lane == 0) sh[k * 4 + wave] = acc[k]; }
         __syncthreads();
         if (threadIdx.x < 5)
-            atomicAdd(&a.s1[c * 5 + threadIdx.x],
+            cfn_add64(&a.s1[c * 5 + threadIdx.x],
                       (double)(sh[threadIdx.x * 4] + sh[threadIdx.x * 4 + 1] + sh[threadIdx.x * 4 + 2] + sh[threadIdx.x * 4 + 3]));
     } else if (MODE == T5_FWD && a.s1) {
         st1 = cfn_wave_sum(st1); st2 = cfn_wave_sum(st2);
         if (lane == 0) { sh[wave] = st1; sh[4 + wave] = st2; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            atomicAdd(&a.s1[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
-            atomicAdd(&a.s2[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
+            cfn_add64(&a.s1[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
+            cfn_add64(&a.s2[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
         }
     }
 }
@@ -234,8 +234,8 @@ __global__ __launch_bounds__(256) void dwt5_fwd_stream_kernel(const T5Args a) {
         if (lane == 0) { sh[wave] = st1; sh[4 + wave] = st2; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            atomicAdd(&a.s1[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
-            atomicAdd(&a.s2[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
+            cfn_add64(&a.s1[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
+            cfn_add64(&a.s2[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
         }
     }
 }
@@ -296,8 +296,8 @@ __global__ __launch_bounds__(256) void dwt5_fwd_flat_kernel(const T5Args a) {
         if (lane == 0) { sh[wave] = st1; sh[4 + wave] = st2; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            atomicAdd(&a.s1[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
-            atomicAdd(&a.s2[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
+            cfn_add64(&a.s1[nc], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
+            cfn_add64(&a.s2[nc], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
         }
     }
 }
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void dwt5_bwd_fused_kernel(const T5Args a) {
     }
     __syncthreads();
     if (threadIdx.x < 5)
-        atomicAdd(&a.s1[c * 5 + threadIdx.x], (double)(sh[threadIdx.x * 4] + sh[threadIdx.x * 4 + 1] + sh[threadIdx.x * 4 + 2] + sh[threadIdx.x * 4 + 3]));
+        cfn_add64(&a.s1[c * 5 + threadIdx.x], (double)(sh[threadIdx.x * 4] + sh[threadIdx.x * 4 + 1] + sh[threadIdx.x * 4 + 2] + sh[threadIdx.x * 4 + 3]));
 }
 
 // FLAT fused backward (same mapping as dwt5_fwd_flat_kernel): one thread = TO consecutive frames of one float4 position.
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void dwt5_bwd_flat_kernel(const T5Args a) {
     }
     __syncthreads();
     if (threadIdx.x < 5)
-        atomicAdd(&a.s1[c * 5 + threadIdx.x], (double)(sh[threadIdx.x * 4] + sh[threadIdx.x * 4 + 1] + sh[threadIdx.x * 4 + 2] + sh[threadIdx.x * 4 + 3]));
+        cfn_add64(&a.s1[c * 5 + threadIdx.x], (double)(sh[threadIdx.x * 4] + sh[threadIdx.x * 4 + 1] + sh[threadIdx.x * 4 + 2] + sh[threadIdx.x * 4 + 3]));
 }
 
 // -1 = not handled (the plane is not a whole number of float4s): the caller runs the two separate kernels

@@ -104,9 +104,9 @@ __global__ __launch_bounds__(256) void bn_add_relu_bwd_g_kernel(const float* __r
     }
     block_sum<3>(acc, sh);
     if (threadIdx.x == 0) {
-        atomicAdd(&gA[nc], (double)acc[0]);
-        atomicAdd(&gB[nc], (double)acc[1]);
-        if (gAr) atomicAdd(&gAr[nc], (double)acc[2]);
+        cfn_add64(&gA[nc], (double)acc[0]);
+        cfn_add64(&gB[nc], (double)acc[1]);
+        if (gAr) cfn_add64(&gAr[nc], (double)acc[2]);
     }
 }
 
@@ -197,9 +197,9 @@ __global__ __launch_bounds__(256) void bn_add_relu_bwd_g_flat_kernel(const EwFla
     }
     block_sum<3>(acc, sh);
     if (threadIdx.x == 0) {
-        atomicAdd(&a.gA[nc], (double)acc[0]);
-        atomicAdd(&a.gB[nc], (double)acc[1]);
-        if (hasr) atomicAdd(&a.gAr[nc], (double)acc[2]);
+        cfn_add64(&a.gA[nc], (double)acc[0]);
+        cfn_add64(&a.gB[nc], (double)acc[1]);
+        if (hasr) cfn_add64(&a.gAr[nc], (double)acc[2]);
     }
 }
 
@@ -250,9 +250,9 @@ __global__ __launch_bounds__(256) void bn_add_relu_bwd_kernel(const float* __res
     }
     block_sum<3>(acc, sh);
     if (threadIdx.x == 0) {
-        atomicAdd(&gA[nc], (double)acc[0]);
-        atomicAdd(&gB[nc], (double)acc[1]);
-        if (gAr) atomicAdd(&gAr[nc], (double)acc[2]);
+        cfn_add64(&gA[nc], (double)acc[0]);
+        cfn_add64(&gB[nc], (double)acc[1]);
+        if (gAr) cfn_add64(&gAr[nc], (double)acc[2]);
     }
 }
 
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __rest
         }
     }
     block_sum<2>(acc, sh);
-    if (threadIdx.x == 0) { atomicAdd(&gA[nc], (double)acc[0]); atomicAdd(&gB[nc], (double)acc[1]); }
+    if (threadIdx.x == 0) { cfn_add64(&gA[nc], (double)acc[0]); cfn_add64(&gB[nc], (double)acc[1]); }
 }
 
 template <int VEC>
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
         }
     }
     block_sum<2>(acc, sh);
-    if (threadIdx.x == 0) { atomicAdd(&sum[nc], (double)acc[0]); atomicAdd(&sumsq[nc], (double)acc[1]); }
+    if (threadIdx.x == 0) { cfn_add64(&sum[nc], (double)acc[0]); cfn_add64(&sumsq[nc], (double)acc[1]); }
 }
 
 // ---- adaptive spatial average of act(A*x+B): (N,C,T,H,W) -> (N,C,T,OH,OW) -----------------------------
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void pool_hw_bwd_kernel(const float* __restric
     }
     if (gA) {
         block_sum<2>(acc, sh);
-        if (threadIdx.x == 0) { atomicAdd(&gA[nc], (double)acc[0]); atomicAdd(&gB[nc], (double)acc[1]); }
+        if (threadIdx.x == 0) { cfn_add64(&gA[nc], (double)acc[0]); cfn_add64(&gB[nc], (double)acc[1]); }
     }
 }
 
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void pool_hw1_bwd_kernel(const float* __restri
     }
     if (gA) {
         block_sum<2>(acc, sh);
-        if (threadIdx.x == 0) { atomicAdd(&gA[nc], (double)acc[0]); atomicAdd(&gB[nc], (double)acc[1]); }
+        if (threadIdx.x == 0) { cfn_add64(&gA[nc], (double)acc[0]); cfn_add64(&gB[nc], (double)acc[1]); }
     }
 }
 

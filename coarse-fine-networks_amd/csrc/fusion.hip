@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256) void conv3d_dense_bwd_data_kernel(const DenseB
         if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s1; sh[4 + (threadIdx.x >> 6)] = s2; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            atomicAdd(&a.gA[nci], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
-            atomicAdd(&a.gB[nci], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
+            cfn_add64(&a.gA[nci], (double)(sh[0] + sh[1] + sh[2] + sh[3]));
+            cfn_add64(&a.gB[nci], (double)(sh[4] + sh[5] + sh[6] + sh[7]));
         }
     }
 }
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(256) void conv3d_dense_bwd_data_allci_kernel(const 
     if (a.A && a.gA) {
         __syncthreads();
         for (int i = threadIdx.x; i < a.Cin; i += 256) {
-            atomicAdd(&a.gA[(long)n * a.Cin + i], (double)((red[2 * i] + red[2 * CI + 2 * i]) + (red[4 * CI + 2 * i] + red[6 * CI + 2 * i])));
-            atomicAdd(&a.gB[(long)n * a.Cin + i], (double)((red[2 * i + 1] + red[2 * CI + 2 * i + 1]) + (red[4 * CI + 2 * i + 1] + red[6 * CI + 2 * i + 1])));
+            cfn_add64(&a.gA[(long)n * a.Cin + i], (double)((red[2 * i] + red[2 * CI + 2 * i]) + (red[4 * CI + 2 * i] + red[6 * CI + 2 * i])));
+            cfn_add64(&a.gB[(long)n * a.Cin + i], (double)((red[2 * i + 1] + red[2 * CI + 2 * i + 1]) + (red[4 * CI + 2 * i + 1] + red[6 * CI + 2 * i + 1])));
         }
     }
 }

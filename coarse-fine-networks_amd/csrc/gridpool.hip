@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void time_sample_bwd_cdf_kernel(const float* _
     acc = cfn_wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&gcdf[(long)b * K + k], (double)(sh[0] + sh[1] + sh[2] + sh[3]) * (double)(Tin - 1));
+    if (threadIdx.x == 0) cfn_add64(&gcdf[(long)b * K + k], (double)(sh[0] + sh[1] + sh[2] + sh[3]) * (double)(Tin - 1));
 }
 
 // ---- Interp1d ----------------------------------------------------------------------------------

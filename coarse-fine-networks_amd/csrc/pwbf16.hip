@@ -311,8 +311,8 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_kernel(const PwbArgs a) {
                 float t1 = 0.0f, t2 = 0.0f;
 #pragma unroll
                 for (int w = 0; w < PWB_WAVES; ++w) { t1 += red[(w * BM + m) * 2]; t2 += red[(w * BM + m) * 2 + 1]; }
-                atomicAdd(&a.s1[(long)n * M + m0 + m], (double)t1);
-                atomicAdd(&a.s2[(long)n * M + m0 + m], (double)t2);
+                cfn_add64(&a.s1[(long)n * M + m0 + m], (double)t1);
+                cfn_add64(&a.s2[(long)n * M + m0 + m], (double)t2);
             }
         }
     }
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_wgrad_kernel(const PwbWgAr
         const int ln = idx & 63, e = (idx >> 6) & 15, tl = idx >> 10;
         const int i = tl / NTW, jn = tl - i * NTW;
         const int m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5), k = k0 + 32 * jn + (ln & 31);
-        if (m < M && k < K) atomicAdd(&a.gw[(long)m * K + k], (double)t);
+        if (m < M && k < K) cfn_add64(&a.gw[(long)m * K + k], (double)t);
     }
 }
 

@@ -279,8 +279,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwArgs a) {
             if (m0 + m < M) {
                 const float s = (slot[m * 2] + slot[(BM + m) * 2]) + (slot[(2 * BM + m) * 2] + slot[(3 * BM + m) * 2]);
                 const float qq = (slot[m * 2 + 1] + slot[(BM + m) * 2 + 1]) + (slot[(2 * BM + m) * 2 + 1] + slot[(3 * BM + m) * 2 + 1]);
-                atomicAdd(&a.s1[(long)n * M + m0 + m], (double)s);
-                atomicAdd(&a.s2[(long)n * M + m0 + m], (double)qq);
+                cfn_add64(&a.s1[(long)n * M + m0 + m], (double)s);
+                cfn_add64(&a.s2[(long)n * M + m0 + m], (double)qq);
             }
         }
     }
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
         const int ml = e / BN, kl = e - ml * BN;
         const int o = ml * CWP + kl;
         const float v = (smem[o] + smem[BM * CWP + o]) + (smem[2 * BM * CWP + o] + smem[3 * BM * CWP + o]);
-        if (m0 + ml < M && k0 + kl < K) atomicAdd(&a.gw[(long)(m0 + ml) * K + k0 + kl], (double)v);
+        if (m0 + ml < M && k0 + kl < K) cfn_add64(&a.gw[(long)(m0 + ml) * K + k0 + kl], (double)v);
     }
 }
 

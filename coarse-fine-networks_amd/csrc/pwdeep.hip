@@ -296,8 +296,8 @@ __global__ __launch_bounds__(64 * PWD_WAVES) void pw_deep_kernel(const PwArgs a)
                 float s = 0.0f, qq = 0.0f;
 #pragma unroll
                 for (int w = 0; w < PWD_WAVES; ++w) { s += slot[(w * BM + m) * 2]; qq += slot[(w * BM + m) * 2 + 1]; }
-                atomicAdd(&a.s1[(long)n * M + m0 + m], (double)s);
-                atomicAdd(&a.s2[(long)n * M + m0 + m], (double)qq);
+                cfn_add64(&a.s1[(long)n * M + m0 + m], (double)s);
+                cfn_add64(&a.s2[(long)n * M + m0 + m], (double)qq);
             }
         }
     }

@@ -274,13 +274,13 @@ __global__ __launch_bounds__(256, ACT < 0 ? 3 : 2) void pw_bwd_fused_kernel(cons
         const int ml = e / BN, kl = e - ml * BN;
         const int o = ml * CWP + kl;
         const float v = (smem[o] + smem[BM * CWP + o]) + (smem[2 * BM * CWP + o] + smem[3 * BM * CWP + o]);
-        if (ml < M && kl < K) atomicAdd(&a.gw[(long)ml * K + kl], (double)v);
+        if (ml < M && kl < K) cfn_add64(&a.gw[(long)ml * K + kl], (double)v);
     }
     if (EPI && tid < K) {
         const float u = (sSt[2 * tid] + sSt[(BN + tid) * 2]) + (sSt[(2 * BN + tid) * 2] + sSt[(3 * BN + tid) * 2]);
         const float v = (sSt[2 * tid + 1] + sSt[(BN + tid) * 2 + 1]) + (sSt[(2 * BN + tid) * 2 + 1] + sSt[(3 * BN + tid) * 2 + 1]);
-        atomicAdd(&a.gA[(long)n * K + tid], (double)u);
-        atomicAdd(&a.gB[(long)n * K + tid], (double)v);
+        cfn_add64(&a.gA[(long)n * K + tid], (double)u);
+        cfn_add64(&a.gB[(long)n * K + tid], (double)v);
     }
 }
 

@@ -340,8 +340,8 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
         ssum += __shfl_xor(ssum, 32, 64);
         qsum += __shfl_xor(qsum, 32, 64);
         if (kg == 0 && row < M) {
-            atomicAdd(&a.s1[(long)n * Mfull + m0 + row], (double)ssum);
-            atomicAdd(&a.s2[(long)n * Mfull + m0 + row], (double)qsum);
+            cfn_add64(&a.s1[(long)n * Mfull + m0 + row], (double)ssum);
+            cfn_add64(&a.s2[(long)n * Mfull + m0 + row], (double)qsum);
         }
     }
 }

@@ -476,8 +476,8 @@ __global__ __launch_bounds__(64 * PWS_WAVES) void pws_kernel(const PwArgs a) {
                 float t1 = 0.0f, t2 = 0.0f;
 #pragma unroll
                 for (int w = 0; w < PWS_WAVES; ++w) { t1 += red[(w * BM + m) * 2]; t2 += red[(w * BM + m) * 2 + 1]; }
-                atomicAdd(&a.s1[(long)n * M + m0 + m], (double)t1);
-                atomicAdd(&a.s2[(long)n * M + m0 + m], (double)t2);
+                cfn_add64(&a.s1[(long)n * M + m0 + m], (double)t1);
+                cfn_add64(&a.s2[(long)n * M + m0 + m], (double)t2);
             }
         }
     }

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64 * PWSW_WAVES) void pws_wgrad_kernel(const WsArgs
 #pragma unroll
                     for (int w = 0; w < PWSW_WAVES; ++w) v += cw[w][ml * 33 + kl];
                     const int m = m0 + i * 32 + ml, k = k0 + jn * 32 + kl;
-                    if (m < M && k < K) atomicAdd(&a.gw[(long)m * K + k], (double)v);
+                    if (m < M && k < K) cfn_add64(&a.gw[(long)m * K + k], (double)v);
                 }
                 __syncthreads();
             }
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
-                if (m < M && k < K) atomicAdd(&a.gw[(long)m * K + k], (double)acc[tt][e]);
+                if (m < M && k < K) cfn_add64(&a.gw[(long)m * K + k], (double)acc[tt][e]);
             }
         }
     }

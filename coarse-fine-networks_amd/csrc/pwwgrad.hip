@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64 * WD_WAVES) void pw_wgrad_direct_kernel(const Wd
                     const int m = m0 + i * 32 + ml, k = k0 + j * 32 + kl;
                     if (m < M && k < K) {
                         if (a.gsc) v *= wd_zfloor((float)a.gsc[(long)n * M + m]);
-                        atomicAdd(&a.gw[(long)m * K + k], (double)v);
+                        cfn_add64(&a.gw[(long)m * K + k], (double)v);
                     }
                 }
                 __syncthreads();

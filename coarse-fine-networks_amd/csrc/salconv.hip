@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256, NT == 4 ? 1 : 2) void sal_fwd_kernel(const Sal
             for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
             const int co = (r & 3) + 8 * (mq + (r >> 2)) + 4 * half;
             if (p == 0 && co < Cout) {
-                atomicAdd(&a.s1[(long)n * Cout + co], (double)s);
-                atomicAdd(&a.s2[(long)n * Cout + co], (double)q);
+                cfn_add64(&a.s1[(long)n * Cout + co], (double)s);
+                cfn_add64(&a.s2[(long)n * Cout + co], (double)q);
             }
         }
     }
@@ -462,8 +462,8 @@ __global__ __launch_bounds__(512, 2) void sal_dgrad_kernel(const SalBwdArgs a) {
             for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
             const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
             if (p == 0) {
-                atomicAdd(&a.gA[(long)n * 24 + ci], (double)s);
-                atomicAdd(&a.gB[(long)n * 24 + ci], (double)q);
+                cfn_add64(&a.gA[(long)n * 24 + ci], (double)s);
+                cfn_add64(&a.gB[(long)n * 24 + ci], (double)q);
             }
         }
     }
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(512, 2) void sal_wgrad_kernel(const SalBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 12; ++r) {
                 const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
-                atomicAdd(&a.gw[(long)co * 648 + col], (double)acc[tt][r]);
+                cfn_add64(&a.gw[(long)co * 648 + col], (double)acc[tt][r]);
             }
         }
     }

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void stem_wgrad_kernel(const StemWgArgs a) 
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) s += gbuf[(w * 16 + r) * 64 + l];
-        if (co < 24 && col < 27) atomicAdd(&a.gw[co * 27 + col], (double)s);
+        if (co < 24 && col < 27) cfn_add64(&a.gw[co * 27 + col], (double)s);
     }
 }
 

@@ -118,9 +118,9 @@ __global__ __launch_bounds__(256) void bn_add_relu_bwd_g_bf16_kernel(const uint1
     }
     sb_block_sum<3>(acc, sh);
     if (threadIdx.x == 0) {
-        atomicAdd(&gA[nc], (double)acc[0]);
-        atomicAdd(&gB[nc], (double)acc[1]);
-        if (gAr) atomicAdd(&gAr[nc], (double)acc[2]);
+        cfn_add64(&gA[nc], (double)acc[0]);
+        cfn_add64(&gB[nc], (double)acc[1]);
+        if (gAr) cfn_add64(&gAr[nc], (double)acc[2]);
     }
 }
 
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void pool_hw_bwd_bf16_kernel(const float* __re
     }
     if (gA) {
         sb_block_sum<2>(acc, sh);
-        if (threadIdx.x == 0) { atomicAdd(&gA[nc], (double)acc[0]); atomicAdd(&gB[nc], (double)acc[1]); }
+        if (threadIdx.x == 0) { cfn_add64(&gA[nc], (double)acc[0]); cfn_add64(&gB[nc], (double)acc[1]); }
     }
 }
 

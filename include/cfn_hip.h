@@ -101,6 +101,16 @@ int cfn_pwconv_bwd_weight(const float* gy, const float* y, const double* gsum, c
  * Default 6 (env CFN_PW_SPLIT).  -1 only queries.  Returns the previous setting.  Host-side, no stream. */
 int cfn_pw_split_terms(int terms);
 
+/* Deterministic mode ("Threading / streams": "deterministic reductions preferred for parity tests (atomics order) -- offer a
+ * deterministic mode"; the reference's own reductions are PyTorch's, train_fine.py:199-226 runs them in whatever mode torch is in).
+ * on = 1: every cross-workgroup fp64 accumulation of the library (BN statistics, coefficient / weight gradients: ~100 sites) is recorded as an
+ * (address, addend) pair instead of being added atomically; at the end of each entry point's launches the records are sorted by (address, addend
+ * bits) and committed in that order, so results do not depend on the order in which workgroups finish: two identical calls give identical bits by
+ * construction.  Costs a device synchronisation and a sort per entry point (parity runs, not benchmarks); not usable during hipGraph capture.
+ * on = 0: fp64 atomics (default; env CFN_DETERMINISTIC=1 switches the mode on when the library is loaded by cfn_hip).  -1 only queries.
+ * Returns the previous setting, < 0 on error.  Per process, bound to the device that is current at the call.  Host-side, no stream. */
+int cfn_deterministic(int on);
+
 /* Data AND weight gradient of a stride-1 pointwise conv with few channels in ONE pass (Cin, Cout <= 64 and not both > 32:
  * X3D layer 1, where the backward is HBM bound): gy, y, x leave HBM once for both products.  Same arguments and results
  * as cfn_pwconv_bwd_data_acc (stride 1) + cfn_pwconv_bwd_weight; x is always required.  Returns -1 WITHOUT launching
