@@ -178,9 +178,10 @@ def main():
                          'to end, fine tower on 128 frames feeding the coarse stream on the centre 64 (BASELINE configs[4] per-GPU shard)')
     ap.add_argument('--frames', type=int, default=None, help='default 256 (fine) / 64 (coarse) / 128 fine frames (joint)')
     ap.add_argument('--batch', type=int, default=8, help='clips per GPU per step')
-    ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32',
+    ap.add_argument('--dtype', choices=('f32', 'bf16', 'fp16'), default='f32',
                     help='storage type of activations / activation gradients (fine stream): f32 = the reference precision (the '
-                         'headline), bf16 = BASELINE configs[1] (bf16 MFMA pointwise, fp32 accumulation and statistics)')
+                         'headline), bf16 = BASELINE configs[1] (bf16 MFMA pointwise, fp32 accumulation and statistics), fp16 = BASELINE configs[4] (IEEE-half '
+                         'storage, fp16 MFMA pointwise, static loss scale)')
     ap.add_argument('--graph', action='store_true', help='replay the step from captured hipGraphs (one graph on a single GPU; with --gpus > 1: forward+backward graph, eager all-reduce, optimizer graph)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-coarse-roofline', action='store_true', help='skip the coarse-stream roofline leg (figure B) of the default line')
@@ -328,9 +329,10 @@ def main():
             'dtype_note': ('fp32 tensors everywhere; pointwise contractions with >= 48 channels run as split-bf16 (each fp32 operand = 3 bf16 '
                            'terms, 6 bf16 MFMAs per k-block, fp32 accumulation: an fp32-accurate product), all other arithmetic fp32'
                            if args.dtype == 'f32' else
-                           'bf16 activations / activation gradients, fp32 weights, statistics and accumulation'
-                           + ('; bf16 stands in for BASELINE configs[4]\'s "fp16 MFMA pointwise" (same MFMA rate on gfx950, no loss-scaling '
-                              'needed: the engine has no fp16 path)' if joint else '')),
+                           ('fp16 (IEEE half) activations / activation gradients with a static loss scale, v_mfma_f32_32x32x16_f16 pointwise products, '
+                            'fp32 weights, statistics and accumulation' if args.dtype == 'fp16' else
+                            'bf16 activations / activation gradients, fp32 weights, statistics and accumulation')
+                           + (' (Fine tower; the Coarse stream and the fusion stay fp32)' if joint else '')),
             'config': {'workload': workload, 'clips_per_gpu': B, 'frames': T, 'parallelism': 'dp%d' % world,
                        'launch': ('hipGraph replay' if args.graph else 'eager') +
                                  (' (two graphs around an eager bucketed all-reduce: the all-reduce runs AFTER the replayed backward, not '

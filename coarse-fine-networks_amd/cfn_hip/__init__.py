@@ -48,6 +48,8 @@ def header_prototypes(path=HEADER):
                     at.append(ctypes.c_int)
                 else:
                     raise ValueError('unhandled C type in %s: %r' % (name, a))
+        if name.endswith('_f16'):                # the fp16 twins of the bf16 entry points: `unsigned short*` = IEEE half there
+            dt = [torch.float16 if d == torch.bfloat16 else d for d in dt]
         out[name] = (ctypes.c_char_p if 'char' in ret else (ctypes.c_long if ret == 'long' else ctypes.c_int), at, dt)
     return out
 
@@ -155,8 +157,8 @@ def query(name, *args):
 
 
 def check(t, dtype=torch.float32):
-    """activation tensors are fp32 or bf16 (the *_bf16 entry points); anything else is refused"""
-    if t is not None and t.dtype != dtype and not (dtype == torch.float32 and t.dtype == torch.bfloat16):
+    """activation tensors are fp32, bf16 or fp16 (the *_bf16 / *_f16 entry points); anything else is refused"""
+    if t is not None and t.dtype != dtype and not (dtype == torch.float32 and t.dtype in (torch.bfloat16, torch.float16)):
         raise RuntimeError('expected %s tensor, got %s' % (dtype, t.dtype))
     return t
 

@@ -225,14 +225,15 @@ class TailLink(object):
 
 
 def _bf(t):
-    return t is not None and t.dtype == torch.bfloat16
+    """2-byte activation tensor (bf16 or fp16: the *_bf16 / *_f16 entry points)"""
+    return t is not None and t.dtype in (torch.bfloat16, torch.float16)
 
 
 def subsample_hw(x, s):
     """x[..., ::s, ::s] of a bf16 (N,C,T,H,W) tensor (cfn_subsample_hw_bf16); no autograd (used inside the conv ops)"""
     N, C, T, H, W = x.shape
     out = torch.empty(N, C, T, (H - 1) // s + 1, (W - 1) // s + 1, dtype=x.dtype, device=x.device)
-    call('cfn_subsample_hw_bf16', x, out, N * C * T, H, W, s)
+    call('cfn_subsample_hw' + _sfx(x), x, out, N * C * T, H, W, s)
     return out
 
 
@@ -255,7 +256,7 @@ class _PwConv(Function):
         xs = None
         if _bf(x):
             xs = subsample_hw(x, stride) if stride > 1 else x
-            call('cfn_pwconv_fwd_bf16', xs, A, B, act, w2, y, s, q, N, Cin, Cout, T * Ho * Wo)
+            call('cfn_pwconv_fwd' + _sfx(x), xs, A, B, act, w2, y, s, q, N, Cin, Cout, T * Ho * Wo)
         else:
             call('cfn_pwconv_fwd', x, A, B, act, w2, y, s, q, N, Cin, Cout, T, H, W, stride)
         ctx.save_for_backward(x, A, B, w2, y, xs if stride > 1 else None)
@@ -337,7 +338,7 @@ class _PwConv(Function):
         if ctx.needs_input_grad[0] or (A is not None and ctx.needs_input_grad[1]):
             if token is not None and role == 'short' and stride > 1 and not token.main_done:
                 da = torch.empty(N, Cin, T, Ho, Wo, dtype=x.dtype, device=x.device)      # compact, no epilogue
-                call('cfn_pwconv_bwd_data_bf16', gy, y, gs, gq, w2, None, None, None, ACT_NONE, da, None, None, N, Cin, Cout, T,
+                call('cfn_pwconv_bwd_data' + _sfx(gy), gy, y, gs, gq, w2, None, None, None, ACT_NONE, da, None, None, N, Cin, Cout, T,
                      Ho, Wo, None, 1, gsc)
                 token.acc, token.acc_stride = da, stride
             else:
@@ -351,7 +352,7 @@ class _PwConv(Function):
                     else:
                         token.main_done = True
                 gxc = torch.empty_like(xin)
-                call('cfn_pwconv_bwd_data_bf16', gy, y, gs, gq, w2, xin, A, B, act, gxc, a64, b64, N, Cin, Cout, T, Ho, Wo,
+                call('cfn_pwconv_bwd_data' + _sfx(gy), gy, y, gs, gq, w2, xin, A, B, act, gxc, a64, b64, N, Cin, Cout, T, Ho, Wo,
                      acc, acc_stride, gsc)
                 if stride > 1:      # only reached when conv1's backward ran before the shortcut's: scatter onto the lattice
                     gx = torch.zeros_like(x)
@@ -362,7 +363,7 @@ class _PwConv(Function):
                     gA, gB = ab[0], ab[1]
         if ctx.needs_input_grad[3]:
             g64, fin = _gw_buffers(ctx.wparam, Cout, Cin, x.device)
-            call('cfn_pwconv_bwd_weight_bf16', gy, y, gs, gq, xin, A, B, act, g64, N, Cin, Cout, T * Ho * Wo, gsc)
+            call('cfn_pwconv_bwd_weight' + _sfx(gy), gy, y, gs, gq, xin, A, B, act, g64, N, Cin, Cout, T * Ho * Wo, gsc)
             gw = fin()
         return gx, gA, gB, gw, None, None, None, None, None, None, None
 
@@ -415,7 +416,7 @@ def pwconv(x, w, A=None, B=None, act=ACT_NONE, stride=1, stats=True, token=None,
 
 def _sfx(t):
     """entry-point suffix for the element type of an activation tensor"""
-    return '_bf16' if t.dtype == torch.bfloat16 else ''
+    return '_bf16' if t.dtype == torch.bfloat16 else ('_f16' if t.dtype == torch.float16 else '')
 
 
 class _DwConv3d(Function):
@@ -683,7 +684,7 @@ class _BnAddRelu(Function):
             return g, gA, gB, g2, gAr, gBr, None, None
         if _bf(y):   # no link (a tail used on its own): one-tensor kernel, then the two per-(n,c) scalings as tensor ops
             g = torch.empty_like(y)
-            call('cfn_bn_add_relu_bwd_g_bf16', gout.contiguous(), gout2, out, None, y, res if Ar is not None else None, g, gA, gB,
+            call('cfn_bn_add_relu_bwd_g' + _sfx(y), gout.contiguous(), gout2, out, None, y, res if Ar is not None else None, g, gA, gB,
                  gAr, N * C, vol)
             shp = (N, C) + (1,) * (y.dim() - 2)
             gres = g if Ar is None else (g.float() * Ar.float().view(shp)).to(y.dtype)

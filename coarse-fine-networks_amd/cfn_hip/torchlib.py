@@ -27,7 +27,7 @@ _lib = 'cfn'
 
 
 def _sfx(t):
-    return '_bf16' if t.dtype == torch.bfloat16 else ''
+    return '_bf16' if t.dtype == torch.bfloat16 else ('_f16' if t.dtype == torch.float16 else '')
 
 
 def _f64(*shape, dev):

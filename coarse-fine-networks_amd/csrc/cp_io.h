@@ -4,6 +4,7 @@
 // dwconv3d.hip / dwconv3d_bf16.hip.  LDS images, accumulators, statistics and every reduction stay fp32 / fp64.
 #pragma once
 #include "cfn_common.h"
+#include "h16.h"
 
 typedef float __attribute__((ext_vector_type(4))) cp_f4;
 typedef float __attribute__((ext_vector_type(2))) cp_f2;
@@ -13,11 +14,10 @@ typedef unsigned __attribute__((ext_vector_type(4))) cp_u4;
 #ifdef DW_BF16
 typedef unsigned short cpe_t;
 #define CP_ES 2
-#define CPN(name) name##_bf16
-typedef __bf16 __attribute__((ext_vector_type(2))) cp_b2;
-__device__ __forceinline__ float cp_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float cp_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
-__device__ __forceinline__ unsigned cp_pk(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((cp_f2){a, b}, cp_b2)); }
+#define CPN(name) H16N(name)
+__device__ __forceinline__ float cp_lo(unsigned u) { return h16_lo(u); }
+__device__ __forceinline__ float cp_hi(unsigned u) { return h16_hi(u); }
+__device__ __forceinline__ unsigned cp_pk(float a, float b) { return h16_pk(a, b); }
 // 4 consecutive elements (8 bytes; the offset is 8-byte aligned)
 __device__ __forceinline__ cp_f4 cp_ld4(__amdgpu_buffer_rsrc_t r, int vo, int so) {
     const cp_u2 u = __builtin_bit_cast(cp_u2, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0));

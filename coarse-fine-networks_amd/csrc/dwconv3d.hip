@@ -17,6 +17,7 @@
 // blockIdx is remapped so that the t-chunks / bands of one (n, channel group) run on one XCD and
 // find their halo frames in that XCD's L2.
 #include "cfn_common.h"
+#include "h16.h"
 
 // Element type of the activation tensors.  This file is compiled twice: as is (fp32 storage) and through
 // dwconv3d_bf16.hip (#define DW_BF16: bf16 storage, identical fp32 arithmetic, entry points suffixed _bf16, argument
@@ -25,7 +26,7 @@
 #ifdef DW_BF16
 typedef unsigned short dwe_t;
 #define DW_ES 2
-#define DWN(name) name##_bf16
+#define DWN(name) H16N(name)
 #else
 typedef float dwe_t;
 #define DW_ES 4
@@ -34,10 +35,9 @@ typedef float dwe_t;
 typedef float __attribute__((ext_vector_type(4))) dw_f4;
 typedef float __attribute__((ext_vector_type(2))) dw_f2;
 #ifdef DW_BF16
-typedef __bf16 __attribute__((ext_vector_type(2))) dw_b2;
-__device__ __forceinline__ float dw_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float dw_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
-__device__ __forceinline__ unsigned dw_pk(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((dw_f2){a, b}, dw_b2)); }
+__device__ __forceinline__ float dw_lo(unsigned u) { return h16_lo(u); }
+__device__ __forceinline__ float dw_hi(unsigned u) { return h16_hi(u); }
+__device__ __forceinline__ unsigned dw_pk(float a, float b) { return h16_pk(a, b); }
 __device__ __forceinline__ float dw_ld(const dwe_t* p) { return dw_lo(*p); }
 __device__ __forceinline__ void dw_st(dwe_t* p, float v) { *p = (unsigned short)(dw_pk(v, 0.0f) & 0xffffu); }
 __device__ __forceinline__ void dw_st2(dwe_t* p, dw_f2 v) { *reinterpret_cast<unsigned*>(p) = dw_pk(v.x, v.y); }

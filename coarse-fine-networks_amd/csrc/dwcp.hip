@@ -25,7 +25,7 @@
 #include <stdlib.h>
 
 #ifdef DW_BF16
-#define DwCpArgs DwCpArgsBf16
+#define DwCpArgs H16N(DwCpArgs)
 #endif
 struct DwCpArgs {
     const cpe_t* x; const double* A; const double* B; const float* w; cpe_t* y; double* s1; double* s2;

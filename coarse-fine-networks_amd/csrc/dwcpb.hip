@@ -26,7 +26,7 @@
 #include <stdlib.h>
 
 #ifdef DW_BF16
-#define DwCpbArgs DwCpbArgsBf16
+#define DwCpbArgs H16N(DwCpbArgs)
 #endif
 struct DwCpbArgs {
     const cpe_t* gy; const cpe_t* y; const double* gs; const double* gq; const float* w; const cpe_t* x;

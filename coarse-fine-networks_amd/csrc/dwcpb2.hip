@@ -25,7 +25,7 @@
 #include <stdlib.h>
 
 #ifdef DW_BF16
-#define DwCpb2Args DwCpb2ArgsBf16
+#define DwCpb2Args H16N(DwCpb2Args)
 #endif
 struct DwCpb2Args {
     const cpe_t* gy; const cpe_t* y; const double* gs; const double* gq; const float* w; const cpe_t* x;

@@ -17,7 +17,7 @@
 #include <stdlib.h>
 
 #ifdef DW_BF16
-#define DwCpb2xArgs DwCpb2xArgsBf16
+#define DwCpb2xArgs H16N(DwCpb2xArgs)
 #endif
 
 struct DwCpb2xArgs {

@@ -19,7 +19,7 @@
 #include <stdlib.h>
 
 #ifdef DW_BF16
-#define DwCpbxArgs DwCpbxArgsBf16
+#define DwCpbxArgs H16N(DwCpbxArgs)
 #endif
 
 struct DwCpbxArgs {

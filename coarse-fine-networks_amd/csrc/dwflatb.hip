@@ -20,7 +20,7 @@
 #include <stdlib.h>
 
 #ifdef DW_BF16
-#define DwFlatBArgs DwFlatBArgsBf16
+#define DwFlatBArgs H16N(DwFlatBArgs)
 #endif
 struct DwFlatBArgs {
     const cpe_t* gy; const cpe_t* y; const double* gs; const double* gq; const float* w; const cpe_t* x;

@@ -21,7 +21,7 @@
 #include <stdlib.h>
 
 #ifdef DW_BF16
-#define DwSmallArgs DwSmallArgsBf16
+#define DwSmallArgs H16N(DwSmallArgs)
 #endif
 struct DwSmallArgs {
     const cpe_t* x; const double* A; const double* B; const float* w; cpe_t* y; double* s1; double* s2;

@@ -6,6 +6,7 @@
 //   T5_DGRAD  gx = conv_flipped(gy + gs + 2 y gq)
 //   T5_WGRAD  gw[c][kt] += sum (gy + gs + 2 y gq)[t] * x[t+kt-2]
 #include "cfn_common.h"
+#include "h16.h"
 
 typedef float __attribute__((ext_vector_type(4))) f4v;
 typedef unsigned __attribute__((ext_vector_type(4))) u4v_t5;
@@ -26,15 +27,16 @@ struct T5Args {
     long plane;
 };
 
-__device__ __forceinline__ f4v t5_ld(const void* ptr, long idx, bool b16, int vec) {
+// b16: 0 = fp32 elements, H16_BF16 / H16_F16 = 2-byte elements of that kind (h16.h)
+__device__ __forceinline__ f4v t5_ld(const void* ptr, long idx, int b16, int vec) {
     f4v v = {0.f, 0.f, 0.f, 0.f};
     if (b16) {
         const unsigned short* p = static_cast<const unsigned short*>(ptr) + idx;
         if (vec == 4) {
             const uint2 u = *reinterpret_cast<const uint2*>(p);
-            v.x = __builtin_bit_cast(float, u.x << 16); v.y = __builtin_bit_cast(float, u.x & 0xffff0000u);
-            v.z = __builtin_bit_cast(float, u.y << 16); v.w = __builtin_bit_cast(float, u.y & 0xffff0000u);
-        } else v.x = __builtin_bit_cast(float, (unsigned)p[0] << 16);
+            if (b16 == H16_F16) { v.x = h16k_lo<H16_F16>(u.x); v.y = h16k_hi<H16_F16>(u.x); v.z = h16k_lo<H16_F16>(u.y); v.w = h16k_hi<H16_F16>(u.y); }
+            else { v.x = h16k_lo<H16_BF16>(u.x); v.y = h16k_hi<H16_BF16>(u.x); v.z = h16k_lo<H16_BF16>(u.y); v.w = h16k_hi<H16_BF16>(u.y); }
+        } else v.x = b16 == H16_F16 ? h16k_lo<H16_F16>((unsigned)p[0]) : h16k_lo<H16_BF16>((unsigned)p[0]);
     } else {
         const float* p = static_cast<const float*>(ptr) + idx;
         if (vec == 4) v = *reinterpret_cast<const f4v*>(p);
@@ -43,11 +45,11 @@ __device__ __forceinline__ f4v t5_ld(const void* ptr, long idx, bool b16, int ve
     return v;
 }
 
-template <int MODE, int VEC, bool BF>
+template <int MODE, int VEC, int BF>
 __global__ __launch_bounds__(256) void dwt5_kernel(const T5Args a) {
-    typedef __bf16 __attribute__((ext_vector_type(4))) bf4;
-    constexpr bool SRC16 = BF && MODE == T5_DGRAD;      // element type of src / src2
-    constexpr bool DST16 = BF && MODE == T5_FWD;        // element type of dst
+    typedef typename h16_types<BF ? BF : H16_BF16>::v4 bf4;
+    constexpr int SRC16 = MODE == T5_DGRAD ? BF : 0;      // element type of src / src2
+    constexpr int DST16 = MODE == T5_FWD ? BF : 0;        // element type of dst
     __shared__ float sh[20];
     const long nc = blockIdx.y + (long)blockIdx.z * gridDim.y;
     const int c = (int)(nc % a.C);
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void dwt5_kernel(const T5Args a) {
     const float gsv = (MODE != T5_FWD && a.gs) ? (float)a.gs[nc] : 0.0f;
     const float gqv = (MODE != T5_FWD && a.gq) ? 2.0f * (float)a.gq[nc] : 0.0f;
 
-    auto ldt = [&](const void* ptr, int t, bool b16) -> f4v {
+    auto ldt = [&](const void* ptr, int t, int b16) -> f4v {
         f4v v = {0.f, 0.f, 0.f, 0.f};
         if (ok && t >= 0 && t < a.T) v = t5_ld(ptr, base + (long)t * a.plane, b16, VEC);
         return v;
@@ -176,9 +178,9 @@ __global__ __launch_bounds__(256) void dwt5_kernel(const T5Args a) {
 // only wait with vmcnt(0), i.e. for the load it issued a moment ago as well: one HBM round trip per frame and 4.9 TB/s; with
 // exact vmcnt(N) waits the PF look-ahead loads really stay in flight (a one-float4-per-thread copy of the same tensor runs at
 // 6.35 TB/s on this box, tools/probe/stream_probe.hip).  env CFN_T5_STREAM=0 falls back to dwt5_kernel<T5_FWD>.
-template <bool BF>
+template <int BF>
 __global__ __launch_bounds__(256) void dwt5_fwd_stream_kernel(const T5Args a) {
-    typedef __bf16 __attribute__((ext_vector_type(4))) bf4;
+    typedef typename h16_types<BF ? BF : H16_BF16>::v4 bf4;
     typedef unsigned __attribute__((ext_vector_type(2))) u2v;
     constexpr int PF = 3, OOB = 0x7ffffff0, OES = BF ? 2 : 4;
     __shared__ float sh[8];
@@ -247,9 +249,9 @@ __global__ __launch_bounds__(256) void dwt5_fwd_stream_kernel(const T5Args a) {
 // flat kernel without the XCD remap 3.6 TB/s, with the block order scrambled inside each XCD 3.4-4.1 TB/s, TO = 1 (5 x L2 reads)
 // 4.0 TB/s: what this kernel responds to is the ORDER in which the chip walks memory and the L2 re-read factor, not the
 // look-ahead depth.  Ragged T / planes: surplus frames and threads get out-of-range offsets.
-template <bool BF, int TO>
+template <int BF, int TO>
 __global__ __launch_bounds__(256) void dwt5_fwd_flat_kernel(const T5Args a) {
-    typedef __bf16 __attribute__((ext_vector_type(4))) bf4;
+    typedef typename h16_types<BF ? BF : H16_BF16>::v4 bf4;
     typedef unsigned __attribute__((ext_vector_type(2))) u2v;
     constexpr int OOB = 0x7ffffff0, OES = BF ? 2 : 4;
     __shared__ float sh[8];
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(256) void dwt5_fwd_flat_kernel(const T5Args a) {
 }
 
 // -1 = not handled
-template <bool BF>
+template <int BF>
 static int t5_fwd_flat(T5Args& a, int N, hipStream_t st) {
     static const int on = getenv("CFN_T5_FLAT") ? atoi(getenv("CFN_T5_FLAT")) : 1;       // 0: marching kernel, 4 / 8: force TO
     if (!on || a.plane % 4 != 0 || (long)a.T * a.plane * 4 >= 0x7ffffff0L) return -1;
@@ -323,7 +325,7 @@ static int t5_fwd_flat(T5Args& a, int N, hipStream_t st) {
 // register rings, unconditional buffer accesses.  Ring slot (k % RING) holds frame t0 - 2 + k of g' = gy + gs + 2 y gq and of
 // x; a frame's raw gy / y land PF steps before it enters the 5-frame window and are combined in place at that step.
 //   gx(t)  = sum_k g'(t - 2 + k) w[4 - k]          gw[k] += sum_t g'(t) x(t - 2 + k)
-template <bool BF, bool HASY>
+template <int BF, bool HASY>
 __global__ __launch_bounds__(256) void dwt5_bwd_fused_kernel(const T5Args a) {
     typedef unsigned __attribute__((ext_vector_type(2))) u2v;
     constexpr int PF = 3, RING = 5 + PF, OOB = 0x7ffffff0, GES = BF ? 2 : 4;
@@ -352,8 +354,7 @@ __global__ __launch_bounds__(256) void dwt5_bwd_fused_kernel(const T5Args a) {
         const int vo = tv ? vg : OOB, so = tv ? t * plane * GES : 0;
         if (BF) {
             const u2v u = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0));
-            return (f4v){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
-                         __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+            return (f4v){h16k_lo<BF ? BF : H16_BF16>(u.x), h16k_hi<BF ? BF : H16_BF16>(u.x), h16k_lo<BF ? BF : H16_BF16>(u.y), h16k_hi<BF ? BF : H16_BF16>(u.y)};
         }
         return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0));
     };
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(256) void dwt5_bwd_fused_kernel(const T5Args a) {
 //   gx(t) = sum_k g'(t - 2 + k) w[4 - k]                      t in the thread's TO frames (g' over TO + 4 frames)
 //   gw[k] += sum_s x(s) g'(s + 2 - k)                          s in the thread's TO frames -- the weight-gradient sum re-indexed by
 // the frame of x, so that x needs NO halo (gy and y are read (TO + 4) / TO times out of L2, x once).
-template <bool BF, bool HASY, int TO>
+template <int BF, bool HASY, int TO>
 __global__ __launch_bounds__(256) void dwt5_bwd_flat_kernel(const T5Args a) {
     typedef unsigned __attribute__((ext_vector_type(2))) u2v;
     constexpr int OOB = 0x7ffffff0, GES = BF ? 2 : 4;
@@ -439,8 +440,7 @@ __global__ __launch_bounds__(256) void dwt5_bwd_flat_kernel(const T5Args a) {
     auto ldg = [&](__amdgpu_buffer_rsrc_t r, int vo) -> f4v {
         if (BF) {
             const u2v u = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(r, vo, 0, 0));
-            return (f4v){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
-                         __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+            return (f4v){h16k_lo<BF ? BF : H16_BF16>(u.x), h16k_hi<BF ? BF : H16_BF16>(u.x), h16k_lo<BF ? BF : H16_BF16>(u.y), h16k_hi<BF ? BF : H16_BF16>(u.y)};
         }
         return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, vo, 0, 0));
     };
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void dwt5_bwd_flat_kernel(const T5Args a) {
 }
 
 // -1 = not handled (the plane is not a whole number of float4s): the caller runs the two separate kernels
-template <bool BF>
+template <int BF>
 static int t5_bwd_fused(const void* gy, const void* y, const double* gs, const double* gq, const float* w, const float* x, float* gx,
                         double* gw, int N, int C, int T, long plane, hipStream_t st) {
     static const int on = getenv("CFN_T5_FUSED") ? atoi(getenv("CFN_T5_FUSED")) : 1;
@@ -528,7 +528,7 @@ static int t5_bwd_fused(const void* gy, const void* y, const double* gs, const d
     return cfn_check_launch("dwconv_t5 fused backward");
 }
 
-template <int MODE, bool BF = false>
+template <int MODE, int BF = 0>
 static int t5_launch(T5Args& a, int N, hipStream_t st) {
     if (MODE == T5_FWD) {
         const int rc = t5_fwd_flat<BF>(a, N, st);
@@ -598,7 +598,7 @@ extern "C" int cfn_dwconv_t5_fwd_bf16(const float* x, const float* w, unsigned s
     a.src = x; a.w = w; a.dst = y; a.s1 = sum; a.s2 = sumsq; a.C = C; a.T = T; a.plane = plane;
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_DWCONV_FWD, st, 6.0 * N * C * T * plane);
-    return t5_launch<T5_FWD, true>(a, N, st);
+    return t5_launch<T5_FWD, H16_BF16>(a, N, st);
 }
 
 extern "C" int cfn_dwconv_t5_bwd_data_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum,
@@ -610,7 +610,7 @@ extern "C" int cfn_dwconv_t5_bwd_data_bf16(const unsigned short* gy, const unsig
     a.src = gy; a.src2 = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.w = w; a.dst = gx; a.C = C; a.T = T; a.plane = plane;
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_DWCONV_BWD, st, N * (double)C * T * plane * (a.src2 ? 8.0 : 6.0));
-    return t5_launch<T5_DGRAD, true>(a, N, st);
+    return t5_launch<T5_DGRAD, H16_BF16>(a, N, st);
 }
 
 extern "C" int cfn_dwconv_t5_bwd_weight_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum,
@@ -622,7 +622,7 @@ extern "C" int cfn_dwconv_t5_bwd_weight_bf16(const unsigned short* gy, const uns
     a.src = x; a.gy = gy; a.yout = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.s1 = gw; a.C = C; a.T = T; a.plane = plane;
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_DWCONV_BWD, st, N * (double)C * T * plane * (a.yout ? 8.0 : 6.0));
-    return t5_launch<T5_WGRAD, true>(a, N, st);
+    return t5_launch<T5_WGRAD, H16_BF16>(a, N, st);
 }
 
 // data AND weight gradient in one pass (gy, y, x read once); -1 = not handled, call the two entry points above
@@ -632,7 +632,7 @@ extern "C" int cfn_dwconv_t5_bwd_fused(const float* gy, const float* y, const do
     CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv_t5_bwd_fused: gsumsq needs y");
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_DWCONV_BWD, st, 4.0 * N * C * T * plane * (gsumsq ? 4 : 3));
-    return t5_bwd_fused<false>(gy, gsumsq ? y : nullptr, gsum, gsumsq, w, x, gx, gw, N, C, T, plane, st);
+    return t5_bwd_fused<0>(gy, gsumsq ? y : nullptr, gsum, gsumsq, w, x, gx, gw, N, C, T, plane, st);
 }
 
 extern "C" int cfn_dwconv_t5_bwd_fused_bf16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
@@ -642,5 +642,52 @@ extern "C" int cfn_dwconv_t5_bwd_fused_bf16(const unsigned short* gy, const unsi
     CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv_t5_bwd_fused_bf16: gsumsq needs y");
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_DWCONV_BWD, st, N * (double)C * T * plane * (gsumsq ? 12.0 : 10.0));
-    return t5_bwd_fused<true>(gy, gsumsq ? y : nullptr, gsum, gsumsq, w, x, gx, gw, N, C, T, plane, st);
+    return t5_bwd_fused<H16_BF16>(gy, gsumsq ? y : nullptr, gsum, gsumsq, w, x, gx, gw, N, C, T, plane, st);
 }
+
+// ---- fp16 activation path (BASELINE configs[4]): the same kernels with IEEE-half elements on the output side (h16.h) ------------
+extern "C" int cfn_dwconv_t5_fwd_f16(const float* x, const float* w, unsigned short* y, double* sum, double* sumsq, int N, int C,
+                                      int T, long plane, void* stream) {
+    CFN_REQUIRE(x && w && y, "cfn_dwconv_t5_fwd_f16: null tensor");
+    CFN_REQUIRE((sum == nullptr) == (sumsq == nullptr), "cfn_dwconv_t5_fwd_f16: sum/sumsq mismatch");
+    T5Args a = {};
+    a.src = x; a.w = w; a.dst = y; a.s1 = sum; a.s2 = sumsq; a.C = C; a.T = T; a.plane = plane;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DWCONV_FWD, st, 6.0 * N * C * T * plane);
+    return t5_launch<T5_FWD, H16_F16>(a, N, st);
+}
+
+extern "C" int cfn_dwconv_t5_bwd_data_f16(const unsigned short* gy, const unsigned short* y, const double* gsum,
+                                           const double* gsumsq, const float* w, float* gx, int N, int C, int T, long plane,
+                                           void* stream) {
+    CFN_REQUIRE(gy && w && gx, "cfn_dwconv_t5_bwd_data_f16: null tensor");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv_t5_bwd_data_f16: gsumsq needs y");
+    T5Args a = {};
+    a.src = gy; a.src2 = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.w = w; a.dst = gx; a.C = C; a.T = T; a.plane = plane;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DWCONV_BWD, st, N * (double)C * T * plane * (a.src2 ? 8.0 : 6.0));
+    return t5_launch<T5_DGRAD, H16_F16>(a, N, st);
+}
+
+extern "C" int cfn_dwconv_t5_bwd_weight_f16(const unsigned short* gy, const unsigned short* y, const double* gsum,
+                                             const double* gsumsq, const float* x, double* gw, int N, int C, int T, long plane,
+                                             void* stream) {
+    CFN_REQUIRE(gy && x && gw, "cfn_dwconv_t5_bwd_weight_f16: null tensor");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv_t5_bwd_weight_f16: gsumsq needs y");
+    T5Args a = {};
+    a.src = x; a.gy = gy; a.yout = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.s1 = gw; a.C = C; a.T = T; a.plane = plane;
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DWCONV_BWD, st, N * (double)C * T * plane * (a.yout ? 8.0 : 6.0));
+    return t5_launch<T5_WGRAD, H16_F16>(a, N, st);
+}
+
+extern "C" int cfn_dwconv_t5_bwd_fused_f16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                                            const float* w, const float* x, float* gx, double* gw, int N, int C, int T, long plane,
+                                            void* stream) {
+    CFN_REQUIRE(gy && w && x && gx && gw, "cfn_dwconv_t5_bwd_fused_f16: null tensor");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_dwconv_t5_bwd_fused_f16: gsumsq needs y");
+    hipStream_t st = (hipStream_t)stream;
+    CfnProfScope prof(CFN_K_DWCONV_BWD, st, N * (double)C * T * plane * (gsumsq ? 12.0 : 10.0));
+    return t5_bwd_fused<H16_F16>(gy, gsumsq ? y : nullptr, gsum, gsumsq, w, x, gx, gw, N, C, T, plane, st);
+}
+

@@ -17,8 +17,12 @@
 #include "pw_common.h"
 #include <stdint.h>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// element kind of the 2-byte tensors: bf16, or IEEE half when compiled through pwf16.hip (h16.h); "bf16" in the names below = "16-bit"
+#include "h16.h"
+typedef h16x8 bf16x8;
+#define PwbArgs H16N(PwbArgs)
+#define PwbWgArgs H16N(PwbWgArgs)
+#define subsample_hw_bf16_kernel H16N(subsample_hw_kernel)
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
@@ -48,12 +52,9 @@ struct PwbArgs {
     int Kp, mslabs, wgs, rowb;   // Kp: K padded to 32; wgs: workgroups per (n, slab); rowb: LDS bytes per weight row
 };
 
-__device__ __forceinline__ float pwb_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float pwb_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
-__device__ __forceinline__ unsigned pwb_pack(float lo, float hi) {
-    const bf16x2 b = __builtin_convertvector((f2v){lo, hi}, bf16x2);   // v_cvt_pk_bf16_f32 (round to nearest even)
-    return __builtin_bit_cast(unsigned, b);
-}
+__device__ __forceinline__ float pwb_lo(unsigned u) { return h16_lo(u); }
+__device__ __forceinline__ float pwb_hi(unsigned u) { return h16_hi(u); }
+__device__ __forceinline__ unsigned pwb_pack(float lo, float hi) { return h16_pk(lo, hi); }   // v_cvt_pk_{bf16,f16}_f32 (round to nearest even)
 
 // transpose-reduce over the 32 column lanes: a lane starts with 16 row values (its column); level 1 (pwb_fold16) exchanges
 // rows i / i+8 with lane ^ 16 as soon as both exist (8 live registers instead of 16), pwb_rowsum finishes: the lane ends up
@@ -223,8 +224,8 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_kernel(const PwbArgs a) {
             for (int mt = 0; mt < MT; ++mt) {
                 if (m0 + mt * 32 < M) {                                      // block-uniform: a ragged last slab skips its empty tiles
                     const bf16x8 A = *reinterpret_cast<const bf16x8*>(wrow + (size_t)mt * 32 * rowb + kb * 32);
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Be, acc[mt][0], 0, 0, 0);
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bo, acc[mt][1], 0, 0, 0);
+                    acc[mt][0] = H16_MFMA32(A, Be, acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = H16_MFMA32(A, Bo, acc[mt][1], 0, 0, 0);
                 }
             }
         };
@@ -320,12 +321,12 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_kernel(const PwbArgs a) {
 
 // rows per weight slab: 128 forward, 64 backward (two staged tensors and the act' epilogue need the registers)
 static int pwb_plan(PwbArgs& a, int& MT, unsigned& blocks, size_t& lds, int max_rows) {
-    if (a.Q % 2) return cfn_fail(CFN_ERR_UNSUPPORTED, "bf16 pointwise conv: T*H*W = %d must be even (position pairs share a dword)", a.Q);
+    if (a.Q % 2) return cfn_fail(CFN_ERR_UNSUPPORTED, H16_NAME " pointwise conv: T*H*W = %d must be even (position pairs share a dword)", a.Q);
     a.Kp = (a.K + 31) / 32 * 32;
     // every descriptor spans one sample's (rows x positions) block: the contraction side (K rows, padded k-blocks address up
     // to Kp), the output / epilogue side (M rows)
     if ((long)a.Kp * a.Q * 2 >= 0x3ffffff0L || (long)a.M * a.Q * 2 >= 0x3ffffff0L)
-        return cfn_fail(CFN_ERR_UNSUPPORTED, "bf16 pointwise conv: a sample's (channels x positions) block exceeds the 1 GiB buffer range");
+        return cfn_fail(CFN_ERR_UNSUPPORTED, H16_NAME " pointwise conv: a sample's (channels x positions) block exceeds the 1 GiB buffer range");
     a.mslabs = (a.M + max_rows - 1) / max_rows;
     const int per = (a.M + a.mslabs - 1) / a.mslabs;
     MT = (per + 31) / 32;
@@ -334,7 +335,7 @@ static int pwb_plan(PwbArgs& a, int& MT, unsigned& blocks, size_t& lds, int max_
     if (((a.rowb / 16) & 1) == 0) a.rowb += 16;                          // odd number of 16-byte slots per row
     const int BM = 32 * MT;
     lds = (size_t)BM * a.rowb + (size_t)a.Kp * 16 + (size_t)BM * 8 + (size_t)PWB_WAVES * BM * 2 * 4;
-    if (lds > 160 * 1024) return cfn_fail(CFN_ERR_UNSUPPORTED, "bf16 pointwise conv: K = %d does not fit the LDS weight slab", a.K);
+    if (lds > 160 * 1024) return cfn_fail(CFN_ERR_UNSUPPORTED, H16_NAME " pointwise conv: K = %d does not fit the LDS weight slab", a.K);
     const int ntiles = (a.Q + 63) / 64;
     const long groups = (long)a.N * a.mslabs;
     long wgs = (512 + groups - 1) / groups;                              // ~2 rounds of the chip
@@ -365,7 +366,7 @@ static int pwb_launch_mt(const PwbArgs& a, int MT, unsigned blocks, size_t lds, 
         }
     }
 #undef PWB_GO
-    return cfn_check_launch("pwconv bf16");
+    return cfn_check_launch("pwconv " H16_NAME);
 }
 
 template <int MODE, bool STATS, bool TWO = false>
@@ -377,12 +378,12 @@ static int pwb_launch(const PwbArgs& a, int MT, unsigned blocks, size_t lds, hip
     }
 }
 
-extern "C" int cfn_pwconv_fwd_bf16(const uint16_t* x, const double* A, const double* B, int act, const float* w, uint16_t* y,
+extern "C" int H16N(cfn_pwconv_fwd)(const uint16_t* x, const double* A, const double* B, int act, const float* w, uint16_t* y,
                                    double* sum, double* sumsq, int N, int Cin, int Cout, long Q, void* stream) {
-    CFN_REQUIRE(x && w && y, "cfn_pwconv_fwd_bf16: null tensor");
-    CFN_REQUIRE((A == nullptr) == (B == nullptr) && (sum == nullptr) == (sumsq == nullptr), "cfn_pwconv_fwd_bf16: A/B, sum/sumsq go together");
-    CFN_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && Q > 0 && Q < 0x7fffffffL, "cfn_pwconv_fwd_bf16: bad shape");
-    CFN_REQUIRE(act >= CFN_ACT_NONE && act <= CFN_ACT_SWISH, "cfn_pwconv_fwd_bf16: bad activation %d", act);
+    CFN_REQUIRE(x && w && y, "cfn_pwconv_fwd_" H16_NAME ": null tensor");
+    CFN_REQUIRE((A == nullptr) == (B == nullptr) && (sum == nullptr) == (sumsq == nullptr), "cfn_pwconv_fwd_" H16_NAME ": A/B, sum/sumsq go together");
+    CFN_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && Q > 0 && Q < 0x7fffffffL, "cfn_pwconv_fwd_" H16_NAME ": bad shape");
+    CFN_REQUIRE(act >= CFN_ACT_NONE && act <= CFN_ACT_SWISH, "cfn_pwconv_fwd_" H16_NAME ": bad activation %d", act);
     PwbArgs a = {};
     a.src = x; a.pa = A; a.pb = B; a.act = A ? act : CFN_ACT_NONE; a.w = w; a.dst = y; a.s1 = sum; a.s2 = sumsq;
     a.N = N; a.M = Cout; a.K = Cin; a.Q = (int)Q; a.Cin = Cin; a.Cout = Cout; a.H = a.W = 1;
@@ -394,22 +395,22 @@ extern "C" int cfn_pwconv_fwd_bf16(const uint16_t* x, const double* A, const dou
     return sum ? pwb_launch<PWB_FWD, true>(a, MT, blocks, lds, st) : pwb_launch<PWB_FWD, false>(a, MT, blocks, lds, st);
 }
 
-extern "C" int cfn_pwconv_bwd_data_bf16(const uint16_t* gy, const uint16_t* y, const double* gsum, const double* gsumsq,
+extern "C" int H16N(cfn_pwconv_bwd_data)(const uint16_t* gy, const uint16_t* y, const double* gsum, const double* gsumsq,
                                         const float* w, const uint16_t* x, const double* A, const double* B, int act,
                                         uint16_t* gx, double* gA, double* gB, int N, int Cin, int Cout, int T, int H, int W,
                                         const uint16_t* acc, int acc_stride, const double* gscale, void* stream) {
-    CFN_REQUIRE(gy && w && gx, "cfn_pwconv_bwd_data_bf16: null tensor");
-    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pwconv_bwd_data_bf16: A/B mismatch");
-    CFN_REQUIRE(A == nullptr || (x && gA && gB), "cfn_pwconv_bwd_data_bf16: prologue needs x, gA, gB");
-    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_pwconv_bwd_data_bf16: gsumsq needs y");
-    CFN_REQUIRE(acc == nullptr || acc_stride >= 1, "cfn_pwconv_bwd_data_bf16: bad acc_stride");
+    CFN_REQUIRE(gy && w && gx, "cfn_pwconv_bwd_data_" H16_NAME ": null tensor");
+    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pwconv_bwd_data_" H16_NAME ": A/B mismatch");
+    CFN_REQUIRE(A == nullptr || (x && gA && gB), "cfn_pwconv_bwd_data_" H16_NAME ": prologue needs x, gA, gB");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_pwconv_bwd_data_" H16_NAME ": gsumsq needs y");
+    CFN_REQUIRE(acc == nullptr || acc_stride >= 1, "cfn_pwconv_bwd_data_" H16_NAME ": bad acc_stride");
     PwbArgs a = {};
     a.src = gy; a.src2 = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.gsc = gscale; a.w = w; a.dst = gx;
     a.ex = A ? x : nullptr; a.ea = A; a.eb = B; a.act = A ? act : CFN_ACT_NONE; a.s1 = gA; a.s2 = gB;
     a.acc = acc; a.acc_s = acc ? acc_stride : 1; a.H = H; a.W = W;
     a.aHo = (H - 1) / a.acc_s + 1; a.aWo = (W - 1) / a.acc_s + 1;
     a.N = N; a.M = Cin; a.K = Cout; a.Q = T * H * W; a.Cin = Cin; a.Cout = Cout;
-    CFN_REQUIRE((long)T * H * W < 0x7fffffffL, "cfn_pwconv_bwd_data_bf16: too many positions");
+    CFN_REQUIRE((long)T * H * W < 0x7fffffffL, "cfn_pwconv_bwd_data_" H16_NAME ": too many positions");
     int MT; unsigned blocks; size_t lds;
     int rc = pwb_plan(a, MT, blocks, lds, 64);
     if (rc) return rc;
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_wgrad_kernel(const PwbWgAr
 #pragma unroll
         for (int i = 0; i < MTW; ++i)
 #pragma unroll
-            for (int jn = 0; jn < NTW; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aop[i], Bop[jn], acc[i][jn], 0, 0, 0);
+            for (int jn = 0; jn < NTW; ++jn) acc[i][jn] = H16_MFMA32(Aop[i], Bop[jn], acc[i][jn], 0, 0, 0);
     };
     issue(s0, ga[0], ya[0], xb[0]);
     for (int s = s0; s < s1; s += 2) {
@@ -554,14 +555,14 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_wgrad_kernel(const PwbWgAr
     }
 }
 
-extern "C" int cfn_pwconv_bwd_weight_bf16(const uint16_t* gy, const uint16_t* y, const double* gsum, const double* gsumsq,
+extern "C" int H16N(cfn_pwconv_bwd_weight)(const uint16_t* gy, const uint16_t* y, const double* gsum, const double* gsumsq,
                                           const uint16_t* x, const double* A, const double* B, int act, double* gw, int N,
                                           int Cin, int Cout, long Q, const double* gscale, void* stream) {
-    CFN_REQUIRE(gy && x && gw, "cfn_pwconv_bwd_weight_bf16: null tensor");
-    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pwconv_bwd_weight_bf16: A/B mismatch");
-    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_pwconv_bwd_weight_bf16: gsumsq needs y");
-    CFN_REQUIRE(Q > 0 && Q % 8 == 0, "cfn_pwconv_bwd_weight_bf16: T*H*W = %ld must be a multiple of 8 (16-byte operand loads)", Q);
-    CFN_REQUIRE((long)Cout * Q * 2 < 0x3ffffff0L && (long)Cin * Q * 2 < 0x3ffffff0L, "cfn_pwconv_bwd_weight_bf16: sample block exceeds the 1 GiB buffer range");
+    CFN_REQUIRE(gy && x && gw, "cfn_pwconv_bwd_weight_" H16_NAME ": null tensor");
+    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pwconv_bwd_weight_" H16_NAME ": A/B mismatch");
+    CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_pwconv_bwd_weight_" H16_NAME ": gsumsq needs y");
+    CFN_REQUIRE(Q > 0 && Q % 8 == 0, "cfn_pwconv_bwd_weight_" H16_NAME ": T*H*W = %ld must be a multiple of 8 (16-byte operand loads)", Q);
+    CFN_REQUIRE((long)Cout * Q * 2 < 0x3ffffff0L && (long)Cin * Q * 2 < 0x3ffffff0L, "cfn_pwconv_bwd_weight_" H16_NAME ": sample block exceeds the 1 GiB buffer range");
     PwbWgArgs a = {};
     a.gy = gy; a.y = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.gsc = gscale; a.x = x; a.pa = A; a.pb = B; a.gw = gw;
     a.N = N; a.M = Cout; a.K = Cin; a.Q = (int)Q; a.act = A ? act : CFN_ACT_NONE;
@@ -580,11 +581,13 @@ extern "C" int cfn_pwconv_bwd_weight_bf16(const uint16_t* gy, const uint16_t* y,
     const size_t lds = (size_t)PWB_WAVES * MTW * NTW * 1024 * 4;
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_WGRAD, st, 2.0 * N * ((double)Cout * Q * (a.y ? 2 : 1) + (double)Cin * Q));
-    {   // LDS-staged kernel (pwsplitw.hip): whole-line loads, operands formed once per element
+#ifndef CFN_F16
+    {   // LDS-staged kernel (pwsplitw.hip): whole-line loads, operands formed once per element (bf16 tensors; the fp16 build keeps the direct kernel)
         const int rc = pwss_wgrad_try_bf16(gy, gsumsq ? y : nullptr, gsum, gsumsq, gscale, x, A, B, A ? act : CFN_ACT_NONE, gw, N, Cout, Cin, (int)Q,
                                            st);
         if (rc >= 0) return rc;
     }
+#endif
     const dim3 grid((unsigned)(groups * strips));
 #define PWB_WG_GO(MV, NV, AV)                                                                                              \
     do {                                                                                                                   \
@@ -609,7 +612,7 @@ extern "C" int cfn_pwconv_bwd_weight_bf16(const uint16_t* gy, const uint16_t* y,
 #undef PWB_WG_ACT
 #undef PWB_WG_GO
 #undef PWB_WG_GO2
-    return cfn_check_launch("pwconv wgrad bf16");
+    return cfn_check_launch("pwconv wgrad " H16_NAME);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -635,12 +638,12 @@ __global__ __launch_bounds__(256) void subsample_hw_bf16_kernel(const uint16_t* 
     else out[e] = (uint16_t)lo;
 }
 
-extern "C" int cfn_subsample_hw_bf16(const uint16_t* x, uint16_t* out, long planes, int H, int W, int s, void* stream) {
-    CFN_REQUIRE(x && out && planes > 0 && H > 0 && W > 0 && s >= 1, "cfn_subsample_hw_bf16: bad arguments");
+extern "C" int H16N(cfn_subsample_hw)(const uint16_t* x, uint16_t* out, long planes, int H, int W, int s, void* stream) {
+    CFN_REQUIRE(x && out && planes > 0 && H > 0 && W > 0 && s >= 1, "cfn_subsample_hw_" H16_NAME ": bad arguments");
     const int Ho = (H - 1) / s + 1, Wo = (W - 1) / s + 1;
     const long total = planes * Ho * Wo;
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_ELEMWISE, st, 2.0 * planes * ((double)H * W / s + (double)Ho * Wo));
     hipLaunchKernelGGL(subsample_hw_bf16_kernel, dim3((unsigned)cfn_cdiv(cfn_cdiv(total, 2), 256)), dim3(256), 0, st, x, out, H, W, Ho, Wo, s, total);
-    return cfn_check_launch("subsample_hw_bf16");
+    return cfn_check_launch("subsample_hw " H16_NAME);
 }

@@ -5,15 +5,18 @@
 #include <stdint.h>
 
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// element kind of the 2-byte tensors: bf16, or IEEE half when compiled through streamf16.hip (h16.h)
+#include "h16.h"
+#define bn_add_relu_fwd_bf16_kernel H16N(bn_add_relu_fwd_h_kernel)
+#define bn_add_relu_bwd_g_bf16_kernel H16N(bn_add_relu_bwd_g_h_kernel)
+#define pool_hw_fwd_bf16_kernel H16N(pool_hw_fwd_h_kernel)
+#define pool_hw_bwd_bf16_kernel H16N(pool_hw_bwd_h_kernel)
 typedef float f2v __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float sb_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float sb_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
-__device__ __forceinline__ unsigned sb_pack(float lo, float hi) {
-    return __builtin_bit_cast(unsigned, __builtin_convertvector((f2v){lo, hi}, bf16x2));
-}
-__device__ __forceinline__ float sb_ld1(const uint16_t* p) { return __builtin_bit_cast(float, (unsigned)p[0] << 16); }
+__device__ __forceinline__ float sb_lo(unsigned u) { return h16_lo(u); }
+__device__ __forceinline__ float sb_hi(unsigned u) { return h16_hi(u); }
+__device__ __forceinline__ unsigned sb_pack(float lo, float hi) { return h16_pk(lo, hi); }
+__device__ __forceinline__ float sb_ld1(const uint16_t* p) { return h16_lo((unsigned)p[0]); }
 __device__ __forceinline__ void sb_st1(uint16_t* p, float v) { p[0] = (uint16_t)(sb_pack(v, 0.0f) & 0xffffu); }
 
 template <int NV>
@@ -128,43 +131,43 @@ static bool sb_vec_ok(long vol, const void* p0, const void* p1, const void* p2) 
     return vol % 8 == 0 && ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
 }
 
-extern "C" long cfn_bn_add_relu_mask_words_bf16(long NC, long vol) {
+extern "C" long H16N(cfn_bn_add_relu_mask_words)(long NC, long vol) {
     if (vol % 8 != 0) return 0;
     return NC * cfn_cdiv(vol, 256L * SB_ITEMS * 8) * 256;
 }
 
-extern "C" int cfn_bn_add_relu_fwd_bf16(const uint16_t* y, const double* A, const double* B, const uint16_t* res, const double* Ar,
+extern "C" int H16N(cfn_bn_add_relu_fwd)(const uint16_t* y, const double* A, const double* B, const uint16_t* res, const double* Ar,
                                         const double* Br, uint16_t* out, int* mask, long NC, long vol, void* stream) {
-    CFN_REQUIRE(y && A && B && res && out, "cfn_bn_add_relu_fwd_bf16: null tensor");
-    CFN_REQUIRE((Ar == nullptr) == (Br == nullptr), "cfn_bn_add_relu_fwd_bf16: Ar/Br mismatch");
+    CFN_REQUIRE(y && A && B && res && out, "cfn_bn_add_relu_fwd_" H16_NAME ": null tensor");
+    CFN_REQUIRE((Ar == nullptr) == (Br == nullptr), "cfn_bn_add_relu_fwd_" H16_NAME ": Ar/Br mismatch");
     unsigned gy_, gz_;
-    CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "cfn_bn_add_relu_fwd_bf16: N*C = %ld exceeds grid.y", NC);
+    CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "cfn_bn_add_relu_fwd_" H16_NAME ": N*C = %ld exceeds grid.y", NC);
     const bool vec = sb_vec_ok(vol, y, res, out);
-    CFN_REQUIRE(mask == nullptr || vec, "cfn_bn_add_relu_fwd_bf16: the bit mask needs the vector path (volume %% 8 == 0, 16-byte aligned)");
+    CFN_REQUIRE(mask == nullptr || vec, "cfn_bn_add_relu_fwd_" H16_NAME ": the bit mask needs the vector path (volume %% 8 == 0, 16-byte aligned)");
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_ELEMWISE, st, 6.0 * NC * vol);
     const dim3 grid((unsigned)cfn_cdiv(vol, 256L * SB_ITEMS * 8), gy_, gz_);
     if (vec) hipLaunchKernelGGL(bn_add_relu_fwd_bf16_kernel<true>, grid, dim3(256), 0, st, y, A, B, res, Ar, Br, out, (unsigned*)mask, vol);
     else hipLaunchKernelGGL(bn_add_relu_fwd_bf16_kernel<false>, grid, dim3(256), 0, st, y, A, B, res, Ar, Br, out, (unsigned*)nullptr, vol);
-    return cfn_check_launch("bn_add_relu_fwd_bf16");
+    return cfn_check_launch("bn_add_relu_fwd " H16_NAME);
 }
 
-extern "C" int cfn_bn_add_relu_bwd_g_bf16(const uint16_t* gout, const uint16_t* gout2, const uint16_t* out, const int* mask,
+extern "C" int H16N(cfn_bn_add_relu_bwd_g)(const uint16_t* gout, const uint16_t* gout2, const uint16_t* out, const int* mask,
                                           const uint16_t* y, const uint16_t* res, uint16_t* g, double* gA, double* gB, double* gAr,
                                           long NC, long vol, void* stream) {
-    CFN_REQUIRE(gout && y && g && gA && gB, "cfn_bn_add_relu_bwd_g_bf16: null tensor");
-    CFN_REQUIRE((out != nullptr) != (mask != nullptr), "cfn_bn_add_relu_bwd_g_bf16: give exactly one of out / mask");
-    CFN_REQUIRE(gAr == nullptr || res != nullptr, "cfn_bn_add_relu_bwd_g_bf16: gAr needs res");
+    CFN_REQUIRE(gout && y && g && gA && gB, "cfn_bn_add_relu_bwd_g_" H16_NAME ": null tensor");
+    CFN_REQUIRE((out != nullptr) != (mask != nullptr), "cfn_bn_add_relu_bwd_g_" H16_NAME ": give exactly one of out / mask");
+    CFN_REQUIRE(gAr == nullptr || res != nullptr, "cfn_bn_add_relu_bwd_g_" H16_NAME ": gAr needs res");
     unsigned gy_, gz_;
-    CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "cfn_bn_add_relu_bwd_g_bf16: N*C = %ld exceeds grid.y", NC);
+    CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "cfn_bn_add_relu_bwd_g_" H16_NAME ": N*C = %ld exceeds grid.y", NC);
     const bool vec = sb_vec_ok(vol, gout, y, g) && sb_vec_ok(vol, gout2, out, res);
-    CFN_REQUIRE(mask == nullptr || vec, "cfn_bn_add_relu_bwd_g_bf16: the bit mask needs the vector path");
+    CFN_REQUIRE(mask == nullptr || vec, "cfn_bn_add_relu_bwd_g_" H16_NAME ": the bit mask needs the vector path");
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_ELEMWISE, st, (6.0 + (gout2 ? 2.0 : 0.0) + (out ? 2.0 : 0.125) + (gAr ? 2.0 : 0.0)) * NC * vol);
     const dim3 grid((unsigned)cfn_cdiv(vol, 256L * SB_ITEMS * 8), gy_, gz_);
     if (vec) hipLaunchKernelGGL(bn_add_relu_bwd_g_bf16_kernel<true>, grid, dim3(256), 0, st, gout, gout2, out, (const unsigned*)mask, y, res, g, gA, gB, gAr, vol);
     else hipLaunchKernelGGL(bn_add_relu_bwd_g_bf16_kernel<false>, grid, dim3(256), 0, st, gout, gout2, out, (const unsigned*)nullptr, y, res, g, gA, gB, gAr, vol);
-    return cfn_check_launch("bn_add_relu_bwd_g_bf16");
+    return cfn_check_launch("bn_add_relu_bwd_g " H16_NAME);
 }
 
 // ---- adaptive spatial mean of act(A x + B), x bf16 -> pooled fp32 (the head / feature tower leave the bf16 domain here:
@@ -223,29 +226,29 @@ __global__ __launch_bounds__(256) void pool_hw_bwd_bf16_kernel(const float* __re
     }
 }
 
-extern "C" int cfn_pool_hw_fwd_bf16(const uint16_t* x, const double* A, const double* B, int act, float* out, long NC, int T, int H,
+extern "C" int H16N(cfn_pool_hw_fwd)(const uint16_t* x, const double* A, const double* B, int act, float* out, long NC, int T, int H,
                                     int W, int OH, int OW, void* stream) {
-    CFN_REQUIRE(x && out, "cfn_pool_hw_fwd_bf16: null tensor");
-    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pool_hw_fwd_bf16: A/B mismatch");
+    CFN_REQUIRE(x && out, "cfn_pool_hw_fwd_" H16_NAME ": null tensor");
+    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pool_hw_fwd_" H16_NAME ": A/B mismatch");
     unsigned gy_, gz_;
-    CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "cfn_pool_hw_fwd_bf16: N*C = %ld exceeds grid.y", NC);
+    CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "cfn_pool_hw_fwd_" H16_NAME ": N*C = %ld exceeds grid.y", NC);
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_ELEMWISE, st, 2.0 * NC * T * H * W);
     hipLaunchKernelGGL(pool_hw_fwd_bf16_kernel, dim3((unsigned)cfn_cdiv((long)T * OH * OW, 256), gy_, gz_), dim3(256), 0, st, x, A, B, act, out,
                        T, H, W, OH, OW);
-    return cfn_check_launch("pool_hw_fwd_bf16");
+    return cfn_check_launch("pool_hw_fwd " H16_NAME);
 }
 
-extern "C" int cfn_pool_hw_bwd_bf16(const float* gout, const uint16_t* x, const double* A, const double* B, int act, uint16_t* gx,
+extern "C" int H16N(cfn_pool_hw_bwd)(const float* gout, const uint16_t* x, const double* A, const double* B, int act, uint16_t* gx,
                                     double* gA, double* gB, long NC, int T, int H, int W, int OH, int OW, void* stream) {
-    CFN_REQUIRE(gout && x && gx, "cfn_pool_hw_bwd_bf16: null tensor");
-    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pool_hw_bwd_bf16: A/B mismatch");
-    CFN_REQUIRE(A == nullptr || (gA && gB), "cfn_pool_hw_bwd_bf16: prologue needs gA, gB");
+    CFN_REQUIRE(gout && x && gx, "cfn_pool_hw_bwd_" H16_NAME ": null tensor");
+    CFN_REQUIRE((A == nullptr) == (B == nullptr), "cfn_pool_hw_bwd_" H16_NAME ": A/B mismatch");
+    CFN_REQUIRE(A == nullptr || (gA && gB), "cfn_pool_hw_bwd_" H16_NAME ": prologue needs gA, gB");
     unsigned gy_, gz_;
-    CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "cfn_pool_hw_bwd_bf16: N*C = %ld exceeds grid.y", NC);
+    CFN_REQUIRE(cfn_split_nc(NC, gy_, gz_), "cfn_pool_hw_bwd_" H16_NAME ": N*C = %ld exceeds grid.y", NC);
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_ELEMWISE, st, 4.0 * NC * T * H * W);
     hipLaunchKernelGGL(pool_hw_bwd_bf16_kernel, dim3((unsigned)cfn_cdiv((long)T * H * W, 256), gy_, gz_), dim3(256), 0, st, gout, x, A, B, act, gx,
                        A ? gA : nullptr, A ? gB : nullptr, T, H, W, OH, OW);
-    return cfn_check_launch("pool_hw_bwd_bf16");
+    return cfn_check_launch("pool_hw_bwd " H16_NAME);
 }

@@ -120,8 +120,25 @@ def forward_backward(net, inputs, labels, masks, gamma_tau=5, mask_total=None):
     logits = net([inputs, masks_clip])
     cls_loss, loc_loss, probs = detection_loss(logits, labels, masks, True, mask_total=mask_total)
     loss = (cls_loss + loc_loss) / 2
-    loss.backward()
+    (loss * loss_scale(net)).backward()          # (scale 1 unless the activations are fp16; unscale_grads() before the optimizer)
     return cls_loss.detach(), loc_loss.detach(), probs.detach()
+
+
+# fp16 activation path (x3d_fine act_dtype='fp16', BASELINE configs[4]): activation gradients are stored as IEEE half (5 exponent bits), so the
+# backward pass runs on a scaled loss; weight gradients accumulate in fp64 / fp32 and are divided by the scale before the optimizer step.
+# Static scale (gradients of this loss at the logits are ~1 / (B x 157 x T)).
+LOSS_SCALE_FP16 = 4096.0
+
+
+def loss_scale(*nets):
+    return LOSS_SCALE_FP16 if any(getattr(n, 'act_dtype', None) == torch.float16 for n in nets) else 1.0
+
+
+def unscale_grads(params, scale):
+    if scale != 1.0:
+        grads = [p.grad for p in params if p.grad is not None]
+        if grads:
+            torch._foreach_mul_(grads, 1.0 / scale)
 
 
 def train_step(net, reducer, optimizer, inputs, labels, masks, gamma_tau=5, pre_step=None):
@@ -130,6 +147,7 @@ def train_step(net, reducer, optimizer, inputs, labels, masks, gamma_tau=5, pre_
     (train_fine.py:241-244)."""
     cls_loss, loc_loss, probs = forward_backward(net, inputs, labels, masks, gamma_tau)
     reducer.finish()
+    unscale_grads(net.parameters(), loss_scale(net))
     if pre_step is not None:
         pre_step()
     optimizer.step()

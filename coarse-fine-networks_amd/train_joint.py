@@ -23,7 +23,8 @@ import torch.optim as optim
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import x3d_fine                                   # noqa: E402
-import train_coarse_fineFEAT as tc                # noqa: E402
+import train_coarse_fineFEAT as tc
+import train_fine                # noqa: E402
 from cfn_hip import dist as cdist                 # noqa: E402
 from train_fine import lr_warmup                  # noqa: E402
 
@@ -53,9 +54,9 @@ class SyntheticJoint(object):
 
 def build_models(device, pretrained_fine=None, pretrained_coarse=None, dropout=0.5, fine_act_dtype=None):
     """(fine tower, coarse net).  The tower has no classifier of its own on this path (fc1 / fc2 get no gradient).
-    fine_act_dtype='bf16': the Fine stream -- 2/3 of the joint step's bytes and flops -- stores its activations in bf16 and
-    runs its pointwise convs on bf16 MFMA (BASELINE configs[4] "fp16 MFMA pointwise"; CDNA4 bf16 = fp16 rate); its pooled
-    feature maps are fp32, so the Coarse stream and the fusion are unchanged."""
+    fine_act_dtype='fp16' / 'bf16': the Fine stream -- 2/3 of the joint step's bytes and flops -- stores its activations as IEEE half / bf16 and
+    runs its pointwise convs on v_mfma_f32_32x32x16_{f16,bf16} (BASELINE configs[4] "fp16 MFMA pointwise"; both kinds run at the same MFMA rate
+    on CDNA4; fp16 adds a static loss scale, train_step); its pooled feature maps are fp32, so the Coarse stream and the fusion are unchanged."""
     fine = x3d_fine.generate_model(x3d_version='M', n_classes=NUM_CLASSES, n_input_channels=3, task='loc', dropout=dropout,
                                    base_bn_splits=1, global_tower=True, act_dtype=fine_act_dtype)
     if pretrained_fine:
@@ -95,8 +96,10 @@ def param_groups(fine, coarse, lr):
 def train_step(fine, coarse, reducer, optimizer, clip, labels, masks, pre_step=None):
     logits, _ = joint_forward(fine, coarse, clip)
     cls_loss, loc_loss, probs = tc.detection_loss(logits, labels, masks)
-    ((cls_loss + loc_loss) / 2).backward()
+    scale = train_fine.loss_scale(fine)            # fp16 fine tower (BASELINE configs[4]): static loss scale, see train_fine.LOSS_SCALE_FP16
+    (((cls_loss + loc_loss) / 2) * scale).backward()
     reducer.finish()
+    train_fine.unscale_grads([p for g in optimizer.param_groups for p in g['params']], scale)
     if pre_step is not None:
         pre_step()
     optimizer.step()

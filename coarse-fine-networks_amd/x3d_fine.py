@@ -291,7 +291,9 @@ class ResNet(nn.Module):
         # weights, fp32/fp64 statistics (BASELINE configs[1]).  The clip, the stem conv output and everything after the
         # spatial pooling of the head stay fp32.
         self.act_dtype = {None: torch.float32, 'f32': torch.float32, 'fp32': torch.float32, torch.float32: torch.float32,
-                          'bf16': torch.bfloat16, torch.bfloat16: torch.bfloat16}[act_dtype]
+                          'bf16': torch.bfloat16, torch.bfloat16: torch.bfloat16,
+                          # 'fp16': IEEE-half storage + v_mfma_f32_32x32x16_f16 (BASELINE configs[4]); activation gradients then need a loss scale
+                          'fp16': torch.float16, 'f16': torch.float16, torch.float16: torch.float16}[act_dtype]
         self.in_planes = block_inplanes[0][1]
 
         self.conv1_s = nn.Conv3d(n_input_channels, self.in_planes, kernel_size=(1, 3, 3), stride=(1, 2, 2),

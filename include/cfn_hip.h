@@ -319,6 +319,70 @@ int cfn_pool_hw_fwd_bf16(const unsigned short* x, const double* A, const double*
 int cfn_pool_hw_bwd_bf16(const float* gout, const unsigned short* x, const double* A, const double* B, int act,
                          unsigned short* gx, double* gA, double* gB, long NC, int T, int H, int W, int OH, int OW, void* stream);
 
+/* =====================================================================================================================
+ * fp16 activation path (BASELINE configs[4]: "fp16 MFMA pointwise"; the reference itself is fp32 only, x3d_fine.py:100-105).
+ * The entry points of the bf16 path above with IEEE-half tensors: `unsigned short*` = fp16 tensor (round to nearest even on
+ * store), pointwise contractions on v_mfma_f32_32x32x16_f16 with fp32 accumulation, everything else exactly as for bf16
+ * (csrc/h16.h: the same sources compiled for the other 2-byte element kind).  fp16 has 3 more mantissa bits than bf16 and 5 exponent
+ * bits: activation GRADIENTS need a loss scale (train_joint.py LOSS_SCALE; weight gradients accumulate in fp64 and are unscaled there).
+ * The weight gradient keeps the direct-operand kernel (the LDS-staged one of pwsplitw.hip serves fp32 and bf16 tensors).
+ * ===================================================================================================================== */
+/* conv1x1x1 x3d_fine.py:100-105 (stride 1; Q = T*H*W positions per (n, channel) row) */
+int cfn_pwconv_fwd_f16(const unsigned short* x, const double* A, const double* B, int act, const float* w, unsigned short* y,
+                        double* sum, double* sumsq, int N, int Cin, int Cout, long Q, void* stream);
+/* as cfn_pwconv_bwd_data_acc: acc = compact (N,Cin,T,ceil(H/s),ceil(W/s)) gradient of a strided second consumer, gscale (N,Cout) */
+int cfn_pwconv_bwd_data_f16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                             const float* w, const unsigned short* x, const double* A, const double* B, int act,
+                             unsigned short* gx, double* gA, double* gB, int N, int Cin, int Cout, int T, int H, int W,
+                             const unsigned short* acc, int acc_stride, const double* gscale, void* stream);
+int cfn_pwconv_bwd_weight_f16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                               const unsigned short* x, const double* A, const double* B, int act, double* gw, int N, int Cin,
+                               int Cout, long Q, const double* gscale, void* stream);
+/* x[..., ::s, ::s] of (planes = N*C*T, H, W): the gather in front of a strided shortcut conv (x3d_fine.py:284-287) */
+int cfn_subsample_hw_f16(const unsigned short* x, unsigned short* out, long planes, int H, int W, int s, void* stream);
+
+/* conv3x3x3 depthwise x3d_fine.py:89-97: cfn_dwconv3d_* with fp16 tensors (same kernels compiled for 2-byte elements) */
+int cfn_dwconv3d_fwd_f16(const unsigned short* x, const double* A, const double* B, int act, const float* w, unsigned short* y,
+                          double* sum, double* sumsq, int N, int C, int T, int Hi, int Wi, int stride, void* stream);
+int cfn_dwconv3d_bwd_data_f16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                               const float* w, const unsigned short* x, const double* A, const double* B, int act,
+                               unsigned short* gx, double* gA, double* gB, int N, int C, int T, int Hi, int Wi, int stride,
+                               void* stream);
+int cfn_dwconv3d_bwd_weight_f16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                                 const unsigned short* x, const double* A, const double* B, int act, double* gw, int N, int C,
+                                 int T, int Hi, int Wi, int stride, void* stream);
+int cfn_dwconv3d_bwd_fused_f16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                                const float* w, const unsigned short* x, const double* A, const double* B, int act,
+                                unsigned short* gx, double* gA, double* gB, double* gw, int N, int C, int T, int H, int W,
+                                void* stream);
+int cfn_dwconv3d_bwd_fused_s2_f16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                                   const float* w, const unsigned short* x, const double* A, const double* B, int act,
+                                   unsigned short* gx, double* gA, double* gB, double* gw, int N, int C, int T, int H, int W,
+                                   void* stream);
+
+/* conv1_t depthwise 5x1x1 x3d_fine.py:216-222: x / gx fp32, y / gy fp16 */
+int cfn_dwconv_t5_fwd_f16(const float* x, const float* w, unsigned short* y, double* sum, double* sumsq, int N, int C, int T,
+                           long plane, void* stream);
+int cfn_dwconv_t5_bwd_data_f16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                                const float* w, float* gx, int N, int C, int T, long plane, void* stream);
+int cfn_dwconv_t5_bwd_weight_f16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                                  const float* x, double* gw, int N, int C, int T, long plane, void* stream);
+int cfn_dwconv_t5_bwd_fused_f16(const unsigned short* gy, const unsigned short* y, const double* gsum, const double* gsumsq,
+                                 const float* w, const float* x, float* gx, double* gw, int N, int C, int T, long plane,
+                                 void* stream);
+
+/* block tail x3d_fine.py:167-173 (cfn_bn_add_relu_fwd / _bwd_g) and spatial pooling :255,:345-366 (fp16 in, fp32 pooled) */
+long cfn_bn_add_relu_mask_words_f16(long NC, long vol);
+int cfn_bn_add_relu_fwd_f16(const unsigned short* y, const double* A, const double* B, const unsigned short* res,
+                             const double* Ar, const double* Br, unsigned short* out, int* mask, long NC, long vol, void* stream);
+int cfn_bn_add_relu_bwd_g_f16(const unsigned short* gout, const unsigned short* gout2, const unsigned short* out, const int* mask,
+                               const unsigned short* y, const unsigned short* res, unsigned short* g, double* gA, double* gB,
+                               double* gAr, long NC, long vol, void* stream);
+int cfn_pool_hw_fwd_f16(const unsigned short* x, const double* A, const double* B, int act, float* out, long NC, int T, int H,
+                         int W, int OH, int OW, void* stream);
+int cfn_pool_hw_bwd_f16(const float* gout, const unsigned short* x, const double* A, const double* B, int act,
+                         unsigned short* gx, double* gA, double* gB, long NC, int T, int H, int W, int OH, int OW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
