@@ -36,17 +36,21 @@ struct CfnProfScope {
 // (the order in which workgroups arrive decides the rounding of the running sum -- exact unless an addend is below 2^-29 of it).  In
 // deterministic mode the (address, addend) pair is appended to a record buffer instead, and after the entry point's launches capi.hip sorts
 // the records by (address, addend bits) and adds every address's addends to it in that order: the result no longer depends on the order of
-// arrival, by construction.  The state lives in one __device__ variable per translation unit (no relocatable device code in this build);
+// arrival, by construction.  The state lives in one __constant__ variable per translation unit (no relocatable device code in this build);
 // each unit registers a setter with capi.hip.
 struct CfnDetState { unsigned long long* keys; unsigned long long* vals; unsigned long long* count; unsigned long long cap; };
-static __device__ CfnDetState cfn_det_dev;
+static __constant__ CfnDetState cfn_det_dev;      // constant address space: read with ONE scalar load (a __device__ global is fetched with a vector load, and the wait for it also drains the wave's stores: the stride-2 depthwise forward kernels lost 7 %)
 int cfn_det_register(void (*set)(const CfnDetState*));
 static void cfn_det_tu_set(const CfnDetState* st) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(cfn_det_dev), st, sizeof(*st)) != hipSuccess) (void)hipGetLastError();   // (a unit without accumulations has no symbol)
 }
 static const int cfn_det_tu_registered = cfn_det_register(&cfn_det_tu_set);
-__device__ __forceinline__ void cfn_add64(double* p, double v) {
-    unsigned long long* const keys = cfn_det_dev.keys;
+// (wave-per-item kernels fetch the mode word at their START with cfn_det_keys() and pass it on: the two dependent scalar loads then overlap
+// the item's tensor loads instead of sitting in every wave's tail -- 2 % on the 14x14 / 7x7 depthwise forward kernels)
+__device__ __forceinline__ unsigned long long* cfn_det_keys() { return cfn_det_dev.keys; }
+__device__ __forceinline__ void cfn_add64(double* p, double v, unsigned long long* keys);
+__device__ __forceinline__ void cfn_add64(double* p, double v) { cfn_add64(p, v, cfn_det_dev.keys); }
+__device__ __forceinline__ void cfn_add64(double* p, double v, unsigned long long* const keys) {
     if (__builtin_expect(keys != nullptr, 0)) {
         const unsigned long long i = atomicAdd(cfn_det_dev.count, 1ull);
         if (i < cfn_det_dev.cap) { keys[i] = (unsigned long long)(uintptr_t)p; cfn_det_dev.vals[i] = __builtin_bit_cast(unsigned long long, v); }

@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat_fwd_kernel(const DwFlatArgs 
 // zero row above and below the plane; its rows are 14 floats apart.
 template <int TO>
 __global__ __launch_bounds__(256, 4) void dw3d_flat14_fwd_kernel(const DwFlatArgs a) {
+    unsigned long long* const det_keys = cfn_det_keys();
     constexpr int W = 14, P = 196, U = 49, PIT = 14, IR = 16, NF = TO + 2, FR = IR * PIT, OOB = 0x7fff0000;
     __shared__ __attribute__((aligned(16))) float smem[4 * NF * FR];
     const int lane = threadIdx.x & 63, wv = cfn_uni((int)(threadIdx.x >> 6));
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat14_fwd_kernel(const DwFlatArg
     }
     if (a.s1) {
         st1 = cfn_wave_sum(st1); st2 = cfn_wave_sum(st2);
-        if (lane == 0) { cfn_add64(&a.s1[nc], (double)st1); cfn_add64(&a.s2[nc], (double)st2); }
+        if (lane == 0) { cfn_add64(&a.s1[nc], (double)st1, det_keys); cfn_add64(&a.s2[nc], (double)st2, det_keys); }
     }
 }
 
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat_s2_fwd_kernel(const DwFlatAr
 // was measured at 110 us with 8-frame items and 94 us with 16-frame items against 95 us of dw3d_small_fwd_kernel: not kept.)
 template <int TO>
 __global__ __launch_bounds__(256, 4) void dw3d_flat14to7_fwd_kernel(const DwFlatArgs a) {
+    unsigned long long* const det_keys = cfn_det_keys();
     constexpr int WI = 14, PI = 196, PO = 49, IR = 16, FR = IR * WI, NF = TO + 2, OOB = 0x7fff0000;
     __shared__ __attribute__((aligned(16))) float smem[4 * NF * FR];
     const int lane = threadIdx.x & 63, wv = cfn_uni((int)(threadIdx.x >> 6));
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat14to7_fwd_kernel(const DwFlat
     }
     if (a.s1) {
         st1 = cfn_wave_sum(st1); st2 = cfn_wave_sum(st2);
-        if (lane == 0) { cfn_add64(&a.s1[nc], (double)st1); cfn_add64(&a.s2[nc], (double)st2); }
+        if (lane == 0) { cfn_add64(&a.s1[nc], (double)st1, det_keys); cfn_add64(&a.s2[nc], (double)st2, det_keys); }
     }
 }
 

@@ -31,6 +31,7 @@ struct DwSmallArgs {
 
 template <int PH, int HS>
 __global__ __launch_bounds__(256, 4) void dw3d_small_fwd_kernel(const DwSmallArgs a) {
+    unsigned long long* const det_keys = cfn_det_keys();
     constexpr int RG = (PH + HS - 1) / HS;            // row groups per column
     constexpr int ROWS = RG * HS + 2;                 // image rows incl. halo (and the unused rows of a ragged last group)
     constexpr int PIT = PH == 14 ? 20 : 9;            // row pitch in floats
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256, 4) void dw3d_small_fwd_kernel(const DwSmallArg
     if (a.s1) {
         st1 = cfn_wave_sum(st1);
         st2 = cfn_wave_sum(st2);
-        if (lane == 0) { cfn_add64(&a.s1[nc], (double)st1); cfn_add64(&a.s2[nc], (double)st2); }
+        if (lane == 0) { cfn_add64(&a.s1[nc], (double)st1, det_keys); cfn_add64(&a.s2[nc], (double)st2, det_keys); }
     }
 }
 
