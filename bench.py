@@ -296,7 +296,8 @@ def main():
         # passes, gfx950 correction applied) is measured offline -- bench.py cannot run under the counter tool -- and
         # committed in profiles/; quoted only for the configuration it was measured on
         traffic = traffic_note = None
-        for name in ('r04_pmc_dwfwd.json', 'r03_pmc_dwfwd.json', 'r02_pmc_dwfwd.json', 'r01_pmc_dwfwd.json'):
+        import glob
+        for name in sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_dwfwd.json'))), reverse=True):     # the newest round's
             pmc = os.path.join(ROOT, 'profiles', name)
             if not coarse and args.dtype == 'f32' and os.path.exists(pmc):
                 doc = json.load(open(pmc))

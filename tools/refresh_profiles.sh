@@ -13,6 +13,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_coarse -- pytho
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_coarse_t256 -- python $R/bench.py --stream coarse --frames 256 --no-cpu-baseline > $O/bench_coarse_t256.json 2>> $O/bench.err
 python $R/bench.py --stream joint > $O/bench_joint.json 2>> $O/bench.err
 python $R/bench.py --stream joint --dtype bf16 > $O/bench_joint_bf16tower.json 2>> $O/bench.err
+python $R/bench.py --stream joint --dtype fp16 > $O/bench_joint_fp16tower.json 2>> $O/bench.err
+python $R/bench.py --dtype fp16 --no-cpu-baseline > $O/bench_fp16.json 2>> $O/bench.err
 # HBM traffic of the depthwise forward family: separate --pmc passes, kernel trace only
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/tools/dwfwd_only.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/tools/dwfwd_only.py > /dev/null 2>&1
