@@ -92,7 +92,9 @@ class GradReducer(object):
         self._flat = [None] * nb     # static flat buffer per bucket: [gradients ..., one flag per parameter]
         self._views = [None] * nb
         self._inflight = []
-        self._rerun = False          # a gradient arrived for a bucket that had already been sent (a second backward before finish())
+        self._rerun = False          # more than one backward pass since the last finish(): every bucket is sent again with the accumulated gradients
+        self._passes = 0             # backward passes completed since the last finish() (counted by an engine callback: the SAME number on every rank,
+        self._in_pass = False        # whatever gradients a rank's data produced -- ADVICE r4: the decision to re-send must not depend on hook arrival)
         self.filled = []
         self._stream = None
         self._hooks = []
@@ -154,18 +156,30 @@ class GradReducer(object):
     def _on_grad(self, p):
         if self.suspended:
             return
+        if not self._in_pass:        # first gradient of this backward pass: count the pass when the engine finishes it
+            self._in_pass = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_pass)
+        if self._passes > 0:
+            # gradient accumulation without no_sync(): a second (third ...) backward before finish().  The first pass's collectives are in flight with
+            # ITS gradients; p.grad holds the local sum of all passes (results are only written back in finish()), so nothing is launched from inside
+            # this pass (a bucket would travel with partial sums) and finish() sends every bucket again, in bucket order on every rank -- decided by
+            # the pass COUNT, which every rank shares, not by which hooks happened to fire here.
+            self._rerun = True
+            return
         bi = self._bucket_of[p]
         self._pending[bi] -= 1
-        if bi < self._next or self._pending[bi] < 0:
-            # gradient accumulation without no_sync(): this bucket's collective is already in flight with the FIRST backward's
-            # gradients.  p.grad holds the local sum of all passes (results are only written back in finish()), so finish()
-            # sends every bucket again, in bucket order on every rank, and the stale results are dropped.
+        if bi < self._next or self._pending[bi] < 0:     # (a parameter that accumulates twice inside one pass: treated like a second pass)
             self._rerun = True
             return
         # collectives are matched across ranks by issue order: buckets are launched strictly in bucket order, a complete
         # bucket behind an incomplete one waits (for that one, or for finish())
         while self._next < len(self.buckets) and self._pending[self._next] == 0:
             self._launch(self._next)
+
+    def _end_pass(self):
+        self._in_pass = False
+        if not self.suspended:
+            self._passes += 1
 
     def _launch(self, bi):
         b = self.buckets[bi]
@@ -203,6 +217,8 @@ class GradReducer(object):
             return
         while self._next < len(self.buckets):
             self._launch(self._next)
+        if self._passes > 1:
+            self._rerun = True
         if self._rerun:              # several backward passes since the last finish(): reduce the accumulated gradients
             for work, bi in self._inflight:
                 work.wait()
@@ -225,6 +241,7 @@ class GradReducer(object):
         self._inflight = []
         self._pending = [len(b) for b in self.buckets]
         self._next = 0
+        self._passes = 0
 
 
 def global_mask_count(masks, group=None, local=False):

@@ -209,7 +209,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 1 : 2) void sal_fwd_kernel(const Sal
     }
 }
 
-static int sal_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+// environment switches are read ONCE per process (getenv on every launch); INT_MIN = not set
+static int sal_env_raw(const char* name) { const char* e = getenv(name); return e ? atoi(e) : -2147483647 - 1; }
+#define SAL_ENV(name, dflt) ([&]() { static const int v_ = sal_env_raw(name); return v_ == -2147483647 - 1 ? (dflt) : v_; }())
 
 // -1 = shape not handled (the caller runs the implicit GEMM)
 int sal_fwd_try_launch(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum,
@@ -219,10 +221,10 @@ int sal_fwd_try_launch(const float* x, const double* A, const double* B, int act
     if (Cin != SAL_CIN || Cout > 32 || (Wi != 56 && Wi != 28) || (Hi & 1) || Hi < 2 || ((uintptr_t)x & 15)) return -1;
     if (A && act != CFN_ACT_RELU) return -1;
     if (!A && act != CFN_ACT_NONE) return -1;
-    if (sal_env("CFN_SAL_OFF", 0)) return -1;
+    if (SAL_ENV("CFN_SAL_OFF", 0)) return -1;
     if ((long)SAL_CW * T * Hi * Wi * 4 >= 0x7fff0000L) return -1;
     SalArgs a = {x, A, B, w, y, sum, sumsq, N, Cout, T, (T - 1) / 2 + 1, Hi, Hi / 2};
-    const int NT = sal_env("CFN_SAL_NT", 1);
+    const int NT = SAL_ENV("CFN_SAL_NT", 1);
     if (NT != 1 && NT != 4) return -1;
     const int WO = Wi / 2, TR = 32 / WO, RB = NT * TR, RIN = 2 * RB + 1, PITCH = Wi + 4;
     a.bands = cfn_cdiv(a.Ho, RB);
@@ -237,7 +239,7 @@ int sal_fwd_try_launch(const float* x, const double* A, const double* B, int act
         const double cost = rounds * (3.0 * to + 1.0);          // MFMA sets per block: 3 per output frame + the halo frame's one
         if (cost < bestc - 1e-9) { bestc = cost; best = to; }
     }
-    a.TO = sal_env("CFN_SAL_TO", best);
+    a.TO = SAL_ENV("CFN_SAL_TO", best);
     if (a.TO < 1) a.TO = 1;
     a.nchunks = cfn_cdiv(a.To, a.TO);
     const long blocks = (long)N * a.bands * a.nchunks;
@@ -478,7 +480,7 @@ int sal_dgrad_try_launch(const float* gy, const float* y, const double* gs, cons
     if (Cin != SAL_CIN || Cout != 24 || (Wi != 56 && Wi != 28) || (Hi & 1) || Hi < 2) return -1;
     if (A && act != CFN_ACT_RELU) return -1;
     if (!A && act != CFN_ACT_NONE) return -1;
-    if (sal_env("CFN_SAL_OFF", 0) || sal_env("CFN_SAL_DGRAD_OFF", 0)) return -1;
+    if (SAL_ENV("CFN_SAL_OFF", 0) || SAL_ENV("CFN_SAL_DGRAD_OFF", 0)) return -1;
     if ((long)24 * T * Hi * Wi * 4 >= 0x7fff0000L) return -1;
     SalBwdArgs a = {};
     a.gy = gy; a.y = gq ? y : nullptr; a.gs = gs; a.gq = gq; a.w = w; a.x = x; a.pa = A; a.pb = B; a.gx = gx; a.gA = gA; a.gB = gB;
@@ -496,7 +498,7 @@ int sal_dgrad_try_launch(const float* gy, const float* y, const double* gs, cons
         const double cost = rounds * (ch + 1.5);                // + the workgroup's start-up (weights, two frames) in steps
         if (cost < bestc - 1e-9) { bestc = cost; best = ch; }
     }
-    a.CH = sal_env("CFN_SAL_DG_CH", best);
+    a.CH = SAL_ENV("CFN_SAL_DG_CH", best);
     if (a.CH < 2) a.CH = 2;
     a.CH &= ~1;
     a.nchunks = cfn_cdiv(NU, a.CH);
@@ -705,7 +707,7 @@ int sal_wgrad_try_launch(const float* gy, const float* y, const double* gs, cons
     if (Cin != SAL_CIN || Cout != 24 || (Wi != 56 && Wi != 28) || (Hi & 1) || Hi < 2 || ((uintptr_t)x & 15)) return -1;
     if (A && act != CFN_ACT_RELU) return -1;
     if (!A && act != CFN_ACT_NONE) return -1;
-    if (sal_env("CFN_SAL_OFF", 0) || sal_env("CFN_SAL_WGRAD_OFF", 0)) return -1;
+    if (SAL_ENV("CFN_SAL_OFF", 0) || SAL_ENV("CFN_SAL_WGRAD_OFF", 0)) return -1;
     if ((long)24 * T * Hi * Wi * 4 >= 0x7fff0000L) return -1;
     SalBwdArgs a = {};
     a.gy = gy; a.y = gq ? y : nullptr; a.gs = gs; a.gq = gq; a.x = x; a.pa = A; a.pb = B; a.gw = gw;
@@ -722,7 +724,7 @@ int sal_wgrad_try_launch(const float* gy, const float* y, const double* gs, cons
         const double cost = per * (ch + 0.75);
         if (cost < bestc - 1e-9) { bestc = cost; best = ch; }
     }
-    a.CH = sal_env("CFN_SAL_WG_CH", best);
+    a.CH = SAL_ENV("CFN_SAL_WG_CH", best);
     if (a.CH < 2) a.CH = 2;
     a.CH &= ~1;
     a.nchunks = cfn_cdiv(a.To, a.CH);
