@@ -44,12 +44,13 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(frames_full, sample_frames=64, repeats=3, stream='fine'):
+def cpu_baseline(frames_full, sample_frames=None, repeats=3, stream='fine'):
     """CPU oracle (oracle/x3d_ref.py, stock torch CPU ops) fwd+bwd on a bounded sample of the same workload, SURVEY 8d protocol:
     one untimed warm-up, then the MEDIAN of `repeats` timed runs.
-    fine: one clip of 3 x sample_frames x 224 x 224 per run; cost is linear in T, so clips/s at T=frames_full =
-    (1 / t_median) * sample_frames / frames_full.  coarse: one clip with T'=128 fine features (the full unit)."""
+    fine: one clip of 3 x sample_frames x 224 x 224 per run (default sample_frames = frames_full: ~8 s per run at T = 256 on 16 threads, ~35 s in all; a
+    shorter sample is scaled by sample_frames / frames_full and the JSON says so).  coarse: one clip at the metric's T with T'=128 fine features (the full unit)."""
     from oracle import spec, x3d_ref
+    sample_frames = sample_frames or frames_full          # default: the metric's own clip length, nothing scaled
     # torch's CPU conv kernels stop scaling (and thrash) far below the hardware threads of the GPU box: 16 threads is near
     # the measured optimum.  `cores` = threads used; the box's logical CPU count and model are stated next to it
     threads = min(os.cpu_count() or 1, int(os.environ.get('CFN_CPU_THREADS', '16')))
@@ -69,7 +70,7 @@ def cpu_baseline(frames_full, sample_frames=64, repeats=3, stream='fine'):
     if stream == 'coarse':
         import train_coarse_fineFEAT as tc
         sd = leaves(spec.procedural_fill(spec.coarse_keys('M', 157, 1)))
-        cf = min(frames_full, 64)                         # bounded: a 64-frame clip per run, scaled linearly in T
+        cf = frames_full                                   # the full unit at the metric's T (a 64-frame sample scaled by T overestimates -- the fusion branch does not scale with T)
         x, labels, masks, feat, fm, meta, _, _ = next(iter(tc.SyntheticCoarse(1, 1, cf)))
         ts = []
         for r in range(repeats + 1):                      # run 0 = warm-up
@@ -97,8 +98,9 @@ def cpu_baseline(frames_full, sample_frames=64, repeats=3, stream='fine'):
         del y
     dt = median(ts[1:])
     return dict(host, value=round((1.0 / dt) * sample_frames / frames_full, 5), unit='clips/s',
-                sample='1 warm-up + median of %d runs of 1 clip 3x%dx224x224 fwd+bwd fp32 (%.1f s each), scaled by %d/%d to T=%d clips'
-                       % (repeats, sample_frames, dt, sample_frames, frames_full, frames_full))
+                sample='1 warm-up (quarter-length clip) + median of %d runs of 1 clip 3x%dx224x224 fwd+bwd fp32 (%.1f s each)%s'
+                       % (repeats, sample_frames, dt, '' if sample_frames == frames_full else
+                          ', scaled by %d/%d to T=%d clips (linear in T: every op of the fine stream is per frame)' % (sample_frames, frames_full, frames_full)))
 
 
 # kernel families whose HIP-event times make up the roofline leg (cfn_prof_*): the metric's kernel set is the depthwise-conv
@@ -185,7 +187,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay the step from captured hipGraphs (one graph on a single GPU; with --gpus > 1: forward+backward graph, eager all-reduce, optimizer graph)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-coarse-roofline', action='store_true', help='skip the coarse-stream roofline leg (figure B) of the default line')
-    ap.add_argument('--cpu-sample-frames', type=int, default=64)
+    ap.add_argument('--cpu-sample-frames', type=int, default=None, help='frames of the CPU baseline clip (default: the metric\'s T -- no scaling; a shorter sample is scaled linearly and says so)')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(_self_launch(args.gpus))
