@@ -21,9 +21,49 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import call, call_try, check, ACT_NONE  # noqa: F401
+import os
+
+from . import call, call_try, check, load, ACT_NONE  # noqa: F401
 
 _lib = 'cfn'
+
+# Native registration (csrc/torch/cfn_torch.cpp -> cfn_hip/libcfn_torch.so, built by __graft_entry__.build()): the hot path's operators --
+# cfn::dwconv3d, cfn::pwconv, cfn::time_sample and their backward operators -- are defined and implemented by TORCH_LIBRARY inside a shared
+# library.  When it is present the Python definitions of those six operators below are skipped; their fake implementations and
+# autograd formulas are attached to the native operators.  CFN_NATIVE_OPS=0: Python custom_op definitions for everything (the round-3/4 route).
+NATIVE_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libcfn_torch.so')
+NATIVE = False
+if os.environ.get('CFN_NATIVE_OPS', '1') != '0' and os.path.exists(NATIVE_LIB):
+    load()                                   # libcfn_hip.so first: the native library is linked against it
+    torch.ops.load_library(NATIVE_LIB)
+    NATIVE = True
+
+
+class _NativeOp(object):
+    """what torch.library.custom_op returns, for an operator that a TORCH_LIBRARY block already defined"""
+
+    def __init__(self, qualname):
+        self.qualname = qualname
+        ns, name = qualname.split('::')
+        self._op = getattr(getattr(torch.ops, ns), name)
+
+    def __call__(self, *a, **k):
+        return self._op(*a, **k)
+
+    def register_fake(self, fn):
+        torch.library.register_fake(self.qualname)(fn)
+        return fn
+
+    def register_autograd(self, backward, setup_context=None):
+        torch.library.register_autograd(self.qualname, backward, setup_context=setup_context)
+
+
+def _custom_or_native(qualname, **kw):
+    def deco(fn):
+        if NATIVE:
+            return _NativeOp(qualname)
+        return torch.library.custom_op(qualname, **kw)(fn)
+    return deco
 
 
 def _sfx(t):
@@ -41,7 +81,7 @@ def _c64(t):
 # ---------------------------------------------------------------------------------------------------------------------------
 # depthwise 3x3x3
 # ---------------------------------------------------------------------------------------------------------------------------
-@torch.library.custom_op(_lib + '::dwconv3d', mutates_args=(), device_types='cuda')
+@_custom_or_native(_lib + '::dwconv3d', mutates_args=(), device_types='cuda')
 def dwconv3d(x: torch.Tensor, w: torch.Tensor, A: Optional[torch.Tensor] = None, B: Optional[torch.Tensor] = None, act: int = 0,
              stride: int = 1) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     x = check(x).contiguous()
@@ -60,7 +100,7 @@ def _(x, w, A=None, B=None, act=0, stride=1):
     return (x.new_empty(N, C, T, Ho, Wo), x.new_empty(N, C, dtype=torch.float64), x.new_empty(N, C, dtype=torch.float64))
 
 
-@torch.library.custom_op(_lib + '::dwconv3d_backward', mutates_args=(), device_types='cuda')
+@_custom_or_native(_lib + '::dwconv3d_backward', mutates_args=(), device_types='cuda')
 def dwconv3d_backward(gy: torch.Tensor, gs: torch.Tensor, gq: torch.Tensor, x: torch.Tensor, w: torch.Tensor, y: torch.Tensor,
                       A: Optional[torch.Tensor] = None, B: Optional[torch.Tensor] = None, act: int = 0,
                       stride: int = 1) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -114,7 +154,7 @@ dwconv3d.register_autograd(_dw_backward, setup_context=_dw_setup)
 # ---------------------------------------------------------------------------------------------------------------------------
 # pointwise 1x1x1
 # ---------------------------------------------------------------------------------------------------------------------------
-@torch.library.custom_op(_lib + '::pwconv', mutates_args=(), device_types='cuda')
+@_custom_or_native(_lib + '::pwconv', mutates_args=(), device_types='cuda')
 def pwconv(x: torch.Tensor, w: torch.Tensor, A: Optional[torch.Tensor] = None, B: Optional[torch.Tensor] = None, act: int = 0,
            stride: int = 1) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     x = check(x).contiguous()
@@ -137,7 +177,7 @@ def _(x, w, A=None, B=None, act=0, stride=1):
             x.new_empty(N, w.shape[0], dtype=torch.float64))
 
 
-@torch.library.custom_op(_lib + '::pwconv_backward', mutates_args=(), device_types='cuda')
+@_custom_or_native(_lib + '::pwconv_backward', mutates_args=(), device_types='cuda')
 def pwconv_backward(gy: torch.Tensor, gs: torch.Tensor, gq: torch.Tensor, x: torch.Tensor, w: torch.Tensor, y: torch.Tensor,
                     A: Optional[torch.Tensor] = None, B: Optional[torch.Tensor] = None, act: int = 0,
                     stride: int = 1) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -180,7 +220,7 @@ pwconv.register_autograd(_pw_backward, setup_context=_dw_setup)
 # ---------------------------------------------------------------------------------------------------------------------------
 # Grid Pool / Grid Unpool resampler
 # ---------------------------------------------------------------------------------------------------------------------------
-@torch.library.custom_op(_lib + '::time_sample', mutates_args=(), device_types='cuda')
+@_custom_or_native(_lib + '::time_sample', mutates_args=(), device_types='cuda')
 def time_sample(x: torch.Tensor, cdf: torch.Tensor) -> torch.Tensor:
     x, cdf = check(x).contiguous(), check(cdf).contiguous()
     B, C, Tin = x.shape[:3]
@@ -195,7 +235,7 @@ def _(x, cdf):
     return x.new_empty((x.shape[0], x.shape[1], cdf.shape[1]) + tuple(x.shape[3:]))
 
 
-@torch.library.custom_op(_lib + '::time_sample_backward', mutates_args=(), device_types='cuda')
+@_custom_or_native(_lib + '::time_sample_backward', mutates_args=(), device_types='cuda')
 def time_sample_backward(g: torch.Tensor, x: torch.Tensor, cdf: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     B, C, Tin = x.shape[:3]
     K = cdf.shape[1]

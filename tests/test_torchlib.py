@@ -243,3 +243,58 @@ def test_bottleneck_on_torch_ops_compiles_without_graph_breaks(train, monkeypatc
     xe = x.clone().requires_grad_(True)
     m(xe).square().sum().backward()
     assert relerr(xg.grad, xe.grad) <= 1e-5
+
+
+# ---- native registration: TORCH_LIBRARY inside a shared library (csrc/torch/cfn_torch.cpp -> cfn_hip/libcfn_torch.so) -------------
+NATIVE_OPS = ('dwconv3d', 'dwconv3d_backward', 'pwconv', 'pwconv_backward', 'time_sample', 'time_sample_backward')
+
+
+def test_native_library_defines_the_hot_path_operators():
+    """the library exists, loads next to libcfn_hip.so, and the six operators carry a native kernel under the CUDA (= HIP) dispatch key whose
+    schema is the one the Python definitions declare; everything else of the operator set is still registered (from Python)"""
+    import os
+    from cfn_hip import torchlib
+    assert os.path.exists(torchlib.NATIVE_LIB), 'run python __graft_entry__.py (build_torch_library)'
+    if os.environ.get('CFN_NATIVE_OPS', '1') == '0':
+        pytest.skip('native operators switched off')
+    assert torchlib.NATIVE
+    for name in NATIVE_OPS:
+        assert torch._C._dispatch_has_kernel_for_dispatch_key('cfn::' + name, 'CUDA'), name
+        assert isinstance(getattr(torchlib, name), torchlib._NativeOp), name          # not a Python custom_op
+    assert str(torch.ops.cfn.pwconv_backward.default._schema) == (
+        'cfn::pwconv_backward(Tensor gy, Tensor gs, Tensor gq, Tensor x, Tensor w, Tensor y, Tensor? A=None, Tensor? B=None, SymInt act=0, '
+        'SymInt stride=1) -> (Tensor, Tensor, Tensor, Tensor)')
+    assert hasattr(torch.ops.cfn, 'bn_add_relu') and hasattr(torch.ops.cfn, 'fusion_gather')
+
+
+@pytest.mark.gpu
+def test_native_operators_equal_the_ctypes_route_bit_for_bit():
+    """the native operators and cfn_hip.ops (ctypes) call the same C-ABI entry points on the same stream: identical bits, forward and backward,
+    fp32 and bf16 / fp16 depthwise; errors of the C ABI surface as RuntimeError"""
+    from cfn_hip import ops, torchlib
+    if not torchlib.NATIVE:
+        pytest.skip('native operators switched off')
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        x = rnd(1, 2, 6, 5, 14, 14).to(DEV).to(dt).requires_grad_(True)
+        w = (0.3 * rnd(2, 6, 1, 3, 3, 3)).to(DEV).requires_grad_(True)
+        A, B = (1 + 0.2 * rnd(3, 2, 6)).to(DEV).requires_grad_(True), (0.1 * rnd(4, 2, 6)).to(DEV).requires_grad_(True)
+        outs = []
+        for route in (lambda: torch.ops.cfn.dwconv3d(x, w, A, B, 1, 1), lambda: ops.dwconv3d(x, w, A.double(), B.double(), 1, 1, True)):
+            y, s, q = route()
+            g = torch.autograd.grad((y.float().square().sum() + s.sum() + 0.1 * q.sum(),), (x, w, A, B))
+            outs.append([y, s, q] + list(g))
+        for a, b in zip(*outs):
+            assert torch.equal(a.float(), b.float()) or relerr(a.double(), b.double()) <= 1e-6      # (fp64 -> fp32 casts of the coefficient gradients differ in where they happen)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][3], outs[1][3])          # y and gx: same kernels, same bits
+    x = rnd(5, 2, 48, 3, 8, 8).to(DEV).requires_grad_(True)
+    w = (0.2 * rnd(6, 108, 48, 1, 1, 1)).to(DEV).requires_grad_(True)
+    y1, s1, q1 = torch.ops.cfn.pwconv(x, w, None, None, 0, 1)
+    y2, s2, q2 = ops.pwconv(x, w, None, None, 0, 1, True)
+    assert torch.equal(y1, y2) and torch.equal(s1, s2) and torch.equal(q1, q2)
+    g1 = torch.autograd.grad((y1.square().sum(),), (x, w))
+    g2 = torch.autograd.grad((y2.square().sum(),), (x, w))
+    assert torch.equal(g1[0], g2[0]) and relerr(g1[1], g2[1]) <= 1e-6
+    with pytest.raises(RuntimeError):
+        torch.ops.cfn.pwconv(x.double(), w, None, None, 0, 1)
+    with pytest.raises(RuntimeError):
+        torch.ops.cfn.time_sample(x.cpu(), torch.rand(2, 5))
