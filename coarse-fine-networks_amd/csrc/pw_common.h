@@ -53,6 +53,8 @@ int pwd_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st);
 int pws_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st);
 // pwregk.hip: split-bf16 forward with register-resident weights, two k slices per row tile (128 < K <= 224, M <= 128); tried first
 int pwk_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st);
+// pwstream.hip: pws_kernel with the weights pre-split into a workspace and STREAMED through LDS (K >= 400: layer 4); tried after pwk_try_launch
+int pwt_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st);
 int pws_terms_now();     // 0 = fp32 MFMA kernels, 3 / 6 = bf16 MFMAs per k-block (cfn_pw_split_terms / CFN_PW_SPLIT)
 int pws_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const double* gsc, const float* x,
                          const double* pa, const double* pb, int act, double* gw, int N, int M, int K, int Q, hipStream_t st);

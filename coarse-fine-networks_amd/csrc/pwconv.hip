@@ -605,6 +605,7 @@ extern "C" int cfn_pwconv_fwd(const float* x, const double* A, const double* B, 
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_FWD, st, 4.0 * N * ((double)Cin * a.Q + (double)Cout * a.Q) + 4.0 * Cin * Cout);
     { const int rc = pwk_try_launch(a, PW_FWD, sum != nullptr, st); if (rc >= 0) return rc; }
+    { const int rc = pwt_try_launch(a, PW_FWD, sum != nullptr, st); if (rc >= 0) return rc; }
     { const int rc = pws_try_launch(a, PW_FWD, sum != nullptr, st); if (rc >= 0) return rc; }
     { const int rc = pwd_try_launch(a, PW_FWD, sum != nullptr, st); if (rc >= 0) return rc; }
     int MT; unsigned blocks; size_t lds;
@@ -634,6 +635,7 @@ extern "C" int cfn_pwconv_bwd_data_acc(const float* gy, const float* y, const do
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_BWD, st, 4.0 * N * ((double)Cout * a.Q * (a.src2 ? 2 : 1) + (double)Cin * a.Q * (A ? 2 : 1)));
     { const int rc = pwk_try_launch(a, PW_DGRAD, A != nullptr, st); if (rc >= 0) return rc; }
+    { const int rc = pwt_try_launch(a, PW_DGRAD, A != nullptr, st); if (rc >= 0) return rc; }
     { const int rc = pws_try_launch(a, PW_DGRAD, A != nullptr, st); if (rc >= 0) return rc; }
     { const int rc = pwd_try_launch(a, PW_DGRAD, A != nullptr, st); if (rc >= 0) return rc; }
     int MT; unsigned blocks; size_t lds;
