@@ -589,6 +589,22 @@ static void pw_geom(PwArgs& a, int T, int Hi, int Wi, int stride) {
     a.Q = T * a.Ho * a.Wo;
 }
 
+// gx (N*M, T, Hi, Wi) += acc (N*M, T, Ho, Wo) on the lattice h % s == w % s == 0: the compact gradient of the strided shortcut conv of a stage's
+// first block, for the data gradients WITHOUT act' epilogue whose contraction runs on a split-bf16 kernel (those decline `acc`: the
+// lattice loads cost their many-row variants 90+ registers).  Without an epilogue "W^T g' + acc" is the same fp32 sum whether the second
+// term is added before the store or after it.  One thread = one compact element, rows of the lattice in order.
+__global__ __launch_bounds__(256) void pw_lattice_add_kernel(float* __restrict__ gx, const float* __restrict__ acc, long total, int Ho, int Wo,
+                                                             int Hi, int Wi, int s) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int wo = (int)(e % Wo);
+    const long r = e / Wo;
+    const int ho = (int)(r % Ho);
+    const long plane = r / Ho;                                              // (n, m, t)
+    float* p = gx + (plane * Hi + (long)ho * s) * Wi + (long)wo * s;
+    *p += acc[e];
+}
+
 extern "C" int cfn_pwconv_fwd(const float* x, const double* A, const double* B, int act, const float* w, float* y,
                               double* sum, double* sumsq, int N, int Cin, int Cout, int T, int Hi, int Wi, int stride,
                               void* stream) {
@@ -634,6 +650,22 @@ extern "C" int cfn_pwconv_bwd_data_acc(const float* gy, const float* y, const do
     if (acc) { a.acc = acc; a.acc_s = acc_stride; a.acc_Ho = (Hi - 1) / acc_stride + 1; a.acc_Wo = (Wi - 1) / acc_stride + 1; }
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_PWCONV_BWD, st, 4.0 * N * ((double)Cout * a.Q * (a.src2 ? 2 : 1) + (double)Cin * a.Q * (A ? 2 : 1)));
+    if (acc && !A) {
+        // no act' epilogue: contraction on a split-bf16 kernel (those decline the compact shortcut gradient), lattice add behind it
+        // (stage-first conv1 of layers 3 / 4, 8 clips x 256 frames: 0.77 ms on pw_deep_kernel with the in-kernel lattice loads)
+        static const int lat = getenv("CFN_PW_LATTICE") ? atoi(getenv("CFN_PW_LATTICE")) : 1;
+        PwArgs a2 = a;
+        a2.acc = nullptr;
+        int rc = lat ? pwk_try_launch(a2, PW_DGRAD, false, st) : -1;
+        if (rc < 0 && lat) rc = pwt_try_launch(a2, PW_DGRAD, false, st);
+        if (rc > 0) return rc;
+        if (rc == 0) {
+            const long total = (long)N * Cin * T * a.acc_Ho * a.acc_Wo;
+            hipLaunchKernelGGL(pw_lattice_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gx, acc, total, a.acc_Ho, a.acc_Wo, Hi, Wi,
+                               acc_stride);
+            return cfn_check_launch("pwconv_bwd_data(lattice add)");
+        }
+    }
     { const int rc = pwk_try_launch(a, PW_DGRAD, A != nullptr, st); if (rc >= 0) return rc; }
     { const int rc = pwt_try_launch(a, PW_DGRAD, A != nullptr, st); if (rc >= 0) return rc; }
     { const int rc = pws_try_launch(a, PW_DGRAD, A != nullptr, st); if (rc >= 0) return rc; }

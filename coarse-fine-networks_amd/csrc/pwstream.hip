@@ -17,13 +17,15 @@
 #define PWT_ROWB (PWT_KCH * 32 + 16)
 
 // out[slab][chunk][term][BM][PWT_ROWB bytes]: term s of W[m0 + m][48 c + kk] (FWD: w is (M, K)) or W[48 c + kk][m0 + m] (DGRAD: w is (K, M)),
-// zero beyond M / K.  grid (chunks, slabs); the 16 pad bytes of a row are never read
+// zero beyond M / K.  grid (chunks, slabs, PWT_PRE_Z pieces of a chunk: one pair per thread and trip -- 9 workgroups of 18 dependent load -> store
+// trips each took 14-17 us per launch); the 16 pad bytes of a row are never read
+#define PWT_PRE_Z 8
 template <int MODE>
 __global__ __launch_bounds__(256) void pws_presplit_kernel(const float* __restrict__ w, int pitch, int M, int K, int BM, unsigned char* __restrict__ out) {
     const int c = blockIdx.x, slab = blockIdx.y, nchunks = gridDim.x, m0 = slab * BM;
     unsigned char* blob = out + ((size_t)slab * nchunks + c) * 3 * BM * PWT_ROWB;
     const int total = BM * (PWT_KCH * 8);                                  // pairs of one chunk
-    for (int e = threadIdx.x; e < total; e += 256) {
+    for (int e = blockIdx.z * 256 + threadIdx.x; e < total; e += 256 * PWT_PRE_Z) {
         int m, kk;
         if (MODE == PW_FWD) { m = e / (PWT_KCH * 8); kk = (e - m * (PWT_KCH * 8)) * 2; }      // consecutive threads along k (w rows)
         else { kk = (e / BM) * 2; m = e - (e / BM) * BM; }                                     // consecutive threads along m (w rows)
@@ -125,8 +127,8 @@ int pwt_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
     if (lds > 160 * 1024) return -1;
     unsigned char* ws = pwt_workspace((size_t)slabs * nchunks * 3 * BM * PWT_ROWB, st);
     if (!ws) return -1;
-    if (mode == PW_FWD) hipLaunchKernelGGL(pws_presplit_kernel<PW_FWD>, dim3(nchunks, slabs), dim3(256), 0, st, a.w, a.Cin, a.M, a.K, BM, ws);
-    else hipLaunchKernelGGL(pws_presplit_kernel<PW_DGRAD>, dim3(nchunks, slabs), dim3(256), 0, st, a.w, a.Cin, a.M, a.K, BM, ws);
+    if (mode == PW_FWD) hipLaunchKernelGGL(pws_presplit_kernel<PW_FWD>, dim3(nchunks, slabs, PWT_PRE_Z), dim3(256), 0, st, a.w, a.Cin, a.M, a.K, BM, ws);
+    else hipLaunchKernelGGL(pws_presplit_kernel<PW_DGRAD>, dim3(nchunks, slabs, PWT_PRE_Z), dim3(256), 0, st, a.w, a.Cin, a.M, a.K, BM, ws);
     { const int rc = cfn_check_launch("pwconv(split bf16, streamed weights) pre-split"); if (rc) return rc; }
     b.w = reinterpret_cast<const float*>(ws);
     b.mtiles = slabs;

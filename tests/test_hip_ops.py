@@ -231,6 +231,38 @@ def test_pwconv_few_channel_data_gradient(N, Cin, Cout, T, H, W, two):
     assert relerr(outs[0].double(), ref) <= 2e-6
 
 
+@pytest.mark.parametrize('N,Cin,Cout,T,H,W,s', [(2, 96, 432, 3, 14, 14, 2),     # layer-4 block 0 conv1: streamed-weight split-bf16 kernel + lattice add
+                                                (1, 48, 216, 2, 28, 28, 2),     # layer-3 block 0 conv1: pwk_kernel + lattice add
+                                                (1, 96, 432, 2, 7, 9, 2),       # odd plane width: 4 x 5 lattice
+                                                (2, 48, 216, 1, 6, 6, 3),       # stride 3
+                                                (1, 54, 108, 2, 8, 8, 2)])      # layer-2 shape: stays on the in-kernel lattice loads
+@pytest.mark.parametrize('two', [True, False])
+def test_pwconv_data_gradient_with_compact_shortcut_gradient(N, Cin, Cout, T, H, W, s, two):
+    """cfn_pwconv_bwd_data_acc WITHOUT act' epilogue and WITH the compact gradient of a strided shortcut conv (first block of a stage):
+    gx = W^T (gsc gy + gs + 2 gq y) + acc on the lattice h % s == w % s == 0, against fp64, bit-repeatable.  The deep shapes run the
+    contraction on a split-bf16 kernel and add the lattice behind it (csrc/pwconv.hip pw_lattice_add_kernel)."""
+    import cfn_hip
+    f64 = lambda seed, *shape, scale=1.0: (rnd(seed, *shape) * scale).double().to(DEV)
+    gy, y = rnd(1, N, Cout, T, H, W).to(DEV), rnd(2, N, Cout, T, H, W).to(DEV)
+    w = ((2.0 / Cout) ** 0.5 * rnd(4, Cout, Cin)).to(DEV)
+    gs, gq, gsc = f64(5, N, Cout, scale=0.05), (f64(6, N, Cout, scale=0.01) if two else None), 1.0 + f64(7, N, Cout, scale=0.3)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    acc = rnd(8, N, Cin, T, Ho, Wo).to(DEV)
+    outs = []
+    for _ in range(3):
+        gx = torch.full((N, Cin, T, H, W), float('nan'), device=DEV)
+        cfn_hip.call('cfn_pwconv_bwd_data_acc', gy, y if two else None, gs, gq, w, None, None, None, 0, gx, None, None, N, Cin, Cout, T, H, W, 1,
+                     acc, s, gsc)
+        outs.append(gx)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    gp = gy.double() * gsc.view(N, Cout, 1, 1, 1) + gs.view(N, Cout, 1, 1, 1)
+    if two:
+        gp = gp + 2.0 * gq.view(N, Cout, 1, 1, 1) * y.double()
+    ref = torch.einsum('nkthw,km->nmthw', gp, w.double())
+    ref[:, :, :, ::s, ::s] += acc.double()
+    assert relerr(outs[0].double(), ref) <= 2e-6
+
+
 @pytest.mark.parametrize('act', [None, 0, 1, 2])
 @pytest.mark.parametrize('cfg', [(2, 24, 54, 3, 8, 8, 0), (2, 54, 24, 2, 12, 12, 0), (1, 24, 24, 5, 6, 6, 2), (2, 64, 32, 1, 10, 10, 0),
                                  (1, 20, 12, 3, 6, 6, 2), (2, 24, 54, 4, 8, 8, 2), (1, 3, 7, 2, 4, 6, 0)])
