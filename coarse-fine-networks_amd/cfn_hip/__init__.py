@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
-LIB_PATH = os.path.join(_HERE, 'libcfn_hip.so')
+LIB_PATH = os.environ.get('CFN_HIP_LIB') or os.path.join(_HERE, 'libcfn_hip.so')     # CFN_HIP_LIB: a variant build for a same-box A/B (tools/variant_lib.sh)
 HEADER = os.path.join(_ROOT, 'include', 'cfn_hip.h')
 
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
