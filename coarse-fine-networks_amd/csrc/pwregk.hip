@@ -181,19 +181,27 @@ __global__ __launch_bounds__(64 * PWK_WAVES) void pwk_kernel(const PwArgs a) {
     float ssum = 0.0f, qsum = 0.0f;
 
     // staging: wave w loads k-blocks w and w + 8 (position j, channels kb*16 + kg*8 + i), two tiles ahead
+    // The row part of a load address is SCALAR and RUNNING (one s_add + one s_min per load): written as `row * Q * 4` per (k-block, i) the
+    // compiler hoists all 16 products and their 16 lane predicates out of the tile loop -- 22-39 SGPRs spilled, 23 v_readlane per tile.
+    // A row at or beyond K must not enter the scalar offset (the range check  voffset >= num_records - soffset  wraps), so the scalar row
+    // is clamped to K - 1: the kg = 0 lanes of a padding row read the finite activations of row K - 1, which meet the zero-padded weight
+    // columns k >= K; rows K .. K + 7 reached through the lane offset (8 kg) fail the range check by themselves and read as 0.
+    const int so_cap = (K - 1) * Q * 4;
     auto issue = [&](int tile, float (&ld)[NST][8], float (&ld2)[TWO ? NST : 1][8]) {
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
             const int kb = wave + PWK_WAVES * u;
-            const bool live = kb < NKB && tile < ntiles;
-            const int vo = (live && tile * 32 + j < Q) ? lane_ld : PWK_OOB;
-            const int base = live ? tile * 32 * 4 : 0;
+            const bool live = (int)(kb < NKB) & (int)(tile < ntiles);       // wave uniform
+            const int vo = ((int)live & (int)(tile * 32 + j < Q)) ? lane_ld : PWK_OOB;
+            const int base = cfn_uni(live ? tile * 32 * 4 : 0);
+            const int cap = cfn_uni(live ? so_cap + base : 0), q4 = cfn_uni(live ? Q * 4 : 0);
+            int so = cfn_uni(live ? kb * 16 * Q * 4 + base : 0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = kb * 16 + i;                                  // + 8 kg through the lane offset
-                const int so = cfn_uni((live && r < K) ? r * Q * 4 + base : base);
-                ld[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (live && r + 8 * kg < K) ? vo : PWK_OOB, so, 0));
-                if (TWO) ld2[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, (live && r + 8 * kg < K) ? vo : PWK_OOB, so, 0));
+            for (int i = 0; i < 8; ++i) {                                   // channel 16 kb + i (+ 8 kg through the lane offset)
+                const int sc = min(so, cap);
+                ld[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, sc, 0));
+                if (TWO) ld2[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, vo, sc, 0));
+                so += q4;
             }
         }
     };
