@@ -257,7 +257,17 @@ struct WssArgs {      // gy, y, x: fp32 (ES = 4) or bf16 (ES = 2) tensors
 
 // ES = 2: bf16 tensors (the bf16 activation path, section 4b of DESIGN.md): the same staging with 8-byte loads of 4 positions and
 // ONE bf16 term per operand (NS = 1: the operands are bf16 already; G' and the prologue are formed in fp32 and rounded once)
-template <int SM, int TPW, int ACT, bool HASY, int NS, int ES>
+// BR x BC > 0 (round 5): a wave owns a BLOCK of BR x BC tiles instead of every 8th tile of the row-major order.  Dealt round robin, a wave's
+// tiles share no operand: each of its 18 MFMAs per k-block (3 tiles x 6 terms) has its own pair of 16-byte LDS reads, 288 KB of LDS reads per
+// half-stage and workgroup = 2,304 cycles of the LDS pipe next to 2,304 cycles of matrix pipe per SIMD -- and the multiply phase of a half-stage
+// cannot hide behind anything (the barriers of section 4.1 keep every wave in the same phase).  A 1 x 3 (3 x 1) block reads its row (column)
+// operand once per k-block and streams the other side: 12 reads per 18 MFMAs.
+// PIPE (with blocks): the conversion of half-stage h + 1 runs in the SAME barrier interval as the MFMAs of half-stage h, cut into 12 SM pieces (a
+// pair of elements through one stage of the split) that are pinned behind the MFMAs one by one -- a wave's MFMA chain is dependency paced (32+ cycles
+// per instruction), and in the phase structure above that time hides nothing: convert -> barrier -> multiply costs the SUM of a VALU-bound and a
+// matrix-bound phase (7,750 cycles per half-stage at layer 3 with 2,304 cycles of matrix pipe per SIMD in it).  One barrier per half-stage; the
+// prologue coefficients sit in registers for the whole strip (no LDS read feeds the conversion: DESIGN 4.1).
+template <int SM, int TPW, int ACT, bool HASY, int NS, int ES, int BR = 0, int BC = 0, bool PIPE = false>
 __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const WssArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = cfn_uni(tid >> 6), lane = tid & 63, kg = lane >> 5, r = lane & 31;
@@ -315,14 +325,25 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
     const int pbeg = strip * a.per, pend = min(pbeg + a.per, Q);
     const int nh = pend > pbeg ? (pend - pbeg + PWSS_P - 1) / PWSS_P : 0;
 
-    // this wave's tiles: tiles wave, wave + 8, ... of the group's mtn x ktn (row major)
-    int aoff[TPW], boff[TPW];
+    // this wave's tiles: tiles wave, wave + 8, ... of the group's mtn x ktn (row major), or (BLK) the block (wave / WC, wave % WC) of BR x BC tiles
+    constexpr bool BLK = BR > 0;
+    static_assert(!BLK || BR * BC == TPW, "block = the wave's tile slots");
+    int aoff[TPW], boff[TPW], tix[TPW];                           // tix: row-major tile index in the group (the workspace / gW slot)
     bool live[TPW];
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
-        const int t = wave + (PWSS_THREADS / 64) * tt;            // tiles dealt round robin (groups of < 8 tiles still leave waves without one: `uneven` below)
-        live[tt] = t < mtn * ktn;                                 // wave uniform
-        const int ti = live[tt] ? t / ktn : 0, tj = live[tt] ? t - ti * ktn : 0;
+        int ti, tj;
+        if constexpr (BLK) {
+            const int WC = (ktn + BC - 1) / BC;
+            ti = (wave / WC) * BR + tt / BC; tj = (wave % WC) * BC + tt % BC;
+            live[tt] = ti < mtn && tj < ktn;                          // wave uniform (a wave beyond the last block row owns nothing)
+        } else {
+            const int t = wave + (PWSS_THREADS / 64) * tt;            // tiles dealt round robin (groups of < 8 tiles still leave waves without one: `uneven` below)
+            live[tt] = t < mtn * ktn;                                 // wave uniform
+            ti = live[tt] ? t / ktn : 0; tj = live[tt] ? t - ti * ktn : 0;
+        }
+        if (!live[tt]) { ti = 0; tj = 0; }
+        tix[tt] = ti * ktn + tj;
         aoff[tt] = (ti * 32 + r) * PWSS_PITCH + kg * 16;
         boff[tt] = NS * gimg + (tj * 32 + r) * PWSS_PITCH + kg * 16;
     }
@@ -422,6 +443,42 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
         }
     };
     auto mfma = [&](const unsigned char* buf) {
+        if constexpr (BLK) {
+            // the operand of the block's short side is read once per k-block and kept, the long side streams past it
+            constexpr bool HOLD_A = BR <= BC;
+            constexpr int NH = HOLD_A ? BR : BC, NSTR = HOLD_A ? BC : BR;
+#pragma unroll
+            for (int kb = 0; kb < PWSS_P / 16; ++kb) {
+                bf16x8 H[NH][NS];
+#pragma unroll
+                for (int i = 0; i < NH; ++i)
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp)
+                        H[i][sp] = HOLD_A ? *reinterpret_cast<const bf16x8*>(buf + sp * gimg + aoff[i * BC] + kb * 32)
+                                          : *reinterpret_cast<const bf16x8*>(buf + sp * ximg + boff[i] + kb * 32);
+#pragma unroll
+                for (int j = 0; j < NSTR; ++j) {
+                    bf16x8 S[NS];
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp)
+                        S[sp] = HOLD_A ? *reinterpret_cast<const bf16x8*>(buf + sp * ximg + boff[j] + kb * 32)
+                                       : *reinterpret_cast<const bf16x8*>(buf + sp * gimg + aoff[j * BC] + kb * 32);
+#pragma unroll
+                    for (int i = 0; i < NH; ++i) {
+                        const int tt = HOLD_A ? i * BC + j : j * BC + i;
+                        if (live[tt]) {
+#define PWSS_MMB(SA, SB) acc[tt] = HOLD_A ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(H[i][SA], S[SB], acc[tt], 0, 0, 0) \
+                                          : __builtin_amdgcn_mfma_f32_32x32x16_bf16(S[SA], H[i][SB], acc[tt], 0, 0, 0)
+                            if constexpr (NS == 3) { PWSS_MMB(2, 0); PWSS_MMB(0, 2); PWSS_MMB(1, 1); }
+                            if constexpr (NS >= 2) { PWSS_MMB(1, 0); PWSS_MMB(0, 1); }
+                            PWSS_MMB(0, 0);
+#undef PWSS_MMB
+                        }
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
             if (live[tt]) {
@@ -444,11 +501,123 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
     };
 
     unsigned char* buf1 = buf0 + bufb;
+    if constexpr (PIPE) {
+        static_assert(!PIPE || (BLK && NS == 3), "the pipelined loop is built on the block dealing and the 6-term product");
+        float4 kG4[SM];
+        float2 kX4[SM];
+#pragma unroll
+        for (int i = 0; i < SM; ++i) {
+            const int row = (tid + PWSS_THREADS * i) >> 3;
+            kG4[i] = row < GR ? cG[row] : float4{0.f, 0.f, 1.f, 0.f};
+            kX4[i] = row < XR ? cX[row] : float2{1.f, 0.f};
+        }
+        constexpr bool HOLD_A = BR <= BC;
+        constexpr int NH = HOLD_A ? BR : BC, NSTR = HOLD_A ? BC : BR;
+        constexpr int NSUB = 12 * SM, NMF = 6 * TPW * (PWSS_P / 16);           // conversion pieces, MFMAs per half-stage
+        // multiply half-stage `bufM` and convert half-stage hc (register set g / yy / xx) into bufC
+        auto pipe_step = [&](const unsigned char* bufM, int hc, unsigned char* bufC, const f4v (&g)[SM], const f4v (&yy)[SM], const f4v (&xx)[SM]) __attribute__((always_inline)) {
+            const int pe = pbeg + hc * PWSS_P + c4 * 4;
+            const bool ragged = (Q & 3) != 0;                           // uniform
+            const float vm0 = (hc < nh && pe < pend) ? 1.0f : 0.0f;
+            float vm[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vm[e] = (hc < nh && pe + e < pend) ? 1.0f : 0.0f;
+            float v[4];
+            unsigned p0[NS], p1[NS];
+            // piece sidx: unit u = sidx / 6 (slot u >> 1, g' operand or x operand), pair q, stage st of the split; the unit's LDS writes behind its last piece
+            auto sub = [&](int sidx) __attribute__((always_inline)) {
+                const int u = sidx / 6, w = sidx % 6, q = w & 1, st = w >> 1, i = u >> 1;
+                const bool isX = (u & 1) != 0;
+                if (st == 0 && q == 0) {
+                    if (!isX) {
+                        const float4 c = kG4[i];
+                        const float c0 = c.x * vm0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = fmaf(g[i][e], c.z, c0);
+                            if (HASY) v[e] = fmaf(yy[i][e], c.y, v[e]);
+                        }
+                    } else {
+                        const float2 c = kX4[i];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = cfn_act<ACT>(fmaf(xx[i][e], c.x, c.y));
+                    }
+                    if (ragged) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = vm[e] != 0.0f ? v[e] : 0.0f;
+                    }
+                }
+                unsigned (&pp)[NS] = q == 0 ? p0 : p1;
+                if (st > 0) { v[2 * q] -= pwsw_lo(pp[st - 1]); v[2 * q + 1] -= pwsw_hi(pp[st - 1]); }
+                pp[st] = pwsw_pack(v[2 * q], v[2 * q + 1]);
+                if (w == 5) {
+                    const int off = isX ? ldsX[i] : ldsG[i];
+                    if (off >= 0) {
+#pragma unroll
+                        for (int sp = 0; sp < NS; ++sp)
+                            *reinterpret_cast<uint2*>(bufC + (isX ? NS * gimg + sp * ximg : sp * gimg) + off) = uint2{p0[sp], p1[sp]};
+                    }
+                }
+            };
+            auto subs_of = [&](int m) __attribute__((always_inline)) {     // the pieces pinned behind MFMA m of the half-stage
+#pragma unroll
+                for (int sidx = NSUB * m / NMF; sidx < NSUB * (m + 1) / NMF; ++sidx) sub(sidx);
+            };
+#pragma unroll
+            for (int kb = 0; kb < PWSS_P / 16; ++kb) {
+                bf16x8 H[NH][NS];
+#pragma unroll
+                for (int i = 0; i < NH; ++i)
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp)
+                        H[i][sp] = HOLD_A ? *reinterpret_cast<const bf16x8*>(bufM + sp * gimg + aoff[i * BC] + kb * 32)
+                                          : *reinterpret_cast<const bf16x8*>(bufM + sp * ximg + boff[i] + kb * 32);
+#pragma unroll
+                for (int j = 0; j < NSTR; ++j) {
+                    bf16x8 S[NS];
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp)
+                        S[sp] = HOLD_A ? *reinterpret_cast<const bf16x8*>(bufM + sp * ximg + boff[j] + kb * 32)
+                                       : *reinterpret_cast<const bf16x8*>(bufM + sp * gimg + aoff[j * BC] + kb * 32);
+#pragma unroll
+                    for (int i = 0; i < NH; ++i) {
+                        const int tt = HOLD_A ? i * BC + j : j * BC + i;
+                        const int m0f = ((kb * NSTR + j) * NH + i) * 6;    // first MFMA of this tile in the half-stage
+                        constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};
+                        if (live[tt]) {
+#pragma unroll
+                            for (int tm = 0; tm < 6; ++tm) {
+                                acc[tt] = HOLD_A ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(H[i][SA[tm]], S[SB[tm]], acc[tt], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_32x32x16_bf16(S[SA[tm]], H[i][SB[tm]], acc[tt], 0, 0, 0);
+                                subs_of(m0f + tm);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int tm = 0; tm < 6; ++tm) subs_of(m0f + tm);
+                        }
+                    }
+                }
+            }
+        };
+        issue(0, rG[0], rY[0], rX[0]);
+        issue(1, rG[1], rY[1], rX[1]);
+        convert(0, buf0, rG[0], rY[0], rX[0]);
+        issue(2, rG[0], rY[0], rX[0]);
+        for (int h = 0; h < nh; h += 2) {
+            __syncthreads();                                        // half-stage h is complete in buf0; buf1's readers have finished
+            pipe_step(buf0, h + 1, buf1, rG[1], rY[1], rX[1]);      // h + 1 == nh: zeros (masked loads, masked constant term)
+            issue(h + 3, rG[1], rY[1], rX[1]);
+            __syncthreads();
+            pipe_step(buf1, h + 2, buf0, rG[0], rY[0], rX[0]);
+            issue(h + 4, rG[0], rY[0], rX[0]);
+        }
+    } else {
     // uneven: the tile count of the group is not a multiple of the wave count, i.e. in the last tile slot some waves multiply and some do not.  The
     // round-3 failure needed waves that convert while others multiply (with an extra barrier behind every multiply phase: 0 of 1,200 passes, same
     // binary otherwise); such groups (layer 2's 48 x 108 = 8 tiles is even; 48 x 96 = 6 tiles, the coarse stream's fusion convs) pay two more
     // barriers per pair of half-stages and keep every wave in the same phase.
-    const bool uneven = (mtn * ktn) % (PWSS_THREADS / 64) != 0;   // workgroup uniform
+    const bool uneven = BLK || (mtn * ktn) % (PWSS_THREADS / 64) != 0;   // workgroup uniform (blocks: a ragged grid leaves waves with fewer tiles)
     issue(0, rG[0], rY[0], rX[0]);
     issue(1, rG[1], rY[1], rX[1]);
     for (int h = 0; h < nh; h += 2) {
@@ -463,6 +632,7 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
         mfma(buf1);
         if (uneven) __syncthreads();
     }
+    }
 
     if (a.ws) {     // partial tiles of this workgroup: [group][n * nstrips + strip][tile][element e][lane]
         const int S = a.N * a.nstrips, TPG = a.mtg * a.ktg;
@@ -470,7 +640,7 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
             if (live[tt]) {
-                const int t = wave + (PWSS_THREADS / 64) * tt;
+                const int t = tix[tt];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) wb[(size_t)t * 1024 + e * 64] = acc[tt][e];
             }
@@ -481,7 +651,7 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
         if (live[tt]) {
-            const int t = wave + (PWSS_THREADS / 64) * tt, ti = t / ktn, tj = t - ti * ktn;
+            const int t = tix[tt], ti = t / ktn, tj = t - ti * ktn;
             const int k = k0 + tj * 32 + r;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -563,11 +733,11 @@ static size_t pwss_lds(int mtg, int ktg, int NS) {
     return (size_t)2 * NS * 32 * (mtg + ktg) * PWSS_PITCH + (size_t)32 * mtg * 16 + (size_t)32 * ktg * 8;
 }
 
-template <int SM, int TPW, int NS, int ES = 4>
+template <int SM, int TPW, int NS, int ES = 4, int BR = 0, int BC = 0, bool PIPE = false>
 static int pwss_launch(const WssArgs& a, unsigned blocks, size_t lds, hipStream_t st) {
 #define PWSS_GO(AV, HY)                                                                                                    \
     do {                                                                                                                   \
-        auto k = pws_wgrad_staged_kernel<SM, TPW, AV, HY, NS, ES>;                                                             \
+        auto k = pws_wgrad_staged_kernel<SM, TPW, AV, HY, NS, ES, BR, BC, PIPE>;                                                           \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(k, dim3(blocks), dim3(PWSS_THREADS), lds, st, a);                                               \
     } while (0)
@@ -633,7 +803,15 @@ static int pwss_launch_any(const WssArgs& a, unsigned blocks, size_t lds, int ti
     // a just-returned LDS coefficient as zero in lanes 48-63; the coefficients are registers now and uneven groups keep every wave in one phase)
     if (a.mtg <= 4 && a.ktg <= 4 && tiles <= 8) return NS == 2 ? pwss_launch<2, 1, 2>(a, blocks, lds, st) : pwss_launch<2, 1, 3>(a, blocks, lds, st);
     if (a.mtg <= 4 && a.ktg <= 4) return NS == 2 ? pwss_launch<2, 2, 2>(a, blocks, lds, st) : pwss_launch<2, 2, 3>(a, blocks, lds, st);
-    if (tiles <= 24) return NS == 2 ? pwss_launch<4, 3, 2>(a, blocks, lds, st) : pwss_launch<4, 3, 3>(a, blocks, lds, st);
+    if (tiles <= 24) {
+        // blocks of 1 x 3 / 3 x 1 tiles per wave where the group's grid fits the 8 waves (layer 3: 7 x 3 / 3 x 7 tiles, layer 4: 4 x 6 / 3 x 7)
+        static const int blk = getenv("CFN_PWSS_BLOCKS") ? atoi(getenv("CFN_PWSS_BLOCKS")) : 1;
+        if (blk && NS == 3) {
+            if (a.mtg * cfn_cdiv(a.ktg, 3) <= 8) return blk == 1 ? pwss_launch<4, 3, 3, 4, 1, 3, true>(a, blocks, lds, st) : pwss_launch<4, 3, 3, 4, 1, 3>(a, blocks, lds, st);
+            if (cfn_cdiv(a.mtg, 3) * a.ktg <= 8) return blk == 1 ? pwss_launch<4, 3, 3, 4, 3, 1, true>(a, blocks, lds, st) : pwss_launch<4, 3, 3, 4, 3, 1>(a, blocks, lds, st);
+        }
+        return NS == 2 ? pwss_launch<4, 3, 2>(a, blocks, lds, st) : pwss_launch<4, 3, 3>(a, blocks, lds, st);
+    }
     return NS == 2 ? pwss_launch<4, 6, 2>(a, blocks, lds, st) : pwss_launch<4, 6, 3>(a, blocks, lds, st);
 }
 
