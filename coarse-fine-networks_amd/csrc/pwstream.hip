@@ -110,10 +110,12 @@ int pwt_try_launch(PwArgs& a, int mode, bool stats, hipStream_t st) {
     // than 256 rows also from K = 160 (layer-4 conv3: contraction over 192, 432 rows in three slabs: 0.273 -> 0.223 ms; pwk_kernel takes the
     // shapes of up to 256 rows first)
     const bool deep = a.K >= mink, epi = mode == PW_DGRAD && stats && a.K >= mink_epi && a.M > 256;
-    if (!(deep || epi) || a.M <= 32 || (a.Q & 3)) return -1;
+    // whole 16-byte groups per row (Q % 4 == 0) are only needed by the forward's transposed epilogue (16-byte stores); the data gradient moves 4-byte
+    // elements both ways -- the coarse stream's layer 4 (65 x 7 x 7 = 3,185 positions per row) runs its data gradients here
+    if (!(deep || epi) || a.M <= 32 || (mode == PW_FWD && (a.Q & 3))) return -1;
     if (a.act != CFN_ACT_NONE && a.act != CFN_ACT_RELU && a.act != CFN_ACT_SWISH) return -1;
     if ((long)a.K * a.Q * 4 >= 0x3ffffff0L || (long)a.M * a.Q * 4 >= 0x3ffffff0L) return -1;
-    if (((uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)(a.src2 ? a.src2 : a.src) | (uintptr_t)(a.ex ? a.ex : a.src)) & 15) return -1;
+    if (((uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)(a.src2 ? a.src2 : a.src) | (uintptr_t)(a.ex ? a.ex : a.src)) & (mode == PW_FWD ? 15 : 3)) return -1;
     PwArgs b = a;
     b.Kpad = (a.K + 47) / 48 * 48;
     if (mode == PW_DGRAD && !stats) b.act = CFN_ACT_NONE;

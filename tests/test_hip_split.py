@@ -282,6 +282,40 @@ def test_pwt_data_gradient_vs_fp64(split, N, K, M, T, H, W, two):
     assert relerr(gx.double(), gxr) <= 1e-6
 
 
+@pytest.mark.parametrize('N,K,M,T,H,W', [(2, 432, 192, 65, 7, 7), (1, 432, 96, 5, 7, 9), (1, 192, 432, 65, 7, 7)])
+@pytest.mark.parametrize('two', [True, False])
+def test_pwt_data_gradient_odd_volume(split, N, K, M, T, H, W, two):
+    """the coarse stream's layer 4: 65 x 7 x 7 = 3,185 positions per row (rows on 4-byte boundaries only) -- the data gradients (4-byte accesses both
+    ways) run on the streamed-weight kernel, the last case with the act' epilogue (contraction over 192, 432 rows); against fp64, bit-repeatable"""
+    split(6)
+    epi = K < 400
+    x = rnd(1, N, M, T, H, W).to(DEV).requires_grad_(True)
+    w = rnd(2, K, M, 1, 1, 1, scale=(2.0 / M) ** 0.5).to(DEV)
+    A = (1 + 0.2 * rnd(3, N, M)).to(DEV) if epi else None
+    B = (0.3 * rnd(4, N, M)).to(DEV) if epi else None
+    y, s, q = ops().pwconv(x, w, A, B, 2 if epi else 0, 1, True)
+    gy, gs, gq = rnd(5, *y.shape).to(DEV), (0.01 * rnd(6, *s.shape)).to(DEV).to(s.dtype), (0.001 * rnd(7, *q.shape)).to(DEV).to(q.dtype)
+    outs, gos = ((y, s, q), (gy, gs, gq)) if two else ((y, s), (gy, gs))
+    gx, = torch.autograd.grad(outs, (x,), gos, retain_graph=True)
+    for _ in range(3):
+        gx2, = torch.autograd.grad(outs, (x,), gos, retain_graph=True)
+        assert torch.equal(gx, gx2)
+    wd = w.double().view(K, M)
+    xd = x.detach().double()
+    if epi:
+        z = xd * A.double().view(N, M, 1, 1, 1) + B.double().view(N, M, 1, 1, 1)
+        sg = torch.sigmoid(z)
+        a_, da = z * sg, sg * (1 + z * (1 - sg))
+    else:
+        a_, da = xd, None
+    yd = torch.einsum('nmthw,km->nkthw', a_, wd)
+    gp = gy.double() + gs.double().view(N, K, 1, 1, 1) + (2.0 * yd * gq.double().view(N, K, 1, 1, 1) if two else 0.0)
+    gxr = torch.einsum('nkthw,km->nmthw', gp, wd)
+    if epi:
+        gxr = gxr * da * A.double().view(N, M, 1, 1, 1)
+    assert relerr(gx.double(), gxr) <= 2e-6
+
+
 def test_pwt_stress_bit_repeatable(split):
     """200 launches of the layer-4 forward and data gradient between other kernels: every result bit-identical (LDS chunk buffers are overwritten behind ONE barrier per chunk while
     other waves still multiply the previous chunk -- exactly the kind of schedule a missing wait shows up in)"""
