@@ -677,7 +677,10 @@ class _BnAddRelu(Function):
             mask = out if ctx.has_mask else None
             call('cfn_bn_add_relu_bwd_g' + _sfx(y), gout.contiguous(), gout2, None if ctx.has_mask else out, mask, y,
                  res if Ar is not None else None, g, gA, gB, gAr, N * C, vol)
-            link.y_scale, link.res_scale, link.done = A, Ar, True
+            # DETACHED: A / Ar come back from saved_tensors with their grad_fn, and that graph contains the conv whose ctx holds this link -- a
+            # reference cycle through C++ autograd nodes that Python's collector cannot break (it leaked the ctx objects, the link and the (N, C)
+            # factors of every block: ~190 KB per step at 8 clips)
+            link.y_scale, link.res_scale, link.done = A.detach(), (None if Ar is None else Ar.detach()), True
             # one tensor, two consumers: a second tensor object over the same storage keeps autograd from accumulating
             # into it in place
             g2 = torch.empty(0, dtype=g.dtype, device=g.device).set_(g.untyped_storage(), g.storage_offset(), g.shape, g.stride())

@@ -452,3 +452,71 @@ def test_x3d_xl_matches_oracle():
     yt = m([spec.rand_input(43, (2, 3, 4, 160, 160)).to(DEV), None])
     yto = x3d_ref.x3d_fine_forward(spec.procedural_fill(spec.fine_keys('XL', 157, 1)), spec.rand_input(43, (2, 3, 4, 160, 160)), 'XL', training=True)
     assert maxdiff(yt, yto) <= 1e-3
+
+
+@pytest.mark.gpu
+def test_training_steps_do_not_leak_device_memory():
+    """120 train steps of x3d_fine: torch.cuda.memory_allocated() after step 20 and after step 120 must agree to a few KB.  (Round 5 found 190 KB per
+    step: the tail's backward left BN factors WITH their grad_fn in the TailLink object that the conv3 ctx holds -- a cycle through C++ autograd
+    nodes, invisible to gc.collect().)"""
+    import gc
+    import x3d_fine
+    from oracle import spec
+    dev = torch.device('cuda:0')
+    net = x3d_fine.generate_model('M', n_classes=157, task='loc', base_bn_splits=1, dropout=0.5)
+    spec.fill_module_(net)
+    net.to(dev).train(True)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+    x = torch.randn(2, 3, 8, 96, 96, device=dev)
+    lab = (torch.rand(2, 157, 8, device=dev) < 0.05).float()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(net([x, None]), lab)
+        loss.backward()
+        opt.step()
+
+    def settled():
+        torch.cuda.synchronize()
+        gc.collect()
+        return torch.cuda.memory_allocated()
+    for _ in range(20):
+        step()
+    m0 = settled()
+    for _ in range(100):
+        step()
+    m1 = settled()
+    assert m1 - m0 < 64 * 1024, 'device memory grew by %d bytes over 100 steps' % (m1 - m0)
+
+
+@pytest.mark.gpu
+def test_coarse_training_steps_do_not_leak_device_memory():
+    """the same for the coarse stream's own train step (Grid Pool, fusion modules, gradient reducer)"""
+    import gc
+    import torch.optim as optim
+    import train_coarse_fineFEAT as tc
+    from cfn_hip import dist as cdist
+    dev = torch.device('cuda:0')
+    net = tc.build_model(dev, pretrained=None)
+    optimizer = optim.SGD(tc.param_groups(net, 0.02), lr=0.02, momentum=0.9, weight_decay=1e-5)
+    x, labels, masks, feat, fm, meta, _, _ = next(iter(tc.SyntheticCoarse(2, 1, 16, seed=4321)))
+    x = x[:, 0].contiguous().to(dev)
+    labels, masks, fm, meta = labels.to(dev), masks.to(dev), fm.to(dev), meta.to(dev)
+    feat = {k: v.to(dev) for k, v in feat.items()}
+    net.train(True)
+    reducer = cdist.GradReducer(net.parameters())
+
+    def settled():
+        torch.cuda.synchronize()
+        gc.collect()
+        return torch.cuda.memory_allocated()
+    try:
+        for _ in range(20):
+            tc.train_step(net, reducer, optimizer, x, labels, masks, feat, fm, meta)
+        m0 = settled()
+        for _ in range(60):
+            tc.train_step(net, reducer, optimizer, x, labels, masks, feat, fm, meta)
+        m1 = settled()
+    finally:
+        reducer.close()
+    assert m1 - m0 < 64 * 1024, 'device memory grew by %d bytes over 60 steps' % (m1 - m0)
