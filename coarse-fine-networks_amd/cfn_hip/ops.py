@@ -195,9 +195,15 @@ def _opt(t):
     return None if t is None else t.contiguous()
 
 
-def _coef(t):
-    """prologue coefficients (N,C): the ABI takes fp64 (bn_fold emits fp64; hand-made fp32 ones are widened here)"""
-    return None if t is None else t.to(torch.float64).contiguous()
+def _coef(t, rows=None, cols=None):
+    """prologue coefficients (N,C): the ABI takes fp64 (bn_fold emits fp64; hand-made fp32 ones are widened here).  rows / cols: the (N, C)
+    the kernel will index -- the C ABI sees a pointer only, so a coefficient tensor of another size is refused here instead of being read
+    out of bounds on the device"""
+    if t is None:
+        return None
+    if rows is not None and t.numel() != rows * cols:
+        raise RuntimeError('per-sample coefficients of %d x %d channels expected, got a tensor of shape %s' % (rows, cols, tuple(t.shape)))
+    return t.to(torch.float64).contiguous()
 
 
 class ShortcutToken(object):
@@ -252,7 +258,7 @@ class _PwConv(Function):
         if want_stats:
             s, q = _f64(N, Cout, x.device), _f64(N, Cout, x.device)
         w2 = w.reshape(Cout, Cin).contiguous()
-        A, B = _coef(A), _coef(B)
+        A, B = _coef(A, N, Cin), _coef(B, N, Cin)
         xs = None
         if _bf(x):
             xs = subsample_hw(x, stride) if stride > 1 else x
@@ -432,7 +438,7 @@ class _DwConv3d(Function):
         if want_stats:
             s, q = _f64(N, C, x.device), _f64(N, C, x.device)
         w2 = w.reshape(C, 27).contiguous()
-        A, B = _coef(A), _coef(B)
+        A, B = _coef(A, N, C), _coef(B, N, C)
         call('cfn_dwconv3d_fwd' + _sfx(x), x, A, B, act, w2, y, s, q, N, C, T, H, W, stride)
         ctx.save_for_backward(x, A, B, w2, y)
         ctx.meta = (act, stride, tuple(w.shape))
@@ -640,8 +646,10 @@ class _BnAddRelu(Function):
         y, res = check(y).contiguous(), check(res).contiguous()
         N, C = y.shape[:2]
         vol = y[0, 0].numel()
+        if tuple(res.shape) != tuple(y.shape):
+            raise RuntimeError('bn_add_relu: residual %s does not match y %s' % (tuple(res.shape), tuple(y.shape)))
         out = torch.empty_like(y)
-        A, B, Ar, Br = _coef(A), _coef(B), _coef(Ar), _coef(Br)
+        A, B, Ar, Br = _coef(A, N, C), _coef(B, N, C), _coef(Ar, N, C), _coef(Br, N, C)
         mask = None
         sfx = _sfx(y)
         if link is not None:   # ReLU bit mask for the one-tensor backward (1/32 of a tensor instead of re-reading out)
@@ -709,7 +717,7 @@ class _AffineAct(Function):
         x = check(x).contiguous()
         N, C = x.shape[:2]
         out = torch.empty_like(x)
-        A, B = _coef(A), _coef(B)
+        A, B = _coef(A, N, C), _coef(B, N, C)
         call('cfn_affine_act_fwd', x, A, B, act, out, N * C, x[0, 0].numel())
         ctx.save_for_backward(x, A, B)
         ctx.act = act
@@ -766,7 +774,7 @@ class _PoolHW(Function):
         x = check(x).contiguous()
         N, C, T, H, W = x.shape
         out = torch.empty(N, C, T, OH, OW, dtype=torch.float32, device=x.device)     # pooled tensors are fp32 in both precisions
-        A, B = _coef(A), _coef(B)
+        A, B = _coef(A, N, C), _coef(B, N, C)
         call('cfn_pool_hw_fwd' + _sfx(x), x, A, B, act, out, N * C, T, H, W, OH, OW)
         ctx.save_for_backward(x, A, B)
         ctx.meta = (act, OH, OW)
@@ -798,6 +806,12 @@ class _Film(Function):
     def forward(ctx, x, m, c, f):
         x, m, c = check(x).contiguous(), check(m).contiguous(), check(c).contiguous()
         N, C, T, H, W = x.shape
+        want = (N, C, T, H // f if f > 0 else -1, W // f if f > 0 else -1)
+        if f <= 0 or H % f or W % f or tuple(m.shape) != want or tuple(c.shape) != want:
+            # (the C ABI sees pointers only: block-constant coefficients of another plane size would be read out of bounds -- 96 x 96 clips
+            # against 7 x 7 fine features faulted the device before this check)
+            raise RuntimeError('film: coefficients %s / %s do not tile x %s with %d x %d blocks (expected %s)'
+                               % (tuple(m.shape), tuple(c.shape), tuple(x.shape), f, f, want))
         out = torch.empty_like(x)
         call('cfn_film_fwd', x, m, c, out, N * C, T, H, W, f)
         ctx.save_for_backward(x, m)
@@ -967,7 +981,7 @@ class _ConvDense(Function):
         if want_stats:
             s, q = _f64(N, Co, x.device), _f64(N, Co, x.device)
         w2 = w.reshape(Co, -1).contiguous()
-        A, B = _coef(A), _coef(B)
+        A, B = _coef(A, N, Ci), _coef(B, N, Ci)
         call('cfn_conv3d_dense_fwd', x, A, B, act, w2, y, s, q, N, Ci, Co, T, H, W, g)
         ctx.save_for_backward(x, A, B, w2, y)
         ctx.meta = (act, tuple(kernel), tuple(stride), tuple(padding), tuple(w.shape))

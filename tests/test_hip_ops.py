@@ -771,3 +771,24 @@ def test_more_than_65535_channel_rows(op, dtype):
     hi_o, hi_g = run(slice(N // 2, N))
     for f, a, b in zip(full_o + full_g, lo_o + lo_g, hi_o + hi_g):
         assert torch.equal(f, torch.cat([a, b], 0))
+
+
+def test_shape_mismatches_raise_instead_of_reading_out_of_bounds():
+    """the C ABI takes pointers and sizes: tensors whose RELATIVE shapes do not fit are refused by the ops layer (a 96 x 96 coarse clip against
+    7 x 7 fine features used to fault the device inside the FiLM kernel)"""
+    o = ops()
+    x = rnd(1, 2, 8, 3, 24, 24).to(DEV)
+    m7, c7 = rnd(2, 2, 8, 3, 7, 7).to(DEV), rnd(3, 2, 8, 3, 7, 7).to(DEV)
+    with pytest.raises(RuntimeError, match='do not tile'):
+        o.film(x, m7, c7, 24 // 7)
+    m8 = rnd(4, 2, 8, 3, 8, 8).to(DEV)
+    assert o.film(x, m8, m8, 3).shape == x.shape
+    w = rnd(5, 16, 8, 1, 1, 1).to(DEV)
+    with pytest.raises(RuntimeError, match='coefficients'):
+        o.pwconv(x, w, torch.ones(2, 7, device=DEV), torch.zeros(2, 7, device=DEV), 0, 1, True)
+    wd = rnd(6, 8, 1, 3, 3, 3).to(DEV)
+    with pytest.raises(RuntimeError, match='coefficients'):
+        o.dwconv3d(x, wd, torch.ones(1, 8, device=DEV), torch.zeros(1, 8, device=DEV), 0, 1, True)
+    y = rnd(7, 2, 8, 3, 12, 12).to(DEV)
+    with pytest.raises(RuntimeError, match='residual'):
+        o.bn_add_relu(y, torch.ones(2, 8, device=DEV), torch.zeros(2, 8, device=DEV), x)
