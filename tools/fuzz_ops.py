@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Random-shape fuzz of the conv operators against fp64 references computed with plain tensor ops (no MIOpen): depthwise 3x3x3 (stride 1 / 2),
+pointwise (stride 1 / 2, prologue, statistics), their backward passes.  Every case prints its shape BEFORE it launches (a device fault kills the
+process: the last line names the culprit).   python tools/fuzz_ops.py [--cases 200] [--seed 0]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'coarse-fine-networks_amd'))
+import torch                      # noqa: E402
+import torch.nn.functional as F   # noqa: E402
+from cfn_hip import ops           # noqa: E402
+
+DEV = 'cuda'
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+def act_ref(z, act):
+    return z if act == 0 else (z.clamp(min=0) if act == 1 else z * torch.sigmoid(z))
+
+
+def dw_case(g, rng):
+    N, C, T = rng.choice([1, 2, 3]), rng.choice([1, 3, 8, 24, 54, 108, 216, 432, 7, 33]), rng.choice([1, 2, 3, 5, 8, 9, 16, 17])
+    H = rng.choice([1, 2, 3, 5, 7, 8, 13, 14, 15, 28, 29, 56, 57, 112])
+    W = rng.choice([H, H, H + 1, max(1, H - 1), 7, 12])
+    if C * T * H * W > 4e6:
+        T = max(1, int(4e6 // (C * H * W)))
+    stride, act, pro = rng.choice([1, 2]), rng.choice([0, 1, 2]), rng.choice([True, False])
+    print('dw  N=%d C=%d T=%d H=%d W=%d stride=%d act=%d prologue=%s' % (N, C, T, H, W, stride, act, pro), flush=True)
+    x = torch.randn(N, C, T, H, W, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(C, 1, 3, 3, 3, generator=g) * 0.2).to(DEV).requires_grad_(True)
+    A = (1 + 0.2 * torch.randn(N, C, generator=g)).to(DEV).requires_grad_(True) if pro else None
+    B = (0.3 * torch.randn(N, C, generator=g)).to(DEV).requires_grad_(True) if pro else None
+    y, s, q = ops.dwconv3d(x, w, A, B, act if pro else 0, stride, True)
+    xd = x.detach().double().requires_grad_(True)
+    wd = w.detach().double().requires_grad_(True)
+    Ad = A.detach().double().requires_grad_(True) if pro else None
+    Bd = B.detach().double().requires_grad_(True) if pro else None
+    z = act_ref(xd * Ad.view(N, C, 1, 1, 1) + Bd.view(N, C, 1, 1, 1), act) if pro else xd
+    yr = F.conv3d(z, wd, stride=(1, stride, stride), padding=1, groups=C)
+    e = [relerr(y, yr), relerr(s, yr.sum((2, 3, 4))), relerr(q, (yr * yr).sum((2, 3, 4)))]
+    gy = torch.randn(y.shape, generator=g).to(DEV)
+    ins = (x, w) + ((A, B) if pro else ())
+    gr = torch.autograd.grad((y,), ins, (gy,))
+    grr = torch.autograd.grad((yr,), (xd, wd) + ((Ad, Bd) if pro else ()), (gy.double(),))
+    e += [relerr(a, b) for a, b in zip(gr, grr)]
+    return max(e), e
+
+
+def pw_case(g, rng):
+    N, Ci, Co = rng.choice([1, 2, 3]), rng.choice([3, 24, 48, 54, 96, 108, 192, 216, 432, 50, 100]), rng.choice([1, 24, 33, 48, 54, 96, 108, 157, 192, 216, 432])
+    T, H = rng.choice([1, 2, 3, 4, 5, 8, 13]), rng.choice([1, 2, 3, 4, 7, 8, 14, 15, 28])
+    W = rng.choice([H, H, H + 1, 6])
+    if max(Ci, Co) * T * H * W > 3e6:
+        T = max(1, int(3e6 // (max(Ci, Co) * H * W)))
+    stride, act, pro = rng.choice([1, 1, 1, 2]), rng.choice([0, 1, 2]), rng.choice([True, False])
+    print('pw  N=%d Cin=%d Cout=%d T=%d H=%d W=%d stride=%d act=%d prologue=%s' % (N, Ci, Co, T, H, W, stride, act, pro), flush=True)
+    x = torch.randn(N, Ci, T, H, W, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(Co, Ci, 1, 1, 1, generator=g) * (2.0 / Ci) ** 0.5).to(DEV).requires_grad_(True)
+    A = (1 + 0.2 * torch.randn(N, Ci, generator=g)).to(DEV).requires_grad_(True) if pro else None
+    B = (0.3 * torch.randn(N, Ci, generator=g)).to(DEV).requires_grad_(True) if pro else None
+    y, s, q = ops.pwconv(x, w, A, B, act if pro else 0, stride, True)
+    xd = x.detach().double().requires_grad_(True)
+    wd = w.detach().double().requires_grad_(True)
+    Ad = A.detach().double().requires_grad_(True) if pro else None
+    Bd = B.detach().double().requires_grad_(True) if pro else None
+    z = act_ref(xd * Ad.view(N, Ci, 1, 1, 1) + Bd.view(N, Ci, 1, 1, 1), act) if pro else xd
+    yr = torch.einsum('nkthw,mk->nmthw', z[:, :, :, ::stride, ::stride], wd.view(Co, Ci))
+    e = [relerr(y, yr), relerr(s, yr.sum((2, 3, 4))), relerr(q, (yr * yr).sum((2, 3, 4)))]
+    gy = torch.randn(y.shape, generator=g).to(DEV)
+    gs, gq = (0.01 * torch.randn(s.shape, generator=g)).to(DEV).to(s.dtype), (0.001 * torch.randn(q.shape, generator=g)).to(DEV).to(q.dtype)
+    ins = (x, w) + ((A, B) if pro else ())
+    gr = torch.autograd.grad((y, s, q), ins, (gy, gs, gq))
+    sr, qr = yr.sum((2, 3, 4)), (yr * yr).sum((2, 3, 4))
+    grr = torch.autograd.grad((yr, sr, qr), (xd, wd) + ((Ad, Bd) if pro else ()), (gy.double(), gs.double(), gq.double()))
+    e += [relerr(a, b) for a, b in zip(gr, grr)]
+    return max(e), e
+
+
+def main():
+    import random
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', type=int, default=200)
+    ap.add_argument('--seed', type=int, default=0)
+    args = ap.parse_args()
+    rng = random.Random(args.seed)
+    g = torch.Generator().manual_seed(args.seed)
+    bad = 0
+    for i in range(args.cases):
+        fn = dw_case if i % 2 == 0 else pw_case
+        try:
+            worst, e = fn(g, rng)
+        except RuntimeError as ex:
+            print('   -> refused / error: %s' % str(ex)[:160], flush=True)
+            continue
+        torch.cuda.synchronize()
+        if not worst <= 2e-4:
+            bad += 1
+            print('   -> MISMATCH %s' % ['%.1e' % v for v in e], flush=True)
+    print('fuzz: %d cases, %d mismatches' % (args.cases, bad))
+
+
+if __name__ == '__main__':
+    main()
