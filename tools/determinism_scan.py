@@ -18,7 +18,7 @@ DEV = 'cuda'
 
 
 def scan(name, net, inp, runs):
-    from oracle import spec
+    import _init as spec
     net.train(True)
     ref = None
     worst = {}
@@ -57,7 +57,7 @@ def main():
     cfn_hip.load()
     if a.det:
         cfn_hip.query('cfn_deterministic', 1)
-    from oracle import spec
+    import _init as spec
     bad = 0
     if a.stream in ('fine', 'both'):
         import x3d_fine

@@ -14,7 +14,8 @@ from cfn_hip import ops           # noqa: E402
 if os.environ.get('CFN_LIB'):
     cfn_hip.LIB_PATH = os.environ['CFN_LIB']
 cfn_hip.load()
-from oracle import spec           # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _init as spec              # noqa: E402
 import x3d_fine                   # noqa: E402
 
 MODE = int(os.environ.get('DIAG_MODE', '3'))      # bit 0: input checksums, bit 1: accumulator snapshots
