@@ -81,17 +81,84 @@ def pw_case(g, rng):
     return max(e), e
 
 
+def t5_case(g, rng):
+    N, C, T = rng.choice([1, 2]), rng.choice([1, 8, 24, 25]), rng.choice([1, 2, 4, 5, 9, 16, 33])
+    H, W = rng.choice([1, 3, 8, 28, 56, 112]), rng.choice([1, 3, 8, 28, 56, 112, 5])
+    if C * T * H * W > 3e6:
+        T = max(1, int(3e6 // (C * H * W)))
+    print('t5  N=%d C=%d T=%d H=%d W=%d' % (N, C, T, H, W), flush=True)
+    x = torch.randn(N, C, T, H, W, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(C, 1, 5, 1, 1, generator=g) * 0.3).to(DEV).requires_grad_(True)
+    y, s, q = ops.dwconv_t5(x, w, True)
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    yr = F.conv3d(xd, wd, padding=(2, 0, 0), groups=C)
+    e = [relerr(y, yr), relerr(s, yr.sum((2, 3, 4))), relerr(q, (yr * yr).sum((2, 3, 4)))]
+    gy = torch.randn(y.shape, generator=g).to(DEV)
+    gr = torch.autograd.grad((y,), (x, w), (gy,))
+    grr = torch.autograd.grad((yr,), (xd, wd), (gy.double(),))
+    e += [relerr(a, b) for a, b in zip(gr, grr)]
+    return max(e), e
+
+
+def tail_case(g, rng):
+    N, C, T, H = rng.choice([1, 2, 3]), rng.choice([1, 24, 48, 96, 192, 7]), rng.choice([1, 2, 5, 8]), rng.choice([1, 3, 7, 14, 28, 56, 9])
+    W = rng.choice([H, H + 1, 4])
+    two = rng.choice([True, False])
+    print('tail N=%d C=%d T=%d H=%d W=%d shortcut-bn=%s' % (N, C, T, H, W, two), flush=True)
+    mk = lambda sc, off=0.0: (off + sc * torch.randn(N, C, generator=g)).to(DEV).requires_grad_(True)
+    y = torch.randn(N, C, T, H, W, generator=g).to(DEV).requires_grad_(True)
+    res = torch.randn(N, C, T, H, W, generator=g).to(DEV).requires_grad_(True)
+    A, B = mk(0.2, 1.0), mk(0.3)
+    Ar, Br = (mk(0.2, 1.0), mk(0.3)) if two else (None, None)
+    out = ops.bn_add_relu(y, A, B, res, Ar, Br)
+    d = lambda t: None if t is None else t.detach().double().requires_grad_(True)
+    yd, rd, Ad, Bd, Ard, Brd = d(y), d(res), d(A), d(B), d(Ar), d(Br)
+    v = lambda c: c.view(N, C, 1, 1, 1)
+    ref = (yd * v(Ad) + v(Bd) + (rd * v(Ard) + v(Brd) if two else rd)).clamp(min=0)
+    e = [relerr(out, ref)]
+    go = torch.randn(out.shape, generator=g).to(DEV)
+    ins = (y, A, B, res) + ((Ar, Br) if two else ())
+    gr = torch.autograd.grad((out,), ins, (go,))
+    grr = torch.autograd.grad((ref,), (yd, Ad, Bd, rd) + ((Ard, Brd) if two else ()), (go.double(),))
+    e += [relerr(a, b) for a, b in zip(gr, grr)]
+    return max(e), e
+
+
+def pool_case(g, rng):
+    N, C, T, H = rng.choice([1, 2]), rng.choice([1, 24, 192, 432, 5]), rng.choice([1, 3, 8]), rng.choice([7, 14, 28, 56, 8, 12])
+    W = H
+    O = rng.choice([o for o in (1, 2, 7, H) if H % o == 0])
+    act, pro = rng.choice([0, 1, 2]), rng.choice([True, False])
+    print('pool N=%d C=%d T=%d H=%d -> %d act=%d prologue=%s' % (N, C, T, H, O, act, pro), flush=True)
+    x = torch.randn(N, C, T, H, W, generator=g).to(DEV).requires_grad_(True)
+    A = (1 + 0.2 * torch.randn(N, C, generator=g)).to(DEV).requires_grad_(True) if pro else None
+    B = (0.3 * torch.randn(N, C, generator=g)).to(DEV).requires_grad_(True) if pro else None
+    out = ops.pool_hw(x, O, O, A, B, act if pro else 0)
+    xd = x.detach().double().requires_grad_(True)
+    Ad = A.detach().double().requires_grad_(True) if pro else None
+    Bd = B.detach().double().requires_grad_(True) if pro else None
+    z = act_ref(xd * Ad.view(N, C, 1, 1, 1) + Bd.view(N, C, 1, 1, 1), act) if pro else xd
+    ref = F.adaptive_avg_pool3d(z, (T, O, O))
+    e = [relerr(out, ref)]
+    go = torch.randn(out.shape, generator=g).to(DEV)
+    gr = torch.autograd.grad((out,), (x,) + ((A, B) if pro else ()), (go,))
+    grr = torch.autograd.grad((ref,), (xd,) + ((Ad, Bd) if pro else ()), (go.double(),))
+    e += [relerr(a, b) for a, b in zip(gr, grr)]
+    return max(e), e
+
+
 def main():
     import random
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=200)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--all', action='store_true', help='also conv1_t (5x1x1 depthwise), the block tail and the spatial pooling')
     args = ap.parse_args()
     rng = random.Random(args.seed)
     g = torch.Generator().manual_seed(args.seed)
     bad = 0
     for i in range(args.cases):
-        fn = dw_case if i % 2 == 0 else pw_case
+        fn = (dw_case, pw_case, t5_case, tail_case, pool_case)[i % 5] if args.all else (dw_case if i % 2 == 0 else pw_case)
         try:
             worst, e = fn(g, rng)
         except RuntimeError as ex:
