@@ -526,3 +526,63 @@ def test_coarse_training_steps_do_not_leak_device_memory():
     finally:
         reducer.close()
     assert m1 - m0 < 50, 'live device tensors grew by %d over 60 steps' % (m1 - m0)
+
+
+@pytest.mark.gpu
+def test_two_threads_on_one_device_match_the_sequential_run():
+    """the reference drives its model through nn.DataParallel: N Python threads of ONE process call forward concurrently and the autograd engine
+    runs backward on worker threads.  Two threads, each with its own copy of x3d_fine on its own stream of the same device, run
+    forward + backward concurrently; logits and every gradient must equal the sequential run (per-thread scratch arenas, per-(device, stream)
+    workspaces, no unguarded global state)."""
+    import threading
+    import x3d_fine
+    from oracle import spec
+    dev = torch.device('cuda:0')
+
+    def make():
+        net = x3d_fine.generate_model('M', n_classes=157, task='loc', base_bn_splits=1, dropout=0.0)
+        spec.fill_module_(net)
+        return net.to(dev).train(True)
+    xs = [spec.rand_input(40 + i, (2, 3, 8, 64, 64)).to(dev) for i in range(2)]
+    rs = [spec.rand_input(50 + i, (2, 157, 8)).to(dev) for i in range(2)]
+
+    def run(net, x, r, out, stream=None):
+        def body():
+            for _ in range(3):
+                net.zero_grad(set_to_none=True)
+                y = net([x, None])
+                (y * r).sum().backward()
+            out.append((y.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
+        if stream is None:
+            body()
+        else:
+            with torch.cuda.stream(stream):
+                body()
+                stream.synchronize()
+    ref = []
+    for i in range(2):
+        o = []
+        run(make(), xs[i], rs[i], o)
+        torch.cuda.synchronize()
+        ref.append(o[0])
+    nets = [make(), make()]
+    outs = [[], []]
+    errs = []
+
+    def worker(i):
+        try:
+            run(nets[i], xs[i], rs[i], outs[i], torch.cuda.Stream(device=dev))
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i in range(2):
+        y, gr = outs[i][0]
+        assert torch.allclose(y, ref[i][0], rtol=1e-5, atol=1e-6)
+        for k, gv in gr.items():
+            assert relerr(gv, ref[i][1][k]) <= 1e-5, k
