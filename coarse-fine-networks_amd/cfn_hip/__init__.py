@@ -114,6 +114,9 @@ def _marshal(name, args):
         if isinstance(a, torch.Tensor):
             if dts[i] is not None and a.dtype != dts[i]:   # element types are part of the ABI: refuse a mismatch
                 raise RuntimeError('%s: argument %d must be a %s tensor, got %s' % (name, i, dts[i], a.dtype))
+            if a.device.type != 'cuda':             # a host pointer handed to a kernel is a device fault, not an exception
+                raise RuntimeError('%s: argument %d is a %s tensor; the Coarse-Fine HIP ops run on the GPU only (no CPU fallback): '
+                                   'move the module and its inputs to a cuda device' % (name, i, a.device.type))
             if dev is None:
                 dev = a.device
             elif a.device != dev:
