@@ -10,6 +10,7 @@ full-size tensor is touched only inside the HIP kernels.
 """
 import torch
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 import ctypes
 import threading
@@ -275,6 +276,7 @@ class _PwConv(Function):
         return y, s, q
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy, gs, gq):
         x, A, B, w2, y, xs = ctx.saved_tensors
         act, stride, wshape = ctx.meta
@@ -448,6 +450,7 @@ class _DwConv3d(Function):
         return y, s, q
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy, gs, gq):
         x, A, B, w2, y = ctx.saved_tensors
         act, stride, wshape = ctx.meta
@@ -508,6 +511,7 @@ class _DwConvT5(Function):
         return y, s, q
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy, gs, gq):
         x, w2, y = ctx.saved_tensors
         N, C, T, H, W = x.shape
@@ -554,6 +558,7 @@ class _StemConv(Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
         N, Ci, T, H, W = x.shape
@@ -600,6 +605,7 @@ class _BnFold(Function):
         return A, B
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gA, gB):
         s, gamma, mean, rstd, A0, B0, gate, hbuf, pooled, w1c, w2c = ctx.saved_tensors
         training, N, C, S, Wd, count, pool_count, w1s, w2s = ctx.cfg
@@ -666,6 +672,7 @@ class _BnAddRelu(Function):
         return out, alias
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gout, gout2=None):
         y, A, res, Ar, out = ctx.saved_tensors
         N, C = y.shape[:2]
@@ -724,6 +731,7 @@ class _AffineAct(Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gout):
         x, A, B = ctx.saved_tensors
         N, C = x.shape[:2]
@@ -750,6 +758,7 @@ class _ChannelStats(Function):
         return s, q
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gs, gq):
         (x,) = ctx.saved_tensors
         N, C = x.shape[:2]
@@ -781,6 +790,7 @@ class _PoolHW(Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gout):
         x, A, B = ctx.saved_tensors
         act, OH, OW = ctx.meta
@@ -819,6 +829,7 @@ class _Film(Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         x, m = ctx.saved_tensors
         N, C, T, H, W = x.shape
@@ -846,6 +857,7 @@ class _TimeSample(Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         x, cdf = ctx.saved_tensors
         B, C, Tin = x.shape[:3]
@@ -876,6 +888,7 @@ class _TimePool(Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
         mode, R = ctx.meta
@@ -915,6 +928,7 @@ class _Interp1d(Function):
         return ynew, ind
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g, _gind):
         x, y, xnew, ind = ctx.saved_tensors
         B, Pq = ind.shape
@@ -946,6 +960,7 @@ class _TimeResize(Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         shape, L, ac = ctx.meta
         gx = torch.empty(shape, dtype=torch.float32, device=g.device)
@@ -991,6 +1006,7 @@ class _ConvDense(Function):
         return y, s, q
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy, gs, gq):
         x, A, B, w2, y = ctx.saved_tensors
         act, kernel, stride, padding, wshape = ctx.meta
@@ -1039,6 +1055,7 @@ class _FusionGather(Function):
         return z
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gz):
         x, at_raw, at_bias, GX, mask, z, den = ctx.saved_tensors
         B, C, Tf, P = x.shape
@@ -1077,6 +1094,7 @@ class _GaussAlign(Function):
         return GX
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gGX):
         meta, mask, gx = ctx.saved_tensors
         tx, ratio, crops, K = ctx.cfg
@@ -1106,6 +1124,7 @@ class _GridCdf(Function):
         return cdf
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gcdf):
         g, bias = ctx.saved_tensors
         B, Kin = g.shape

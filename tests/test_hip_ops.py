@@ -792,3 +792,19 @@ def test_shape_mismatches_raise_instead_of_reading_out_of_bounds():
     y = rnd(7, 2, 8, 3, 12, 12).to(DEV)
     with pytest.raises(RuntimeError, match='residual'):
         o.bn_add_relu(y, torch.ones(2, 8, device=DEV), torch.zeros(2, 8, device=DEV), x)
+
+
+def test_double_backward_is_refused_loudly():
+    """the backward passes are kernels, not differentiable graphs: asking for a second derivative raises instead of returning gradients that
+    silently ignore it"""
+    o = ops()
+    x = rnd(1, 1, 8, 2, 8, 8).to(DEV).requires_grad_(True)
+    w = rnd(2, 8, 1, 3, 3, 3).to(DEV).requires_grad_(True)
+    y, _, _ = o.dwconv3d(x, w, None, None, 0, 1, True)
+    gx, = torch.autograd.grad(y.sum(), x, create_graph=True)
+    with pytest.raises(RuntimeError):                       # the first derivative carries no graph at all ...
+        gx.sum().backward()
+    gy = torch.ones_like(y).requires_grad_(True)
+    gx, = torch.autograd.grad(y, x, gy, create_graph=True)
+    with pytest.raises(RuntimeError, match='once_differentiable|differentiate twice'):   # ... and says so when a graph is forced through it
+        gx.sum().backward()
