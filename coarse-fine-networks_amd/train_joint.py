@@ -81,7 +81,10 @@ def joint_forward(fine, coarse, clip, coarse_frames=None, start=None):
     xc, s = coarse_window(clip, coarse_frames, start)
     feat, _ = fine([clip, None])
     feat_masks = torch.ones(b, tf, device=clip.device)
-    meta = torch.tensor([[s, xc.shape[2], tf, 1]] * b, dtype=torch.int64, device=clip.device)
+    # filled ON the device (four fill kernels): a host list -> device copy is not permitted while the stream is being captured into a hipGraph
+    meta = torch.empty(b, 4, dtype=torch.int64, device=clip.device)
+    for col, val in enumerate((s, xc.shape[2], tf, 1)):
+        meta[:, col] = val
     return coarse([xc, feat, feat_masks, 0, meta]), feat
 
 
