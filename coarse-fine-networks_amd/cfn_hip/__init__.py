@@ -25,7 +25,8 @@ _protos = None
 
 def header_prototypes(path=HEADER):
     """{name: (restype, [argtype, ...])} parsed from the C header."""
-    txt = open(path).read()
+    with open(path) as fh:
+        txt = fh.read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     out = {}
     for m in re.finditer(r'(const\s+char\s*\*|int|long)\s+(cfn_\w+)\s*\(([^)]*)\)\s*;', txt):
