@@ -249,7 +249,7 @@ def main():
         assert not (coarse or joint), '--graph with --gpus > 1 covers the fine stream'
         from cfn_hip.graph import GraphedDPStep
         graphed = GraphedDPStep(lambda x_, l_, m_, tot: train_fine.forward_backward(net, x_, l_, m_, mask_total=tot)[:2], reducer, optimizer,
-                                pre=lambda x_, l_, m_: (cdist.global_mask_count(m_),))
+                                pre=lambda x_, l_, m_: (cdist.global_mask_count(m_),), post_reduce=lambda: train_fine.post_reduce(net))
 
         def step():
             return tuple(v.clone() for v in graphed(x, labels, masks))

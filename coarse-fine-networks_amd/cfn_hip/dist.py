@@ -95,6 +95,8 @@ class GradReducer(object):
         self._rerun = False          # more than one backward pass since the last finish(): every bucket is sent again with the accumulated gradients
         self._passes = 0             # backward passes completed since the last finish() (counted by an engine callback: the SAME number on every rank,
         self._in_pass = False        # whatever gradients a rank's data produced -- ADVICE r4: the decision to re-send must not depend on hook arrival)
+        self._begun = 0              # begin_pass() calls since the last finish(): the rank-independent pass count -- the engine-callback count
+                                     # above misses a pass that produced no gradient for any of this reducer's parameters on THIS rank
         self.filled = []
         self._stream = None
         self._hooks = []
@@ -140,8 +142,20 @@ class GradReducer(object):
 
             def __exit__(self, *exc):
                 reducer.suspended = self.prev
+                reducer._in_pass = False      # (a backward that raised drops the engine's callbacks: never leave the flag set)
                 return False
         return _NoSync()
+
+    def begin_pass(self):
+        """Call right before every backward() this reducer takes part in (the train steps of this package do).  It makes the number of
+        backward passes since the last finish() -- which decides whether the buckets are sent again with accumulated gradients -- a
+        count of CALLS, identical on every rank by construction; without it the count comes from autograd-engine callbacks queued by the
+        first gradient hook of a pass, which a rank whose pass produced no gradient for any reducer parameter never queues."""
+        if not self.suspended:       # (passes under no_sync() / inside a graph capture only accumulate: they are not counted, as in _end_pass)
+            self._begun += 1
+
+    def _completed_passes(self):
+        return self._begun - 1 if self._begun > 0 else self._passes
 
     def close(self):
         """Detach from the parameters: removes the bucket hooks and withdraws the lazy-gradient-cast opt-in (it is only safe
@@ -159,7 +173,7 @@ class GradReducer(object):
         if not self._in_pass:        # first gradient of this backward pass: count the pass when the engine finishes it
             self._in_pass = True
             torch.autograd.Variable._execution_engine.queue_callback(self._end_pass)
-        if self._passes > 0:
+        if self._completed_passes() > 0:
             # gradient accumulation without no_sync(): a second (third ...) backward before finish().  The first pass's collectives are in flight with
             # ITS gradients; p.grad holds the local sum of all passes (results are only written back in finish()), so nothing is launched from inside
             # this pass (a bucket would travel with partial sums) and finish() sends every bucket again, in bucket order on every rank -- decided by
@@ -217,7 +231,7 @@ class GradReducer(object):
             return
         while self._next < len(self.buckets):
             self._launch(self._next)
-        if self._passes > 1:
+        if (self._begun if self._begun > 0 else self._passes) > 1:
             self._rerun = True
         if self._rerun:              # several backward passes since the last finish(): reduce the accumulated gradients
             for work, bi in self._inflight:
@@ -242,6 +256,8 @@ class GradReducer(object):
         self._pending = [len(b) for b in self.buckets]
         self._next = 0
         self._passes = 0
+        self._begun = 0
+        self._in_pass = False        # (engine callbacks are dropped when a backward raises: the flag must not survive the step)
 
 
 def global_mask_count(masks, group=None, local=False):

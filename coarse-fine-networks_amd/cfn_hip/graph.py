@@ -16,6 +16,10 @@ Rules the captured callable has to respect (checked where possible):
   * gradients live in the graph's memory pool: never `zero_grad(set_to_none=True)` between replays from outside (the
     captured step may do it internally: backward then re-creates them at the same addresses at capture time);
   * the learning rate is baked into the optimizer kernels: a changed `lr` (scheduler, warm-up) triggers a re-capture;
+  * a graph is REPLAYED ON THE STREAM IT WAS CAPTURED ON (`_replay`): the library's per-(device, stream) scratch buffers (pre-split weight
+    images, weight-gradient partial tiles: csrc/pwstream.hip, csrc/pwsplitw.hip) are baked into the graph by address and are only ordered
+    against other users by in-stream order -- replayed on another stream, eager work on the capture stream (or a second graph captured on it)
+    could overwrite them mid-contraction (ADVICE r5).  Every GraphedStep owns its side stream, so two graphed steps never share scratch;
   * multi-GPU: collectives are NOT captured, and GradReducer's hooks would launch RCCL on a side stream inside the capture:
     with torch.distributed initialised at world_size > 1 a GraphedStep refuses to capture (RuntimeError).  Use GraphedDPStep:
     graph A = forward + loss + backward (reducer suspended), then the bucketed all-reduce EAGERLY on the reducer's static flat
@@ -98,6 +102,18 @@ class GraphedStep(object):
         ops.reset_scratch()                    # ... and must not leak into later eager calls
         return graph, static_in, static_out, _lr_signature(self.optimizer)
 
+    def _replay(self, graph):
+        """launch `graph` on the capture stream, ordered behind the caller's stream and in front of its later work"""
+        st = self.stream
+        cur = torch.cuda.current_stream(st.device)
+        if cur == st:
+            graph.replay()
+            return
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            graph.replay()
+        cur.wait_stream(st)
+
     def __call__(self, *args):
         if self.calls < self.eager_first:
             self.calls += 1
@@ -116,7 +132,7 @@ class GraphedStep(object):
         graph, static_in, static_out, _ = entry
         for dst, src in zip(static_in, args):
             self._copy(dst, src)
-        graph.replay()
+        self._replay(graph)
         return static_out
 
 
@@ -124,7 +140,7 @@ class GraphedDPStep(GraphedStep):
     """Data-parallel step as two hipGraphs around an eager gradient all-reduce (world_size >= 1):
 
         step = GraphedDPStep(lambda x, l, m, tot: train_fine.forward_backward(net, x, l, m, mask_total=tot), reducer, optimizer,
-                             pre=lambda x, l, m: (cdist.global_mask_count(m),))
+                             pre=lambda x, l, m: (cdist.global_mask_count(m),), post_reduce=lambda: train_fine.post_reduce(net))
         cls, loc, probs = step(x, labels, masks)
 
     `fwd_bwd(*args, *pre(*args))` must do forward + loss + backward and NOTHING collective (`pre` runs eagerly before it every step:
@@ -140,9 +156,13 @@ class GraphedDPStep(GraphedStep):
     The all-reduce runs AFTER the replayed backward (the reducer is suspended inside the capture), i.e. it is not overlapped with
     backward as in the eager path: 13-18 MB per step, ~0.2 ms against >= 10 ms of step."""
 
-    def __init__(self, fwd_bwd, reducer, optimizer, pre=None, eager_first=1, pool=None):
+    def __init__(self, fwd_bwd, reducer, optimizer, pre=None, eager_first=1, pool=None, post_reduce=None):
         super(GraphedDPStep, self).__init__(fwd_bwd, optimizer=optimizer, eager_first=eager_first, pool=pool)
         self.reducer, self.pre = reducer, pre
+        # runs between the all-reduce and optimizer.step(), eagerly in the first step(s) and as the head of the captured optimizer graph
+        # afterwards: the un-scaling of an fp16 net's gradients (train_fine.post_reduce) -- forward_backward scales the loss, so without
+        # this hook the optimizer would step on gradients `scale` times too large (ADVICE r5)
+        self.post_reduce = post_reduce
         self._opt_graphs = {}
 
     def _params(self):
@@ -158,6 +178,8 @@ class GraphedDPStep(GraphedStep):
             with torch.cuda.stream(st):
                 out = self.fn(*full)
                 self.reducer.finish()
+                if self.post_reduce is not None:
+                    self.post_reduce()
                 self.optimizer.step()
                 self.optimizer.zero_grad(set_to_none=True)
             torch.cuda.current_stream(st.device).wait_stream(st)
@@ -181,6 +203,8 @@ class GraphedDPStep(GraphedStep):
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self.pool, stream=self._side_stream(full), capture_error_mode=_capture_mode()):
+                if self.post_reduce is not None:
+                    self.post_reduce()
                 self.optimizer.step()
             og = (g, lr)
             self._opt_graphs[sig] = og
@@ -188,7 +212,7 @@ class GraphedDPStep(GraphedStep):
         graph, static_in, static_out, _ = entry
         for dst, src in zip(static_in, full):
             self._copy(dst, src)
-        graph.replay()
+        self._replay(graph)
         self.reducer.finish()                      # eager: bucket order, static flat buffers, RCCL on the reducer's side stream
         if self.reducer.filled:
             names = len(self.reducer.filled)
@@ -197,5 +221,5 @@ class GraphedDPStep(GraphedStep):
             raise RuntimeError('GraphedDPStep: %d parameter(s) have a gradient on another rank but none in this rank\'s captured '
                                'step; the captured optimizer graph would skip them and the replicas would diverge -- run this '
                                'model with the eager GradReducer path' % names)
-        og[0].replay()
+        self._replay(og[0])
         return static_out

@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256) void pws_presplit_kernel(const float* __restri
 
 // One workspace per (device, stream), grown geometrically, never freed (a captured graph may have the address baked in); no allocation
 // while the stream is being captured: the call is then declined and the fp32-MFMA kernel runs.  Launches on one stream run in order, so
-// the next conv's pre-split cannot overtake this conv's contraction.
+// the next conv's pre-split cannot overtake this conv's contraction.  A hipGraph bakes the address in at capture time: it has to be REPLAYED ON THE
+// STREAM IT WAS CAPTURED ON (cfn_hip/graph.py GraphedStep._replay does), otherwise eager work on the capture stream -- or a second graph captured
+// on it and replayed elsewhere -- overwrites the split weights mid-contraction; the same holds for pwss_workspace (pwsplitw.hip).  Retired
+// buffers stay allocated on purpose (a captured graph may still hold them); geometric growth bounds them by the size of the live one.
 static unsigned char* pwt_workspace(size_t bytes, hipStream_t st) {
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, std::pair<unsigned char*, size_t>> bufs;

@@ -33,11 +33,36 @@ inline void check_act(const Tensor& t, const char* op) {
     TORCH_CHECK(t.scalar_type() == at::kFloat || t.scalar_type() == at::kBFloat16 || t.scalar_type() == at::kHalf, op, ": fp32 / bf16 / fp16 tensors, got ", t.scalar_type());
 }
 inline Tensor f64(at::IntArrayRef shape, const Tensor& like) { return at::zeros(shape, like.options().dtype(at::kDouble)); }
+// The C ABI sees pointers and sizes only: everything a kernel will index is checked against the shapes HERE, so that a tensor of another size /
+// type raises instead of being read out of bounds on the device (cfn_hip/ops.py has the same checks on the ctypes route).
+inline void check_coef(OptT A, OptT B, int64_t N, int64_t C, const Tensor& x, const char* op) {
+    const bool a = A.has_value() && A->defined(), b = B.has_value() && B->defined();
+    TORCH_CHECK(a == b, op, ": the prologue coefficients A and B come together");
+    if (!a) return;
+    TORCH_CHECK(A->numel() == N * C && B->numel() == N * C, op, ": per-sample coefficients of ", N, " x ", C, " channels expected, got A ", A->sizes(), ", B ", B->sizes());
+    TORCH_CHECK(A->device() == x.device() && B->device() == x.device(), op, ": A / B live on another device than x");
+}
+inline void check_like(const Tensor& t, const Tensor& ref, const char* op, const char* name, const char* refname) {
+    TORCH_CHECK(t.sizes() == ref.sizes(), op, ": ", name, " ", t.sizes(), " does not have the shape of ", refname, " ", ref.sizes());
+    TORCH_CHECK(t.scalar_type() == ref.scalar_type(), op, ": ", name, " is ", t.scalar_type(), ", ", refname, " is ", ref.scalar_type());
+    TORCH_CHECK(t.device() == ref.device(), op, ": ", name, " lives on another device than ", refname);
+}
+inline void check_stat(const Tensor& g, int64_t N, int64_t C, const Tensor& x, const char* op, const char* name) {
+    TORCH_CHECK(g.numel() == N * C && g.device() == x.device(), op, ": ", name, " must hold ", N, " x ", C, " values on x's device, got ", g.sizes());
+}
+inline void check_out_shape(const Tensor& y, const Tensor& x, int64_t Cout, int64_t stride, const char* op) {
+    TORCH_CHECK(stride >= 1, op, ": stride ", stride);
+    TORCH_CHECK(y.dim() == 5 && y.size(0) == x.size(0) && y.size(1) == Cout && y.size(2) == x.size(2) && y.size(3) == (x.size(3) - 1) / stride + 1 &&
+                    y.size(4) == (x.size(4) - 1) / stride + 1,
+                op, ": y ", y.sizes(), " is not the output of x ", x.sizes(), " at stride ", stride, " with ", Cout, " channels");
+}
 
 // ---- depthwise 3x3x3 --------------------------------------------------------------------------------------------------------------------
 std::tuple<Tensor, Tensor, Tensor> dwconv3d(const Tensor& x_, const Tensor& w, OptT A, OptT B, int64_t act, int64_t stride) {
     check_act(x_, "cfn::dwconv3d");
     TORCH_CHECK(x_.dim() == 5, "cfn::dwconv3d: x must be (N, C, T, H, W)");
+    TORCH_CHECK(stride >= 1 && w.numel() == x_.size(1) * 27 && w.device() == x_.device(), "cfn::dwconv3d: w must hold C x 27 taps on x's device, got ", w.sizes());
+    check_coef(A, B, x_.size(0), x_.size(1), x_, "cfn::dwconv3d");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x_.device());
     const Tensor x = x_.contiguous();
     const int64_t N = x.size(0), C = x.size(1), T = x.size(2), H = x.size(3), W = x.size(4);
@@ -64,6 +89,14 @@ std::tuple<Tensor, Tensor, Tensor> dwconv3d(const Tensor& x_, const Tensor& w, O
 std::tuple<Tensor, Tensor, Tensor, Tensor> dwconv3d_backward(const Tensor& gy_, const Tensor& gs, const Tensor& gq, const Tensor& x_, const Tensor& w,
                                                              const Tensor& y_, OptT A, OptT B, int64_t act, int64_t stride) {
     check_act(x_, "cfn::dwconv3d_backward");
+    TORCH_CHECK(x_.dim() == 5, "cfn::dwconv3d_backward: x must be (N, C, T, H, W)");
+    TORCH_CHECK(w.numel() == x_.size(1) * 27 && w.device() == x_.device(), "cfn::dwconv3d_backward: w must hold C x 27 taps on x's device, got ", w.sizes());
+    check_out_shape(y_, x_, x_.size(1), stride, "cfn::dwconv3d_backward");
+    TORCH_CHECK(y_.scalar_type() == x_.scalar_type() && y_.device() == x_.device(), "cfn::dwconv3d_backward: y must have x's element type and device");
+    check_like(gy_, y_, "cfn::dwconv3d_backward", "gy", "y");          // gy is reinterpreted with x's element type below
+    check_stat(gs, x_.size(0), x_.size(1), x_, "cfn::dwconv3d_backward", "gs");
+    check_stat(gq, x_.size(0), x_.size(1), x_, "cfn::dwconv3d_backward", "gq");
+    check_coef(A, B, x_.size(0), x_.size(1), x_, "cfn::dwconv3d_backward");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x_.device());
     const Tensor x = x_.contiguous(), y = y_.contiguous(), gy = gy_.contiguous();
     const int64_t N = x.size(0), C = x.size(1), T = x.size(2), H = x.size(3), W = x.size(4);
@@ -103,6 +136,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> dwconv3d_backward(const Tensor& gy_, 
 std::tuple<Tensor, Tensor, Tensor> pwconv(const Tensor& x_, const Tensor& w, OptT A, OptT B, int64_t act, int64_t stride) {
     TORCH_CHECK(x_.is_cuda() && x_.scalar_type() == at::kFloat, "cfn::pwconv: fp32 device tensors (the bf16 / fp16 pointwise path is reached through cfn_hip.ops)");
     TORCH_CHECK(x_.dim() == 5, "cfn::pwconv: x must be (N, Cin, T, H, W)");
+    TORCH_CHECK(stride >= 1 && w.dim() >= 2 && w.numel() == w.size(0) * x_.size(1) && w.device() == x_.device(), "cfn::pwconv: w must be (Cout, Cin[, 1, 1, 1]) on x's device, got ", w.sizes());
+    check_coef(A, B, x_.size(0), x_.size(1), x_, "cfn::pwconv");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x_.device());
     const Tensor x = x_.contiguous();
     const int64_t N = x.size(0), Cin = x.size(1), T = x.size(2), H = x.size(3), W = x.size(4), Cout = w.size(0);
@@ -119,6 +154,14 @@ std::tuple<Tensor, Tensor, Tensor> pwconv(const Tensor& x_, const Tensor& w, Opt
 std::tuple<Tensor, Tensor, Tensor, Tensor> pwconv_backward(const Tensor& gy_, const Tensor& gs, const Tensor& gq, const Tensor& x_, const Tensor& w,
                                                            const Tensor& y_, OptT A, OptT B, int64_t act, int64_t stride) {
     TORCH_CHECK(x_.is_cuda() && x_.scalar_type() == at::kFloat, "cfn::pwconv_backward: fp32 device tensors");
+    TORCH_CHECK(x_.dim() == 5, "cfn::pwconv_backward: x must be (N, Cin, T, H, W)");
+    TORCH_CHECK(w.dim() >= 2 && w.numel() == w.size(0) * x_.size(1) && w.device() == x_.device(), "cfn::pwconv_backward: w must be (Cout, Cin[, 1, 1, 1]) on x's device, got ", w.sizes());
+    check_out_shape(y_, x_, w.size(0), stride, "cfn::pwconv_backward");
+    TORCH_CHECK(y_.scalar_type() == x_.scalar_type() && y_.device() == x_.device(), "cfn::pwconv_backward: y must have x's element type and device");
+    check_like(gy_, y_, "cfn::pwconv_backward", "gy", "y");
+    check_stat(gs, x_.size(0), w.size(0), x_, "cfn::pwconv_backward", "gs");
+    check_stat(gq, x_.size(0), w.size(0), x_, "cfn::pwconv_backward", "gq");
+    check_coef(A, B, x_.size(0), x_.size(1), x_, "cfn::pwconv_backward");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x_.device());
     const Tensor x = x_.contiguous(), y = y_.contiguous(), gy = gy_.contiguous();
     const int64_t N = x.size(0), Cin = x.size(1), T = x.size(2), H = x.size(3), W = x.size(4), Cout = w.size(0);
@@ -144,7 +187,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> pwconv_backward(const Tensor& gy_, co
 // ---- Grid Pool / Grid Unpool resampler --------------------------------------------------------------------------------------------------
 Tensor time_sample(const Tensor& x_, const Tensor& cdf_) {
     TORCH_CHECK(x_.is_cuda() && x_.scalar_type() == at::kFloat && cdf_.scalar_type() == at::kFloat, "cfn::time_sample: fp32 device tensors");
-    TORCH_CHECK(x_.dim() >= 3 && cdf_.dim() == 2, "cfn::time_sample: x (B, C, T, ...), cdf (B, K)");
+    TORCH_CHECK(x_.dim() >= 3 && cdf_.dim() == 2 && cdf_.size(0) == x_.size(0) && cdf_.device() == x_.device(), "cfn::time_sample: x (B, C, T, ...), cdf (B, K) on one device");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x_.device());
     const Tensor x = x_.contiguous(), cdf = cdf_.contiguous();
     const int64_t B = x.size(0), C = x.size(1), Tin = x.size(2), K = cdf.size(1);
@@ -157,7 +200,14 @@ Tensor time_sample(const Tensor& x_, const Tensor& cdf_) {
 }
 
 std::tuple<Tensor, Tensor> time_sample_backward(const Tensor& g_, const Tensor& x_, const Tensor& cdf_) {
-    TORCH_CHECK(x_.is_cuda() && x_.scalar_type() == at::kFloat, "cfn::time_sample_backward: fp32 device tensors");
+    TORCH_CHECK(x_.is_cuda() && x_.scalar_type() == at::kFloat && cdf_.scalar_type() == at::kFloat, "cfn::time_sample_backward: fp32 device tensors");
+    TORCH_CHECK(x_.dim() >= 3 && cdf_.dim() == 2 && cdf_.size(0) == x_.size(0) && cdf_.device() == x_.device(), "cfn::time_sample_backward: x (B, C, T, ...), cdf (B, K) on one device");
+    {
+        std::vector<int64_t> gshape = x_.sizes().vec();
+        gshape[2] = cdf_.size(1);
+        TORCH_CHECK(g_.sizes() == at::IntArrayRef(gshape) && g_.scalar_type() == at::kFloat && g_.device() == x_.device(), "cfn::time_sample_backward: g ", g_.sizes(),
+                    " is not the fp32 gradient of the (B, C, K, ...) output");
+    }
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x_.device());
     const Tensor g = g_.contiguous(), x = x_.contiguous(), cdf = cdf_.contiguous();
     const int64_t B = x.size(0), C = x.size(1), Tin = x.size(2), K = cdf.size(1);

@@ -116,6 +116,7 @@ def forward_video(net, inputs, feat, feat_masks, i, meta, t_lim=1000):
 def train_step(net, reducer, optimizer, inputs, labels, masks, feat, feat_masks, meta, i=0, pre_step=None):
     logits = net([inputs, feat, feat_masks, i, meta])
     cls_loss, loc_loss, probs = detection_loss(logits, labels, masks)
+    reducer.begin_pass()
     ((cls_loss + loc_loss) / 2).backward()
     reducer.finish()
     if pre_step is not None:       # warm-up learning rate is set before optimizer.step() (train_coarse_fineFEAT.py:274-277)

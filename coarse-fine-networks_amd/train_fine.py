@@ -115,39 +115,99 @@ def build_model(device, n_classes=NUM_CLASSES, pretrained=None, dropout=0.5, act
 
 def forward_backward(net, inputs, labels, masks, gamma_tau=5, mask_total=None):
     """forward + loss + backward of one shard (no collective when mask_total is given, no optimizer): the capturable part of a
-    data-parallel step (cfn_hip.graph.GraphedDPStep)"""
+    data-parallel step (cfn_hip.graph.GraphedDPStep).  With fp16 activations the loss is multiplied by the net's loss scale:
+    EVERY caller runs `post_reduce(net)` between the gradient reduction and the optimizer (train_step below does; GraphedDPStep takes it
+    as its `post_reduce` hook and captures it in front of the optimizer graph)."""
     masks_clip = masks[:, ::gamma_tau * 2]
     logits = net([inputs, masks_clip])
     cls_loss, loc_loss, probs = detection_loss(logits, labels, masks, True, mask_total=mask_total)
     loss = (cls_loss + loc_loss) / 2
-    (loss * loss_scale(net)).backward()          # (scale 1 unless the activations are fp16; unscale_grads() before the optimizer)
+    scaler = loss_scaler(net)
+    (loss if scaler is None else scaler.scale_loss(loss)).backward()
     return cls_loss.detach(), loc_loss.detach(), probs.detach()
 
 
 # fp16 activation path (x3d_fine act_dtype='fp16', BASELINE configs[4]): activation gradients are stored as IEEE half (5 exponent bits), so the
 # backward pass runs on a scaled loss; weight gradients accumulate in fp64 / fp32 and are divided by the scale before the optimizer step.
-# Static scale (gradients of this loss at the logits are ~1 / (B x 157 x T)).
+# Initial scale (gradients of this loss at the logits are ~1 / (B x 157 x T)); it is halved on the device whenever a gradient overflowed.
 LOSS_SCALE_FP16 = 4096.0
 
 
+class LossScaler(object):
+    """Loss scale of the fp16 path, kept ON THE DEVICE: no host synchronisation, so the whole sequence survives hipGraph capture.
+
+    `scale_loss` multiplies by the current scale; `unscale_` divides the gradients by it, and if ANY gradient is inf / nan (a half-stored
+    activation gradient saturated) it zeroes ALL of them -- the optimizer step that follows then applies momentum and weight decay only,
+    instead of poisoning the weights -- and halves the scale; after `interval` clean steps the scale doubles (torch's GradScaler rule,
+    `torch._amp_update_scale_`, without its `.item()`)."""
+
+    def __init__(self, device, init=LOSS_SCALE_FP16, backoff=0.5, growth=2.0, interval=2000):
+        self.scale = torch.full((1,), float(init), dtype=torch.float32, device=device)
+        self.found_inf = torch.zeros(1, dtype=torch.float32, device=device)
+        self.tracker = torch.zeros(1, dtype=torch.int32, device=device)
+        self.backoff, self.growth, self.interval = backoff, growth, interval
+
+    def scale_loss(self, loss):
+        return loss * self.scale.to(loss.dtype).squeeze(0)
+
+    def unscale_(self, params):
+        grads = [p.grad for p in params if p.grad is not None]
+        if not grads:
+            return
+        self.found_inf.zero_()
+        by_kind = {}
+        for g in grads:
+            by_kind.setdefault((g.device, g.dtype), []).append(g)
+        inv = self.scale.double().reciprocal().float()
+        for gs in by_kind.values():
+            torch._amp_foreach_non_finite_check_and_unscale_(gs, self.found_inf, inv)
+        keep = 1.0 - self.found_inf                      # 1 = clean step, 0 = an overflow somewhere
+        for g in grads:                                   # inf * 0 = nan: the non-finite entries go first
+            g.nan_to_num_(nan=0.0, posinf=0.0, neginf=0.0)
+        torch._foreach_mul_(grads, keep.squeeze(0))
+        torch._amp_update_scale_(self.scale, self.tracker, self.found_inf, self.growth, self.backoff, self.interval)
+
+
 def loss_scale(*nets):
+    """the INITIAL loss scale of a set of nets (1 unless one of them stores fp16 activations)"""
     return LOSS_SCALE_FP16 if any(getattr(n, 'act_dtype', None) == torch.float16 for n in nets) else 1.0
 
 
+def loss_scaler(*nets):
+    """the LossScaler shared by `nets` (created on first use, kept on the first fp16 net); None when no net stores fp16 activations"""
+    for n in nets:
+        if getattr(n, 'act_dtype', None) == torch.float16:
+            sc = getattr(n, '_cfn_loss_scaler', None)
+            if sc is None:
+                sc = LossScaler(next(n.parameters()).device)
+                object.__setattr__(n, '_cfn_loss_scaler', sc)
+            return sc
+    return None
+
+
 def unscale_grads(params, scale):
-    if scale != 1.0:
+    """scale: a LossScaler (overflow-checked, see there), None / 1.0 (nothing to do) or a plain factor"""
+    if isinstance(scale, LossScaler):
+        scale.unscale_(list(params))
+    elif scale is not None and scale != 1.0:
         grads = [p.grad for p in params if p.grad is not None]
         if grads:
             torch._foreach_mul_(grads, 1.0 / scale)
+
+
+def post_reduce(net):
+    """what has to run between the gradient reduction and optimizer.step() -- the other half of forward_backward's loss scale"""
+    unscale_grads(net.parameters(), loss_scaler(net))
 
 
 def train_step(net, reducer, optimizer, inputs, labels, masks, gamma_tau=5, pre_step=None):
     """one optimisation step on this rank's shard; returns (cls_loss, loc_loss, probs).  pre_step() runs between the
     gradient reduction and optimizer.step() -- where the reference adjusts the warm-up learning rate
     (train_fine.py:241-244)."""
+    reducer.begin_pass()
     cls_loss, loc_loss, probs = forward_backward(net, inputs, labels, masks, gamma_tau)
     reducer.finish()
-    unscale_grads(net.parameters(), loss_scale(net))
+    post_reduce(net)
     if pre_step is not None:
         pre_step()
     optimizer.step()

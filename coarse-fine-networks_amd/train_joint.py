@@ -99,10 +99,12 @@ def param_groups(fine, coarse, lr):
 def train_step(fine, coarse, reducer, optimizer, clip, labels, masks, pre_step=None):
     logits, _ = joint_forward(fine, coarse, clip)
     cls_loss, loc_loss, probs = tc.detection_loss(logits, labels, masks)
-    scale = train_fine.loss_scale(fine)            # fp16 fine tower (BASELINE configs[4]): static loss scale, see train_fine.LOSS_SCALE_FP16
-    (((cls_loss + loc_loss) / 2) * scale).backward()
+    scaler = train_fine.loss_scaler(fine)          # fp16 fine tower (BASELINE configs[4]): device-side loss scale, see train_fine.LossScaler
+    loss = (cls_loss + loc_loss) / 2
+    reducer.begin_pass()
+    (loss if scaler is None else scaler.scale_loss(loss)).backward()
     reducer.finish()
-    train_fine.unscale_grads([p for g in optimizer.param_groups for p in g['params']], scale)
+    train_fine.unscale_grads([p for g in optimizer.param_groups for p in g['params']], scaler)
     if pre_step is not None:
         pre_step()
     optimizer.step()

@@ -289,3 +289,68 @@ def test_gradient_accumulation_two_backwards_per_finish():
         for mode in ('plain', 'no_sync'):
             for g, r in zip(out[rank][mode], ref):
                 assert torch.allclose(g, r, rtol=1e-5, atol=1e-7), mode
+
+
+def _worker_begin_pass(rank, port, out):
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD), LOCAL_RANK=str(rank))
+    from cfn_hip import dist as cdist
+    import train_fine
+    cdist.init_from_env(backend='gloo')
+    x, labels, masks = _batch()
+    net = _model()
+    other = nn.Parameter(torch.ones(3))                                   # not one of the reducer's parameters
+    reducer = cdist.GradReducer(net.parameters(), bucket_bytes=256)
+    # a backward that raises drops the engine's end-of-pass callback: the reducer must not stay "inside a pass"
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError('boom')
+    try:
+        reducer.begin_pass()
+        (Boom.apply(net(x[:1])).sum() + net(x[:1]).sum()).backward()
+    except RuntimeError:
+        pass
+    net.zero_grad()
+    reducer.finish()                                                      # (both ranks: one collective per bucket, state back to idle)
+    assert not reducer._in_pass and reducer._begun == 0 and reducer._passes == 0
+    for _ in range(2):
+        net.zero_grad()
+        for mb in range(2):
+            i = rank * 2 + mb
+            reducer.begin_pass()
+            if rank == 1 and mb == 0:                                     # this rank's first pass yields NO gradient for any reducer parameter:
+                (other * 2.0).sum().backward()                            # no hook fires, no engine callback counts the pass here
+            else:
+                cls, loc, _ = train_fine.detection_loss(net(x[i:i + 1]), labels[i:i + 1], masks[i:i + 1], align_corners=False, local_norm=True)
+                ((cls + loc) / 4).backward()
+        reducer.finish()
+    out[rank] = [p.grad.clone() for p in net.parameters()]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_explicit_pass_count_is_rank_independent():
+    """the number of backward passes since the last finish() decides whether every bucket is sent again; counted from
+    autograd-engine callbacks it differs between ranks when one rank's pass produces no gradient for any reducer parameter (rank 0 would
+    re-send, rank 1 would not: mismatched collectives).  `begin_pass()` counts calls instead.  Also: a backward that raised leaves no state."""
+    sys.path.insert(0, PKG)
+    import train_fine
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker_begin_pass, args=(port, out), nprocs=WORLD, join=True)
+    x, labels, masks = _batch()
+    net = _model()
+    # rank 0 accumulated samples 0 and 1, rank 1 only sample 3; the reducer averages the per-rank sums over the 2 ranks (local_norm: rank 1 never
+    # enters detection_loss in its first pass, so the loss must not hold a collective of its own)
+    for i in (0, 1, 3):
+        cls, loc, _ = train_fine.detection_loss(net(x[i:i + 1]), labels[i:i + 1], masks[i:i + 1], align_corners=False, local_norm=True)
+        ((cls + loc) / 4).backward()
+    ref = [p.grad / WORLD for p in net.parameters()]
+    for rank in range(WORLD):
+        for g, r in zip(out[rank], ref):
+            assert torch.allclose(g, r, rtol=1e-5, atol=1e-7)

@@ -150,3 +150,36 @@ def test_learning_rate_steps_once_per_val_phase(which):
     trains = [s for s in seen if s[0] == 'train']
     assert len(trains) == per_val * 40 and abs(trains[0][2][0] - 0.02) <= 1e-12
     assert abs(vals[14][2][0] - 0.002) <= 1e-12 and abs(vals[13][2][0] - 0.02) <= 1e-12     # first decay after the 15th val phase
+
+
+def test_loss_scaler_unscales_and_survives_an_overflow():
+    """train_fine.LossScaler (fp16 activation path): clean gradients are divided by the scale; ONE inf / nan anywhere zeroes
+    every gradient (the step that follows moves nothing but momentum / weight decay) and halves the scale -- all on tensors, no .item()"""
+    import train_fine
+    sc = train_fine.LossScaler('cpu', init=1024.0, interval=2)
+    ps = [torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2, 2)), torch.nn.Parameter(torch.ones(1))]
+    for p in ps[:2]:
+        p.grad = torch.full_like(p, 2048.0)
+    assert float(sc.scale_loss(torch.tensor(0.5))) == 512.0
+    sc.unscale_(ps)                                   # (a parameter without a gradient is skipped)
+    assert all(bool((p.grad == 2.0).all()) for p in ps[:2]) and float(sc.scale) == 1024.0 and float(sc.found_inf) == 0.0
+    for p in ps[:2]:
+        p.grad = torch.full_like(p, 2048.0)
+    ps[1].grad[0, 0] = float('inf')
+    ps[0].grad[1] = float('nan')
+    sc.unscale_(ps)
+    assert all(bool((p.grad == 0.0).all()) for p in ps[:2]) and float(sc.scale) == 512.0 and float(sc.found_inf) == 1.0
+    for _ in range(2):                                # `interval` clean steps: the scale grows back
+        for p in ps[:2]:
+            p.grad = torch.full_like(p, 512.0)
+        sc.unscale_(ps)
+    assert float(sc.scale) == 1024.0 and bool((ps[0].grad == 1.0).all())
+    # the plain-factor and no-op spellings of unscale_grads
+    ps[0].grad = torch.full((3,), 8.0)
+    train_fine.unscale_grads(ps, 4.0)
+    assert bool((ps[0].grad == 2.0).all())
+    train_fine.unscale_grads(ps, None)
+    train_fine.unscale_grads(ps, 1.0)
+    assert bool((ps[0].grad == 2.0).all())
+    net = torch.nn.Linear(2, 2)
+    assert train_fine.loss_scaler(net) is None and train_fine.loss_scale(net) == 1.0
