@@ -154,6 +154,47 @@ def coarse_roofline(dev, B, T, steps=3, warmup=1):
             'coarse_ms_per_step': round(dt / steps * 1e3, 3)}
 
 
+def _flat(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for k in obj:
+            yield from _flat(obj[k])
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _flat(v)
+
+
+def staged_leg(step, resident, dev, steps, warmup, world):
+    """The same K steps with the inputs arriving from HOST memory every step: a pinned host copy of the batch is handed to
+    cfn_hip.staging.HostStager each step -- what a DataLoader(pin_memory=True) / a collate into pinned memory delivers -- and reaches HBM on the copy
+    stream one batch ahead of the step that consumes it.  Returns (seconds for `steps` steps, bytes per step)."""
+    from cfn_hip.staging import HostStager, _map_tensors
+    host = _map_tensors(resident, lambda t: t.detach().cpu().pin_memory())
+    stager = HostStager(dev)
+
+    def loader():
+        for _ in range(warmup + steps):
+            yield host
+    it = stager.stage(loader())
+    keep = []
+    for _ in range(warmup):
+        keep.append(step(next(it))[:2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        keep.append(step(next(it))[:2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    it.close()
+    assert all(float(v) == float(v) for pair in keep[-1:] for v in pair)
+    return dt, stager.bytes_staged // max(stager.batches, 1)
+
+
 def _self_launch(n):
     """`python bench.py --gpus N` outside torchrun: one rank per GPU under torch.distributed.run (as train_fine._spawn)"""
     import socket
@@ -184,7 +225,11 @@ def main():
                     help='storage type of activations / activation gradients (fine stream): f32 = the reference precision (the '
                          'headline), bf16 = BASELINE configs[1] (bf16 MFMA pointwise, fp32 accumulation and statistics), fp16 = BASELINE configs[4] (IEEE-half '
                          'storage, fp16 MFMA pointwise, static loss scale)')
-    ap.add_argument('--graph', action='store_true', help='replay the step from captured hipGraphs (one graph on a single GPU; with --gpus > 1: forward+backward graph, eager all-reduce, optimizer graph)')
+    ap.add_argument('--graph', action='store_true', help='replay the step from captured hipGraphs (one graph on a single GPU; with --gpus > 1: forward+backward graph, eager all-reduce, optimizer graph).  '
+                                                         'DEFAULT for --stream coarse / joint on one GPU (their eager step is host bound: ~1,200 launches in front of ~25 ms of kernels)')
+    ap.add_argument('--eager', action='store_true', help='--stream coarse / joint: launch every kernel from Python instead of replaying a hipGraph')
+    ap.add_argument('--staged', action='store_true', help='after the resident measurement, time the same steps with the inputs arriving from (pinned) HOST memory every step through '
+                                                          'cfn_hip.staging (copy stream, double buffered) and report pcie_inclusive_clips_per_s beside `value`')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-coarse-roofline', action='store_true', help='skip the coarse-stream roofline leg (figure B) of the default line')
     ap.add_argument('--cpu-sample-frames', type=int, default=None, help='frames of the CPU baseline clip (default: the metric\'s T -- no scaling; a shorter sample is scaled linearly and says so)')
@@ -192,6 +237,9 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(_self_launch(args.gpus))
     coarse, joint = args.stream == 'coarse', args.stream == 'joint'
+    if (coarse or joint) and args.gpus == 1 and not args.eager:
+        args.graph = True
+    assert not (args.graph and args.eager), '--graph and --eager exclude each other'
     assert not (coarse and args.dtype != 'f32'), 'the bf16 activation path covers the fine stream'
     if args.frames is None:
         args.frames = 64 if coarse else (128 if joint else 256)
@@ -237,12 +285,16 @@ def main():
     cdist.sync_module(net)            # one model on every rank, as under DataParallel
     reducer = cdist.GradReducer([p for gr in groups for p in gr['params']] if joint else net.parameters())
 
-    def step():
+    resident = (x, labels, masks, feat, fm, meta) if coarse else (x, labels, masks)
+
+    def step(inp=None):
+        inp = resident if inp is None else inp
         if joint:
-            return tj.train_step(fine_net, net, reducer, optimizer, x, labels, masks)
+            return tj.train_step(fine_net, net, reducer, optimizer, *inp)
         if coarse:
-            return tc.train_step(net, reducer, optimizer, x, labels, masks, feat, fm, meta)
-        return train_fine.train_step(net, reducer, optimizer, x, labels, masks)
+            return tc.train_step(net, reducer, optimizer, *inp)
+        return train_fine.train_step(net, reducer, optimizer, *inp)
+
 
     if args.graph and world > 1:
         # two hipGraphs around the eager bucketed all-reduce (cfn_hip/graph.py GraphedDPStep): fine stream only
@@ -251,14 +303,16 @@ def main():
         graphed = GraphedDPStep(lambda x_, l_, m_, tot: train_fine.forward_backward(net, x_, l_, m_, mask_total=tot)[:2], reducer, optimizer,
                                 pre=lambda x_, l_, m_: (cdist.global_mask_count(m_),), post_reduce=lambda: train_fine.post_reduce(net))
 
-        def step():
-            return tuple(v.clone() for v in graphed(x, labels, masks))
+        def step(inp=None):
+            return tuple(v.clone() for v in graphed(*(resident if inp is None else inp)))
     elif args.graph:
         from cfn_hip.graph import GraphedStep
         eager_step = step
         graphed = GraphedStep(lambda: eager_step()[:2], optimizer=optimizer)
 
-        def step():                   # static loss buffers are overwritten by the next replay: keep copies
+        def step(inp=None):           # static loss buffers are overwritten by the next replay: keep copies
+            if inp is not None:       # staged batch -> the graph's resident input tensors (device to device, on the step's stream)
+                torch._foreach_copy_(list(_flat(resident)), list(_flat(inp)), non_blocking=True)
             return tuple(v.clone() for v in graphed())
 
     losses = []                       # device scalars; read after the timed region (no sync inside it)
@@ -288,6 +342,13 @@ def main():
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
+    staged = None
+    if args.staged:
+        sdt, sbytes = staged_leg(step, resident, dev, args.steps, max(args.warmup, 2), world)
+        st = torch.tensor([sdt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        staged = (float(st.item()), sbytes)
     loss_first = [float(v) for v in losses[0]]
     loss_last = [float(v) for v in losses[-1]]
     assert all(v == v and abs(v) != float('inf') for v in loss_first + loss_last), ('non-finite loss', loss_first, loss_last)
@@ -349,7 +410,16 @@ def main():
                          'launches': launches, 'avg_launch_ms': round(ms / max(launches, 1), 4),
                          'algorithmic_bytes_per_launch': round(by / max(launches, 1))},
         }
-        if world == 1 and args.stream == 'fine' and args.dtype == 'f32' and not args.graph and not args.no_coarse_roofline:
+        if staged is not None:
+            sdt, sbytes = staged
+            out['pcie_inclusive_clips_per_s'] = round(world * B * args.steps / sdt, 4)
+            out['staged'] = {'ms_per_step': round(sdt / args.steps * 1e3, 3), 'host_bytes_per_step_per_gpu': int(sbytes),
+                             'h2d_GBps_needed': round(sbytes / (sdt / args.steps) / 1e9, 2),
+                             'vs_resident': round((sdt / args.steps) / (dt / args.steps), 4),
+                             'note': 'inputs (clip, labels, masks%s) leave PINNED host memory every step through cfn_hip.staging: one device slab per batch, '
+                                     'copy stream, double buffered, event ordered (no host synchronisation); `value` above is the resident measurement'
+                                     % (', 5 fine feature maps, feature masks, meta' if coarse else '')}
+        if world == 1 and args.stream == 'fine' and args.dtype == 'f32' and not args.graph and not args.no_coarse_roofline and not args.staged:
             del losses
             net = optimizer = reducer = x = labels = masks = None          # the fine step's tensors go back to the allocator first
             torch.cuda.empty_cache()

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64 * PWB_WAVES) void pwb_kernel(const PwbArgs a) {
                         if (odd_w) o += pwb_lo((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rac, ao2 + row * (int)accP * 2, 0, 0));
                         if (STATS) {                                         // act' epilogue + prologue-coefficient gradients
                             const unsigned xp = xq[r];
-                            const float2 c = sE[row];
+                            const float2 c = cfn_settle(sE[row]);                // (even / odd position: one packed FMA behind the LDS read, see cfn_settle)
                             const float xe = pwb_lo(xp), xo = pwb_hi(xp);
                             const float de = cv ? e * cfn_act_grad<ACT>(fmaf(xe, c.x, c.y)) : 0.0f;
                             const float dn = cv ? o * cfn_act_grad<ACT>(fmaf(xo, c.x, c.y)) : 0.0f;

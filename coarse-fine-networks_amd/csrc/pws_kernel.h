@@ -436,7 +436,8 @@ __global__ __launch_bounds__(64 * PWS_WAVES) void pws_kernel(const PwArgs a) {
                                 if (NP == 2) t2[i] = fmaf(em, em, t2[i]);
                             }
                         } else if (STATS) {                                  // act' epilogue + prologue-coefficient gradients
-                            const float2 c = sE[row];
+                            // (NP = 2: the two positions' fma(x, A, B) become ONE packed FMA taking B from the high register of the pair just read)
+                            const float2 c = NP == 2 ? cfn_settle(sE[row]) : sE[row];
                             const float xe = xq[r][p];
                             const float de = (FULL || cv) ? e * cfn_act_grad<ACT>(fmaf(xe, c.x, c.y)) : 0.0f;
                             t1[i] = fmaf(de, xe, t1[i]); t2[i] += de;

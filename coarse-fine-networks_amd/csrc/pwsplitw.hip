@@ -356,7 +356,8 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
     // wave that converts while the other wave of its SIMD multiplies, the packed FMA behind `ds_read_b64/b96 coefficient; s_waitcnt lgkmcnt(0)` saw
     // the high register of the returned pair as zero in lanes 48-63 (a = swish(A x) instead of swish(A x + B), g' without its 2 gq y term).
     // (SM = 4 variants -- 96 accumulator + 96 operand registers -- would spill 40-126 registers with 20 more live ones: they keep the table reads;
-    // all their waves own tiles and convert in the same phase, see `uneven` below)
+    // all their waves own tiles and convert in the same phase, see `uneven` below; round 6: what they read passes through cfn_settle, so no packed
+    // instruction is the first reader of a just-returned LDS pair -- tools/pkfma_ldsret_scan.py finds no class-S site inside an MFMA loop any more)
     constexpr bool KREG = SM <= 2;
     float4 kG[KREG ? SM : 1];
     float2 kX[KREG ? SM : 1];
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
 #pragma unroll
         for (int i = 0; i < SM; ++i) {
             if (ldsG[i] >= 0) {
-                const float4 c = KREG ? kG[KREG ? i : 0] : cG[(tid + PWSS_THREADS * i) >> 3];
+                const float4 c = KREG ? kG[KREG ? i : 0] : cfn_settle3(cG[(tid + PWSS_THREADS * i) >> 3]);
                 const float c0 = c.x * vm0;
                 float v[4];
 #pragma unroll
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(PWSS_THREADS) void pws_wgrad_staged_kernel(const Ws
                     *reinterpret_cast<uint2*>(buf + sp * gimg + ldsG[i]) = uint2{p0[sp], p1[sp]};
             }
             if (ldsX[i] >= 0) {
-                const float2 c = KREG ? kX[KREG ? i : 0] : cX[(tid + PWSS_THREADS * i) >> 3];
+                const float2 c = KREG ? kX[KREG ? i : 0] : cfn_settle(cX[(tid + PWSS_THREADS * i) >> 3]);
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = cfn_act<ACT>(fmaf(xx[i][e], c.x, c.y));

@@ -24,6 +24,7 @@ import torch.optim as optim
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import x3d_coarse                                 # noqa: E402
+from cfn_hip import staging                       # noqa: E402
 from cfn_hip import dist as cdist                 # noqa: E402
 from apmeter import APMeter                       # noqa: E402
 from train_fine import lr_warmup                  # noqa: E402
@@ -163,6 +164,9 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
     if rank == 0 and csv_path:
         write_file = open(csv_path, 'w', newline='\n')
         writer = csv.writer(write_file)
+    # clip, labels, masks, the five fine feature maps, their masks and meta travel as ONE pinned slab on a copy stream, one batch ahead of the
+    # step (the reference: a synchronous `.cuda()` per tensor, train_coarse_fineFEAT.py:205-224); the `.to(dev)` calls below are then no-ops
+    stager = staging.HostStager(dev) if dev.type == 'cuda' else None
     steps, epochs = 0, 0
     while epochs < max_epochs:
         for phase in 2 * ['train'] + ['val']:
@@ -176,7 +180,7 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
             tot_loc = tot_cls = 0.0
             n_it = 0
             val_rows = []
-            for i, (inputs, labels, masks, feat, feat_masks, meta, name, dur) in enumerate(dataloaders[phase]):
+            for i, (inputs, labels, masks, feat, feat_masks, meta, name, dur) in enumerate(stager.stage(dataloaders[phase]) if stager else dataloaders[phase]):
                 if train:     # collective skip of a short last batch (:193-194)
                     ok = inputs.shape[0] == local_bs
                     if not (cdist.all_agree(ok, dev) if world > 1 else ok):

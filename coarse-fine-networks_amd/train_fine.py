@@ -26,6 +26,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import x3d_fine                                   # noqa: E402
 from cfn_hip import dist as cdist                 # noqa: E402
+from cfn_hip import staging                       # noqa: E402
 from apmeter import APMeter                       # noqa: E402
 
 BS = 8
@@ -244,6 +245,9 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
     lr_sched = optim.lr_scheduler.MultiStepLR(optimizer, [15, 20, 25])
     reducer = cdist.GradReducer(net.parameters())
     tr_apm, val_apm = APMeter(), APMeter()
+    # batches reach HBM through a pinned slab on a copy stream, one batch ahead of the step (the reference: a synchronous `.cuda()` per tensor
+    # in front of every step, train_fine.py:184-197); the `.to(dev)` calls below are no-ops on staged batches
+    stager = staging.HostStager(dev) if dev.type == 'cuda' else None
     steps, epochs = 0, 0
     while epochs < max_epochs:
         for phase in 4 * ['train'] + ['val']:
@@ -257,7 +261,7 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_epochs=200, mode='rgb', root=None, 
             tot_loc = tot_cls = 0.0
             n_it = 0
             val_rows = []
-            for inputs, labels, masks, _name in dataloaders[phase]:
+            for inputs, labels, masks, _name in (stager.stage(dataloaders[phase]) if stager else dataloaders[phase]):
                 want = local_bs if train else val_bs
                 ok = inputs.shape[0] == want
                 if train:      # the skip is a collective decision: no rank may leave the others alone in an all-reduce

@@ -25,6 +25,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import x3d_fine                                   # noqa: E402
 import train_coarse_fineFEAT as tc
 import train_fine                # noqa: E402
+from cfn_hip import staging                       # noqa: E402
 from cfn_hip import dist as cdist                 # noqa: E402
 from train_fine import lr_warmup                  # noqa: E402
 
@@ -127,7 +128,8 @@ def run(init_lr=INIT_LR, warmup_steps=0, max_steps=None, batch_size=BS, fine_fra
     fine.train(True)
     coarse.train(True)
     steps = 0
-    for clip, labels, masks in dataloader:
+    # (the clip, labels and masks reach HBM one batch ahead of the step, on a copy stream: cfn_hip/staging.py)
+    for clip, labels, masks in staging.stage(dataloader, dev):
         ok = clip.shape[0] == local_bs
         if not (cdist.all_agree(ok, dev) if world > 1 else ok):
             continue

@@ -427,3 +427,56 @@ def test_graphed_dp_step_equals_eager_step(act):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_host_stager_delivers_batches_in_order_and_intact():
+    """cfn_hip.staging.HostStager: nested batches (tuple / dict / strings) of pageable and pinned host tensors of several
+    dtypes arrive on the device bit for bit and in order while earlier batches are still being consumed by (slow) kernels; slabs grow; a loader
+    that raises surfaces in the consumer; an abandoned pass leaves the stager reusable; a staged train step equals the resident one."""
+    from cfn_hip.staging import HostStager
+    g = torch.Generator().manual_seed(0)
+
+    def batch(i, n):
+        b = (torch.randn(n, 3, 4, 8, 8, generator=g), (torch.rand(n, 5, generator=g) < 0.5).float(), {'a': torch.randn(n, 7, generator=g), 'm': torch.arange(n * 4).view(n, 4) + i},
+             ['name%d' % i] * n, torch.randn(n, 6, generator=g).to(torch.bfloat16), torch.zeros(0))
+        if i % 2:          # every other batch: pinned where possible
+            b = (b[0].pin_memory(), b[1], {k: v.pin_memory() for k, v in b[2].items()}, b[3], b[4], b[5])
+        return b
+    batches = [batch(i, 2 + 3 * (i % 3) + (40 if i == 4 else 0)) for i in range(9)]      # batch 4 outgrows the slabs
+    st = HostStager(DEV)
+    busy = torch.randn(4096, 4096, device=DEV)
+    got = []
+    for b in st.stage(batches):
+        for _ in range(3):
+            busy = torch.tanh(busy @ busy * 1e-4)          # keep the compute stream behind the producer
+        got.append((b[0] * 1.0, b[1].clone(), {k: v.clone() for k, v in b[2].items()}, b[3], b[4].clone(), b[5]))
+    assert len(got) == len(batches) and st.batches == len(batches)
+    for h, d in zip(batches, got):
+        assert torch.equal(h[0], d[0].cpu()) and torch.equal(h[1], d[1].cpu()) and d[3] == h[3] and torch.equal(h[4], d[4].cpu())
+        assert all(torch.equal(h[2][k], d[2][k].cpu()) for k in h[2]) and d[2]['m'].dtype == torch.int64
+        assert d[0].is_cuda and d[5].numel() == 0
+
+    def bad():
+        yield batches[0]
+        raise ValueError('loader failed')
+    with pytest.raises(ValueError):
+        for _ in st.stage(bad()):
+            pass
+    it = st.stage(batches)               # abandoned after one batch ...
+    next(it)
+    it.close()
+    assert sum(1 for _ in st.stage(batches[:3])) == 3      # ... and the stager still works
+    # a staged step == the resident step
+    import copy
+    import torch.optim as optim
+    import train_fine
+    from cfn_hip import dist as cdist
+    torch.manual_seed(0)
+    net = train_fine.build_model(DEV, pretrained=None, dropout=0.0).train(True)
+    net2 = copy.deepcopy(net)
+    data = [(x.view((x.shape[0],) + tuple(x.shape[2:])), l, m) for x, l, m, _ in train_fine.SyntheticCharades(2, 3, frames=8, crop=64)]
+    o1, o2 = (optim.SGD(n.parameters(), lr=0.01, momentum=0.9) for n in (net, net2))
+    r1, r2 = cdist.GradReducer(net.parameters()), cdist.GradReducer(net2.parameters())
+    l1 = [float(train_fine.train_step(net, r1, o1, *[t.to(DEV) for t in b])[1]) for b in data]
+    l2 = [float(train_fine.train_step(net2, r2, o2, *b)[1]) for b in st.stage(data)]
+    assert l1 == l2

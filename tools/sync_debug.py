@@ -43,4 +43,17 @@ torch.cuda.synchronize()
 torch.cuda.set_sync_debug_mode("warn")
 print("=== joint step"); tj.train_step(fine_net, net2, jred, jopt, xj, labj, mj)
 torch.cuda.set_sync_debug_mode("default"); torch.cuda.synchronize(); jred.close()
+# staged inputs (cfn_hip/staging.py): pageable AND pinned host batches through the copy stream; the consumer's thread must not synchronise either
+from cfn_hip.staging import HostStager
+stager = HostStager(dev)
+host_pageable = (xc.cpu(), labels.cpu(), masks.cpu(), {k: v.cpu() for k, v in feat.items()}, fm.cpu(), meta.cpu())
+host_pinned = tuple({k: v.pin_memory() for k, v in t.items()} if isinstance(t, dict) else t.pin_memory() for t in host_pageable)
+cred = cdist.GradReducer(cn.parameters())
+it = stager.stage([host_pageable, host_pinned, host_pageable, host_pinned])
+tc.train_step(cn, cred, copt, *next(it))
+torch.cuda.synchronize()
+torch.cuda.set_sync_debug_mode("warn")
+print("=== coarse steps on staged batches (pinned, pageable, pinned)")
+for batch in it: tc.train_step(cn, cred, copt, *batch)
+torch.cuda.set_sync_debug_mode("default"); torch.cuda.synchronize(); cred.close()
 print("done")
