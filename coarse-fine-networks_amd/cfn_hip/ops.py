@@ -61,25 +61,9 @@ class _GradCast(object):
     def __init__(self):
         self._reset()
         self.last_total = 0
-        # side streams that hold weight-gradient launches of the running pass (_side_wgrad).  Kept HERE, not in the thread-local state: the
-        # hand-outs happen on the autograd engine's worker thread, the end-of-pass flush on the thread that called backward()
-        self.side, self.side_busy = {}, set()
 
     def _reset(self):
         self.cur, self.live, self.scheduled, self.seen, self.task = {}, [], False, set(), None
-
-    def side_stream(self, dev):
-        key = (dev.type, dev.index)
-        st = self.side.get(key)
-        if st is None:
-            st = self.side[key] = torch.cuda.Stream(device=dev)
-        return st
-
-    def join_side_streams(self):
-        """the current stream (of each device that has side work pending) waits for it"""
-        for key in list(self.side_busy):
-            torch.cuda.current_stream(torch.device(key[0], key[1])).wait_stream(self.side[key])
-        self.side_busy.clear()
 
     def begin(self):
         """called before every hand-out: a new autograd graph task means a new pass"""
@@ -114,7 +98,6 @@ class _GradCast(object):
         return ch['f64'][o:o + numel], ch['f32'][o:o + numel].view(shape)
 
     def flush(self):
-        self.join_side_streams()   # weight gradients that were computed on the side stream (see _side_wgrad) land in the fp64 chunks first
         for ch in self.live:
             if ch['off'] > ch['done']:
                 ch['f32'][ch['done']:ch['off']].copy_(ch['f64'][ch['done']:ch['off']])
@@ -138,40 +121,6 @@ class _PerThread(threading.local):
 
 _tls = _PerThread()
 LAZY_GRAD_CAST = True     # set False to cast every weight gradient immediately (one small kernel each)
-
-# Weight gradients on a SIDE STREAM (round 6).  Nothing inside a backward pass reads a pointwise conv's weight gradient: its only consumer is
-# the end-of-pass cast (_GradCast.flush).  The backward chain on the main stream, on the other hand, is a strict dependency chain that holds
-# ~130 single-workgroup kernels per step (bn_fold_bwd between every two convs, the fixed-order reduce of the staged weight gradient: 8-11 us
-# each with 255 CUs idle, ~1.4 ms per fine step).  With CFN_WGRAD_STREAM=1 (default) the stand-alone weight-gradient launches of layers 2-4
-# go to a per-(thread, device) side stream, forked behind the kernels that produced their inputs and joined by the flush, so their
-# workgroups fill those holes.  Only when the gradient is handed out lazily (otherwise the immediate cast would have to wait for it anyway),
-# never during hipGraph capture (record_stream and private pools do not mix) and never in deterministic mode (its commit drains the device
-# per entry point).
-import os as _os
-WGRAD_STREAM = _os.environ.get('CFN_WGRAD_STREAM', '1') != '0'
-
-
-def _side_ok(dev):
-    if not WGRAD_STREAM or dev.type != 'cuda' or torch.cuda.is_current_stream_capturing():
-        return False
-    from . import deterministic
-    return not deterministic()
-
-
-def _side_wgrad(dev, tensors, launch):
-    """run `launch()` (which enqueues on the current stream) on the side stream of `dev`, behind everything enqueued so far on the current one;
-    `tensors`: what the launch reads / writes -- the caching allocator must not hand their memory out again before the side stream is done"""
-    gc = _tls.gradcast
-    cur = torch.cuda.current_stream(dev)
-    side = gc.side_stream(dev)
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        launch()
-    for t in tensors:
-        if t is not None:
-            t.record_stream(side)
-    gc.side_busy.add((dev.type, dev.index))
-
 
 
 def _f64(n, c, dev):
@@ -235,9 +184,7 @@ def _gw_buffers(w, rows, cols, dev):
         gc.begin()
         if gc.first_use(w):
             g64, g32 = gc.take(rows * cols, tuple(w.shape), dev)
-            fin = (lambda: g32)
-            fin.lazy = True            # the gradient is only read behind _GradCast.flush: its kernel may run on the side stream
-            return g64.view(rows, cols), fin
+            return g64.view(rows, cols), (lambda: g32)
         # second gradient of the same parameter in this pass: autograd is about to ADD it to the view handed out for the
         # first one -- fill that view now (its accumulation was enqueued before this call), and cast this one eagerly
         gc.flush()
@@ -380,12 +327,7 @@ class _PwConv(Function):
             if g64 is None:
                 g64, fin = _gw_buffers(ctx.wparam, Cout, Cin, x.device)
             if not fused:
-                def wgrad():
-                    call('cfn_pwconv_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, Cin, Cout, T, H, W, stride, gsc)
-                if getattr(fin, 'lazy', False) and min(Cin, Cout) >= 48 and _side_ok(x.device):
-                    _side_wgrad(x.device, (gy, y, gs, gq, x, A, B, g64, gsc), wgrad)
-                else:
-                    wgrad()
+                call('cfn_pwconv_bwd_weight', gy, y, gs, gq, x, A, B, act, g64, N, Cin, Cout, T, H, W, stride, gsc)
             gw = fin()
         return gx, gA, gB, gw, None, None, None, None, None, None, None
 
