@@ -27,10 +27,11 @@ from . import call, call_try, check, load, ACT_NONE  # noqa: F401
 
 _lib = 'cfn'
 
-# Native registration (csrc/torch/cfn_torch.cpp -> cfn_hip/libcfn_torch.so, built by __graft_entry__.build()): the hot path's operators --
-# cfn::dwconv3d, cfn::pwconv, cfn::time_sample and their backward operators -- are defined and implemented by TORCH_LIBRARY inside a shared
-# library.  When it is present the Python definitions of those six operators below are skipped; their fake implementations and
-# autograd formulas are attached to the native operators.  CFN_NATIVE_OPS=0: Python custom_op definitions for everything (the round-3/4 route).
+# Native registration (csrc/torch/cfn_torch.cpp -> cfn_hip/libcfn_torch.so, built by __graft_entry__.build()): ALL 16 forward + 16 backward
+# operators of the set are defined and implemented by TORCH_LIBRARY inside a shared library (round 5: dwconv3d / pwconv /
+# time_sample, round 6: the other 13 pairs).  When it is present the Python definitions below are skipped; their fake implementations and
+# autograd formulas are attached to the native operators.  CFN_NATIVE_OPS=0: Python custom_op definitions over ctypes for everything (the
+# round-3/4 route; also what serves 16-bit tensors through bn_add_relu / pool_hw / dwconv_t5 -- the native operators are fp32).
 NATIVE_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libcfn_torch.so')
 NATIVE = False
 if os.environ.get('CFN_NATIVE_OPS', '1') != '0' and os.path.exists(NATIVE_LIB):
@@ -312,7 +313,8 @@ def _gz(g, like, dtype=None):
 
 
 def _op(name, **kw):
-    return torch.library.custom_op(_lib + '::' + name, mutates_args=kw.pop('mutates_args', ()), device_types='cuda', **kw)
+    """round 6: these 26 operators are native too (csrc/torch/cfn_torch.cpp); the Python bodies below are what CFN_NATIVE_OPS=0 registers"""
+    return _custom_or_native(_lib + '::' + name, mutates_args=kw.pop('mutates_args', ()), device_types='cuda', **kw)
 
 
 # ---- conv1_t: depthwise 5x1x1 ------------------------------------------------------------------------------------------------
