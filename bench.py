@@ -222,7 +222,7 @@ def main():
     ap.add_argument('--frames', type=int, default=None, help='default 256 (fine) / 64 (coarse) / 128 fine frames (joint)')
     ap.add_argument('--batch', type=int, default=8, help='clips per GPU per step')
     ap.add_argument('--dtype', choices=('f32', 'bf16', 'fp16'), default='f32',
-                    help='storage type of activations / activation gradients (fine stream): f32 = the reference precision (the '
+                    help='storage type of activations / activation gradients (fine stream; coarse stream: stem + layer 1): f32 = the reference precision (the '
                          'headline), bf16 = BASELINE configs[1] (bf16 MFMA pointwise, fp32 accumulation and statistics), fp16 = BASELINE configs[4] (IEEE-half '
                          'storage, fp16 MFMA pointwise, static loss scale)')
     ap.add_argument('--graph', action='store_true', help='replay the step from captured hipGraphs (one graph on a single GPU; with --gpus > 1: forward+backward graph, eager all-reduce, optimizer graph).  '
@@ -240,7 +240,6 @@ def main():
     if (coarse or joint) and args.gpus == 1 and not args.eager:
         args.graph = True
     assert not (args.graph and args.eager), '--graph and --eager exclude each other'
-    assert not (coarse and args.dtype != 'f32'), 'the bf16 activation path covers the fine stream'
     if args.frames is None:
         args.frames = 64 if coarse else (128 if joint else 256)
 
@@ -258,7 +257,7 @@ def main():
     g = torch.Generator().manual_seed(1234 + rank)
     if joint:
         import train_joint as tj
-        fine_net, net = tj.build_models(dev, fine_act_dtype=args.dtype)
+        fine_net, net = tj.build_models(dev, fine_act_dtype=args.dtype, coarse_act_dtype=args.dtype)
         groups = tj.param_groups(fine_net, net, 0.02)
         optimizer = optim.SGD(groups, lr=0.02, momentum=0.9, weight_decay=1e-5)
         x = torch.randn(B, 3, T, 224, 224, generator=g).to(dev)
@@ -268,7 +267,7 @@ def main():
         fine_net.train(True)
         cdist.sync_module(fine_net)
     elif coarse:
-        net = tc.build_model(dev, pretrained=None)
+        net = tc.build_model(dev, pretrained=None, act_dtype=args.dtype)
         optimizer = optim.SGD(tc.param_groups(net, 0.02), lr=0.02, momentum=0.9, weight_decay=1e-5)
         x, labels, masks, feat, fm, meta, _, _ = next(iter(tc.SyntheticCoarse(B, 1, T, seed=1234 + rank)))
         x = x[:, 0].contiguous().to(dev)
@@ -404,7 +403,9 @@ def main():
                            ('fp16 (IEEE half) activations / activation gradients with a static loss scale, v_mfma_f32_32x32x16_f16 pointwise products, '
                             'fp32 weights, statistics and accumulation' if args.dtype == 'fp16' else
                             'bf16 activations / activation gradients, fp32 weights, statistics and accumulation')
-                           + (' (Fine tower; the Coarse stream and the fusion stay fp32)' if joint else '')),
+                           + (' (Fine tower, and the stem + layer 1 of the Coarse stream -- every tensor with the clip\'s full frame count; Grid Pool, layers 2-4 at '
+                              'T/4 + 1 frames, the fusion and the heads stay fp32)' if joint else
+                              (' (stem + layer 1, the full-frame-count part of the stream; Grid Pool, layers 2-4 at T/4 + 1 frames, fusion and head stay fp32)' if coarse else ''))),
             'config': {'workload': workload, 'clips_per_gpu': B, 'frames': T, 'parallelism': 'dp%d' % world,
                        'launch': ('hipGraph replay' if args.graph else 'eager') +
                                  (' (two graphs around an eager bucketed all-reduce: the all-reduce runs AFTER the replayed backward, not '

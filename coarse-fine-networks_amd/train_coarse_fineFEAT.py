@@ -80,10 +80,11 @@ def detection_loss(per_frame_logits, labels, masks, group=None, crops=1, local_n
     return _loss(per_frame_logits, labels, masks, False, group, crops, local_norm)
 
 
-def build_model(device, n_classes=NUM_CLASSES, pretrained=None, dropout=0.5):
+def build_model(device, n_classes=NUM_CLASSES, pretrained=None, dropout=0.5, act_dtype=None):
+    """act_dtype 'bf16' / 'fp16': 16-bit stem + layer 1 (x3d_coarse.ResNet); None / 'f32': the reference's fp32"""
     net = x3d_coarse.generate_model(x3d_version=X3D_VERSION, n_classes=400, n_input_channels=3, feat_depth=FEAT_DEPTH,
                                     task='loc', dropout=dropout, base_bn_splits=1, learnedMixing=True, isMixing=True,
-                                    t_pool='grid')
+                                    t_pool='grid', act_dtype=act_dtype)
     if pretrained:      # a missing file raises, as in the reference (train_coarse_fineFEAT.py:112)
         ckpt = torch.load(pretrained, map_location='cpu')
         state = net.state_dict()
@@ -117,9 +118,13 @@ def forward_video(net, inputs, feat, feat_masks, i, meta, t_lim=1000):
 def train_step(net, reducer, optimizer, inputs, labels, masks, feat, feat_masks, meta, i=0, pre_step=None):
     logits = net([inputs, feat, feat_masks, i, meta])
     cls_loss, loc_loss, probs = detection_loss(logits, labels, masks)
+    from train_fine import loss_scaler, unscale_grads
+    scaler = loss_scaler(net)      # fp16 stem + layer 1: device-side loss scale (train_fine.LossScaler); None otherwise
+    loss = (cls_loss + loc_loss) / 2
     reducer.begin_pass()
-    ((cls_loss + loc_loss) / 2).backward()
+    (loss if scaler is None else scaler.scale_loss(loss)).backward()
     reducer.finish()
+    unscale_grads(net.parameters(), scaler)
     if pre_step is not None:       # warm-up learning rate is set before optimizer.step() (train_coarse_fineFEAT.py:274-277)
         pre_step()
     optimizer.step()

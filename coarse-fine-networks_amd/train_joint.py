@@ -53,7 +53,7 @@ class SyntheticJoint(object):
             yield x, labels, torch.ones(self.bs, tl)
 
 
-def build_models(device, pretrained_fine=None, pretrained_coarse=None, dropout=0.5, fine_act_dtype=None):
+def build_models(device, pretrained_fine=None, pretrained_coarse=None, dropout=0.5, fine_act_dtype=None, coarse_act_dtype=None):
     """(fine tower, coarse net).  The tower has no classifier of its own on this path (fc1 / fc2 get no gradient).
     fine_act_dtype='fp16' / 'bf16': the Fine stream -- 2/3 of the joint step's bytes and flops -- stores its activations as IEEE half / bf16 and
     runs its pointwise convs on v_mfma_f32_32x32x16_{f16,bf16} (BASELINE configs[4] "fp16 MFMA pointwise"; both kinds run at the same MFMA rate
@@ -64,7 +64,9 @@ def build_models(device, pretrained_fine=None, pretrained_coarse=None, dropout=0
         state = fine.state_dict()
         state.update(torch.load(pretrained_fine, map_location='cpu')['model_state_dict'])
         fine.load_state_dict(state)
-    coarse = tc.build_model(device, pretrained=pretrained_coarse, dropout=dropout)
+    # coarse_act_dtype: the stem + layer 1 of the Coarse stream in 16 bits as well (x3d_coarse.ResNet) -- the joint step then runs 16-bit in both
+    # trunks wherever a tensor has the clip's full frame count
+    coarse = tc.build_model(device, pretrained=pretrained_coarse, dropout=dropout, act_dtype=coarse_act_dtype)
     return fine.to(device), coarse
 
 
@@ -100,7 +102,7 @@ def param_groups(fine, coarse, lr):
 def train_step(fine, coarse, reducer, optimizer, clip, labels, masks, pre_step=None):
     logits, _ = joint_forward(fine, coarse, clip)
     cls_loss, loc_loss, probs = tc.detection_loss(logits, labels, masks)
-    scaler = train_fine.loss_scaler(fine)          # fp16 fine tower (BASELINE configs[4]): device-side loss scale, see train_fine.LossScaler
+    scaler = train_fine.loss_scaler(fine, coarse)  # fp16 fine tower / fp16 coarse layer 1 (BASELINE configs[4]): device-side loss scale, see train_fine.LossScaler
     loss = (cls_loss + loc_loss) / 2
     reducer.begin_pass()
     (loss if scaler is None else scaler.scale_loss(loss)).backward()
@@ -114,12 +116,12 @@ def train_step(fine, coarse, reducer, optimizer, clip, labels, masks, pre_step=N
 
 
 def run(init_lr=INIT_LR, warmup_steps=0, max_steps=None, batch_size=BS, fine_frames=128, coarse_frames=64, dataloader=None,
-        pretrained_fine=None, pretrained_coarse=None, save_model='models/joint_charades_', log=print, fine_act_dtype=None):
+        pretrained_fine=None, pretrained_coarse=None, save_model='models/joint_charades_', log=print, fine_act_dtype=None, coarse_act_dtype=None):
     rank, world, dev = cdist.init_from_env()
     local_bs = max(batch_size // world, 1)
     if dataloader is None:
         dataloader = SyntheticJoint(local_bs, tc.CHARADES_TR_SIZE // batch_size, fine_frames, coarse_frames, seed=rank)
-    fine, coarse = build_models(dev, pretrained_fine, pretrained_coarse, fine_act_dtype=fine_act_dtype)
+    fine, coarse = build_models(dev, pretrained_fine, pretrained_coarse, fine_act_dtype=fine_act_dtype, coarse_act_dtype=coarse_act_dtype)
     cdist.sync_module(fine)
     cdist.sync_module(coarse)
     groups = param_groups(fine, coarse, init_lr)

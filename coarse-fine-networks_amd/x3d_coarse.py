@@ -278,7 +278,11 @@ class ResNet(x3d_fine.ResNet):
 
     def __init__(self, block, layers, block_inplanes, n_input_channels=3, feat_depth={}, conv1_t_size=7,
                  conv1_t_stride=1, shortcut_type='B', widen_factor=1.0, dropout=0.5, n_classes=400, base_bn_splits=8,
-                 task='class', extract_feat=False, t_pool=None, learnedMixing=False, isMixing=False):
+                 task='class', extract_feat=False, t_pool=None, learnedMixing=False, isMixing=False, act_dtype=None):
+        # act_dtype (an addition to the reference's signature, as in x3d_fine): 'bf16' / 'fp16' = the stem's temporal conv and layer 1 -- the part of
+        # the coarse stream that runs at the clip's full frame count, ~3/4 of its bytes -- store their activations and activation gradients as 2-byte
+        # elements (16-bit MFMA pointwise products, fp32 accumulation / statistics / weights); the output of layer 1 is widened once, in front of
+        # Grid Pool, and everything behind it (saliency convs, resampler, layers 2-4 at T/4 + 1 frames, fusion, head) stays fp32.
         self.feat_depth, self.learnedMixing, self.isMixing, self.t_pool = feat_depth, learnedMixing, isMixing, t_pool
         nn.Module.__init__(self)
         planes = [(int(x * widen_factor), int(y * widen_factor)) for x, y in block_inplanes]
@@ -291,7 +295,7 @@ class ResNet(x3d_fine.ResNet):
         x3d_fine.ResNet.__init__(self, block, layers, block_inplanes, n_input_channels=n_input_channels,
                                  shortcut_type=shortcut_type, widen_factor=widen_factor, dropout=dropout,
                                  n_classes=n_classes, base_bn_splits=base_bn_splits, task=task,
-                                 extract_feat=extract_feat, _skip_module_init=True)
+                                 extract_feat=extract_feat, _skip_module_init=True, act_dtype=act_dtype)
         self.rw2 = RewightLayer(planes[0][1], planes[0][1], feat_depth['layer1'], 56)
         self.rw3 = RewightLayer(planes[1][1], planes[1][1], feat_depth['layer2'], 28)
         self.rw4 = RewightLayer(planes[2][1], planes[2][1], feat_depth['layer3'], 14)
@@ -316,6 +320,8 @@ class ResNet(x3d_fine.ResNet):
         x, feat, feat_masks, i, meta = inp
         tl = x.shape[2]
         x = self.layer1(self._stem(x))
+        if self.act_dtype != torch.float32:          # 16-bit stem + layer 1: one widening pass, then the fp32 path (see __init__)
+            x = (x.materialize() if isinstance(x, Deferred) else x).float()
         if self.t_pool == 'grid':
             x, gx = self.pool_1(x)
             GX = self.gauss([meta, feat_masks, gx, tl])

@@ -165,3 +165,61 @@ def test_joint_step_with_fp16_fine_tower():
     ct = cosines(*gt)
     print('train-mode: head gradient cosine %.4f, worst %.3f' % (ct['c.fc2.weight'][0], min(v[0] for v in ct.values())))
     assert ct['c.fc2.weight'][0] >= 0.98
+
+
+@pytest.mark.parametrize('dt,bound', [('fp16', 5e-3), ('bf16', 3e-2)])
+def test_coarse_stream_with_16_bit_stem_and_layer1(dt, bound):
+    """x3d_coarse act_dtype (round 6; BASELINE configs[4] "fp16 MFMA pointwise" for the coarse half of the joint step): the stem's temporal conv and
+    layer 1 store 2-byte activations, Grid Pool and everything behind it stay fp32.  Eval logits against the fp32 net; one train step with the
+    device-side loss scale: finite, the parameters move, head gradients agree with the fp32 step's in direction."""
+    import torch.optim as optim
+    import train_coarse_fineFEAT as tc
+    import train_fine
+    from cfn_hip import dist as cdist
+    from oracle import spec
+    nets = []
+    for d in (None, dt):
+        net = tc.build_model(DEV, pretrained=None, dropout=0.0, act_dtype=d)
+        spec.fill_module_(net)
+        net.rw6.dropout.p = 0.0
+        nets.append(net.to(DEV))
+    assert nets[1].act_dtype == (torch.float16 if dt == 'fp16' else torch.bfloat16)
+    x, labels, masks, feat, fm, meta, _, _ = next(iter(tc.SyntheticCoarse(2, 1, 16, seed=5)))
+    x = x[:, 0].contiguous().to(DEV)
+    labels, masks, fm, meta = labels.to(DEV), masks.to(DEV), fm.to(DEV), meta.to(DEV)
+    feat = {k: v.to(DEV) for k, v in feat.items()}
+    outs = []
+    for net in nets:
+        net.eval()
+        with torch.no_grad():
+            outs.append(net([x, feat, fm, 0, meta]))
+    assert outs[1].dtype == torch.float32
+    err = float((outs[1] - outs[0]).abs().max() / outs[0].abs().max())
+    print('coarse eval logits, %s stem + layer 1 vs fp32: %.2e' % (dt, err))
+    assert err <= bound
+    grads = []
+    for net in nets:
+        net.train(True)
+        opt = optim.SGD(tc.param_groups(net, 0.02), lr=0.02, momentum=0.9)
+        red = cdist.GradReducer(net.parameters())
+        before = net.fc2.weight.detach().clone()
+        seen = {}
+        hooks = [p.register_post_accumulate_grad_hook(lambda p_, n_=n: seen.__setitem__(n_, p_.grad.detach().double().flatten().clone()))
+                 for n, p in net.named_parameters() if n in ('fc2.weight', 'conv5.weight', 'layer1.0.conv1.weight')]
+        cls_loss, loc_loss, _ = tc.train_step(net, red, opt, x, labels, masks, feat, fm, meta)
+        for h in hooks:
+            h.remove()
+        red.close()
+        assert bool(torch.isfinite(cls_loss)) and bool(torch.isfinite(loc_loss))
+        assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
+        assert float((net.fc2.weight - before).abs().max()) > 0.0
+        grads.append(seen)
+    sc = train_fine.loss_scaler(nets[1])
+    assert (sc is not None) == (dt == 'fp16')
+    if sc is not None:
+        assert float(sc.found_inf) == 0.0 and float(sc.scale) == train_fine.LOSS_SCALE_FP16
+    for k in ('fc2.weight', 'conv5.weight'):
+        a, b = grads[0][k], grads[1][k] / (train_fine.LOSS_SCALE_FP16 if dt == 'fp16' else 1.0)      # (the hook sees the still-scaled gradient)
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        print('  train-mode gradient %s: cosine %.4f, norm ratio %.3f' % (k, cos, float(b.norm() / a.norm())))
+        assert cos >= 0.97 and 0.8 <= float(b.norm() / a.norm()) <= 1.25
