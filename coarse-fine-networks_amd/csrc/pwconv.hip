@@ -788,7 +788,10 @@ extern "C" int cfn_conv3d_dense_fwd(const float* x, const double* A, const doubl
     a.N = N; a.M = Cout; a.K = Cin * a.kT * a.kH * a.kW; a.Cin = a.K;
     hipStream_t st = (hipStream_t)stream;
     CfnProfScope prof(CFN_K_DENSE_FWD, st, 4.0 * N * ((double)Cin * a.Pin + (double)Cout * a.Q));
-    {   // LDS-tiled kernel (salconv.hip) for the Grid Pool saliency shapes (24 channels, 3x3x3 stride 2, 56 / 28 wide planes)
+    {   // Grid Pool saliency shapes (24 channels, 3x3x3 stride 2, 56 / 28 wide planes): the split-bf16 kernel of salconvb.hip (round 6), then the
+        // exact-fp32 LDS-tiled kernel of salconv.hip
+        const int rb = salb_fwd_try_launch(x, A, B, act, w, y, sum, sumsq, N, Cin, Cout, T, Hi, Wi, geom, st);
+        if (rb >= 0) return rb;
         const int rs = sal_fwd_try_launch(x, A, B, act, w, y, sum, sumsq, N, Cin, Cout, T, Hi, Wi, geom, st);
         if (rs >= 0) return rs;
     }
