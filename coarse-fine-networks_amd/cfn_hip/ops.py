@@ -177,12 +177,24 @@ def _lazy_ok_probe(w):
         return _lazy_ok(w)
 
 
+def _grad_owner(w):
+    """the leaf parameter whose .grad receives w's gradient without a kernel in between: w itself, or -- for a pure reshape of a whole
+    parameter, `conv1d.weight.view(O, I, 1, 1, 1)` of the fusion modules (x3d_coarse._w5), `fc2.weight.view(...)` of the head -- the
+    parameter behind the view (ViewBackward only reshapes the gradient).  The lazy-cast rules are the owner's."""
+    if w is not None and not w.is_leaf and w._is_view():
+        base = w._base
+        if base is not None and base.is_leaf and base.numel() == w.numel() and w.is_contiguous() and base.is_contiguous():
+            return base
+    return w
+
+
 def _gw_buffers(w, rows, cols, dev):
     """(fp64 accumulator (rows, cols), finish() -> fp32 gradient shaped like w)"""
     gc = _tls.gradcast
-    if _lazy_ok(w):
+    owner = _grad_owner(w)
+    if _lazy_ok(owner):
         gc.begin()
-        if gc.first_use(w):
+        if gc.first_use(owner):
             g64, g32 = gc.take(rows * cols, tuple(w.shape), dev)
             return g64.view(rows, cols), (lambda: g32)
         # second gradient of the same parameter in this pass: autograd is about to ADD it to the view handed out for the

@@ -101,3 +101,25 @@ def test_grad_reducer_opts_its_parameters_in():
     w = _param([1.0, 2.0, 3.0], lazy=False)
     cdist.GradReducer([w])
     assert ops._lazy_ok_probe(w)
+
+
+def test_reshaped_view_of_a_parameter_gets_the_lazy_view_too():
+    """round 6: the fusion modules hand `conv1d.weight.view(O, I, 1, 1, 1)` to the conv op (x3d_coarse._w5) -- not a leaf, so every such weight
+    gradient used to be cast on the spot (one conversion kernel per conv and step, 38 per coarse step).  A pure reshape of a whole leaf follows the
+    leaf's rules: lazy view, filled at the end of the pass; a second use in the same pass still gets a valid gradient; a SLICE does not qualify."""
+    w = _param([1.0, 2.0, 3.0, 4.0])
+    x = torch.tensor([[2.0, 2.0], [3.0, 3.0]], requires_grad=True)
+    wv = w.view(2, 2)
+    assert ops._grad_owner(wv) is w
+    with torch.no_grad():
+        assert ops._lazy_ok(ops._grad_owner(wv))
+    _Scale.apply(x, wv, False).sum().backward()
+    assert torch.equal(w.grad, torch.tensor([2.0, 2.0, 3.0, 3.0]))
+    w.grad = None
+    (_Scale.apply(x, w.view(2, 2), False).sum() + _Scale.apply(2 * x.detach(), w.view(2, 2), False).sum()).backward()
+    assert torch.equal(w.grad, torch.tensor([6.0, 6.0, 9.0, 9.0]))
+    sl = w[:2]
+    assert ops._grad_owner(sl) is sl                       # part of a parameter: ordinary (immediate) cast
+    w.grad = None
+    _Scale.apply(torch.tensor([5.0, 7.0], requires_grad=True), sl, False).sum().backward()
+    assert torch.equal(w.grad, torch.tensor([5.0, 7.0, 0.0, 0.0]))

@@ -2,17 +2,20 @@
 # Copy the outputs of tools/refresh_profiles.sh (gpurun_out/refresh, merged back from the GPU box) into profiles/ as the
 # round's tracked artefacts.  Usage: tools/collect_profiles.sh r02
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=gpurun_out/refresh
 P=profiles
 latest() { ls -t $1 | head -1; }
 cp $(latest "$R/bench/runc/*kernel_stats.csv") $P/${TAG}_bench_kernel_stats.csv
 cp $(latest "$R/bench/runc/*domain_stats.csv") $P/${TAG}_bench_domain_stats.csv
 cp $(latest "$R/bench_bf16/runc/*kernel_stats.csv") $P/${TAG}_bench_bf16_kernel_stats.csv
-for f in bench bench_rocprof bench_bf16 bench_fp16 bench_coarse bench_joint bench_joint_bf16tower bench_joint_fp16tower; do tail -1 $R/$f.json > $P/${TAG}_$f.json; done    # bench = the default line (both rooflines + CPU leg), bench_rocprof = the fine step alone under rocprofv3 (matches ${TAG}_bench_kernel_stats.csv)
+for f in bench bench_rocprof bench_bf16 bench_fp16 bench_staged bench_coarse bench_coarse_eager bench_coarse_eager_rocprof bench_coarse_t256_eager bench_coarse_t256_eager_rocprof bench_coarse_bf16 bench_joint bench_joint_bf16tower bench_joint_fp16tower; do tail -1 $R/$f.json > $P/${TAG}_$f.json; done    # bench = the default line (both rooflines + CPU leg), bench_rocprof = the fine step alone under rocprofv3 (matches ${TAG}_bench_kernel_stats.csv)
 cp $(latest "$R/bench_coarse/runc/*kernel_stats.csv") $P/${TAG}_coarse_kernel_stats.csv          # (both coarse CSVs come from THIS refresh: they were stale in r02 / r03)
 cp $(latest "$R/bench_coarse_t256/runc/*kernel_stats.csv") $P/${TAG}_coarse_t256_kernel_stats.csv
 cp $R/sal_bench.txt $P/${TAG}_sal_bench.txt
+cp $R/salb_bench.txt $P/${TAG}_salb_bench.txt
+cp $R/glue_coarse.txt $P/${TAG}_glue_coarse.txt
+cp $R/sync_debug.txt $P/${TAG}_sync_debug.txt
 cp $R/determinism_scan.txt $P/${TAG}_determinism_scan.txt
 cp $R/power_clock.txt $P/${TAG}_power_clock.txt
 cp $R/microbench_b8.txt $P/${TAG}_microbench_b8.txt

@@ -9,12 +9,19 @@ FILT="^RCCL\|^HIP\|^ROCm\|^Host\|^Lib\|amdgpu.ids"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python $R/bench.py --no-coarse-roofline --no-cpu-baseline > $O/bench_rocprof.json 2> $O/bench.err
 python $R/bench.py > $O/bench.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_bf16 -- python $R/bench.py --dtype bf16 > $O/bench_bf16.json 2>> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_coarse -- python $R/bench.py --stream coarse --no-cpu-baseline > $O/bench_coarse.json 2>> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_coarse_t256 -- python $R/bench.py --stream coarse --frames 256 --no-cpu-baseline > $O/bench_coarse_t256.json 2>> $O/bench.err
-python $R/bench.py --stream joint > $O/bench_joint.json 2>> $O/bench.err
+# coarse stream: the kernel tables come from the EAGER step (launch counts per step); the bench lines proper are the default hipGraph replays (round 6)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_coarse -- python $R/bench.py --stream coarse --eager --no-cpu-baseline > $O/bench_coarse_eager_rocprof.json 2>> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_coarse_t256 -- python $R/bench.py --stream coarse --eager --frames 256 --no-cpu-baseline > $O/bench_coarse_t256_eager_rocprof.json 2>> $O/bench.err
+python $R/bench.py --stream coarse --steps 20 --staged > $O/bench_coarse.json 2>> $O/bench.err
+python $R/bench.py --stream coarse --steps 20 --eager --no-cpu-baseline > $O/bench_coarse_eager.json 2>> $O/bench.err
+python $R/bench.py --stream coarse --frames 256 --no-cpu-baseline > $O/bench_coarse_t256.json 2>> $O/bench.err
+python $R/bench.py --stream coarse --frames 256 --eager --no-cpu-baseline > $O/bench_coarse_t256_eager.json 2>> $O/bench.err
+python $R/bench.py --stream coarse --steps 20 --dtype bf16 --no-cpu-baseline > $O/bench_coarse_bf16.json 2>> $O/bench.err
+python $R/bench.py --stream joint --staged > $O/bench_joint.json 2>> $O/bench.err
 python $R/bench.py --stream joint --dtype bf16 > $O/bench_joint_bf16tower.json 2>> $O/bench.err
 python $R/bench.py --stream joint --dtype fp16 > $O/bench_joint_fp16tower.json 2>> $O/bench.err
 python $R/bench.py --dtype fp16 --no-cpu-baseline > $O/bench_fp16.json 2>> $O/bench.err
+python $R/bench.py --staged --no-cpu-baseline --no-coarse-roofline > $O/bench_staged.json 2>> $O/bench.err
 # HBM traffic of the depthwise forward family: separate --pmc passes, kernel trace only
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/tools/dwfwd_only.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/tools/dwfwd_only.py > /dev/null 2>&1
@@ -27,6 +34,9 @@ for v in "0 f32 fp32mfma" "6 f32 split6" "6 bf16 bf16"; do set -- $v
   CFN_PW_SPLIT=$1 DT=$2 CFN_PWS_MAXK=100000 CFN_PWS_MAXSLABS=100 REPS=2 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $O/pmc_pw2_$3 -- python $R/tools/pw_only.py > /dev/null 2> $O/pmc_pw2_$3.err
 done
 python $R/tools/sal_bench.py 2>&1 | grep -v "$FILT" > $O/sal_bench.txt
+python $R/tools/salb_bench.py 2>&1 | grep -v "$FILT" > $O/salb_bench.txt
+python $R/tools/glue_profile_coarse.py 2 2>&1 | grep -v "$FILT" | tail -90 > $O/glue_coarse.txt
+python $R/tools/sync_debug.py 2>&1 | grep -v "$FILT" > $O/sync_debug.txt
 python $R/tools/determinism_scan.py --runs 12 2>&1 | grep -v "$FILT" > $O/determinism_scan.txt
 python $R/tools/microbench.py pw --bwd --batch 8 2>&1 | grep -v "$FILT" > $O/microbench_b8.txt
 python $R/tools/microbench.py dw --bwd --batch 8 2>&1 | grep -v "$FILT" >> $O/microbench_b8.txt
