@@ -80,8 +80,10 @@ int DWN(dw_flatb_try)(const dwe_t* gy, const dwe_t* y, const double* gs, const d
 int DWN(dw_cpbx_try)(const dwe_t* gy, const dwe_t* y, const double* gs, const double* gq, const float* w, const dwe_t* x,
                      const double* A, const double* B, int act, dwe_t* gx, double* gA, double* gB, double* gw,
                      int N, int C, int T, int H, int W, hipStream_t st, bool probe);                   // dwcpbx.hip (both element types)
-int DWN(dw_flat_fwd_try)(const dwe_t* x, const double* A, const double* B, int act, const float* w, dwe_t* y, double* sum, double* sumsq,
-                         int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);    // dwflat.hip (round 6: both element types)
+#ifndef DW_BF16
+int dw_flat_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
+                    int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);    // dwflat.hip
+#endif
 // column-pair wave kernels (dwcp.hip, dwcpb.hip; compiled for both element types like this file: cp_io.h)
 int DWN(dw_cp_fwd_try)(const dwe_t* x, const double* A, const double* B, int act, const float* w, dwe_t* y, double* sum, double* sumsq,
                        int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe);
@@ -1256,12 +1258,14 @@ extern "C" int DWN(cfn_dwconv3d_fwd)(const dwe_t* x, const double* A, const doub
     a.src = x; a.A = A; a.B = B; a.act = act; a.w = w; a.dst = y; a.s1 = sum; a.s2 = sumsq;
     a.N = N; a.C = C; a.T = T; a.Hi = Hi; a.Wi = Wi;
     hipStream_t st = (hipStream_t)stream;
-    if (DWN(dw_flat_fwd_try)(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
-        // output planes 56x56 / 28x28 / 14x14, stride 1 and 2: flat kernels, every load of a work item up front (dwflat.hip; 2-byte tensors since round 6)
+#ifndef DW_BF16
+    if (dw_flat_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
+        // output planes 56x56 / 28x28 / 14x14, stride 1 and 2, fp32: flat kernels, every load of a work item up front (dwflat.hip)
         const double po_ = stride == 1 ? (double)Hi * Wi : ((Hi - 1) / 2 + 1.0) * ((Wi - 1) / 2 + 1.0);
         CfnProfScope prof(CFN_K_DWCONV_FWD, st, (double)DW_ES * N * C * T * ((double)Hi * Wi + po_) + 4.0 * C * 27);
-        return DWN(dw_flat_fwd_try)(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, false);
+        return dw_flat_fwd_try(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, false);
     }
+#endif
     if (DWN(dw_cp_fwd_try)(x, A, B, act, w, y, sum, sumsq, N, C, T, Hi, Wi, stride, st, true) == 0) {
         // output planes 56x56 / 28x28 / 14x14, stride 1 and 2: column-pair wave kernel (dwcp.hip)
         const double po_ = stride == 1 ? (double)Hi * Wi : ((Hi - 1) / 2 + 1.0) * ((Wi - 1) / 2 + 1.0);

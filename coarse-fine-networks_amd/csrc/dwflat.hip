@@ -22,18 +22,12 @@
 // 293 -> 257-261.  What was measured on the way: image rows W + 8 apart with zero columns (3 instead of 4 workgroups per CU)
 // 530 / 274; TO = 6 / 4: 527 / 548 and 263 / 273; a persistent producer / consumer version (4 loader waves that never store + 4 worker waves
 // that never load, LDS double buffer, one barrier per item) 610 / 295; with 8 of the 9 taps per frame switched off 466 (6.0 TB/s).
-// Round 6: the source also builds for 2-byte tensors (cp_io.h: dwflat_bf16.hip / dwflat_f16.hip define DW_BF16 [+ CFN_F16]): a lane then loads its four
-// positions as ONE 8-byte access, unpacks to fp32 while staging, computes in fp32 exactly as below and stores 8 / 4 / 2 rounded bytes; the statistics are
-// taken over the rounded values (what the consumer will read).  Same work-item geometry, same LDS images.
-#include "cp_io.h"
+#include "cfn_common.h"
 #include <stdint.h>
 #include <stdlib.h>
 
-#ifdef DW_BF16
-#define DwFlatArgs H16N(DwFlatArgs)
-#endif
 struct DwFlatArgs {
-    const cpe_t* x; const double* A; const double* B; const float* w; cpe_t* y; double* s1; double* s2;
+    const float* x; const double* A; const double* B; const float* w; float* y; double* s1; double* s2;
     int N, C, T, act, nchunks;
     long total;          // 14x14: number of wave items
 };
@@ -63,16 +57,16 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat_fwd_kernel(const DwFlatArgs 
     const int lr = tid / W4, lc = tid - lr * W4;
     const int grow = band * RB - 1 + lr;
     const bool lvalid = tid < NLOAD && grow >= 0 && grow < W;
-    const int lofs = lvalid ? (grow * W + lc * 4) * CP_ES : OOB;
-    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
-    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
+    const int lofs = lvalid ? (grow * W + lc * 4) * 4 : OOB;
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * P, (unsigned)((long)T * P * 4));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * P, (unsigned)((long)T * P * 4));
 
     fl_f4 R[NF];
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
         const int t = t0 - 1 + k;
         const bool tv = t >= 0 && t < T;                                 // workgroup uniform
-        R[k] = cp_ld4(rx, tv ? lofs : OOB, cfn_uni(tv ? t * P * CP_ES : 0));
+        R[k] = __builtin_bit_cast(fl_f4, __builtin_amdgcn_raw_buffer_load_b128(rx, tv ? lofs : OOB, cfn_uni(tv ? t * P * 4 : 0), 0));
     }
     float wr[27];
 #pragma unroll
@@ -127,9 +121,8 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat_fwd_kernel(const DwFlatArgs 
             if (k >= 2) {                                                // output frame k - 2 is complete
                 const int j = k - 2, t = t0 + j;
                 const bool emit = t < T;
-                const fl_p2 ya = cp_rt2(acc[j][0]), yb = cp_rt2(acc[j][1]);   // (2-byte tensors: as stored)
-                const fl_f4 y = {ya.x, ya.y, yb.x, yb.y};
-                cp_st4(y, ry, emit ? ((band * RB + lr) * W + lc * 4) * CP_ES : OOB, cfn_uni(emit ? t * P * CP_ES : 0));
+                const fl_f4 y = {acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y};
+                cfn_bst128(__builtin_bit_cast(fl_u4, y), ry, emit ? ((band * RB + lr) * W + lc * 4) * 4 : OOB, cfn_uni(emit ? t * P * 4 : 0));
                 const fl_f4 ym = y * (emit ? 1.0f : 0.0f);
                 st1 += ym.x + ym.y + ym.z + ym.w;
                 st2 += ym.x * y.x + ym.y * y.y + ym.z * y.z + ym.w * y.w;
@@ -167,15 +160,15 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat14_fwd_kernel(const DwFlatArg
     float* img = smem + wv * NF * FR;
 
     const bool on = lane < U;
-    const int lofs = on ? lane * 4 * CP_ES : OOB;
-    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
-    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * P, (unsigned)((long)T * P * CP_ES));
+    const int lofs = on ? lane * 16 : OOB;
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * P, (unsigned)((long)T * P * 4));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * P, (unsigned)((long)T * P * 4));
     fl_f4 R[NF];
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
         const int t = t0 - 1 + k;
         const bool tv = t >= 0 && t < T;                                 // wave uniform
-        R[k] = cp_ld4(rx, tv ? lofs : OOB, cfn_uni(tv ? t * P * CP_ES : 0));
+        R[k] = __builtin_bit_cast(fl_f4, __builtin_amdgcn_raw_buffer_load_b128(rx, tv ? lofs : OOB, cfn_uni(tv ? t * P * 4 : 0), 0));
     }
     float wr[27];
 #pragma unroll
@@ -216,7 +209,7 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat14_fwd_kernel(const DwFlatArg
         const float* base = img + (2 * ur) * PIT + 2 * uc;               // image row 2 ur = plane row 2 ur - 1
         const int eL = uc == 0 ? 0 : -1, eR = uc == 6 ? 1 : 2;
         const float mL = uc == 0 ? 0.0f : 1.0f, mR = uc == 6 ? 0.0f : 1.0f;
-        const int yo = ((2 * ur) * W + 2 * uc) * CP_ES;
+        const int yo = ((2 * ur) * W + 2 * uc) * 4;
 #pragma unroll
         for (int k = 0; k < NF; ++k) {
 #pragma unroll
@@ -244,11 +237,11 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat14_fwd_kernel(const DwFlatArg
             if (k >= 2) {
                 const int j = k - 2, t = t0 + j;
                 const bool emit = t < T;
-                const int so = cfn_uni(emit ? t * P * CP_ES : 0);
+                const int so = cfn_uni(emit ? t * P * 4 : 0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const fl_p2 y = cp_rt2(acc[j][i]);
-                    cp_st2(y, ry, emit ? yo + i * W * CP_ES : OOB, so);
+                    const fl_p2 y = acc[j][i];
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fl_u2, y), ry, emit ? yo + i * W * 4 : OOB, so, 0);
                     const fl_p2 ym = y * (emit ? 1.0f : 0.0f);
                     st1 += ym.x + ym.y;
                     st2 += ym.x * y.x + ym.y * y.y;
@@ -288,16 +281,16 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat_s2_fwd_kernel(const DwFlatAr
     const int lr = tid / W4, lc = tid - lr * W4;
     const int grow = 2 * band * RBO - 1 + lr;                            // input row (never beyond the plane: even input sizes)
     const bool lvalid = tid < NLOAD && grow >= 0;
-    const int lofs = lvalid ? (grow * WI + lc * 4) * CP_ES : OOB;
-    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * PI, (unsigned)((long)T * PI * CP_ES));
-    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * PO, (unsigned)((long)T * PO * CP_ES));
+    const int lofs = lvalid ? (grow * WI + lc * 4) * 4 : OOB;
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * PI, (unsigned)((long)T * PI * 4));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * PO, (unsigned)((long)T * PO * 4));
 
     fl_f4 R[NF];
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
         const int t = t0 - 1 + k;
         const bool tv = t >= 0 && t < T;                                 // workgroup uniform
-        R[k] = cp_ld4(rx, tv ? lofs : OOB, cfn_uni(tv ? t * PI * CP_ES : 0));
+        R[k] = __builtin_bit_cast(fl_f4, __builtin_amdgcn_raw_buffer_load_b128(rx, tv ? lofs : OOB, cfn_uni(tv ? t * PI * 4 : 0), 0));
     }
     float wr[27];
 #pragma unroll
@@ -330,7 +323,7 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat_s2_fwd_kernel(const DwFlatAr
         const float* base = img + (2 * orow) * PIT + j;                  // output row orow reads image rows 2 orow .. 2 orow + 2
         const int eL = j == 0 ? W : W - 1;                               // O[j - 1]; the column left of 0 is not stored: valid address x 0
         const float mL = j == 0 ? 0.0f : 1.0f;
-        const int yo = ((band * RBO + orow) * W + j) * CP_ES;
+        const int yo = ((band * RBO + orow) * W + j) * 4;
 #pragma unroll
         for (int k = 0; k < NF; ++k) {
 #pragma unroll
@@ -352,8 +345,8 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat_s2_fwd_kernel(const DwFlatAr
             if (k >= 2) {                                                // output frame k - 2 is complete
                 const int f = k - 2, t = t0 + f;
                 const bool emit = t < T;
-                const fl_p2 y = cp_rt2(acc[f]);
-                cp_st2(y, ry, emit ? yo : OOB, cfn_uni(emit ? t * PO * CP_ES : 0));
+                const fl_p2 y = acc[f];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fl_u2, y), ry, emit ? yo : OOB, cfn_uni(emit ? t * PO * 4 : 0), 0);
                 const fl_p2 ym = y * (emit ? 1.0f : 0.0f);
                 st1 += ym.x + ym.y;
                 st2 += ym.x * y.x + ym.y * y.y;
@@ -390,8 +383,8 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat14to7_fwd_kernel(const DwFlat
     const int c = cfn_uni((int)(nc % a.C));
     const int T = a.T, t0 = chunk * TO;
     float* img = smem + wv * NF * FR;
-    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * PI, (unsigned)((long)T * PI * CP_ES));
-    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * PO, (unsigned)((long)T * PO * CP_ES));
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(a.x + nc * (long)T * PI, (unsigned)((long)T * PI * 4));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(a.y + nc * (long)T * PO, (unsigned)((long)T * PO * 4));
     const bool on = lane < 49;
 
     fl_f4 R[NF];
@@ -399,7 +392,7 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat14to7_fwd_kernel(const DwFlat
     for (int k = 0; k < NF; ++k) {
         const int t = t0 - 1 + k;
         const bool tv = t >= 0 && t < T && on;
-        R[k] = cp_ld4(rx, tv ? lane * 4 * CP_ES : OOB, cfn_uni(tv ? t * PI * CP_ES : 0));
+        R[k] = __builtin_bit_cast(fl_f4, __builtin_amdgcn_raw_buffer_load_b128(rx, tv ? lane * 16 : OOB, cfn_uni(tv ? t * PI * 4 : 0), 0));
     }
     float wr[27];
 #pragma unroll
@@ -456,8 +449,8 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat14to7_fwd_kernel(const DwFlat
             if (k >= 2) {
                 const int j = k - 2, t = t0 + j;
                 const bool emit = t < T;
-                const float y = cp_rt1(acc[j]);
-                cp_st1(y, ry, emit ? lane * CP_ES : OOB, cfn_uni(emit ? t * PO * CP_ES : 0));
+                const float y = acc[j];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), ry, emit ? lane * 4 : OOB, cfn_uni(emit ? t * PO * 4 : 0), 0);
                 const float ym = emit ? y : 0.0f;
                 st1 += ym;
                 st2 = fmaf(ym, y, st2);
@@ -471,21 +464,16 @@ __global__ __launch_bounds__(256, 4) void dw3d_flat14to7_fwd_kernel(const DwFlat
 }
 
 // returns -1 when the shape is not handled; probe: 0 = handled, nothing launched; otherwise the launch status
-int CPN(dw_flat_fwd_try)(const cpe_t* x, const double* A, const double* B, int act, const float* w, cpe_t* y, double* sum, double* sumsq,
+int dw_flat_fwd_try(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum, double* sumsq,
                     int N, int C, int T, int Hi, int Wi, int stride, hipStream_t st, bool probe) {
-    constexpr uintptr_t AL = 4 * CP_ES - 1;          // a lane's four positions are one access
     // bit mask of the planes served: stride 1: 1 = 56x56, 2 = 28x28, 4 = 14x14; stride 2: 8 = 112 -> 56, 16 = 56 -> 28, 32 = 28 -> 14, 64 = 14 -> 7
-#ifdef DW_BF16
-    static const int enabled = getenv("CFN_DW_FLAT_H16") ? atoi(getenv("CFN_DW_FLAT_H16")) : 127;     // 2-byte tensors: own switch (0 = the column-pair wave kernels of dwcp.hip)
-#else
     static const int enabled = getenv("CFN_DW_FLAT") ? atoi(getenv("CFN_DW_FLAT")) : 127;
-#endif
     static const int to_env = getenv("CFN_DW_FLAT_TO") ? atoi(getenv("CFN_DW_FLAT_TO")) : 0;
     if (Hi != Wi) return -1;
     if (stride == 2 && Hi == 14) {
         if (!(enabled & 64)) return -1;
         if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && A != nullptr) return -1;
-        if ((long)T * Hi * Wi * CP_ES >= 0x7fff0000L || (((uintptr_t)x | (uintptr_t)y) & AL) != 0) return -1;
+        if ((long)T * Hi * Wi * 4 >= 0x7fff0000L || (((uintptr_t)x | (uintptr_t)y) & 15) != 0) return -1;
         const int TO = to_env == 4 || to_env == 8 ? to_env : (T >= 12 ? 8 : 4);
         const long nch = (T + TO - 1) / TO, items = (long)N * C * nch, blocks = (items + 3) / 4;
         if (blocks >= 0x7fffffffL) return -1;
@@ -499,7 +487,7 @@ int CPN(dw_flat_fwd_try)(const cpe_t* x, const double* A, const double* B, int a
         if (Hi != 112 && Hi != 56 && Hi != 28) return -1;
         if (!(enabled & (Hi == 112 ? 8 : Hi == 56 ? 16 : 32))) return -1;
         if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && A != nullptr) return -1;
-        if ((long)T * Hi * Wi * CP_ES >= 0x7fff0000L || (((uintptr_t)x | (uintptr_t)y) & AL) != 0) return -1;
+        if ((long)T * Hi * Wi * 4 >= 0x7fff0000L || (((uintptr_t)x | (uintptr_t)y) & 15) != 0) return -1;
         // same-box steady state, 8 clips x T = 256, dwcp.hip / this kernel at TO = 8 / 6 / 4: 112 -> 56 1373 / 1211 / 1260 / 1214 us, 56 -> 28
         // 686 / 622 / 618 / 623, 28 -> 14 358 / 309 / 302 / 311; 2-row bands on 112 -> 56 (7 workgroups per CU, 1.25 x row re-reads): 1250
         const int TO = to_env == 4 || to_env == 8 ? to_env : (T >= 12 ? 8 : 4);
@@ -518,8 +506,8 @@ int CPN(dw_flat_fwd_try)(const cpe_t* x, const double* A, const double* B, int a
     if (stride != 1 || (Hi != 56 && Hi != 28 && Hi != 14)) return -1;
     if (!(enabled & (Hi == 56 ? 1 : Hi == 28 ? 2 : 4))) return -1;
     if (act != CFN_ACT_NONE && act != CFN_ACT_RELU && A != nullptr) return -1;      // branch-free prologue: none / ReLU (every X3D conv2)
-    if ((long)T * Hi * Wi * CP_ES >= 0x7fff0000L) return -1;
-    if ((((uintptr_t)x | (uintptr_t)y) & AL) != 0) return -1;
+    if ((long)T * Hi * Wi * 4 >= 0x7fff0000L) return -1;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0) return -1;
     // 8 output frames per item (10 input frames: 1.25 x temporal re-reads out of L2; 4 frames: 1.5 x, measured 5 % slower); short clips: 4
     const int TO = to_env == 4 || to_env == 8 ? to_env : (T >= 12 ? 8 : 4);
     const int NB = Hi == 56 ? 4 : 1;
