@@ -480,3 +480,37 @@ def test_host_stager_delivers_batches_in_order_and_intact():
     l1 = [float(train_fine.train_step(net, r1, o1, *[t.to(DEV) for t in b])[1]) for b in data]
     l2 = [float(train_fine.train_step(net2, r2, o2, *b)[1]) for b in st.stage(data)]
     assert l1 == l2
+
+
+def test_dataloader_collate_and_staging_feed_the_coarse_run(tmp_path):
+    """The host data path end to end (collate.py wired into a DataLoader; next-step 6: staging): a torch Dataset of RAGGED per-video
+    samples shaped like charades_coarse_fineFEAT's (clips (1,3,T,224,224), labels (157,TL), 5 fine feature maps (C,T',7,7), meta, vid, duration)
+    -> DataLoader(collate_fn=collate.coarse_collate, pin_memory=True, 2 workers) -> train_coarse_fineFEAT.run(dataloaders=...), whose loop stages the
+    batches through cfn_hip.staging.  Two optimisation steps and one validation video: finite losses, parameters move, the CSV is written."""
+    import numpy as np
+    import torch.utils.data as tud
+    import collate
+    import train_coarse_fineFEAT as tc
+
+    class Videos(tud.Dataset):
+        def __init__(self, n, seed):
+            self.n, self.seed = n, seed
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            r = np.random.RandomState(self.seed + i)
+            tf = 20 + 4 * (i % 3)                                     # ragged fine-feature lengths
+            tl = 160 - 10 * (i % 2)                                   # ragged label lengths (the clip window is fixed: 16 frames at stride 10)
+            feat = {k: np.abs(r.randn(c, tf, 7, 7)).astype(np.float32) for k, c in tc.FEAT_DEPTH.items()}
+            return (r.randn(1, 3, 16, 224, 224).astype(np.float32), (r.rand(157, tl) < 0.05).astype(np.float32), feat,
+                    np.array([2 * (i % 3), 16, tf, 1], dtype=np.int64), 'vid%d' % i, 30.0 + i)
+    loaders = {'train': tud.DataLoader(Videos(4, 0), batch_size=2, shuffle=False, num_workers=2, pin_memory=True, collate_fn=collate.coarse_collate),
+               'val': tud.DataLoader(Videos(1, 100), batch_size=1, shuffle=False, num_workers=0, pin_memory=True, collate_fn=collate.coarse_collate)}
+    logs = []
+    csv_path = str(tmp_path / 'loc.csv')
+    net = tc.run(max_epochs=2, batch_size=2, dataloaders=loaders, pretrained=None, save_model=str(tmp_path / 'm_'), csv_path=csv_path, log=logs.append)
+    assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
+    assert any('val Loc Loss' in l for l in logs) and all('nan' not in l.lower() for l in logs), logs
+    assert os.path.getsize(csv_path) > 0

@@ -33,6 +33,7 @@ for v in "0 f32 fp32mfma" "6 f32 split6" "6 bf16 bf16"; do set -- $v
   CFN_PW_SPLIT=$1 DT=$2 CFN_PWS_MAXK=100000 CFN_PWS_MAXSLABS=100 REPS=2 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_pw1_$3 -- python $R/tools/pw_only.py > /dev/null 2> $O/pmc_pw1_$3.err
   CFN_PW_SPLIT=$1 DT=$2 CFN_PWS_MAXK=100000 CFN_PWS_MAXSLABS=100 REPS=2 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $O/pmc_pw2_$3 -- python $R/tools/pw_only.py > /dev/null 2> $O/pmc_pw2_$3.err
 done
+python $R/tools/membw.py 2>&1 | grep -v "$FILT" > $O/membw.txt
 python $R/tools/sal_bench.py 2>&1 | grep -v "$FILT" > $O/sal_bench.txt
 python $R/tools/salb_bench.py 2>&1 | grep -v "$FILT" > $O/salb_bench.txt
 python $R/tools/glue_profile_coarse.py 2 2>&1 | grep -v "$FILT" | tail -90 > $O/glue_coarse.txt
