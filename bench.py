@@ -346,6 +346,13 @@ def main():
     if args.graph and world == 1:
         # the HIP events that time the roofline kernels are recorded by the C ABI at launch time: a replayed graph holds none.  The roofline leg of
         # a graphed line therefore comes from two EAGER steps of the same model behind the timed region (same kernels, same shapes)
+        for f in fams:                    # (nothing was collected under the replays; one untimed eager step first: it allocates the
+            cfn_hip.prof_enable(f, False)  # default stream's kernel workspaces and warms the allocator, which the replays never touched)
+            cfn_hip.prof_collect(f)
+        eager_step()
+        torch.cuda.synchronize()
+        for f in fams:
+            cfn_hip.prof_enable(f, True)
         for _ in range(2):
             eager_step()
         torch.cuda.synchronize()

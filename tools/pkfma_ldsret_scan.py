@@ -235,7 +235,7 @@ def main():
     hip = [s for s in srcs if s.endswith('.hip')]
     with concurrent.futures.ThreadPoolExecutor(max_workers=args.jobs) as ex:
         asm += list(ex.map(lambda s: compile_to_asm(s, tmp), hip))
-    lines = []
+    lines, fam = [], {}
     tot_k = tot_mfma_k = tot_s = tot_w = tot_sl = 0
     for path in sorted(asm):
         ks = kernels(path)
@@ -250,12 +250,27 @@ def main():
             tot_s += len(strict)
             tot_sl += sum(1 for h in strict if h[4] == 'mfma-loop')
             tot_w += wide
-            lines.append('%s: %s\n    mfma %d, wide LDS reads %d, packed fp32 %d | class S (op_sel takes the returned high register into the LOW half): %d | class W: %d'
-                         % (os.path.basename(path), names[name][:160], n_mfma, n_lds, n_pk, len(strict), wide))
-            for d, w, t, gap, wh in strict:
-                lines.append('      S %-9s gap %-3d %s  ->  %s  ->  %s' % (wh, gap, d, w, t))
-    head = ['pkfma_ldsret_scan: %d kernels in %d files, %d of them issue MFMAs; class S hits: %d (%d of them inside a loop that also issues MFMAs), class W hits: %d' % (tot_k, len(asm), tot_mfma_k, tot_s, tot_sl, tot_w)]
-    text = '\n'.join(head + lines) + '\n'
+            m = re.match(r'_Z(\d+)', name)
+            base = name[2 + len(m.group(1)):][:int(m.group(1))] if m else name
+            f = fam.setdefault((os.path.basename(path), base), [0, 0, 0, 0])
+            f[0] += 1
+            f[1] += 1 if strict else 0
+            f[2] += len(strict)
+            f[3] += wide
+            if strict:      # class-S sites are listed one by one; class-W readers are counted per family below
+                lines.append('%s: %s\n    mfma %d, wide LDS reads %d, packed fp32 %d | class S: %d | class W: %d'
+                             % (os.path.basename(path), names[name][:160], n_mfma, n_lds, n_pk, len(strict), wide))
+                for d, w, t, gap, wh in strict:
+                    lines.append('      S %-9s gap %-3d %s  ->  %s  ->  %s' % (wh, gap, d, w, t))
+    head = ['pkfma_ldsret_scan: %d kernels in %d files, %d of them issue MFMAs; class S hits: %d (%d of them inside a loop that also issues MFMAs), class W hits: %d'
+            % (tot_k, len(asm), tot_mfma_k, tot_s, tot_sl, tot_w), '',
+            '# class S = the round-3 signature (DESIGN 4.1): the FIRST reader of a register pair that a wide LDS read just returned is a v_pk_{fma,mul,add}_f32 whose op_sel takes',
+            '#           the pair\'s HIGH register into the instruction\'s LOW half (sites listed one by one at the end).',
+            '# class W = a packed fp32 instruction is the first reader and takes the returned register as the high half in the ordinary way (op_sel_hi, the default) -- not the',
+            '#           failing half in round 3; counted per kernel family.', '']
+    table = ['%-14s %-28s instantiations with packed first readers %4d (with class S: %3d)   class S %4d   class W %6d' % (f, k, v[0], v[1], v[2], v[3])
+             for (f, k), v in sorted(fam.items())]
+    text = '\n'.join(head + table + [''] + lines) + '\n'
     if args.out:
         with open(args.out, 'w') as fh:
             fh.write(text)
