@@ -92,10 +92,12 @@ def _zero_gradient_by_construction(name):
     """biases whose output reaches nothing but train-mode batch norms as a per-channel constant: the Grid Pool convs in front of bn1 / bn2
     (x3d_coarse.py:362-366), the additive FiLM term of a stage-first block (conv1 -> bn1 and shortcut conv -> bn both remove it) and what feeds
     it linearly (mixN.conv_at.bias, the additive branch's rwN.fc2.bias).  Their true gradient is 0; what is computed is rounding noise, equally
-    on both sides -- a relative error means nothing there."""
+    on both sides -- a relative error means nothing there.  Also left out of the per-tensor check: the ONE-element attention biases rwN.at2.bias --
+    a uniform shift of the attention logits all but cancels in the normalised gather (x3d_coarse.py:219-223), the gradient is the small difference
+    of large sums and moves by 6e-2 .. 3e-1 between two evaluations of the same 8-clip step (measured over four boxes)."""
     name = name.split('.', 1)[1] if name[:2] in ('f.', 'c.') else name
     return (name in ('pool_1.conv1.bias', 'pool_1.conv2.bias') or (name.startswith('mix') and name.endswith('.conv_at.bias'))
-            or (name[:3] in ('rw2', 'rw3', 'rw4', 'rw5') and name.endswith('.fc2.bias')))
+            or (name[:3] in ('rw2', 'rw3', 'rw4', 'rw5') and name.endswith('.fc2.bias')) or (name[:2] == 'rw' and name.endswith('.at2.bias')))
 
 
 def _check_batch_equals_single_clips(tag, y8, grads8, y1s, model1):
@@ -104,9 +106,8 @@ def _check_batch_equals_single_clips(tag, y8, grads8, y1s, model1):
     norms = {k: float(p.grad.double().norm()) for k, p in model1.named_parameters() if p.grad is not None}
     assert set(errs) == set(norms)
     med_norm = sorted(norms.values())[len(norms) // 2]
-    # left out of the per-tensor check: gradients that are zero by construction, and gradients below 1e-3 of the median gradient norm (e.g. the
-    # attention bias rwN.at2.bias in the joint net: a uniform shift of the attention logits nearly cancels in the normalised gather) -- rounding
-    # noise on both sides.  They still count in the global figure below.
+    # left out of the per-tensor check: gradients that are zero by construction or cancel almost completely (see above), and gradients below 1e-3 of
+    # the median gradient norm -- rounding noise on both sides.  They still count in the global figure below.
     noise = {k for k in errs if _zero_gradient_by_construction(k) or norms[k] < 1e-3 * med_norm}
     kept = {k: e for k, e in errs.items() if k not in noise}
     top = sorted(kept.items(), key=lambda kv: -kv[1])[:6]
