@@ -122,7 +122,8 @@ def _check_batch_equals_single_clips(tag, y8, grads8, y1s, model1):
     # orders agree to a few per cent per tensor (fine stream at T = 256: median <= 2e-2; here layers 2-4 see 17 frames per clip, and the joint
     # net chains two trunks: measured 2.4e-2 median on the coarse net, 5.4e-2 median / 5.5e-2 overall on the joint one); a wrong batch offset /
     # sample stride in any kernel shows as O(1) on the weights it touches and in the global figure
-    assert glob <= 0.1 and med <= 0.1 and all(e <= 0.3 for e in kept.values()), (glob, med, top)
+    # (per tensor: 0.22 is the worst seen over five boxes, on a squeeze-excite fc with 1e-2 of the median gradient norm)
+    assert glob <= 0.1 and med <= 0.1 and all(e <= 0.5 for e in kept.values()), (glob, med, top)
 
 
 def test_coarse_configuration_n8_t64_tf128():
