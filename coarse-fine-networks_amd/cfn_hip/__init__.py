@@ -5,6 +5,7 @@ fp32 CUDA(HIP) tensor, the ops raise.  Prototypes are generated from the header 
 stays the single source of truth for the ABI.
 """
 import ctypes
+import threading
 import os
 import re
 
@@ -76,14 +77,26 @@ def load():
     if os.environ.get('CFN_DETERMINISTIC', '0') not in ('', '0') and torch.cuda.is_available():
         if lib.cfn_deterministic(1) < 0:                  # include/cfn_hip.h: order-independent commits of every cross-workgroup accumulation
             raise RuntimeError(lib.cfn_last_error().decode())
+        _det_on[0] = True
     return lib
+
+
+# Deterministic mode records every accumulation of an entry point into ONE buffer per process and commits it (device synchronisation, sort) before the
+# entry point returns: two threads inside entry points at the same time would commit each other's half-written records (round 6: the two-thread model
+# test aborted under CFN_DETERMINISTIC=1).  While the mode is on, callers of this binding are serialised -- the mode synchronises the device per entry
+# point anyway.  (A C++ caller of the ABI has to do the same.)
+_det_on = [False]
+_det_lock = threading.Lock()
 
 
 def deterministic(on=None):
     """switch / query the library's deterministic mode (include/cfn_hip.h cfn_deterministic); returns the previous setting"""
-    rc = load().cfn_deterministic(-1 if on is None else (1 if on else 0))
-    if rc < 0:
-        raise RuntimeError(last_error())
+    with _det_lock:                          # (not in the middle of another thread's entry point)
+        rc = load().cfn_deterministic(-1 if on is None else (1 if on else 0))
+        if rc < 0:
+            raise RuntimeError(last_error())
+        if on is not None:
+            _det_on[0] = bool(on)
     return bool(rc)
 
 
@@ -134,6 +147,13 @@ def _launch(name, args):
     lib = load()
     conv, dev = _marshal(name, args)
     fn = getattr(lib, name)
+    if _det_on[0]:
+        with _det_lock:
+            return _launch_now(fn, conv, dev)
+    return _launch_now(fn, conv, dev)
+
+
+def _launch_now(fn, conv, dev):
     if dev is None or dev.index == torch.cuda.current_device():
         return fn(*conv, torch.cuda.current_stream().cuda_stream)
     with torch.cuda.device(dev):

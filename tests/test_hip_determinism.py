@@ -169,3 +169,52 @@ def test_mode_from_the_environment():
     out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, CFN_DETERMINISTIC='1'), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] == '1'
+
+
+def test_two_threads_are_serialised_in_deterministic_mode(det):
+    """the mode keeps ONE record buffer per process and commits it per entry point: while it is on, the binding lets one thread at a time into the
+    library (round 6: the two-thread model test of tests/test_hip_models.py aborted the process under CFN_DETERMINISTIC=1).  Two threads run
+    forward + backward of a bottleneck stack concurrently: no error, and each thread's results equal its own sequential run bit for bit."""
+    import threading
+    import x3d_fine
+    from oracle import spec
+    dev = torch.device('cuda:0')
+
+    def make():
+        net = x3d_fine.generate_model('S', n_classes=157, task='loc', base_bn_splits=1, dropout=0.0)
+        spec.fill_module_(net)
+        return net.to(dev).train(True)
+    xs = [spec.rand_input(70 + i, (2, 3, 8, 64, 64)).to(dev) for i in range(2)]
+
+    def run(net, x, out):
+        for _ in range(2):
+            net.zero_grad(set_to_none=True)
+            y = net([x, None])
+            y.square().mean().backward()
+        out.append((y.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}))
+    ref = []
+    for i in range(2):
+        o = []
+        run(make(), xs[i], o)
+        torch.cuda.synchronize()
+        ref.append(o[0])
+    nets, outs, errs = [make(), make()], [[], []], []
+
+    def worker(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                run(nets[i], xs[i], outs[i])
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i in range(2):
+        assert torch.equal(outs[i][0][0], ref[i][0])
+        for k, g in ref[i][1].items():
+            assert torch.equal(outs[i][0][1][k], g), k
