@@ -183,16 +183,27 @@ class MixingLayer(nn.Module):
             self.conv_at = nn.Conv1d(self.in_depth, depth, kernel_size=1)
             self.conv_at2 = nn.Conv1d(self.in_depth, depth, kernel_size=1)
 
-    def forward7(self, bias, scale):
-        """bias / scale: lists of (raw (B,c_i,K,7,7), bias (c_i,)) -> FiLM coefficients (c7, m7) (B,depth,K,7,7)"""
+    @staticmethod
+    def prepare(items):
+        """list of (raw (B,c_i,K,7,7), bias (c_i,)) -> (concatenated raw tensor, (B, sum c_i) prologue rows of the concatenated biases).  The four
+        mixing layers consume the SAME two lists (x3d_coarse.py:700-716): the caller builds this once per list and hands it to every layer
+        (`forward7(..., prepared=True)`) -- one cat / one bias-row op per list and step instead of one per layer, and one gradient accumulation
+        per layer into the shared tensor instead of one per layer and level."""
+        n = items[0][0].shape[0]
+        return torch.cat([r for r, _ in items], dim=1), _rows(torch.cat([bb for _, bb in items]), n)
+
+    def forward7(self, bias, scale, prepared=False):
+        """bias / scale: lists of (raw (B,c_i,K,7,7), bias (c_i,)) -- or, with prepared=True, the results of `prepare` on those lists
+        -> FiLM coefficients (c7, m7) (B,depth,K,7,7)"""
         if not self.learned:
             raise NotImplementedError('non-learned mixing (x3d_coarse.py:338-344) is unused by the reference scripts')
-        n = bias[0][0].shape[0]
-        one = _ones(n, self.in_depth, bias[0][0].device)
+        if not prepared:
+            bias, scale = self.prepare(bias), self.prepare(scale)
+        n = bias[0].shape[0]
+        one = _ones(n, self.in_depth, bias[0].device)
 
-        def mix(items, conv, act):
-            raw = torch.cat([r for r, _ in items], dim=1)
-            b = _rows(torch.cat([bb for _, bb in items]), n)
+        def mix(prep, conv, act):
+            raw, b = prep
             y, _, _ = _o().pwconv(raw, _w5(conv), one, b, ACT_NONE, stats=False)
             return _o().affine_act(y, _ones(n, y.shape[1], y.device), _rows(conv.bias, n), act)
 
@@ -231,11 +242,11 @@ class GridPoolLayer(nn.Module):
         y, s, q = _o().conv3d_dense(x, conv.weight, (3, 3, 3), st, (1, 1, 1), A, B, act, stats=self.training)
         cnt = _count(y)
         bias = conv.bias.double().view(1, -1)
-        if self.training:
-            q = q + 2.0 * bias * s + cnt * bias * bias
-            s = s + cnt * bias
+        if self.training:      # sum(y + b) = s + cnt b;  sum((y + b)^2) = q + b (2 s + cnt b)      (fused forms: 4 launches instead of 8)
+            q = torch.addcmul(q, bias, torch.add(s * 2.0, bias, alpha=float(cnt)))
+            s = torch.add(s, bias, alpha=float(cnt))
         A2, B2 = (bn.fold_op if x3d_fine.USE_TORCH_OPS else bn.fold)(s, q, cnt, n)
-        return y, A2, B2 + A2 * conv.bias.view(1, -1)
+        return y, A2, torch.addcmul(B2, A2, bias.to(B2.dtype))
 
     def saliency(self, x):
         """(B,C,T,H,W) -> (B, T/4) saliency logits (x3d_coarse.py:379-383)"""
@@ -336,11 +347,11 @@ class ResNet(x3d_fine.ResNet):
         stages = (None, self.layer2, self.layer3, self.layer4)
         if self.isMixing:
             rw = [m.forward7(feat[k], b2, feat_masks, GX, True) for k, m in levels]
-            rb, rs = [r[0] for r in rw], [r[1] for r in rw]
+            rb, rs = MixingLayer.prepare([r[0] for r in rw]), MixingLayer.prepare([r[1] for r in rw])     # shared by the four mixing layers
             for li, mix in enumerate((self.mix2, self.mix3, self.mix4, self.mix5)):
                 if stages[li] is not None:
                     x = stages[li](x)
-                c7, m7 = mix.forward7(rb, rs)
+                c7, m7 = mix.forward7(rb, rs, prepared=True)
                 x = ops.film(x, m7, c7, x.shape[3] // FUSION_HW)
         else:
             for li, (k, m) in enumerate(levels):
