@@ -12,6 +12,8 @@ Hot-path design (all full-size tensors go through the gfx950 kernels of ``cfn_hi
     block-broadcast FiLM kernel; biases ride in the next op's prologue;
   * Grid Unpool: Interp1d (bit-exact indices) + the same temporal lerp + temporal linear resize.
 """
+import threading
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -58,9 +60,123 @@ class _Rows64(torch.autograd.Function):
         return torch.sum(g, 0, dtype=ctx.dt).view(ctx.shape), None
 
 
+_BANK_INDEX = {}
+
+
+def _bank_index(n, widths, device):
+    """gather index of `_RowsBank` and the blocks' start offsets: output group g is the (n, widths[g]) block at starts[g] (rounded up to 32
+    elements = 256 bytes, the alignment a tensor of its own would have), element (r, c) of it reads position sum(widths[:g]) + c of the
+    concatenated vectors.  Cached per (n, widths, device) outside graph capture, like `_ones`."""
+    key = (n, widths, str(device))
+    hit = _BANK_INDEX.get(key)
+    if hit is None:
+        total = sum(widths)
+        grid = torch.arange(total, device=device).view(1, total).expand(n, total)
+        parts, starts, o, pos = [], [], 0, 0
+        for wd in widths:
+            pad = -pos % 32
+            if pad:
+                parts.append(torch.zeros(pad, dtype=torch.int64, device=device))
+            starts.append(pos + pad)
+            parts.append(grid[:, o:o + wd].reshape(-1))
+            pos += pad + n * wd
+            o += wd
+        hit = (torch.cat(parts), tuple(starts))
+        if not (torch.device(device).type == 'cuda' and torch.cuda.is_current_stream_capturing()):
+            _BANK_INDEX[key] = hit
+    return hit
+
+
+class _RowsBank(torch.autograd.Function):
+    """`_Rows64` for MANY vectors at once: groups of (C_i,) fp32 vectors -> one (n, sum C_i) fp64 prologue-coefficient block per group (the
+    vectors of a group side by side).  Three launches for the whole bank (concatenate, widen, gather) and three in the backward (concatenate
+    the blocks' gradients, one column sum in fp64, narrow; the vectors' gradients are views of that one result) -- the fusion branch asks for
+    ~25 such blocks per step, three launches each as single `_Rows64` calls."""
+
+    @staticmethod
+    def forward(ctx, n, group_sizes, *vecs):
+        flat = torch.cat([v.detach().reshape(-1) for v in vecs]).to(torch.float64)
+        widths, k = [], 0
+        for gs in group_sizes:
+            widths.append(sum(v.numel() for v in vecs[k:k + gs]))
+            k += gs
+        widths = tuple(widths)
+        idx, starts = _bank_index(n, widths, flat.device)
+        out = torch.index_select(flat, 0, idx)
+        ctx.n, ctx.widths = n, widths
+        ctx.vec_meta = [(tuple(v.shape), v.dtype) for v in vecs]
+        return tuple(out[st:st + n * wd].view(n, wd) for st, wd in zip(starts, widths))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ref = next(g for g in gs if g is not None)
+        gs = [g if g is not None else ref.new_zeros(ctx.n, wd) for g, wd in zip(gs, ctx.widths)]
+        total = torch.cat(gs, dim=1).sum(0)
+        by_dt = {dt: total.to(dt) for dt in set(dt for _, dt in ctx.vec_meta)}
+        grads, o = [], 0
+        for shape, dt in ctx.vec_meta:
+            c = 1
+            for d in shape:
+                c *= d
+            grads.append(by_dt[dt][o:o + c].view(shape))
+            o += c
+        return (None, None) + tuple(grads)
+
+
+_BANK = threading.local()
+
+
+class _row_bank(object):
+    """`with _row_bank(n, groups):` -- every `_rows(vec, n)` / `_rows_of(vecs, n)` call inside finds its block in ONE `_RowsBank` result instead
+    of launching its own widening copy.  groups: list of lists of (C_i,) parameters; a request is matched by the identity of its vectors
+    and by n, anything else falls back to `_Rows64`."""
+
+    def __init__(self, n, groups):
+        seen, self.groups = set(), []
+        for g in groups:
+            key = tuple(id(v) for v in g)
+            if key not in seen and all(v is not None for v in g):
+                seen.add(key)
+                self.groups.append(list(g))
+        self.n, self.blocks = n, None
+
+    def get(self, vecs, n):
+        if n != self.n:
+            return None
+        if self.blocks is None:       # built at the first request: a forward that never asks launches nothing
+            flat = [v for g in self.groups for v in g]
+            out = _RowsBank.apply(self.n, tuple(len(g) for g in self.groups), *flat)
+            self.blocks = {tuple(id(v) for v in g): o for g, o in zip(self.groups, out)}
+        return self.blocks.get(tuple(id(v) for v in vecs))
+
+    def __enter__(self):
+        self.prev = getattr(_BANK, 'cur', None)
+        _BANK.cur = self
+        return self
+
+    def __exit__(self, *exc):
+        _BANK.cur = self.prev
+        return False
+
+
 def _rows(vec, n):
     """(C,) parameter -> (n, C) per-sample prologue coefficient (fp64 holding fp32 values: what the C ABI takes)"""
+    bank = getattr(_BANK, 'cur', None)
+    if bank is not None:
+        out = bank.get((vec,), n)
+        if out is not None:
+            return out
     return _Rows64.apply(vec, n)
+
+
+def _rows_of(vecs, n):
+    """`_rows` of the concatenation of several parameters"""
+    bank = getattr(_BANK, 'cur', None)
+    if bank is not None:
+        out = bank.get(tuple(vecs), n)
+        if out is not None:
+            return out
+    return _Rows64.apply(torch.cat(list(vecs)), n)
 
 
 _ONES = {}
@@ -190,7 +306,7 @@ class MixingLayer(nn.Module):
         (`forward7(..., prepared=True)`) -- one cat / one bias-row op per list and step instead of one per layer, and one gradient accumulation
         per layer into the shared tensor instead of one per layer and level."""
         n = items[0][0].shape[0]
-        return torch.cat([r for r, _ in items], dim=1), _rows(torch.cat([bb for _, bb in items]), n)
+        return torch.cat([r for r, _ in items], dim=1), _rows_of([bb for _, bb in items], n)
 
     def forward7(self, bias, scale, prepared=False):
         """bias / scale: lists of (raw (B,c_i,K,7,7), bias (c_i,)) -- or, with prepared=True, the results of `prepare` on those lists
@@ -219,6 +335,21 @@ class MixingLayer(nn.Module):
         return _upsample(c7, h), _upsample(m7, h)
 
 
+class _ZeroGradFor(torch.autograd.Function):
+    """identity on `t` that makes `param` a graph input with an exactly-zero gradient (so that the optimizer's weight decay / momentum see the
+    parameter as they do in the reference, where its gradient is zero up to rounding)"""
+
+    @staticmethod
+    def forward(ctx, t, param):
+        ctx.meta = (tuple(param.shape), param.dtype, param.device)
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dt, dev = ctx.meta
+        return g, torch.zeros(shape, dtype=dt, device=dev)
+
+
 class GridPoolLayer(nn.Module):
     """Learned temporal resampler (x3d_coarse.py:355-416)."""
 
@@ -235,18 +366,20 @@ class GridPoolLayer(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def _conv_bn(self, x, conv, bn, A, B, act):
-        """conv (+bias) -> BN folded to the next prologue.  The kernel has no bias: BN(y+b) = A*(y+b)+B and the
-        statistics of y+b follow from those of y."""
+        """conv (+bias) -> BN folded to the next prologue.  The kernel has no bias.  Training: a per-channel constant cancels inside a
+        batch-statistics BN -- BN(y + b) = A y + (beta - A mean(y)) for every b -- so the statistics of the bias-free y give the prologue as
+        they are; only the running mean sees b (mean(y + b) = mean(y) + b), and the gradient of b is exactly zero.  (Rounds 2-5 shifted the
+        sums by b and let autograd differentiate the shift: ~20 small launches per conv for a gradient of rounding noise.)  Eval:
+        A (y + b) + B = A y + (B + A b)."""
         n = x.shape[0]
         st = tuple(conv.stride)
         y, s, q = _o().conv3d_dense(x, conv.weight, (3, 3, 3), st, (1, 1, 1), A, B, act, stats=self.training)
-        cnt = _count(y)
-        bias = conv.bias.double().view(1, -1)
-        if self.training:      # sum(y + b) = s + cnt b;  sum((y + b)^2) = q + b (2 s + cnt b)      (fused forms: 4 launches instead of 8)
-            q = torch.addcmul(q, bias, torch.add(s * 2.0, bias, alpha=float(cnt)))
-            s = torch.add(s, bias, alpha=float(cnt))
-        A2, B2 = (bn.fold_op if x3d_fine.USE_TORCH_OPS else bn.fold)(s, q, cnt, n)
-        return y, A2, torch.addcmul(B2, A2, bias.to(B2.dtype))
+        A2, B2 = (bn.fold_op if x3d_fine.USE_TORCH_OPS else bn.fold)(s, q, _count(y), n)
+        if not self.training:
+            return y, A2, torch.addcmul(B2, A2, conv.bias.to(B2.dtype).view(1, -1))
+        with torch.no_grad():
+            bn.split_bn.running_mean.view(-1, bn.num_features).add_(conv.bias.view(1, -1), alpha=bn.momentum)
+        return y, A2, _ZeroGradFor.apply(B2, conv.bias)
 
     def saliency(self, x):
         """(B,C,T,H,W) -> (B, T/4) saliency logits (x3d_coarse.py:379-383)"""
@@ -345,6 +478,29 @@ class ResNet(x3d_fine.ResNet):
         b2 = x.shape[0]
         levels = (('layer1', self.rw2), ('layer2', self.rw3), ('layer3', self.rw4), ('layer4', self.rw5))
         stages = (None, self.layer2, self.layer3, self.layer4)
+        with _row_bank(b2, self._bias_groups(levels, feat, b2)):
+            return self._fuse(x, feat, feat_masks, GX, gx if self.t_pool == 'grid' else None, b2, levels, stages)
+
+    def _bias_groups(self, levels, feat, b2):
+        """every bias vector the fusion branch turns into (b2, C) prologue rows during one forward (`_row_bank`)"""
+        rws = [m for _, m in levels] + ([] if self.extract_feat else [self.rw6])
+        groups = []
+        for m in rws:
+            groups += [[m.fc1.bias]] + ([[m.fc3.bias]] if m.g_channels is not None else [])
+        for (k, m) in list(levels) + ([] if self.extract_feat else [('conv5', self.rw6)]):
+            if feat[k].shape[0] == b2:               # asked for with the fine features' batch size (b2 / crops at multi-crop validation)
+                groups.append([m.at1.bias])
+        if self.isMixing:
+            groups += [[m.fc2.bias for _, m in levels], [m.fc4.bias for _, m in levels]]
+            for mix in (self.mix2, self.mix3, self.mix4, self.mix5):
+                if mix.learned:
+                    groups += [[mix.conv_at.bias], [mix.conv_at2.bias]]
+        else:
+            for _, m in levels:
+                groups += [[m.fc2.bias], [m.fc4.bias]]
+        return groups
+
+    def _fuse(self, x, feat, feat_masks, GX, gx, b2, levels, stages):
         if self.isMixing:
             rw = [m.forward7(feat[k], b2, feat_masks, GX, True) for k, m in levels]
             rb, rs = MixingLayer.prepare([r[0] for r in rw]), MixingLayer.prepare([r[1] for r in rw])     # shared by the four mixing layers
@@ -369,7 +525,7 @@ class ResNet(x3d_fine.ResNet):
         rw6 = x1.squeeze(4).squeeze(3) + b1.view(1, -1, 1)
         rw6_g = torch.sigmoid(x2.squeeze(4).squeeze(3) + b2_.view(1, -1, 1))
         x = x * rw6_g + rw6                                  # (B, n_classes, K): tiny
-        if self.t_pool == 'grid':
+        if gx is not None:
             x = GridUnpool([x, gx, True])
             x = ops.time_resize(x, (x.shape[2] - 1) * 4)
         return x

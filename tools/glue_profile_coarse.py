@@ -49,3 +49,19 @@ for ev in prof2.key_averages(group_by_stack_n=6):
 print('--- ATen ops by call site')
 for (k, st), v in cnt.most_common(100):
     print('%5d %-16s %s' % (v, k, st))
+# the ops the autograd engine / optimizer issue carry no python frame: group those by operand shapes instead
+with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof3:
+    tc.train_step(net, red, opt, x, labels, masks, feat, fm, meta)
+    torch.cuda.synchronize()
+sc = Counter()
+for ev in prof3.key_averages(group_by_input_shape=True):
+    if ev.key in ('aten::add_', 'aten::add', 'aten::mul', 'aten::sum', 'aten::copy_', 'aten::_to_copy', 'aten::clone', 'aten::fill_', 'aten::zero_'):
+        sc[(ev.key, str(ev.input_shapes)[:110])] += ev.count
+print('--- ATen ops by operand shapes')
+for (k, sh), v in sc.most_common(60):
+    print('%5d %-16s %s' % (v, k, sh))
+if len(sys.argv) > 2:          # full python stacks of one op, e.g. `glue_profile_coarse.py 2 aten::clone`
+    print('--- full stacks of', sys.argv[2])
+    for ev in prof2.key_averages(group_by_stack_n=14):
+        if ev.key == sys.argv[2]:
+            print(ev.count, [x.split('/')[-1][:50] for x in (ev.stack or [])])
