@@ -16,9 +16,15 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (HIP kernels through the C ABI)')
+    config.addinivalue_line('markers', 'capture: captures a hipGraph (the library refuses capture in deterministic mode: skipped under CFN_DETERMINISTIC=1)')
 
 
 def pytest_collection_modifyitems(config, items):
+    if os.environ.get('CFN_DETERMINISTIC', '0') == '1':      # a whole-suite parity run in deterministic mode: graph capture is refused by design
+        nocap = pytest.mark.skip(reason='deterministic mode cannot run inside a stream capture (by design)')
+        for it in items:
+            if 'capture' in it.keywords:
+                it.add_marker(nocap)
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason='no GPU in this container')

@@ -132,6 +132,7 @@ def _joint_nets(dropout=0.0):
     return train_joint, fine, coarse
 
 
+@pytest.mark.capture
 def test_joint_two_stream_step_is_one_graph():
     """BASELINE configs[4]: fine tower -> feature dict -> coarse stream in ONE autograd graph.  (a) the logits equal running
     the two nets separately with the features detached in between; (b) the gradients that reach the Fine stream equal the
@@ -233,6 +234,7 @@ def test_fine_validation_multicrop(tmp_path):
     assert len(val) == 1 and 'nan' not in val[0].lower()
 
 
+@pytest.mark.capture
 @pytest.mark.parametrize('stream', ['fine', 'coarse'])
 def test_graphed_step_equals_eager_step(stream):
     """hipGraph capture of the whole train step (cfn_hip/graph.py): three replayed steps must leave the same parameters,
@@ -283,7 +285,7 @@ def test_graphed_step_equals_eager_step(stream):
     assert moved == 0.0         # SGD at lr 0 leaves every parameter where it was: the re-captured graph holds the new rate
 
 
-@pytest.mark.parametrize('launcher', ['torchrun', 'self', 'self-graph'])
+@pytest.mark.parametrize('launcher', ['torchrun', 'self', pytest.param('self-graph', marks=pytest.mark.capture)])
 def test_bench_two_ranks_sharing_the_gpu(tmp_path, launcher):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), with the two
     ranks sharing the box's single GPU over gloo (RCCL needs a device per rank): parameter sync from rank 0, the bucketed
@@ -377,6 +379,7 @@ def test_forward_video_chunks_long_videos_like_the_reference():
     assert torch.equal(short, whole)
 
 
+@pytest.mark.capture
 @pytest.mark.parametrize('act', [None, 'fp16'])
 def test_graphed_dp_step_equals_eager_step(act):
     """(act = 'fp16': ADVICE r5 -- forward_backward scales the loss, so the un-scaling has to be part of the captured optimizer graph:

@@ -19,7 +19,7 @@ net = tc.build_model(dev, pretrained=None)
 net.train(True)
 opt = optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-5)
 red = cdist.GradReducer(net.parameters())
-x, labels, masks, feat, fm, meta, _, _ = next(iter(tc.SyntheticCoarse(B, 1, 64)))
+x, labels, masks, feat, fm, meta, _, _ = next(iter(tc.SyntheticCoarse(B, 1, int(os.environ.get('FRAMES', '64')))))
 x = x.view((x.shape[0] * x.shape[1],) + tuple(x.shape[2:]))
 x, labels, masks, fm, meta = x.to(dev), labels.to(dev), masks.to(dev), fm.to(dev), meta.to(dev)
 feat = {k: v.to(dev) for k, v in feat.items()}
