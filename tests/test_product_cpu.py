@@ -183,3 +183,55 @@ def test_loss_scaler_unscales_and_survives_an_overflow():
     assert bool((ps[0].grad == 2.0).all())
     net = torch.nn.Linear(2, 2)
     assert train_fine.loss_scaler(net) is None and train_fine.loss_scale(net) == 1.0
+
+
+def test_row_bank_equals_single_row_ops_forward_and_backward():
+    """x3d_coarse._row_bank (round 6): every bias of the fusion branch becomes its (n, C) fp64 prologue rows in ONE autograd Function.  The
+    blocks and the gradients must equal what one `_Rows64` per vector gives; a request with another n or an unknown vector falls back to
+    `_Rows64`; a block nobody used contributes an exactly-zero gradient; banks nest and are per thread."""
+    import threading
+    import x3d_coarse as xc
+    g = torch.Generator().manual_seed(3)
+    sizes = (24, 48, 157, 5, 7)
+    vs = [torch.randn(c, generator=g, requires_grad=True) for c in sizes]
+    ref = [v.detach().clone().requires_grad_(True) for v in vs]
+    n = 3
+    groups = [[vs[0]], [vs[1], vs[2]], [vs[3]], [vs[4]], [vs[0]]]          # (a repeated group is stored once)
+    with xc._row_bank(n, groups) as bank:
+        assert len(bank.groups) == 4
+        a, b, c = xc._rows(vs[0], n), xc._rows_of([vs[1], vs[2]], n), xc._rows(vs[3], n)
+        other_n = xc._rows(vs[4], 2)                                      # n differs: single op
+        assert xc._rows(vs[0], n) is a                                    # one block per group, handed out again
+        with xc._row_bank(n, [[vs[3]]]):                                   # nested: the inner bank answers, the outer one is restored
+            inner = xc._rows(vs[3], n)
+        assert inner is not c and xc._rows(vs[3], n) is c
+        seen = []
+        th = threading.Thread(target=lambda: seen.append(getattr(xc._BANK, 'cur', None)))
+        th.start(); th.join()
+        assert seen == [None]
+    assert getattr(xc._BANK, 'cur', None) is None
+    ra, rb, rc = xc._Rows64.apply(ref[0], n), xc._Rows64.apply(torch.cat([ref[1], ref[2]]), n), xc._Rows64.apply(ref[3], n)
+    for got, want in ((a, ra), (b, rb), (c, rc)):
+        assert got.dtype == torch.float64 and got.is_contiguous() and got.data_ptr() % 8 == 0 and torch.equal(got, want)
+    assert (b.data_ptr() - a.data_ptr()) % 256 == 0 and (c.data_ptr() - a.data_ptr()) % 256 == 0    # each block aligned like a tensor of its own
+    assert other_n.shape == (2, 7)
+    wa, wb = torch.randn(a.shape, generator=g, dtype=torch.float64), torch.randn(b.shape, generator=g, dtype=torch.float64)
+    ((a * wa).sum() + (b * wb).sum() + (other_n * 2.0).sum()).backward()
+    ((ra * wa).sum() + (rb * wb).sum()).backward()
+    for got, want in zip(vs[:3], ref[:3]):       # (the bank sums in fp64 and narrows once; `_Rows64` narrows first)
+        assert maxdiff(got.grad, want.grad) <= 2e-6
+    assert vs[0].grad.dtype == torch.float32 and vs[2].grad.shape == (157,)
+    assert torch.equal(vs[3].grad, torch.zeros(5))                         # block handed out, never used in the loss
+    assert torch.equal(vs[4].grad, torch.full((7,), 4.0))                  # fallback path (+ the unused bank block's zeros)
+
+
+def test_zero_grad_identity_keeps_the_parameter_in_the_graph():
+    """x3d_coarse._ZeroGradFor: the Grid Pool conv biases cancel inside the batch-statistics BN; they stay graph inputs with an exactly-zero
+    gradient so that SGD's weight decay / momentum treat them as in the reference"""
+    import x3d_coarse as xc
+    b2 = torch.randn(2, 5, dtype=torch.float64, requires_grad=True)
+    bias = torch.randn(5, requires_grad=True)
+    out = xc._ZeroGradFor.apply(b2 * 1.0, bias)
+    (out * 3.0).sum().backward()
+    assert torch.equal(b2.grad, torch.full((2, 5), 3.0, dtype=torch.float64))
+    assert bias.grad is not None and bias.grad.dtype == torch.float32 and torch.equal(bias.grad, torch.zeros(5))

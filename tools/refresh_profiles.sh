@@ -36,7 +36,8 @@ done
 python $R/tools/membw.py 2>&1 | grep -v "$FILT" > $O/membw.txt
 python $R/tools/sal_bench.py 2>&1 | grep -v "$FILT" > $O/sal_bench.txt
 python $R/tools/salb_bench.py 2>&1 | grep -v "$FILT" > $O/salb_bench.txt
-python $R/tools/glue_profile_coarse.py 2 2>&1 | grep -v "$FILT" | tail -90 > $O/glue_coarse.txt
+{ echo "# one profiled step at the benchmarked shape (8 clips x 256 frames):"; FRAMES=256 python $R/tools/glue_profile_coarse.py 8 2>&1 | grep "in the step"
+  echo "# 2 clips x 64 frames, with the call sites:"; python $R/tools/glue_profile_coarse.py 2 2>&1 | grep -v "$FILT\|Warn\|_warn_once\|ROCTracer"; } > $O/glue_coarse.txt
 python $R/tools/sync_debug.py 2>&1 | grep -v "$FILT" > $O/sync_debug.txt
 python $R/tools/determinism_scan.py --runs 12 2>&1 | grep -v "$FILT" > $O/determinism_scan.txt
 python $R/tools/microbench.py pw --bwd --batch 8 2>&1 | grep -v "$FILT" > $O/microbench_b8.txt
