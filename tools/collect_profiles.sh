@@ -9,7 +9,7 @@ latest() { ls -t $1 | head -1; }
 cp $(latest "$R/bench/runc/*kernel_stats.csv") $P/${TAG}_bench_kernel_stats.csv
 cp $(latest "$R/bench/runc/*domain_stats.csv") $P/${TAG}_bench_domain_stats.csv
 cp $(latest "$R/bench_bf16/runc/*kernel_stats.csv") $P/${TAG}_bench_bf16_kernel_stats.csv
-for f in bench bench_rocprof bench_bf16 bench_fp16 bench_staged bench_coarse bench_coarse_eager bench_coarse_eager_rocprof bench_coarse_t256_eager bench_coarse_t256_eager_rocprof bench_coarse_bf16 bench_joint bench_joint_bf16tower bench_joint_fp16tower; do tail -1 $R/$f.json > $P/${TAG}_$f.json; done    # bench = the default line (both rooflines + CPU leg), bench_rocprof = the fine step alone under rocprofv3 (matches ${TAG}_bench_kernel_stats.csv)
+for f in bench bench_rocprof bench_bf16 bench_fp16 bench_staged bench_coarse bench_coarse_eager bench_coarse_eager_rocprof bench_coarse_t256_eager bench_coarse_t256_eager_rocprof bench_coarse_bf16 bench_coarse_fp16 bench_coarse_eager_staged bench_joint bench_joint_bf16tower bench_joint_fp16tower; do tail -1 $R/$f.json > $P/${TAG}_$f.json; done    # bench = the default line (both rooflines + CPU leg), bench_rocprof = the fine step alone under rocprofv3 (matches ${TAG}_bench_kernel_stats.csv)
 cp $(latest "$R/bench_coarse/runc/*kernel_stats.csv") $P/${TAG}_coarse_kernel_stats.csv          # (both coarse CSVs come from THIS refresh: they were stale in r02 / r03)
 cp $(latest "$R/bench_coarse_t256/runc/*kernel_stats.csv") $P/${TAG}_coarse_t256_kernel_stats.csv
 cp $R/membw.txt $P/${TAG}_membw.txt

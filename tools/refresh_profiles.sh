@@ -17,6 +17,8 @@ python $R/bench.py --stream coarse --steps 20 --eager --no-cpu-baseline > $O/ben
 python $R/bench.py --stream coarse --frames 256 --no-cpu-baseline > $O/bench_coarse_t256.json 2>> $O/bench.err
 python $R/bench.py --stream coarse --frames 256 --eager --no-cpu-baseline > $O/bench_coarse_t256_eager.json 2>> $O/bench.err
 python $R/bench.py --stream coarse --steps 20 --dtype bf16 --no-cpu-baseline > $O/bench_coarse_bf16.json 2>> $O/bench.err
+python $R/bench.py --stream coarse --steps 20 --dtype fp16 --no-cpu-baseline > $O/bench_coarse_fp16.json 2>> $O/bench.err
+python $R/bench.py --stream coarse --steps 20 --eager --staged --no-cpu-baseline > $O/bench_coarse_eager_staged.json 2>> $O/bench.err
 python $R/bench.py --stream joint --staged > $O/bench_joint.json 2>> $O/bench.err
 python $R/bench.py --stream joint --dtype bf16 > $O/bench_joint_bf16tower.json 2>> $O/bench.err
 python $R/bench.py --stream joint --dtype fp16 > $O/bench_joint_fp16tower.json 2>> $O/bench.err
