@@ -147,18 +147,75 @@ def pool_case(g, rng):
     return max(e), e
 
 
+def dense_case(g, rng):
+    """dense implicit-GEMM conv of the Grid Pool saliency branch (csrc/salconv.hip, salconvb.hip, the im2col route): fp64 reference on the CPU"""
+    N, Ci, Co = rng.choice([1, 2]), rng.choice([3, 4, 5, 8, 24, 24, 24]), rng.choice([1, 4, 7, 20, 24, 24, 40])
+    T, H = rng.choice([1, 2, 5, 6, 9, 12, 17]), rng.choice([7, 8, 9, 14, 16, 20, 28, 56])
+    W = rng.choice([H, H, 28, 56, 16, 7])
+    k, st, pd = rng.choice([((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((1, 3, 3), (1, 2, 2), (0, 1, 1))])
+    act, pro = rng.choice([0, 1]), rng.choice([True, False])      # (the op refuses a swish prologue: the branch has ReLUs only)
+    print('dense N=%d Ci=%d Co=%d T=%d H=%d W=%d k=%s act=%d prologue=%s' % (N, Ci, Co, T, H, W, k, act, pro), flush=True)
+    x = torch.randn(N, Ci, T, H, W, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(Co, Ci, *k, generator=g) * (2.0 / (Ci * k[0] * 9)) ** 0.5).to(DEV).requires_grad_(True)
+    A = (1 + 0.2 * torch.randn(N, Ci, generator=g)).to(DEV).requires_grad_(True) if pro else None
+    B = (0.3 * torch.randn(N, Ci, generator=g)).to(DEV).requires_grad_(True) if pro else None
+    y, s, q = ops.conv3d_dense(x, w, k, st, pd, A, B, act if pro else 0, True)
+    xd, wd = x.detach().double().cpu().requires_grad_(True), w.detach().double().cpu().requires_grad_(True)
+    Ad = A.detach().double().cpu().requires_grad_(True) if pro else None
+    Bd = B.detach().double().cpu().requires_grad_(True) if pro else None
+    z = act_ref(xd * Ad.view(N, Ci, 1, 1, 1) + Bd.view(N, Ci, 1, 1, 1), act) if pro else xd
+    ref = F.conv3d(z, wd, stride=st, padding=pd)
+    e = [relerr(y.cpu(), ref), relerr(s.cpu(), ref.sum((2, 3, 4))), relerr(q.cpu(), (ref * ref).sum((2, 3, 4)))]
+    go = torch.randn(y.shape, generator=g)
+    gs, gq = torch.randn(s.shape, generator=g) * 0.01, torch.randn(q.shape, generator=g) * 0.001
+    ins = (x, w) + ((A, B) if pro else ())
+    gr = torch.autograd.grad((y, s, q), ins, (go.to(DEV), gs.to(DEV).to(s.dtype), gq.to(DEV).to(q.dtype)))
+    loss = (ref * go.double()).sum() + (ref.sum((2, 3, 4)) * gs.double()).sum() + ((ref * ref).sum((2, 3, 4)) * gq.double()).sum()
+    grr = torch.autograd.grad(loss, (xd, wd) + ((Ad, Bd) if pro else ()))
+    e += [relerr(a.cpu(), b) for a, b in zip(gr, grr)]
+    return max(e), e
+
+
+def gather_case(g, rng):
+    """temporal-alignment gather of the fusion branch (csrc/fusion.hip, register-tiled kernels) against the fp64 expression of x3d_coarse.py:209-223"""
+    B, crops, C = rng.choice([1, 2, 3]), rng.choice([1, 1, 2, 3]), rng.choice([5, 8, 24, 48, 96, 192, 432])
+    Tf, K, P = rng.choice([7, 12, 40, 65, 128]), rng.choice([3, 5, 17, 33, 65]), rng.choice([1, 49, 49])
+    print('gather B=%d crops=%d C=%d Tf=%d K=%d P=%d' % (B, crops, C, Tf, K, P), flush=True)
+    x = torch.randn(B, C, Tf, P, generator=g).abs().to(DEV).requires_grad_(True)
+    at = torch.randn(B, Tf, P, generator=g).to(DEV).requires_grad_(True)
+    bias = torch.tensor([0.3]).to(DEV).requires_grad_(True)
+    GX = torch.randn(B * crops, Tf, K, generator=g).abs().to(DEV).requires_grad_(True)
+    mask = torch.ones(B, Tf)
+    mask[:, -rng.choice([1, 2, 3]):] = 0
+    mask = mask.to(DEV)
+    z = ops.fusion_gather(x, at, bias, GX, mask, crops)
+    d = [v.detach().double().requires_grad_(True) for v in (x, at, bias, GX)]
+    rep = lambda v: v.unsqueeze(1).repeat((1, crops) + (1,) * (v.dim() - 1)).view((B * crops,) + tuple(v.shape[1:]))
+    a2 = rep(torch.sigmoid(d[1] + d[2]))
+    wgt = a2.unsqueeze(2) * (d[3] * rep(mask.double()).unsqueeze(2)).unsqueeze(3)
+    ref = torch.einsum('bctp,btkp->bckp', rep(d[0]), wgt) / (wgt.sum(1) + 1e-6).unsqueeze(1)
+    e = [relerr(z, ref)]
+    go = torch.randn(z.shape, generator=g).to(DEV)
+    gr = torch.autograd.grad(z, (x, at, bias, GX), go)
+    grr = torch.autograd.grad(ref, d, go.double())
+    e += [relerr(a_, b_) for a_, b_ in zip(gr, grr)]
+    # the attention bias is ONE scalar: its gradient is an fp32 sum over B x Tf x P signed terms (as in the reference) and carries the cancellation
+    # of that sum (1e-3 relative at Tf = 128 in the first campaign); it is judged against 5e-3, everything else against the common bound
+    return max(e[:3] + [e[3] * 0.04] + e[4:]), e
+
+
 def main():
     import random
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=200)
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--all', action='store_true', help='also conv1_t (5x1x1 depthwise), the block tail and the spatial pooling')
+    ap.add_argument('--all', action='store_true', help='also conv1_t (5x1x1 depthwise), the block tail, the spatial pooling, the dense saliency conv and the fusion gather')
     args = ap.parse_args()
     rng = random.Random(args.seed)
     g = torch.Generator().manual_seed(args.seed)
     bad = 0
     for i in range(args.cases):
-        fn = (dw_case, pw_case, t5_case, tail_case, pool_case)[i % 5] if args.all else (dw_case if i % 2 == 0 else pw_case)
+        fn = (dw_case, pw_case, t5_case, tail_case, pool_case, dense_case, gather_case)[i % 7] if args.all else (dw_case if i % 2 == 0 else pw_case)
         try:
             worst, e = fn(g, rng)
         except RuntimeError as ex:
