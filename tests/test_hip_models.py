@@ -218,6 +218,41 @@ def test_gridpool_layer_vs_reference(tag, depth, mode, op_route):
         assert maxdiff(m.bn2.split_bn.running_var, z['rv2']) <= 1e-5
 
 
+def test_gridpool_conv_bias_gets_an_exact_zero_gradient_and_weight_decay():
+    """x3d_coarse.py:362-366: conv1 / conv2 of Grid Pool feed train-mode batch norms, so their biases cancel (the reference computes a gradient
+    of rounding noise for them and SGD's weight decay still shrinks them).  Round 6 folds the bias-free statistics directly and keeps the
+    bias in the graph through `_ZeroGradFor`: the gradient must be exactly zero, the optimizer must still see the parameter (decay applied),
+    and the output must not depend on the bias while the running mean does."""
+    import x3d_coarse
+    from oracle import spec
+    torch.manual_seed(0)
+    m = x3d_coarse.GridPoolLayer(4, 24)
+    spec.fill_module_(m)
+    m = m.to(DEV).train(True)
+    x = spec.rand_input(77, (2, 24, 16, 28, 28)).to(DEV)
+    b0 = m.conv1.bias.detach().clone()
+    rm0 = m.bn1.split_bn.running_mean.detach().clone()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9, weight_decay=0.1)
+    y, cdf = m(x)
+    (y * spec.rand_input(78, tuple(y.shape)).to(DEV)).sum().backward()
+    for conv in (m.conv1, m.conv2):
+        assert conv.bias.grad is not None and not bool(conv.bias.grad.any())
+        assert float(conv.weight.grad.abs().max()) > 0
+    rm1 = m.bn1.split_bn.running_mean.detach().clone()
+    opt.step()
+    assert maxdiff(m.conv1.bias, b0 * (1 - 0.1 * 0.1)) <= 1e-7
+    # the same input with a shifted bias: same output / CDF, running mean moved by momentum x shift
+    m2 = x3d_coarse.GridPoolLayer(4, 24)
+    spec.fill_module_(m2)
+    m2 = m2.to(DEV).train(True)
+    with torch.no_grad():
+        m2.conv1.bias.add_(0.5)
+    y2, cdf2 = m2(x)
+    assert maxdiff(y2, y) <= 1e-5 and maxdiff(cdf2, cdf) <= 1e-6
+    assert maxdiff(m2.bn1.split_bn.running_mean - rm1, torch.full_like(rm1, 0.5 * m.bn1.momentum)) <= 1e-6
+    assert float((rm1 - rm0).abs().max()) > 0
+
+
 def test_gridunpool_vs_reference(op_route):
     import x3d_coarse
     from cfn_hip import ops
