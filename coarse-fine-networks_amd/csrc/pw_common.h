@@ -83,6 +83,10 @@ int stem_wgrad_try_launch(const float* gy, const float* x, double* gw, int N, in
 int sal_fwd_try_launch(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum,
                        double* sumsq, int N, int Cin, int Cout, int T, int Hi, int Wi, const int* g, hipStream_t st);
 // salconvb.hip: the forward of the same shapes on the split-bf16 matrix pipe (6 bf16 MFMAs per k-block, fp32-accurate); -1 = not handled / switched off
+// pwfuseds.hip: one-pass (data + weight gradient) backward of the layer-2 pointwise convs on the split-bf16 matrix pipe; -1 = not handled
+int pwfs_try_launch(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w, const float* x, const double* A,
+                    const double* B, int act, float* gx, double* gA, double* gB, double* gw, int N, int Cin, int Cout, int T, int Hi, int Wi,
+                    const float* acc, int acc_stride, const double* gscale, hipStream_t st);
 int salb_fwd_try_launch(const float* x, const double* A, const double* B, int act, const float* w, float* y, double* sum,
                         double* sumsq, int N, int Cin, int Cout, int T, int Hi, int Wi, const int* g, hipStream_t st);
 int sal_wgrad_try_launch(const float* gy, const float* y, const double* gs, const double* gq, const float* x, const double* A,

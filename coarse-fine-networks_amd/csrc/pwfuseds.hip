@@ -1,0 +1,440 @@
+// Fused backward of a stride-1 pointwise (1x1x1) convolution at the layer-2 widths (48 / 108 channels, x3d_fine.py:100-105 conv1 / conv3 of
+// res3): data gradient AND weight gradient in one pass over gy, y, x, on the bf16 matrix pipe with every fp32 operand split into three bf16
+// terms (the 6-term product of pws_kernel.h: fp32-accurate).
+//
+// Same pass structure as pw_bwd_fused_kernel (pwfused.hip: layer 1, fp32 MFMA): a workgroup (4 waves) owns one sample and a strip of
+// positions and walks it in stages of 64 positions; G' = gsc*gy + gs + 2*y*gq and the RAW x rows are staged in LDS as fp32 [channel][65]
+// (float4 global loads one stage ahead in registers, double-buffered images, one barrier per stage); wave w owns positions 16w .. 16w+15 of a
+// stage for BOTH products.  What differs is the arithmetic:
+//   weight gradient: v_mfma_f32_32x32x16_bf16, k = the wave's 16 positions: a lane reads 8 consecutive positions of its G' row (x row) from
+//                    the fp32 image, applies the prologue to x, and splits them into three packed-bf16 operands in registers;
+//   data gradient:   v_mfma_f32_16x16x32_bf16, k = 32 output channels: the B operand is the lane's position, 8 consecutive G' rows, split in
+//                    registers; the A operand W^T sits PRE-SPLIT in LDS (three [ci][co] bf16 images written once per workgroup) and is
+//                    read 16 bytes at a time.  The C layout (lane <-> position, 4 channel rows) is the one pw_bwd_fused_kernel's epilogue
+//                    works on: act' epilogue, statistics partials, compact shortcut gradient, 64-byte row-segment stores are the same code.
+// Registers: 8 accumulator tiles of the weight gradient per wave (128) + operands: one wave per SIMD (launch bounds 256, 1); the matrix
+// work per stage (3,072 cycles per SIMD) and the conversions are a third of the stage's HBM time, which is what has to be hidden.
+#include "cfn_common.h"
+#include <stdlib.h>
+
+#include "pw_common.h"
+
+typedef float __attribute__((ext_vector_type(4))) pf4;
+typedef __bf16 pfs_bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pfs_bf2 __attribute__((ext_vector_type(2)));
+typedef float pfs_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned pfs_u4 __attribute__((ext_vector_type(4)));
+
+#define PFS_PT 64
+#define PFS_PITCH 65
+
+__device__ __forceinline__ float pfs_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float pfs_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ unsigned pfs_pack(float lo, float hi) {
+    const pfs_bf2 b = __builtin_convertvector((pfs_f2){lo, hi}, pfs_bf2);
+    return __builtin_bit_cast(unsigned, b);
+}
+// (v0, v1) -> three packed bf16 pairs whose sum is (v0, v1) to fp32 accuracy
+__device__ __forceinline__ void pfs_split3(float v0, float v1, unsigned (&p)[3]) {
+    p[0] = pfs_pack(v0, v1);
+    v0 -= pfs_lo(p[0]); v1 -= pfs_hi(p[0]);
+    p[1] = pfs_pack(v0, v1);
+    v0 -= pfs_lo(p[1]); v1 -= pfs_hi(p[1]);
+    p[2] = pfs_pack(v0, v1);
+}
+// the six leading terms of (a0 + a1 + a2)(b0 + b1 + b2), smallest first (pws_kernel.h)
+#define PFS_TERMS(F) F(2, 0) F(0, 2) F(1, 1) F(1, 0) F(0, 1) F(0, 0)
+
+struct PfsArgs {
+    const float* gy; const float* y; const double* gs; const double* gq; const double* gsc;
+    const float* w;                       // (Cout, Cin) row major
+    const float* x; const double* pa; const double* pb;
+    float* gx; double* gA; double* gB; double* gw;
+    const float* acc; int acc_s, acc_Ho, acc_Wo, Hi, Wi, T;
+    int N, M, K, Q, nstrips, stages;      // M = Cout (rows of G'), K = Cin (rows of x)
+};
+
+// ACT < 0: the forward conv had no prologue (gx = da, no statistics)
+// 8 waves, specialised by product: waves 0-3 own the weight gradient of positions 16 (w & 3) .. + 15 of every stage, waves 4-7 the data gradient,
+// its epilogue and the statistics of the same positions.  Each SIMD then holds one wave of either kind -- the matrix instructions of one
+// overlap the conversions / epilogue of the other -- and neither loop carries the other's registers (128 accumulators here, 32 statistics
+// partials there).  All 512 threads stage.
+template <int MTW, int NTW, int ACT>
+__global__ __launch_bounds__(512, 1) void pw_bwd_fused_split_kernel(const PfsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool EPI = ACT >= 0;
+    constexpr int ACTV = EPI ? ACT : CFN_ACT_NONE;
+    constexpr int BM = 32 * MTW, BN = 32 * NTW;
+    constexpr int NG = BM / 32, NX = BN / 32;      // float4 per thread per stage (G rows / X rows)
+    constexpr int NT16 = BN / 16, KS = BM / 32;     // data gradient: 16-row tiles of input channels, k-steps of 32 output channels
+    constexpr bool ROWSPLIT = MTW >= NTW;           // weight gradient: the two tile halves are split along the longer side
+    constexpr int MI = ROWSPLIT ? MTW / 2 : MTW, NJ = ROWSPLIT ? NTW : NTW / 2;
+    constexpr int BMP = BM + 8;                     // W^T image: bf16 elements per input-channel row (272 / 144 bytes: 16-byte reads, rows 17 / 9 slots apart)
+    const int tid = threadIdx.x, wave = cfn_uni((int)(tid >> 6)), lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int m16 = lane & 15, kq = lane >> 4;
+    unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    const int strip = L % a.nstrips;
+    const int n = L / a.nstrips;
+    const int M = a.M, K = a.K, Q = a.Q;
+
+    constexpr int IMG = (BM + BN) * PFS_PITCH;         // one staged image: G' rows [BM][65] then raw x rows [BN][65]
+    float* img0 = smem;                                // two images (double buffer)
+    float* sCx = smem + 2 * IMG + 3 * BM;              // [BN][2]  (A, B) of the epilogue (3 BM floats in front stay unused: the layer-1 kernel keeps its G' coefficients there)
+    float* sSt = sCx + 2 * BN;                         // [4 waves][BN][2]  statistics of this workgroup
+    unsigned* sW = reinterpret_cast<unsigned*>(sSt + 8 * BN);      // [3 terms][BN][BMP / 2] packed bf16 pairs (co, co + 1) of W^T
+    for (int k = tid; k < BN; k += 512) {
+        const bool ok = EPI && k < K;
+        sCx[2 * k] = ok ? (float)a.pa[(long)n * K + k] : 1.0f;
+        sCx[2 * k + 1] = ok ? (float)a.pb[(long)n * K + k] : 0.0f;
+    }
+    for (int e = tid; e < BN * (BM / 2); e += 512) {   // W^T, split once per workgroup
+        const int ci = e / (BM / 2), mp = e - ci * (BM / 2), co = 2 * mp;
+        const float w0 = (ci < K && co < M) ? a.w[(long)co * K + ci] : 0.0f;
+        const float w1 = (ci < K && co + 1 < M) ? a.w[(long)(co + 1) * K + ci] : 0.0f;
+        unsigned p[3];
+        pfs_split3(w0, w1, p);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) sW[(s * BN + ci) * (BMP / 2) + mp] = p[s];
+    }
+    __syncthreads();
+
+    const int lrow = tid >> 4, c4 = (tid & 15) * 4;          // 16 lanes cover one 64-position row segment; 32 rows per pass
+    // unconditional buffer loads / stores (unwanted ones get an out-of-range offset), as in pw_bwd_fused_kernel
+    constexpr int OOB = 0x7ffffff0;
+    __amdgpu_buffer_rsrc_t rg = cfn_rsrc(const_cast<float*>(a.gy + (long)n * M * Q), (unsigned)((long)M * Q * 4));
+    __amdgpu_buffer_rsrc_t ry = cfn_rsrc(const_cast<float*>((a.y ? a.y : a.gy) + (long)n * M * Q), a.y ? (unsigned)((long)M * Q * 4) : 0u);
+    __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<float*>(a.x + (long)n * K * Q), (unsigned)((long)K * Q * 4));
+    __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + (long)n * K * Q, (unsigned)((long)K * Q * 4));
+    pf4 pg[NG], py[NG], px[NX];
+    int vog[NG], vox[NX];                                    // byte offsets of this thread's row segments (position 0)
+    // the (gs, 2 gq, gsc) of this thread's G' rows live in REGISTERS, read from global memory once: a coefficient pair that a wide LDS read has just
+    // returned must not be the operand of a packed FMA beside a matrix-bound wave (the round-3 race; the first build of this kernel,
+    // which read them from an LDS table inside `stage`, reproduced it: one G' row wrong in lanes 48-63 in 1-7 of 100 launches)
+    float rcs[NG], rcq[NG], rcz[NG];
+#pragma unroll
+    for (int it = 0; it < NG; ++it) {
+        const int row = it * 32 + lrow;
+        const bool ok = row < M;
+        rcs[it] = (ok && a.gs) ? (float)a.gs[(long)n * M + row] : 0.0f;
+        rcq[it] = (ok && a.gq && a.y) ? 2.0f * (float)a.gq[(long)n * M + row] : 0.0f;
+        rcz[it] = (ok && a.gsc) ? (float)a.gsc[(long)n * M + row] : 1.0f;
+    }
+#pragma unroll
+    for (int it = 0; it < NG; ++it) vog[it] = (it * 32 + lrow) < M ? ((it * 32 + lrow) * Q + c4) * 4 : OOB;
+#pragma unroll
+    for (int it = 0; it < NX; ++it) vox[it] = (it * 32 + lrow) < K ? ((it * 32 + lrow) * Q + c4) * 4 : OOB;
+    auto prefetch = [&](int q0) {
+        const bool inq = q0 + c4 < Q;
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            const int vo = inq ? vog[it] : OOB;
+            pg[it] = __builtin_bit_cast(pf4, __builtin_amdgcn_raw_buffer_load_b128(rg, vo, q0 * 4, 0));
+            py[it] = __builtin_bit_cast(pf4, __builtin_amdgcn_raw_buffer_load_b128(ry, vo, q0 * 4, 0));
+        }
+#pragma unroll
+        for (int it = 0; it < NX; ++it)
+            px[it] = __builtin_bit_cast(pf4, __builtin_amdgcn_raw_buffer_load_b128(rx, inq ? vox[it] : OOB, q0 * 4, 0));
+    };
+    auto stage = [&](int q0, float* sG, float* sX) {
+        const bool inq = q0 + c4 < Q;
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            const int row = it * 32 + lrow;
+            const float cs = rcs[it], cq = rcq[it], cz = rcz[it];
+            const bool ok = inq && (row < M);
+            float* d = sG + row * PFS_PITCH + c4;
+            d[0] = ok ? fmaf(py[it].x, cq, fmaf(pg[it].x, cz, cs)) : 0.0f;
+            d[1] = ok ? fmaf(py[it].y, cq, fmaf(pg[it].y, cz, cs)) : 0.0f;
+            d[2] = ok ? fmaf(py[it].z, cq, fmaf(pg[it].z, cz, cs)) : 0.0f;
+            d[3] = ok ? fmaf(py[it].w, cq, fmaf(pg[it].w, cz, cs)) : 0.0f;
+        }
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int row = it * 32 + lrow;
+            float* d = sX + row * PFS_PITCH + c4;            // raw x; rows >= K and positions >= Q were loaded as 0
+            d[0] = px[it].x; d[1] = px[it].y; d[2] = px[it].z; d[3] = px[it].w;
+        }
+    };
+
+    const int qbeg = strip * a.stages * PFS_PT;
+    const int nst = min(a.stages, (Q - qbeg + PFS_PT - 1) / PFS_PT);
+    if (nst > 0) {
+        prefetch(qbeg);
+        stage(qbeg, img0, img0 + BM * PFS_PITCH);
+        if (nst > 1) prefetch(qbeg + PFS_PT);
+    }
+    __syncthreads();
+    const int pbase = (wave & 3) * (PFS_PT / 4);
+    constexpr int CWP = 33, CWT = 32 * CWP;                 // the weight-gradient waves leave their tiles here after the last stage: [4 waves][MTW * NTW][32][33]
+
+    if (wave < 4) {
+        // ================= weight gradient: wave (th, ph) owns HALF the tiles (th) over positions 32 ph .. 32 ph + 31 of every stage (two k-blocks);
+        // lane (row = col, k = 8 half + e).  64 accumulator registers per wave; the two position halves of a tile meet in LDS after the last stage
+        const int th = wave & 1, ph = wave >> 1;
+        const int i0 = ROWSPLIT ? th * MI : 0, j0 = ROWSPLIT ? 0 : th * NJ;
+        float ca[NJ], cb[NJ];                                // prologue coefficients of this lane's x rows (row (j0 + j)*32 + col)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int k = (j0 + j) * 32 + col;
+            const bool ok = EPI && k < K;
+            ca[j] = ok ? (float)a.pa[(long)n * K + k] : 1.0f;
+            cb[j] = ok ? (float)a.pb[(long)n * K + k] : 0.0f;
+        }
+        f16v acc[MI][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int st = 0; st < nst; ++st) {
+            const int q0 = qbeg + st * PFS_PT;
+            float* cur = img0 + (st & 1) * IMG;
+            float* nxt = img0 + ((st + 1) & 1) * IMG;
+            if (st + 1 < nst) {
+                stage(q0 + PFS_PT, nxt, nxt + BM * PFS_PITCH);
+                if (st + 2 < nst) prefetch(q0 + 2 * PFS_PT);
+            }
+            const float* sG = cur;
+            const float* sX = cur + BM * PFS_PITCH;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int p0 = 32 * ph + 16 * kb + 8 * half;
+                pfs_u4 Bf[NJ][3];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const float* r = sX + ((j0 + j) * 32 + col) * PFS_PITCH + p0;
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        float x0 = r[2 * h], x1 = r[2 * h + 1];
+                        if (EPI) { x0 = cfn_act<ACTV>(fmaf(x0, ca[j], cb[j])); x1 = cfn_act<ACTV>(fmaf(x1, ca[j], cb[j])); }
+                        unsigned p[3];
+                        pfs_split3(x0, x1, p);
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) Bf[j][s][h] = p[s];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const float* r = sG + ((i0 + i) * 32 + col) * PFS_PITCH + p0;
+                    pfs_u4 Af[3];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        unsigned p[3];
+                        pfs_split3(r[2 * h], r[2 * h + 1], p);
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) Af[s][h] = p[s];
+                    }
+#define PFS_WG(SA, SB) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pfs_bf8, Af[SA]), __builtin_bit_cast(pfs_bf8, Bf[j][SB]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { PFS_TERMS(PFS_WG) }
+#undef PFS_WG
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();                                     // (A) the data-gradient waves have left their statistics in sSt
+        __syncthreads();                                     // (B) ... and they have been read: the LDS below sW's end is free
+        float* cw = smem + wave * (MI * NJ * CWT);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cw[(i * NJ + j) * CWT + ((r & 3) + 8 * (r >> 2) + 4 * half) * CWP + col] = acc[i][j][r];
+    } else {
+        // ================= data gradient of the same 16 positions: lane (position m16, k = 32 s + 8 kq + e), epilogue, statistics =================
+        float sa[NT16][4], sb[NT16][4];                      // per-lane partial statistics of rows t*16 + 4*kq + r
+#pragma unroll
+        for (int t = 0; t < NT16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sa[t][r] = 0.0f; sb[t][r] = 0.0f; }
+        const int hw = a.Hi * a.Wi;
+        const int acc_pitch4 = a.T * a.acc_Ho * a.acc_Wo * 4;   // bytes per channel of the compact gradient
+        __amdgpu_buffer_rsrc_t racc = cfn_rsrc(const_cast<float*>(a.acc ? a.acc + (long)n * K * (acc_pitch4 / 4) : a.gy), a.acc ? (unsigned)((long)K * acc_pitch4) : 0u);
+        for (int st = 0; st < nst; ++st) {
+            const int q0 = qbeg + st * PFS_PT;
+            float* cur = img0 + (st & 1) * IMG;
+            float* nxt = img0 + ((st + 1) & 1) * IMG;
+            if (st + 1 < nst) {
+                stage(q0 + PFS_PT, nxt, nxt + BM * PFS_PITCH);
+                if (st + 2 < nst) prefetch(q0 + 2 * PFS_PT);
+            }
+            const float* sG = cur;
+            const float* sX = cur + BM * PFS_PITCH;
+            pf4 da[NT16];
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) da[t] = (pf4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const float* r = sG + (32 * s + 8 * kq) * PFS_PITCH + pbase + m16;
+                pfs_u4 Gf[3];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    unsigned p[3];
+                    pfs_split3(r[(2 * h) * PFS_PITCH], r[(2 * h + 1) * PFS_PITCH], p);
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) Gf[u][h] = p[u];
+                }
+#pragma unroll
+                for (int t = 0; t < NT16; ++t) {
+                    const unsigned* wr = sW + ((t * 16 + m16) * BMP + 32 * s + 8 * kq) / 2;
+                    pfs_u4 Wf[3];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) Wf[u] = *reinterpret_cast<const pfs_u4*>(wr + u * BN * (BMP / 2));
+#define PFS_DG(SA, SB) da[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pfs_bf8, Wf[SA]), __builtin_bit_cast(pfs_bf8, Gf[SB]), da[t], 0, 0, 0);
+                    PFS_TERMS(PFS_DG)
+#undef PFS_DG
+                }
+            }
+            const int q = q0 + pbase + m16;
+            const bool qv = q < Q;
+            int aoff = OOB;                                        // compact lattice byte offset of this lane's position
+            if (a.acc && qv) {
+                const int tq = q / hw, rq = q - tq * hw;
+                const int hq = rq / a.Wi, wq_ = rq - hq * a.Wi;
+                if (hq % a.acc_s == 0 && wq_ % a.acc_s == 0) aoff = (((tq * a.acc_Ho + hq / a.acc_s) * a.acc_Wo + wq_ / a.acc_s)) * 4;
+            }
+            const unsigned arow = (unsigned)aoff + (unsigned)(4 * kq) * (unsigned)acc_pitch4;
+            // the compact shortcut gradient of this lane's outputs: all loads up front where the registers allow it (<= 4 channel tiles: 16 values),
+            // tile by tile otherwise; the per-lane part of the row goes into the VECTOR offset (a lane-dependent scalar offset would be a waterfall loop)
+            constexpr bool AV_UPFRONT = NT16 <= 4;
+            float av4[AV_UPFRONT ? NT16 : 1][4];
+            if (AV_UPFRONT) {
+#pragma unroll
+                for (int t = 0; t < NT16; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) av4[AV_UPFRONT ? t : 0][r] = 0.0f;
+                if (a.acc) {                                       // workgroup uniform
+#pragma unroll
+                    for (int t = 0; t < NT16; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            av4[AV_UPFRONT ? t : 0][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                racc, (int)(aoff == OOB ? (unsigned)OOB : arow + (unsigned)r * (unsigned)acc_pitch4), t * 16 * acc_pitch4, 0));
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = t * 16 + 4 * kq + r;
+                    const bool ok = qv && ci < K;
+                    float v = da[t][r];
+                    if (AV_UPFRONT) v += av4[AV_UPFRONT ? t : 0][r];
+                    else if (a.acc)
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            racc, (int)(aoff == OOB ? (unsigned)OOB : arow + (unsigned)r * (unsigned)acc_pitch4), t * 16 * acc_pitch4, 0));
+                    if (EPI) {
+                        const float xr = sX[ci * PFS_PITCH + pbase + m16];
+                        const float2 pab = cfn_settle(*reinterpret_cast<const float2*>(sCx + 2 * ci));      // (an LDS pair in front of FMAs: DESIGN 4.1)
+                        const float pa = pab.x, pb = pab.y;
+                        const float dz = ok ? v * cfn_act_grad<ACTV>(fmaf(xr, pa, pb)) : 0.0f;
+                        sa[t][r] = fmaf(dz, xr, sa[t][r]);
+                        sb[t][r] += dz;
+                        v = dz * pa;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, ok ? (ci * Q + pbase + m16) * 4 : OOB, q0 * 4, 0);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- statistics: reduce over the 16 position lanes, then over the 4 data-gradient waves in LDS, one fp64 atomic per row -------
+        if (EPI) {
+#pragma unroll
+            for (int t = 0; t < NT16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float u = sa[t][r], v = sb[t][r];
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) { u += __shfl_xor(u, o, 64); v += __shfl_xor(v, o, 64); }
+                    if (m16 == 0) {                                // per-wave slot, plain store (fixed summation order below)
+                        const int ci = t * 16 + 4 * kq + r;
+                        sSt[((wave & 3) * BN + ci) * 2] = u;
+                        sSt[((wave & 3) * BN + ci) * 2 + 1] = v;
+                    }
+                }
+        }
+        __syncthreads();                                     // (A)
+        const int t2 = tid - 256;
+        if (EPI && t2 < K) {
+            const float u = (sSt[2 * t2] + sSt[(BN + t2) * 2]) + (sSt[(2 * BN + t2) * 2] + sSt[(3 * BN + t2) * 2]);
+            const float v = (sSt[2 * t2 + 1] + sSt[(BN + t2) * 2 + 1]) + (sSt[(2 * BN + t2) * 2 + 1] + sSt[(3 * BN + t2) * 2 + 1]);
+            cfn_add64(&a.gA[(long)n * K + t2], (double)u);
+            cfn_add64(&a.gB[(long)n * K + t2], (double)v);
+        }
+        __syncthreads();                                     // (B)
+    }
+    __syncthreads();                                         // the weight-gradient tiles of the four waves are in LDS
+    // ---- weight gradient: a tile = wave (th, 0) + wave (th, 1); one fp64 atomic per element and workgroup ----
+    constexpr int WT = MI * NJ;                              // tiles per wave
+    for (int e = tid; e < 2 * WT * 1024; e += 512) {
+        const int th = e / (WT * 1024), tile = (e >> 10) % WT, ml = (e >> 5) & 31, kl = e & 31, o = tile * CWT + ml * CWP + kl;
+        const float v = smem[th * (WT * CWT) + o] + smem[(2 + th) * (WT * CWT) + o];
+        const int i = tile / NJ, j = tile - i * NJ;
+        const int gm = ((ROWSPLIT ? th * MI : 0) + i) * 32 + ml, gk = ((ROWSPLIT ? 0 : th * NJ) + j) * 32 + kl;
+        if (gm < M && gk < K) cfn_add64(&a.gw[(long)gm * K + gk], (double)v);
+    }
+}
+
+template <int MTW, int NTW>
+static int pfs_launch(const PfsArgs& a, int act, bool epi, unsigned blocks, hipStream_t st) {
+    constexpr int BM = 32 * MTW, BN = 32 * NTW, BMP = BM + 8;
+    size_t lds = ((size_t)2 * (BM + BN) * PFS_PITCH + 3 * BM + 10 * BN) * sizeof(float) + (size_t)3 * BN * BMP * 2;
+    const size_t lds_cw = (size_t)4 * (MTW * NTW / 2) * 32 * 33 * sizeof(float);   // the four weight-gradient waves' tiles, after the last stage
+    if (lds_cw > lds) lds = lds_cw;
+#define CFN_PFS_GO(ACTV)                                                                                        \
+    do {                                                                                                        \
+        auto k = pw_bwd_fused_split_kernel<MTW, NTW, ACTV>;                                                     \
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, st, a);                                             \
+    } while (0)
+    if (!epi) CFN_PFS_GO(-1);
+    else if (act == CFN_ACT_RELU) CFN_PFS_GO(CFN_ACT_RELU);
+    else if (act == CFN_ACT_SWISH) CFN_PFS_GO(CFN_ACT_SWISH);
+    else CFN_PFS_GO(CFN_ACT_NONE);
+#undef CFN_PFS_GO
+    return cfn_check_launch("pwconv_bwd_fused (split bf16)");
+}
+
+// -1 = not handled (cfn_pwconv_bwd_fused goes on to its fp32 kernel / declines)
+int pwfs_try_launch(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w, const float* x, const double* A,
+                    const double* B, int act, float* gx, double* gA, double* gB, double* gw, int N, int Cin, int Cout, int T, int Hi, int Wi,
+                    const float* acc, int acc_stride, const double* gscale, hipStream_t st) {
+    const char* env_on = getenv("CFN_PWF_SPLIT");      // read per call: tests and A/B harnesses switch it inside one process
+    const int on = env_on ? atoi(env_on) : 0;
+    if (!on || pws_terms_now() != 6) return -1;
+    // CFN_PWF_SPLIT: 1 = the shapes WITHOUT a prologue (conv1 of the layer-2 blocks, whose input is a materialised block output), 2 = also the
+    // shapes with one (conv3: BN2 + swish in front)
+    const bool wide_m = Cout > 64 && Cout <= 128 && Cin > 32 && Cin <= 64;          // conv1 of layer 2: 48 -> 108
+    const bool thin_k = Cout > 64 && Cout <= 128 && Cin >= 16 && Cin <= 32;         // conv1 of the first block of layer 2: 24 -> 108
+    const bool wide_k = Cin > 64 && Cin <= 128 && Cout > 32 && Cout <= 64;          // conv3 of layer 2: 108 -> 48
+    if (!wide_m && !wide_k && !thin_k) return -1;
+    if (A != nullptr && on < 2) return -1;
+    const long Ql = (long)T * Hi * Wi;
+    if (Ql % 4 != 0 || Ql >= (1L << 30)) return -1;
+    if ((long)Cout * Ql * 4 >= 0x7ffffff0L || (long)Cin * Ql * 4 >= 0x7ffffff0L) return -1;   // 32-bit buffer offsets per sample
+    if (A && act != CFN_ACT_NONE && act != CFN_ACT_RELU && act != CFN_ACT_SWISH) return -1;
+    if ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)(y ? y : gy)) & 15) != 0) return -1;
+    PfsArgs a = {};
+    a.gy = gy; a.y = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.gsc = gscale; a.w = w; a.x = x; a.pa = A; a.pb = B;
+    a.gx = gx; a.gA = gA; a.gB = gB; a.gw = gw;
+    a.acc = acc; a.acc_s = acc ? acc_stride : 1; a.Hi = Hi; a.Wi = Wi; a.T = T;
+    a.acc_Ho = (Hi - 1) / a.acc_s + 1; a.acc_Wo = (Wi - 1) / a.acc_s + 1;
+    a.N = N; a.M = Cout; a.K = Cin; a.Q = (int)Ql;
+    const long nst = cfn_cdiv(Ql, PFS_PT);
+    // one workgroup per CU is resident: 1024 workgroups = 4 whole rounds of the chip
+    static const int wgs = getenv("CFN_PWFS_WGS") ? atoi(getenv("CFN_PWFS_WGS")) : 1024;
+    long want = wgs / N;
+    if (want < 1) want = 1;
+    long stages = cfn_cdiv(nst, want);
+    if (stages < 4) stages = 4;
+    a.stages = (int)stages;
+    a.nstrips = (int)cfn_cdiv(nst, stages);
+    const unsigned blocks = (unsigned)((long)N * a.nstrips);
+    CfnProfScope prof(CFN_K_PWCONV_BWD, st, 4.0 * N * ((double)Cout * Ql * (a.y ? 2 : 1) + (double)Cin * Ql * 2));
+    const bool epi = A != nullptr;
+    if (wide_m) return pfs_launch<4, 2>(a, act, epi, blocks, st);
+    if (thin_k) return pfs_launch<4, 1>(a, act, epi, blocks, st);
+    return pfs_launch<2, 4>(a, act, epi, blocks, st);
+}

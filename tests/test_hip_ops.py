@@ -306,6 +306,54 @@ def test_pwconv_bwd_fused_matches_separate(cfg, act):
             assert relerr(g, r) <= 2e-5, name
 
 
+@pytest.mark.parametrize('act', [None, 0, 1, 2])
+@pytest.mark.parametrize('cfg', [(2, 48, 108, 3, 8, 8, 0), (2, 108, 48, 2, 12, 12, 0), (1, 48, 108, 5, 6, 6, 2), (1, 108, 48, 3, 10, 10, 2),
+                                 (2, 40, 100, 1, 7, 8, 0), (1, 100, 40, 2, 6, 6, 0), (1, 64, 128, 9, 14, 14, 0), (1, 128, 64, 4, 28, 28, 0),
+                                 (2, 24, 108, 3, 12, 12, 0), (1, 32, 128, 2, 10, 10, 2), (1, 16, 70, 5, 6, 6, 0)])
+def test_pwconv_bwd_fused_split_matches_separate(cfg, act, monkeypatch):
+    """the layer-2 widths of cfn_pwconv_bwd_fused (csrc/pwfuseds.hip: one pass, split-bf16 matrix products) against the separate data /
+    weight gradient kernels: prologue / no prologue, statistics gradients, tail scale, compact shortcut gradient, ragged strips"""
+    import cfn_hip
+    monkeypatch.setenv('CFN_PWF_SPLIT', '2')
+    N, Cin, Cout, T, H, W, acc_s = cfg
+    f64 = lambda seed, *shape, scale=1.0: (rnd(seed, *shape) * scale).double().to(DEV)
+    gy, y, x = rnd(1, N, Cout, T, H, W).to(DEV), rnd(2, N, Cout, T, H, W).to(DEV), rnd(3, N, Cin, T, H, W).to(DEV)
+    w = (0.3 * rnd(4, Cout, Cin)).to(DEV)
+    gs, gq, gsc = f64(5, N, Cout, scale=0.05), f64(6, N, Cout, scale=0.01), 1.0 + f64(7, N, Cout, scale=0.3)
+    A = B = None
+    if act is not None:
+        A, B = 1.0 + f64(8, N, Cin, scale=0.2), f64(9, N, Cin, scale=0.2)
+    acc = None
+    if acc_s:
+        acc = rnd(10, N, Cin, T, (H - 1) // acc_s + 1, (W - 1) // acc_s + 1).to(DEV)
+
+    def run(fused):
+        gx = torch.empty_like(x)
+        gA = gB = None
+        if A is not None:
+            gA, gB = (torch.zeros(N, Cin, dtype=torch.float64, device=DEV) for _ in range(2))
+        gw = torch.zeros(Cout, Cin, dtype=torch.float64, device=DEV)
+        a_ = 0 if act is None else act
+        if fused:
+            ok = cfn_hip.call_try('cfn_pwconv_bwd_fused', gy, y, gs, gq, w, x, A, B, a_, gx, gA, gB, gw, N, Cin, Cout, T, H, W,
+                                  acc, acc_s or 1, gsc)
+            assert ok, 'shape should be handled by the split fused kernel'
+        else:
+            cfn_hip.call('cfn_pwconv_bwd_data_acc', gy, y, gs, gq, w, x, A, B, a_, gx, gA, gB, N, Cin, Cout, T, H, W, 1, acc,
+                         acc_s or 1, gsc)
+            cfn_hip.call('cfn_pwconv_bwd_weight', gy, y, gs, gq, x, A, B, a_, gw, N, Cin, Cout, T, H, W, 1, gsc)
+        return gx, gA, gB, gw
+
+    ref, got = run(False), run(True)
+    for name, r, g in zip(('gx', 'gA', 'gB', 'gw'), ref, got):
+        if r is not None:
+            assert relerr(g, r) <= 2e-5, (name, relerr(g, r))
+    again = run(True)                      # run-to-run bits (fp64 atomics of fp32 partials: exact)
+    for r, g in zip(got, again):
+        if r is not None:
+            assert torch.equal(r, g)
+
+
 @pytest.mark.parametrize('shortcut', ['identity', 'conv_s2', 'conv_s1'])
 @pytest.mark.parametrize('cfg', [(2, 54, 24, 4, 8, 8), (1, 108, 48, 3, 6, 6), (2, 216, 96, 2, 14, 14), (1, 20, 12, 3, 5, 7)])
 def test_linked_tail(cfg, shortcut):
