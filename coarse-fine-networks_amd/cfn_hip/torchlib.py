@@ -192,8 +192,10 @@ def pwconv_backward(gy: torch.Tensor, gs: torch.Tensor, gq: torch.Tensor, x: tor
     gw = _f64(Cout, Cin, dev=x.device)
     ab = _f64(2, N, Cin, dev=x.device) if A is not None else None
     a64, b64 = (ab[0], ab[1]) if ab is not None else (None, None)
-    call('cfn_pwconv_bwd_data', gy, y, gs64, gq64, w2, x, A64, B64, act, gx, a64, b64, N, Cin, Cout, T, H, W, stride)
-    call('cfn_pwconv_bwd_weight', gy, y, gs64, gq64, x, A64, B64, act, gw, N, Cin, Cout, T, H, W, stride, None)
+    # one pass over gy, y, x where the library has a fused kernel for the shape (layers 1 and 2: pwfused.hip, pwfuseds.hip), as cfn_hip.ops does
+    if not (stride == 1 and call_try('cfn_pwconv_bwd_fused', gy, y, gs64, gq64, w2, x, A64, B64, act, gx, a64, b64, gw, N, Cin, Cout, T, H, W, None, 1, None)):
+        call('cfn_pwconv_bwd_data', gy, y, gs64, gq64, w2, x, A64, B64, act, gx, a64, b64, N, Cin, Cout, T, H, W, stride)
+        call('cfn_pwconv_bwd_weight', gy, y, gs64, gq64, x, A64, B64, act, gw, N, Cin, Cout, T, H, W, stride, None)
     if ab is None:      # (outputs of a custom op may not alias each other)
         return gx, gw.float().view(w.shape), x.new_zeros(1, dtype=torch.float32), x.new_zeros(1, dtype=torch.float32)
     return gx, gw.float().view(w.shape), ab[0].float(), ab[1].float()

@@ -313,7 +313,7 @@ extern "C" int cfn_pwconv_bwd_fused(const float* gy, const float* y, const doubl
     CFN_REQUIRE(A == nullptr || (gA && gB), "cfn_pwconv_bwd_fused: prologue needs gA, gB");
     CFN_REQUIRE(gsumsq == nullptr || y != nullptr, "cfn_pwconv_bwd_fused: gsumsq needs y");
     CFN_REQUIRE(acc == nullptr || acc_stride >= 1, "cfn_pwconv_bwd_fused: bad acc_stride");
-    {   // layer-2 widths: the split-bf16 kernel of pwfuseds.hip (opt-in while it is being measured: CFN_PWF_SPLIT=1)
+    {   // layer-2 widths: the split-bf16 kernel of pwfuseds.hip (CFN_PWF_SPLIT: 0 off, 1 = default: the shapes without a prologue, 2 = all)
         const int rs = pwfs_try_launch(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, Cin, Cout, T, Hi, Wi, acc, acc_stride, gscale, (hipStream_t)stream);
         if (rs != -1) return rs;
     }

@@ -1,3 +1,4 @@
+// hipcc-flags: -fno-slp-vectorize
 // Fused backward of a stride-1 pointwise (1x1x1) convolution at the layer-2 widths (48 / 108 channels, x3d_fine.py:100-105 conv1 / conv3 of
 // res3): data gradient AND weight gradient in one pass over gy, y, x, on the bf16 matrix pipe with every fp32 operand split into three bf16
 // terms (the 6-term product of pws_kernel.h: fp32-accurate).
@@ -52,6 +53,7 @@ struct PfsArgs {
     float* gx; double* gA; double* gB; double* gw;
     const float* acc; int acc_s, acc_Ho, acc_Wo, Hi, Wi, T;
     int N, M, K, Q, nstrips, stages;      // M = Cout (rows of G'), K = Cin (rows of x)
+    int dbg;                              // knock-outs for tools/pwfs_knockouts.sh (CFN_PWFS_DBG; 0 in the product): 1 weight gradient, 2 data gradient, 4 act' / statistics, 8 gx stores
 };
 
 // ACT < 0: the forward conv had no prologue (gx = da, no statistics)
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split_kernel(const PfsArg
     constexpr bool EPI = ACT >= 0;
     constexpr int ACTV = EPI ? ACT : CFN_ACT_NONE;
     constexpr int BM = 32 * MTW, BN = 32 * NTW;
-    constexpr int NG = BM / 32, NX = BN / 32;      // float4 per thread per stage (G rows / X rows)
+    constexpr int NG = BM / 16, NX = BN / 16;      // float4 per STAGING thread per stage (G rows / X rows): the 256 threads of the weight-gradient waves stage
     constexpr int NT16 = BN / 16, KS = BM / 32;     // data gradient: 16-row tiles of input channels, k-steps of 32 output channels
     constexpr bool ROWSPLIT = MTW >= NTW;           // weight gradient: the two tile halves are split along the longer side
     constexpr int MI = ROWSPLIT ? MTW / 2 : MTW, NJ = ROWSPLIT ? NTW : NTW / 2;
@@ -98,7 +100,8 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split_kernel(const PfsArg
     }
     __syncthreads();
 
-    const int lrow = tid >> 4, c4 = (tid & 15) * 4;          // 16 lanes cover one 64-position row segment; 32 rows per pass
+    const int lrow = (tid & 255) >> 4, c4 = (tid & 15) * 4;  // 16 lanes cover one 64-position row segment; 16 rows per pass (waves 0-3 only: the data-gradient
+                                                             // waves carry 32-64 statistics registers instead of the prefetched rows)
     // unconditional buffer loads / stores (unwanted ones get an out-of-range offset), as in pw_bwd_fused_kernel
     constexpr int OOB = 0x7ffffff0;
     __amdgpu_buffer_rsrc_t rg = cfn_rsrc(const_cast<float*>(a.gy + (long)n * M * Q), (unsigned)((long)M * Q * 4));
@@ -113,16 +116,16 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split_kernel(const PfsArg
     float rcs[NG], rcq[NG], rcz[NG];
 #pragma unroll
     for (int it = 0; it < NG; ++it) {
-        const int row = it * 32 + lrow;
+        const int row = it * 16 + lrow;
         const bool ok = row < M;
         rcs[it] = (ok && a.gs) ? (float)a.gs[(long)n * M + row] : 0.0f;
         rcq[it] = (ok && a.gq && a.y) ? 2.0f * (float)a.gq[(long)n * M + row] : 0.0f;
         rcz[it] = (ok && a.gsc) ? (float)a.gsc[(long)n * M + row] : 1.0f;
     }
 #pragma unroll
-    for (int it = 0; it < NG; ++it) vog[it] = (it * 32 + lrow) < M ? ((it * 32 + lrow) * Q + c4) * 4 : OOB;
+    for (int it = 0; it < NG; ++it) vog[it] = (it * 16 + lrow) < M ? ((it * 16 + lrow) * Q + c4) * 4 : OOB;
 #pragma unroll
-    for (int it = 0; it < NX; ++it) vox[it] = (it * 32 + lrow) < K ? ((it * 32 + lrow) * Q + c4) * 4 : OOB;
+    for (int it = 0; it < NX; ++it) vox[it] = (it * 16 + lrow) < K ? ((it * 16 + lrow) * Q + c4) * 4 : OOB;
     auto prefetch = [&](int q0) {
         const bool inq = q0 + c4 < Q;
 #pragma unroll
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split_kernel(const PfsArg
         const bool inq = q0 + c4 < Q;
 #pragma unroll
         for (int it = 0; it < NG; ++it) {
-            const int row = it * 32 + lrow;
+            const int row = it * 16 + lrow;
             const float cs = rcs[it], cq = rcq[it], cz = rcz[it];
             const bool ok = inq && (row < M);
             float* d = sG + row * PFS_PITCH + c4;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split_kernel(const PfsArg
         }
 #pragma unroll
         for (int it = 0; it < NX; ++it) {
-            const int row = it * 32 + lrow;
+            const int row = it * 16 + lrow;
             float* d = sX + row * PFS_PITCH + c4;            // raw x; rows >= K and positions >= Q were loaded as 0
             d[0] = px[it].x; d[1] = px[it].y; d[2] = px[it].z; d[3] = px[it].w;
         }
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split_kernel(const PfsArg
 
     const int qbeg = strip * a.stages * PFS_PT;
     const int nst = min(a.stages, (Q - qbeg + PFS_PT - 1) / PFS_PT);
-    if (nst > 0) {
+    if (nst > 0 && wave < 4) {
         prefetch(qbeg);
         stage(qbeg, img0, img0 + BM * PFS_PITCH);
         if (nst > 1) prefetch(qbeg + PFS_PT);
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split_kernel(const PfsArg
             }
             const float* sG = cur;
             const float* sX = cur + BM * PFS_PITCH;
+            if (!(a.dbg & 1))
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const int p0 = 32 * ph + 16 * kb + 8 * half;
@@ -255,16 +259,12 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split_kernel(const PfsArg
         for (int st = 0; st < nst; ++st) {
             const int q0 = qbeg + st * PFS_PT;
             float* cur = img0 + (st & 1) * IMG;
-            float* nxt = img0 + ((st + 1) & 1) * IMG;
-            if (st + 1 < nst) {
-                stage(q0 + PFS_PT, nxt, nxt + BM * PFS_PITCH);
-                if (st + 2 < nst) prefetch(q0 + 2 * PFS_PT);
-            }
             const float* sG = cur;
             const float* sX = cur + BM * PFS_PITCH;
             pf4 da[NT16];
 #pragma unroll
             for (int t = 0; t < NT16; ++t) da[t] = (pf4){0.f, 0.f, 0.f, 0.f};
+            if (!(a.dbg & 2))
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const float* r = sG + (32 * s + 8 * kq) * PFS_PITCH + pbase + m16;
@@ -285,10 +285,12 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split_kernel(const PfsArg
 #define PFS_DG(SA, SB) da[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pfs_bf8, Wf[SA]), __builtin_bit_cast(pfs_bf8, Gf[SB]), da[t], 0, 0, 0);
                     PFS_TERMS(PFS_DG)
 #undef PFS_DG
+                    if (NT16 > 4 && (t & 1)) __builtin_amdgcn_sched_barrier(0);      // (two tiles' W^T operands in flight, not all sixteen)
                 }
             }
             const int q = q0 + pbase + m16;
             const bool qv = q < Q;
+            const int gvo = (qv && !(a.dbg & 8)) ? (4 * kq * Q + pbase + m16) * 4 : OOB;
             int aoff = OOB;                                        // compact lattice byte offset of this lane's position
             if (a.acc && qv) {
                 const int tq = q / hw, rq = q - tq * hw;
@@ -319,23 +321,26 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split_kernel(const PfsArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ci = t * 16 + 4 * kq + r;
-                    const bool ok = qv && ci < K;
-                    float v = da[t][r];
+                    float v = da[t][r];                            // exactly 0 for positions >= Q (G' = 0 there) and rows >= K (zero rows of W^T)
                     if (AV_UPFRONT) v += av4[AV_UPFRONT ? t : 0][r];
                     else if (a.acc)
                         v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                             racc, (int)(aoff == OOB ? (unsigned)OOB : arow + (unsigned)r * (unsigned)acc_pitch4), t * 16 * acc_pitch4, 0));
-                    if (EPI) {
+                    if (EPI && !(a.dbg & 4)) {
                         const float xr = sX[ci * PFS_PITCH + pbase + m16];
                         const float2 pab = cfn_settle(*reinterpret_cast<const float2*>(sCx + 2 * ci));      // (an LDS pair in front of FMAs: DESIGN 4.1)
                         const float pa = pab.x, pb = pab.y;
-                        const float dz = ok ? v * cfn_act_grad<ACTV>(fmaf(xr, pa, pb)) : 0.0f;
+                        const float dz = v * cfn_act_grad<ACTV>(fmaf(xr, pa, pb));
                         sa[t][r] = fmaf(dz, xr, sa[t][r]);
                         sb[t][r] += dz;
                         v = dz * pa;
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, ok ? (ci * Q + pbase + m16) * 4 : OOB, q0 * 4, 0);
+                    // ONE lane offset for all the wave's stores (row 4 kq, this position); the (t, r) part of the row is wave uniform and rides in the scalar
+                    // offset; rows >= K fall outside the descriptor and are dropped by the hardware -- 32 per-output offsets kept live across the stage loop
+                    // were what spilled the statistics registers
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, gvo, (q0 + (t * 16 + r) * Q) * 4, 0);
                 }
+                if (NT16 > 4) __builtin_amdgcn_sched_barrier(0);   // one channel tile's LDS reads in flight at a time: hoisting all 8 tiles' reads spills the 64 statistics registers
             }
             __syncthreads();
         }
@@ -402,7 +407,7 @@ int pwfs_try_launch(const float* gy, const float* y, const double* gsum, const d
                     const double* B, int act, float* gx, double* gA, double* gB, double* gw, int N, int Cin, int Cout, int T, int Hi, int Wi,
                     const float* acc, int acc_stride, const double* gscale, hipStream_t st) {
     const char* env_on = getenv("CFN_PWF_SPLIT");      // read per call: tests and A/B harnesses switch it inside one process
-    const int on = env_on ? atoi(env_on) : 0;
+    const int on = env_on ? atoi(env_on) : 1;          // default 1: the no-prologue shapes (measured in the step: -1.3 .. -1.9 ms; level 2 loses 0.5 ms of it)
     if (!on || pws_terms_now() != 6) return -1;
     // CFN_PWF_SPLIT: 1 = the shapes WITHOUT a prologue (conv1 of the layer-2 blocks, whose input is a materialised block output), 2 = also the
     // shapes with one (conv3: BN2 + swish in front)
@@ -422,6 +427,7 @@ int pwfs_try_launch(const float* gy, const float* y, const double* gsum, const d
     a.acc = acc; a.acc_s = acc ? acc_stride : 1; a.Hi = Hi; a.Wi = Wi; a.T = T;
     a.acc_Ho = (Hi - 1) / a.acc_s + 1; a.acc_Wo = (Wi - 1) / a.acc_s + 1;
     a.N = N; a.M = Cout; a.K = Cin; a.Q = (int)Ql;
+    { const char* e = getenv("CFN_PWFS_DBG"); a.dbg = e ? atoi(e) : 0; }
     const long nst = cfn_cdiv(Ql, PFS_PT);
     // one workgroup per CU is resident: 1024 workgroups = 4 whole rounds of the chip
     static const int wgs = getenv("CFN_PWFS_WGS") ? atoi(getenv("CFN_PWFS_WGS")) : 1024;

@@ -177,12 +177,20 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> pwconv_backward(const Tensor& gy_, co
     double* a64 = pro ? ab.data_ptr<double>() : nullptr;
     double* b64 = pro ? a64 + N * Cin : nullptr;
     void* st = stream_of(x);
-    ok(cfn_pwconv_bwd_data(gy.data_ptr<float>(), y.data_ptr<float>(), dptr(gs64), dptr(gq64), w2.data_ptr<float>(), x.data_ptr<float>(), dptr(A64), dptr(B64), (int)act,
-                           gx.data_ptr<float>(), a64, b64, (int)N, (int)Cin, (int)Cout, (int)T, (int)H, (int)W, (int)stride, st),
-       "cfn_pwconv_bwd_data");
-    ok(cfn_pwconv_bwd_weight(gy.data_ptr<float>(), y.data_ptr<float>(), dptr(gs64), dptr(gq64), x.data_ptr<float>(), dptr(A64), dptr(B64), (int)act, gw.data_ptr<double>(),
-                             (int)N, (int)Cin, (int)Cout, (int)T, (int)H, (int)W, (int)stride, nullptr, st),
-       "cfn_pwconv_bwd_weight");
+    // one pass over gy, y, x where the library has a fused kernel for the shape (layers 1 and 2: pwfused.hip, pwfuseds.hip; -1 = it declines), as cfn_hip.ops does
+    int fused = -1;
+    if (stride == 1)
+        fused = cfn_pwconv_bwd_fused(gy.data_ptr<float>(), y.data_ptr<float>(), dptr(gs64), dptr(gq64), w2.data_ptr<float>(), x.data_ptr<float>(), dptr(A64), dptr(B64), (int)act,
+                                     gx.data_ptr<float>(), a64, b64, gw.data_ptr<double>(), (int)N, (int)Cin, (int)Cout, (int)T, (int)H, (int)W, nullptr, 1, nullptr, st);
+    if (fused != -1) ok(fused, "cfn_pwconv_bwd_fused");
+    else {
+        ok(cfn_pwconv_bwd_data(gy.data_ptr<float>(), y.data_ptr<float>(), dptr(gs64), dptr(gq64), w2.data_ptr<float>(), x.data_ptr<float>(), dptr(A64), dptr(B64), (int)act,
+                               gx.data_ptr<float>(), a64, b64, (int)N, (int)Cin, (int)Cout, (int)T, (int)H, (int)W, (int)stride, st),
+           "cfn_pwconv_bwd_data");
+        ok(cfn_pwconv_bwd_weight(gy.data_ptr<float>(), y.data_ptr<float>(), dptr(gs64), dptr(gq64), x.data_ptr<float>(), dptr(A64), dptr(B64), (int)act, gw.data_ptr<double>(),
+                                 (int)N, (int)Cin, (int)Cout, (int)T, (int)H, (int)W, (int)stride, nullptr, st),
+           "cfn_pwconv_bwd_weight");
+    }
     Tensor gwf = gw.to(at::kFloat).view(w.sizes());
     if (!pro) return {gx, gwf, at::zeros({1}, x.options()), at::zeros({1}, x.options())};
     return {gx, gwf, ab[0].to(at::kFloat), ab[1].to(at::kFloat)};
