@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
 #pragma unroll
         for (int it = 0; it < NG; ++it) {
             const int row = it * 16 + lrow;
-            const float cs = sCg[2 * row], cq = sCg[2 * row + 1], cz = sCz[row];
+            const float cs = cfn_settle(sCg[2 * row]), cq = cfn_settle(sCg[2 * row + 1]), cz = cfn_settle(sCz[row]);      // (an LDS pair in front of packed FMAs: DESIGN 4.1; found by the per-half scan)
             const bool ok = m0 + row < M;
             float* d = sG + row * WG_PITCH + c4;
             d[0] = (ok && qa < Q) ? fmaf(py[it].x, cq, fmaf(pg[it].x, cz, cs)) : 0.0f;
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs a) {
             if (chok) {
                 if (isg) {
                     const long base = ((long)n * M + ch) * Q + q0 + cc;
-                    const float cs = sCg[2 * row], cq = sCg[2 * row + 1], cz = sCz[row];
+                    const float cs = cfn_settle(sCg[2 * row]), cq = cfn_settle(sCg[2 * row + 1]), cz = cfn_settle(sCz[row]);      // (an LDS pair in front of packed FMAs: DESIGN 4.1; found by the per-half scan)
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         if (q0 + cc + u < Q) v[u] = fmaf(a.y ? a.y[base + u] : 0.0f, cq, fmaf(a.gy[base + u], cz, cs));

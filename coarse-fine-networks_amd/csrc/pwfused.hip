@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, ACT < 0 ? 3 : 2) void pw_bwd_fused_kernel(cons
 #pragma unroll
         for (int it = 0; it < NG; ++it) {
             const int row = it * 16 + lrow;
-            const float cs = sCg[2 * row], cq = sCg[2 * row + 1], cz = sCz[row];
+            const float cs = cfn_settle(sCg[2 * row]), cq = cfn_settle(sCg[2 * row + 1]), cz = cfn_settle(sCz[row]);      // (an LDS pair in front of packed FMAs: DESIGN 4.1; found by the per-half scan)
             const bool ok = inq && (row < M);
             float* d = sG + row * PF_PITCH + c4;
             d[0] = ok ? fmaf(py[it].x, cq, fmaf(pg[it].x, cz, cs)) : 0.0f;

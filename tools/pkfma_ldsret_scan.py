@@ -186,8 +186,22 @@ def scan_kernel(code):
                         elif i < len(sel_hi) and sel_hi[i] == 1:
                             wide += 1
             read = set()
-            for s in srcs:
-                read.update(vregs(s))
+            if PK.match(op):
+                # a packed fp32 source pair is read per HALF: the low half takes register op_sel[i] of the pair, the high half register op_sel_hi[i]
+                # (default 1).  `v_pk_fma_f32 .., v[2:3], .. op_sel_hi:[..0..]` reads v2 twice and v3 NOT AT ALL -- counting the whole pair as read
+                # hid the sites of csrc/pwfuseds.hip's first build (a third packed FMA took v3 through op_sel, after two that had only read v2)
+                sel = mods.get('op_sel', [0] * len(srcs))
+                sel_hi = mods.get('op_sel_hi', [1] * len(srcs))
+                for i, s in enumerate(srcs):
+                    rs = vregs(s)
+                    if len(rs) == 2:
+                        read.add(rs[sel[i] if i < len(sel) else 0])
+                        read.add(rs[sel_hi[i] if i < len(sel_hi) else 1])
+                    else:
+                        read.update(rs)
+            else:
+                for s in srcs:
+                    read.update(vregs(s))
             for r in list(fresh):
                 if r in read:
                     del fresh[r]
