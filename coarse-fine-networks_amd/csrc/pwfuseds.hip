@@ -100,8 +100,11 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split_kernel(const PfsArg
     }
     __syncthreads();
 
-    const int lrow = (tid & 255) >> 4, c4 = (tid & 15) * 4;  // 16 lanes cover one 64-position row segment; 16 rows per pass (waves 0-3 only: the data-gradient
-                                                             // waves carry 32-64 statistics registers instead of the prefetched rows)
+    // staging threads = waves 0-3 (the data-gradient waves carry 32-64 statistics registers instead of the prefetched rows).  A wave covers 4 rows x 16
+    // float4 segments of a stage; lanes 0-31 take segments 0-7 of the four rows, lanes 32-63 segments 8-15: the four scalar LDS writes of a float4 then
+    // hit 32 distinct banks per half wave (bank = row + 4 seg + e with the odd pitch; 2 rows x 16 segments put two lanes on every bank), and 8 lanes
+    // still load one 128-byte line
+    const int lrow = 4 * ((tid & 255) >> 6) + ((lane >> 3) & 3), c4 = ((lane & 7) + 8 * (lane >> 5)) * 4;
     // unconditional buffer loads / stores (unwanted ones get an out-of-range offset), as in pw_bwd_fused_kernel
     constexpr int OOB = 0x7ffffff0;
     __amdgpu_buffer_rsrc_t rg = cfn_rsrc(const_cast<float*>(a.gy + (long)n * M * Q), (unsigned)((long)M * Q * 4));

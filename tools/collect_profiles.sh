@@ -15,6 +15,7 @@ cp $(latest "$R/bench_coarse_t256/runc/*kernel_stats.csv") $P/${TAG}_coarse_t256
 cp $R/membw.txt $P/${TAG}_membw.txt
 cp $R/sal_bench.txt $P/${TAG}_sal_bench.txt
 cp $R/salb_bench.txt $P/${TAG}_salb_bench.txt
+for f in pwfs_bench pwfs_knockouts pwfs_stress pwfs_step_ab; do cp $R/$f.txt $P/${TAG}_$f.txt; done
 cp $R/glue_coarse.txt $P/${TAG}_glue_coarse.txt
 cp $R/sync_debug.txt $P/${TAG}_sync_debug.txt
 cp $R/determinism_scan.txt $P/${TAG}_determinism_scan.txt

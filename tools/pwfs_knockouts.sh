@@ -4,5 +4,5 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 for d in 0 1 2 3 4 8 7 15; do
   echo "## CFN_PWFS_DBG=$d"
-  CFN_PWFS_DBG=$d python $R/tools/pwfs_bench.py 2>&1 | grep "fused" | sed 's/separate [0-9.]* ms *//'
+  CFN_PWF_SPLIT=2 CFN_PWFS_DBG=$d python $R/tools/pwfs_bench.py 2>&1 | grep "fused" | sed 's/separate [0-9.]* ms *//'
 done
