@@ -17,6 +17,8 @@
 // work per stage (3,072 cycles per SIMD) and the conversions are a third of the stage's HBM time, which is what has to be hidden.
 #include "cfn_common.h"
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 
 #include "pw_common.h"
 
@@ -405,6 +407,319 @@ static int pfs_launch(const PfsArgs& a, int act, bool epi, unsigned blocks, hipS
     return cfn_check_launch("pwconv_bwd_fused (split bf16)");
 }
 
+// ---- layer 3 (conv1 of res4's blocks: 96 -> 216, no prologue): W^T pre-split is 129 KB and does not fit beside the images.  Same products, different budget: ----
+//   * stages of 32 positions (two fp32 images of 320 rows x 33: 84 KB), W^T pre-split ONCE per launch into a global workspace (3 x [96][232] bf16) that the
+//     data-gradient waves read 16 bytes at a time with buffer loads -- every workgroup reads the same 129 KB, so it lives in L2 (126 KB per wave and stage: a seventh
+//     of the L2 rate a CU can draw);
+//   * 4 weight-gradient waves + 3 data-gradient waves + 1 staging wave: wave w < 4 stages the G' rows and owns the row tiles i = w, w + 4 x all three column tiles over
+//     ALL positions of a stage (96 accumulator registers, no cross-wave sum at the end); wave 4 + d (d < 3) owns the data gradient of input channels 32 d .. 32 d + 31 for
+//     all 32 positions and keeps ITS third of W^T resident in 168 registers (read once per workgroup from the workspace); wave 7 stages the x rows.  (Builds with the W^T
+//     operands streamed out of L2 inside the stage loop -- 6 + 2 and 4 + 4 waves -- ran at 0.56-0.57 ms against 0.45 for the separate kernels: seven dependent
+//     load -> MFMA rounds per stage at two waves per SIMD.)
+#define PF3_PT 32
+#define PF3_PITCH 33
+
+struct Pf3Args {
+    const float* gy; const float* y; const double* gs; const double* gq; const double* gsc;
+    const float* x; const unsigned* wsplit;          // wsplit: [3 terms][BN][BMP / 2] packed bf16 pairs (co, co + 1) of W^T (pf3_presplit_kernel)
+    float* gx; double* gw;
+    int N, M, K, Q, nstrips, stages;
+};
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void pf3_presplit_kernel(const float* w, int M, int K, unsigned* ws) {
+    constexpr int BM = 32 * MT, BN = 32 * NT, BMP = BM + 8;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= BN * (BMP / 2)) return;
+    const int ci = e / (BMP / 2), mp = e - ci * (BMP / 2), co = 2 * mp;
+    const float w0 = (ci < K && co < M) ? w[(long)co * K + ci] : 0.0f;
+    const float w1 = (ci < K && co + 1 < M) ? w[(long)(co + 1) * K + ci] : 0.0f;
+    unsigned p[3];
+    pfs_split3(w0, w1, p);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) ws[(s * BN + ci) * (BMP / 2) + mp] = p[s];
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(512, 1) void pw_bwd_fused_split3_kernel(const Pf3Args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BM = 32 * MT, BN = 32 * NT, BMP = BM + 8;
+    constexpr int NG = BM / 32, NX = BN / 32;                    // float4 per staging thread and stage: 32 rows x 8 float4 per pass of 256 threads
+    constexpr int NT16 = BN / 16, KS = BM / 32;
+    constexpr int NR = (MT + 3) / 4;                              // row tiles per weight-gradient wave (i = w + 4 n)
+    static_assert(NT16 == 6, "three data-gradient waves own two 16-channel tiles each");
+    const int tid = threadIdx.x, wave = cfn_uni((int)(tid >> 6)), lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int m16 = lane & 15, kq = lane >> 4;
+    unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    const int strip = L % a.nstrips;
+    const int n = L / a.nstrips;
+    const int M = a.M, K = a.K, Q = a.Q;
+    constexpr int IMG = (BM + BN) * PF3_PITCH;
+    float* img0 = smem;
+    constexpr int OOB = 0x7ffffff0;
+    const int qbeg = strip * a.stages * PF3_PT;
+    const int nst = min(a.stages, (Q - qbeg + PF3_PT - 1) / PF3_PT);
+    const int lrow = (tid & 255) >> 3, c4 = (tid & 7) * 4;           // 8 lanes cover one 32-position row segment (128 bytes); a half wave = 4 rows x 8 segments: 32 banks
+
+    if (wave < 4) {
+        // ================= waves 0-3: stage the G' rows; weight gradient of the row tiles i = w, w + 4 (x all column tiles) over all 32 positions =================
+        __amdgpu_buffer_rsrc_t rg = cfn_rsrc(const_cast<float*>(a.gy + (long)n * M * Q), (unsigned)((long)M * Q * 4));
+        __amdgpu_buffer_rsrc_t ry = cfn_rsrc(const_cast<float*>((a.y ? a.y : a.gy) + (long)n * M * Q), a.y ? (unsigned)((long)M * Q * 4) : 0u);
+        pf4 pg[NG], py[NG];
+        int vog[NG];
+        float rcs[NG], rcq[NG], rcz[NG];                             // (gs, 2 gq, gsc) of this thread's G' rows: registers, read once
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            const int row = it * 32 + lrow;
+            const bool ok = row < M;
+            rcs[it] = (ok && a.gs) ? (float)a.gs[(long)n * M + row] : 0.0f;
+            rcq[it] = (ok && a.gq && a.y) ? 2.0f * (float)a.gq[(long)n * M + row] : 0.0f;
+            rcz[it] = (ok && a.gsc) ? (float)a.gsc[(long)n * M + row] : 1.0f;
+            vog[it] = ok ? (row * Q + c4) * 4 : OOB;
+        }
+        auto prefetch = [&](int q0) {
+            const bool inq = q0 + c4 < Q;
+#pragma unroll
+            for (int it = 0; it < NG; ++it) {
+                const int vo = inq ? vog[it] : OOB;
+                pg[it] = __builtin_bit_cast(pf4, __builtin_amdgcn_raw_buffer_load_b128(rg, vo, q0 * 4, 0));
+                py[it] = __builtin_bit_cast(pf4, __builtin_amdgcn_raw_buffer_load_b128(ry, vo, q0 * 4, 0));
+            }
+        };
+        auto stage = [&](int q0, float* sG) {
+            const bool inq = q0 + c4 < Q;
+#pragma unroll
+            for (int it = 0; it < NG; ++it) {
+                const int row = it * 32 + lrow;
+                const float cs = rcs[it], cq = rcq[it], cz = rcz[it];
+                const bool ok = inq && (row < M);
+                float* d = sG + row * PF3_PITCH + c4;
+                d[0] = ok ? fmaf(py[it].x, cq, fmaf(pg[it].x, cz, cs)) : 0.0f;
+                d[1] = ok ? fmaf(py[it].y, cq, fmaf(pg[it].y, cz, cs)) : 0.0f;
+                d[2] = ok ? fmaf(py[it].z, cq, fmaf(pg[it].z, cz, cs)) : 0.0f;
+                d[3] = ok ? fmaf(py[it].w, cq, fmaf(pg[it].w, cz, cs)) : 0.0f;
+            }
+        };
+        if (nst > 0) {
+            prefetch(qbeg);
+            stage(qbeg, img0);
+            if (nst > 1) prefetch(qbeg + PF3_PT);
+        }
+        __syncthreads();
+        f16v acc[NR][NT];
+#pragma unroll
+        for (int t = 0; t < NR; ++t)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.0f;
+        for (int st = 0; st < nst; ++st) {
+            const int q0 = qbeg + st * PF3_PT;
+            float* cur = img0 + (st & 1) * IMG;
+            float* nxt = img0 + ((st + 1) & 1) * IMG;
+            if (st + 1 < nst) {
+                stage(q0 + PF3_PT, nxt);
+                if (st + 2 < nst) prefetch(q0 + 2 * PF3_PT);
+            }
+            const float* sG = cur;
+            const float* sX = cur + BM * PF3_PITCH;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int p0 = 16 * kb + 8 * half;
+                pfs_u4 Af[NR][3];
+#pragma unroll
+                for (int t = 0; t < NR; ++t) {
+                    const int i = wave + 4 * t;
+                    if (i < MT) {                                    // wave uniform
+                        const float* r = sG + (i * 32 + col) * PF3_PITCH + p0;
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) {
+                            unsigned p[3];
+                            pfs_split3(r[2 * h], r[2 * h + 1], p);
+#pragma unroll
+                            for (int s = 0; s < 3; ++s) Af[t][s][h] = p[s];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    pfs_u4 Bf[3];
+                    const float* r = sX + (j * 32 + col) * PF3_PITCH + p0;
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        unsigned p[3];
+                        pfs_split3(r[2 * h], r[2 * h + 1], p);
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) Bf[s][h] = p[s];
+                    }
+                    // term major: consecutive MFMAs of a wave go to DIFFERENT accumulator tiles (the six terms of one tile are a dependent chain)
+#define PF3_WG(SA, SB)                                                                                                                         \
+                    _Pragma("unroll") for (int t = 0; t < NR; ++t)                                                                              \
+                        if (wave + 4 * t < MT)                                                                                                  \
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pfs_bf8, Af[t][SA]), __builtin_bit_cast(pfs_bf8, Bf[SB]), acc[t][j], 0, 0, 0);
+                    PFS_TERMS(PF3_WG)
+#undef PF3_WG
+                }
+            }
+            __syncthreads();
+        }
+        // every tile has ONE owner: straight from the accumulators, one fp64 atomic per element and workgroup
+#pragma unroll
+        for (int t = 0; t < NR; ++t) {
+            const int i = wave + 4 * t;
+            if (i < MT) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int gm = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, gk = j * 32 + col;
+                        const float v = acc[t][j][r];
+                        if (gm < M && gk < K) cfn_add64(&a.gw[(long)gm * K + gk], (double)v);
+                    }
+            }
+        }
+    } else if (wave < 7) {
+        // ================= waves 4-6: data gradient.  Wave d owns the channel tiles 2 d, 2 d + 1 (input channels 32 d .. 32 d + 31) for ALL 32 positions of a stage, and keeps
+        // its part of W^T -- 2 tiles x 7 k-steps x 3 terms, 168 registers -- RESIDENT: read once from the pre-split workspace, nothing but LDS reads in the stage loop =========
+        const int d = wave - 4;
+        __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + (long)n * K * Q, (unsigned)((long)K * Q * 4));
+        __amdgpu_buffer_rsrc_t rw = cfn_rsrc(const_cast<unsigned*>(a.wsplit), (unsigned)((size_t)3 * BN * (BMP / 2) * 4));
+        const int wlane = ((m16 * BMP + 8 * kq) / 2) * 4;            // byte offset of this lane's (ci = m16, co = 8 kq) in a term image
+        pfs_u4 Wr[2][KS][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    Wr[t][s][u] = __builtin_bit_cast(pfs_u4, __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, (((u * BN + (2 * d + t) * 16) * BMP + 32 * s) / 2) * 4, 0));
+        __syncthreads();
+        for (int st = 0; st < nst; ++st) {
+            const int q0 = qbeg + st * PF3_PT;
+            const float* sG = img0 + (st & 1) * IMG;
+            pf4 da[2][2];                                            // [position block][tile]
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) da[pb][t] = (pf4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    const float* r = sG + (32 * s + 8 * kq) * PF3_PITCH + 16 * pb + m16;
+                    pfs_u4 Gf[3];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        unsigned p[3];
+                        pfs_split3(r[(2 * h) * PF3_PITCH], r[(2 * h + 1) * PF3_PITCH], p);
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) Gf[u][h] = p[u];
+                    }
+#define PF3_DG(SA, SB)                                                                                                                         \
+                    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                               \
+                        da[pb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pfs_bf8, Wr[t][s][SA]), __builtin_bit_cast(pfs_bf8, Gf[SB]), da[pb][t], 0, 0, 0);
+                    PFS_TERMS(PF3_DG)
+#undef PF3_DG
+                }
+            }
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const int q = q0 + 16 * pb + m16;
+                const int gvo = q < Q ? (4 * kq * Q + 16 * pb + m16) * 4 : OOB;    // one lane offset; the (tile, row) part rides in the scalar offset; rows >= K fall outside the descriptor
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = da[pb][t][r];                // (through a scalar: __builtin_bit_cast of a vector ELEMENT took element 0 for every r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, gvo, (q0 + ((2 * d + t) * 16 + r) * Q) * 4, 0);
+                    }
+            }
+            __syncthreads();
+        }
+    } else {
+        // ================= wave 7: stages the x rows (96 rows x 8 float4 = 12 passes of 8 rows) =================
+        __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<float*>(a.x + (long)n * K * Q), (unsigned)((long)K * Q * 4));
+        constexpr int NP = BN / 8;
+        const int xrow = lane >> 3;                                  // 8 lanes per row segment
+        pf4 px[NP];
+        int vox[NP];
+#pragma unroll
+        for (int it = 0; it < NP; ++it) vox[it] = (it * 8 + xrow) < K ? ((it * 8 + xrow) * Q + c4) * 4 : OOB;
+        auto prefetch = [&](int q0) {
+            const bool inq = q0 + c4 < Q;
+#pragma unroll
+            for (int it = 0; it < NP; ++it)
+                px[it] = __builtin_bit_cast(pf4, __builtin_amdgcn_raw_buffer_load_b128(rx, inq ? vox[it] : OOB, q0 * 4, 0));
+        };
+        auto stage = [&](float* sX) {
+#pragma unroll
+            for (int it = 0; it < NP; ++it) {
+                float* dd = sX + (it * 8 + xrow) * PF3_PITCH + c4;
+                dd[0] = px[it].x; dd[1] = px[it].y; dd[2] = px[it].z; dd[3] = px[it].w;
+            }
+        };
+        if (nst > 0) {
+            prefetch(qbeg);
+            stage(img0 + BM * PF3_PITCH);
+            if (nst > 1) prefetch(qbeg + PF3_PT);
+        }
+        __syncthreads();
+        for (int st = 0; st < nst; ++st) {
+            const int q0 = qbeg + st * PF3_PT;
+            float* nxt = img0 + ((st + 1) & 1) * IMG;
+            if (st + 1 < nst) {
+                stage(nxt + BM * PF3_PITCH);
+                if (st + 2 < nst) prefetch(q0 + 2 * PF3_PT);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+static unsigned* pf3_workspace(size_t bytes, hipStream_t st) {
+    // one grow-only buffer per (device, stream), never freed (a captured graph may hold the address); none is allocated while the stream is being captured
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, std::pair<unsigned*, size_t>> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lk(mu);
+    auto& b = bufs[std::make_pair(dev, st)];
+    if (b.second >= bytes) return b.first;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    unsigned* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    b = {p, bytes};
+    return p;
+}
+
+static int pf3_try_launch(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w, const float* x, float* gx, double* gw,
+                          int N, int Cin, int Cout, long Ql, const double* gscale, hipStream_t st) {
+    constexpr int MT = 7, NT = 3, BM = 32 * MT, BN = 32 * NT, BMP = BM + 8;
+    const size_t wbytes = (size_t)3 * BN * (BMP / 2) * 4;
+    unsigned* ws = pf3_workspace(wbytes, st);
+    if (!ws) return -1;
+    hipLaunchKernelGGL((pf3_presplit_kernel<MT, NT>), dim3((BN * (BMP / 2) + 255) / 256), dim3(256), 0, st, w, Cout, Cin, ws);
+    Pf3Args a = {};
+    a.gy = gy; a.y = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.gsc = gscale; a.x = x; a.wsplit = ws; a.gx = gx; a.gw = gw;
+    a.N = N; a.M = Cout; a.K = Cin; a.Q = (int)Ql;
+    const long nst = cfn_cdiv(Ql, PF3_PT);
+    static const int wgs = getenv("CFN_PWFS_WGS") ? atoi(getenv("CFN_PWFS_WGS")) : 1024;
+    long want = wgs / N;
+    if (want < 1) want = 1;
+    long stages = cfn_cdiv(nst, want);
+    if (stages < 4) stages = 4;
+    a.stages = (int)stages;
+    a.nstrips = (int)cfn_cdiv(nst, stages);
+    const unsigned blocks = (unsigned)((long)N * a.nstrips);
+    const size_t lds = (size_t)2 * (BM + BN) * PF3_PITCH * sizeof(float);
+    CfnProfScope prof(CFN_K_PWCONV_BWD, st, 4.0 * N * ((double)Cout * Ql * (a.y ? 2 : 1) + (double)Cin * Ql * 2));
+    auto k = pw_bwd_fused_split3_kernel<MT, NT>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, st, a);
+    return cfn_check_launch("pwconv_bwd_fused (split bf16, layer 3)");
+}
+
 // -1 = not handled (cfn_pwconv_bwd_fused goes on to its fp32 kernel / declines)
 int pwfs_try_launch(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w, const float* x, const double* A,
                     const double* B, int act, float* gx, double* gA, double* gB, double* gw, int N, int Cin, int Cout, int T, int Hi, int Wi,
@@ -417,7 +732,17 @@ int pwfs_try_launch(const float* gy, const float* y, const double* gsum, const d
     const bool wide_m = Cout > 64 && Cout <= 128 && Cin > 32 && Cin <= 64;          // conv1 of layer 2: 48 -> 108
     const bool thin_k = Cout > 64 && Cout <= 128 && Cin >= 16 && Cin <= 32;         // conv1 of the first block of layer 2: 24 -> 108
     const bool wide_k = Cin > 64 && Cin <= 128 && Cout > 32 && Cout <= 64;          // conv3 of layer 2: 108 -> 48
-    if (!wide_m && !wide_k && !thin_k) return -1;
+    // layer-1 widths (24 <-> 54), served by the fp32 kernel of pwfused.hip unless CFN_PWF_SPLIT >= 3 (measurement switch)
+    const bool l1_m = on >= 3 && Cout > 32 && Cout <= 64 && Cin >= 16 && Cin <= 32;      // conv1 of layer 1: 24 -> 54
+    const bool l1_k = on >= 3 && Cin > 32 && Cin <= 64 && Cout >= 16 && Cout <= 32;      // conv3 of layer 1: 54 -> 24
+    // layer 3's conv1 (96 -> 216, no prologue, no shortcut gradient): the variant with W^T resident in the data-gradient waves' registers (CFN_PWF_L3=0 switches it off alone)
+    static const int l3_on = getenv("CFN_PWF_L3") ? atoi(getenv("CFN_PWF_L3")) : 1;
+    if (on >= 1 && l3_on && A == nullptr && acc == nullptr && Cout > 192 && Cout <= 224 && Cin > 64 && Cin <= 96) {
+        const long Ql3 = (long)T * Hi * Wi;
+        if (Ql3 % 4 == 0 && Ql3 < (1L << 30) && (long)Cout * Ql3 * 4 < 0x7ffffff0L && ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)(y ? y : gy)) & 15) == 0))
+            return pf3_try_launch(gy, y, gsum, gsumsq, w, x, gx, gw, N, Cin, Cout, Ql3, gscale, st);
+    }
+    if (!wide_m && !wide_k && !thin_k && !l1_m && !l1_k) return -1;
     if (A != nullptr && on < 2) return -1;
     const long Ql = (long)T * Hi * Wi;
     if (Ql % 4 != 0 || Ql >= (1L << 30)) return -1;
@@ -445,5 +770,7 @@ int pwfs_try_launch(const float* gy, const float* y, const double* gsum, const d
     const bool epi = A != nullptr;
     if (wide_m) return pfs_launch<4, 2>(a, act, epi, blocks, st);
     if (thin_k) return pfs_launch<4, 1>(a, act, epi, blocks, st);
+    if (l1_m) return pfs_launch<2, 1>(a, act, epi, blocks, st);
+    if (l1_k) return pfs_launch<1, 2>(a, act, epi, blocks, st);
     return pfs_launch<2, 4>(a, act, epi, blocks, st);
 }

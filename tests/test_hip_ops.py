@@ -354,6 +354,36 @@ def test_pwconv_bwd_fused_split_matches_separate(cfg, act, monkeypatch):
             assert torch.equal(r, g)
 
 
+@pytest.mark.parametrize('two', [True, False])
+@pytest.mark.parametrize('cfg', [(1, 96, 216, 3, 14, 14), (2, 96, 216, 2, 14, 14), (1, 90, 200, 1, 10, 10), (2, 72, 196, 5, 6, 6), (1, 96, 216, 16, 14, 14)])
+def test_pwconv_bwd_fused_split_layer3_matches_separate(cfg, two, monkeypatch):
+    """the layer-3 variant of the one-pass backward (csrc/pwfuseds.hip, pw_bwd_fused_split3_kernel: W^T pre-split into a workspace and read out of L2, 6 weight-gradient
+    + 2 data-gradient waves, 32-position stages) against the separate kernels; no prologue (conv1 of a block), with / without the batch-norm terms"""
+    import cfn_hip
+    monkeypatch.setenv('CFN_PWF_SPLIT', '1')
+    N, Cin, Cout, T, H, W = cfg
+    f64 = lambda seed, *shape, scale=1.0: (rnd(seed, *shape) * scale).double().to(DEV)
+    gy, y, x = rnd(1, N, Cout, T, H, W).to(DEV), rnd(2, N, Cout, T, H, W).to(DEV), rnd(3, N, Cin, T, H, W).to(DEV)
+    w = (0.3 * rnd(4, Cout, Cin)).to(DEV)
+    gs, gq, gsc = (f64(5, N, Cout, scale=0.05), f64(6, N, Cout, scale=0.01), 1.0 + f64(7, N, Cout, scale=0.3)) if two else (None, None, None)
+
+    def run(fused):
+        gx = torch.full_like(x, float('nan'))
+        gw = torch.zeros(Cout, Cin, dtype=torch.float64, device=DEV)
+        if fused:
+            ok = cfn_hip.call_try('cfn_pwconv_bwd_fused', gy, y, gs, gq, w, x, None, None, 0, gx, None, None, gw, N, Cin, Cout, T, H, W, None, 1, gsc)
+            assert ok, 'shape should be handled by the layer-3 split fused kernel'
+        else:
+            cfn_hip.call('cfn_pwconv_bwd_data_acc', gy, y, gs, gq, w, x, None, None, 0, gx, None, None, N, Cin, Cout, T, H, W, 1, None, 1, gsc)
+            cfn_hip.call('cfn_pwconv_bwd_weight', gy, y, gs, gq, x, None, None, 0, gw, N, Cin, Cout, T, H, W, 1, gsc)
+        return gx, gw
+
+    ref, got, again = run(False), run(True), run(True)
+    for name, r, g, g2 in zip(('gx', 'gw'), ref, got, again):
+        assert relerr(g, r) <= 2e-5, (name, relerr(g, r))
+        assert torch.equal(g, g2), name                # run-to-run bits
+
+
 @pytest.mark.parametrize('shortcut', ['identity', 'conv_s2', 'conv_s1'])
 @pytest.mark.parametrize('cfg', [(2, 54, 24, 4, 8, 8), (1, 108, 48, 3, 6, 6), (2, 216, 96, 2, 14, 14), (1, 20, 12, 3, 5, 7)])
 def test_linked_tail(cfg, shortcut):

@@ -11,7 +11,8 @@ import cfn_hip                    # noqa: E402
 
 DEV = 'cuda'
 N, T, H0 = int(os.environ.get('NB', '8')), int(os.environ.get('FRAMES', '256')), int(os.environ.get('HW', '28'))
-CASES = [('conv1 48->108 (no prologue)', 48, 108, None), ('conv1 24->108 @2H (no prologue)', 24, 108, None), ('conv1 24->108 @2H + compact shortcut gradient', 24, 108, None), ('conv3 108->48 (swish prologue)', 108, 48, 2), ('conv1 48->108 (relu prologue)', 48, 108, 1)]
+CASES = [('L1 conv1 24->54 @2H (no prologue)', 24, 54, None), ('L1 conv3 54->24 @2H (swish prologue)', 54, 24, 2), ('L1 conv1 24->54 @4H (no prologue)', 24, 54, None),
+         ] if os.environ.get('L1') else [('L3 conv1 96->216 @H/2 (no prologue)', 96, 216, None)] if os.environ.get('L3') else [('conv1 48->108 (no prologue)', 48, 108, None), ('conv1 24->108 @2H (no prologue)', 24, 108, None), ('conv1 24->108 @2H + compact shortcut gradient', 24, 108, None), ('conv3 108->48 (swish prologue)', 108, 48, 2), ('conv1 48->108 (relu prologue)', 48, 108, 1)]
 
 
 def timeit(fn, iters=10, warm=3):
@@ -28,7 +29,7 @@ def timeit(fn, iters=10, warm=3):
 
 
 for name, Cin, Cout, act in CASES:
-    H = (2 * H0) if '@2H' in name else H0
+    H = (4 * H0) if '@4H' in name else (2 * H0) if '@2H' in name else (H0 // 2) if '@H/2' in name else H0
     g = torch.Generator().manual_seed(1)
     gy, y = torch.randn(N, Cout, T, H, H, generator=g).to(DEV), torch.randn(N, Cout, T, H, H, generator=g).to(DEV)
     x = torch.randn(N, Cin, T, H, H, generator=g).to(DEV)
@@ -53,8 +54,11 @@ for name, Cin, Cout, act in CASES:
 
     os.environ['CFN_PWF_SPLIT'] = '0'
     ts = timeit(separate)
-    os.environ['CFN_PWF_SPLIT'] = '2'
+    tl1 = timeit(fused) if os.environ.get('L1') else None      # the fp32 fused kernel of pwfused.hip
+    os.environ['CFN_PWF_SPLIT'] = '1' if os.environ.get('L3') else '3' if os.environ.get('L1') else '2'
     tf = timeit(fused)
     Q = N * T * H * H
     floor = 4.0 * Q * (2 * Cout + 2 * Cin) / 1e9          # gy, y, x read once, gx written once
+    if tl1 is not None:
+        print('%-40s fp32 fused kernel (pwfused.hip) %.3f ms' % (name, tl1))
     print('%-32s separate %.3f ms   fused (split bf16) %.3f ms   4-pass traffic %.2f GB = %.2f TB/s fused' % (name, ts, tf, floor, floor / tf))
