@@ -424,6 +424,7 @@ struct Pf3Args {
     const float* x; const unsigned* wsplit;          // wsplit: [3 terms][BN][BMP / 2] packed bf16 pairs (co, co + 1) of W^T (pf3_presplit_kernel)
     float* gx; double* gw;
     int N, M, K, Q, nstrips, stages;
+    int dbg;                                         // knock-outs (CFN_PWFS_DBG, 0 in the product): 1 weight gradient, 2 data gradient, 8 gx stores
 };
 
 template <int MT, int NT>
@@ -523,6 +524,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split3_kernel(const Pf3Ar
             }
             const float* sG = cur;
             const float* sX = cur + BM * PF3_PITCH;
+            if (!(a.dbg & 1))
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const int p0 = 16 * kb + 8 * half;
@@ -602,6 +604,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split3_kernel(const Pf3Ar
             for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) da[pb][t] = (pf4){0.f, 0.f, 0.f, 0.f};
+            if (!(a.dbg & 2))
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split3_kernel(const Pf3Ar
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb) {
                 const int q = q0 + 16 * pb + m16;
-                const int gvo = q < Q ? (4 * kq * Q + 16 * pb + m16) * 4 : OOB;    // one lane offset; the (tile, row) part rides in the scalar offset; rows >= K fall outside the descriptor
+                const int gvo = (q < Q && !(a.dbg & 8)) ? (4 * kq * Q + 16 * pb + m16) * 4 : OOB;    // one lane offset; the (tile, row) part rides in the scalar offset; rows >= K fall outside the descriptor
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -703,6 +706,7 @@ static int pf3_try_launch(const float* gy, const float* y, const double* gsum, c
     Pf3Args a = {};
     a.gy = gy; a.y = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.gsc = gscale; a.x = x; a.wsplit = ws; a.gx = gx; a.gw = gw;
     a.N = N; a.M = Cout; a.K = Cin; a.Q = (int)Ql;
+    { const char* e = getenv("CFN_PWFS_DBG"); a.dbg = e ? atoi(e) : 0; }
     const long nst = cfn_cdiv(Ql, PF3_PT);
     static const int wgs = getenv("CFN_PWFS_WGS") ? atoi(getenv("CFN_PWFS_WGS")) : 1024;
     long want = wgs / N;

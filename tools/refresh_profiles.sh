@@ -39,10 +39,10 @@ python $R/tools/membw.py 2>&1 | grep -v "$FILT" > $O/membw.txt
 python $R/tools/sal_bench.py 2>&1 | grep -v "$FILT" > $O/sal_bench.txt
 python $R/tools/salb_bench.py 2>&1 | grep -v "$FILT" > $O/salb_bench.txt
 # the one-pass split-bf16 pointwise backward of layer 2 (csrc/pwfuseds.hip): same-process A/B against the separate kernels, knock-out table, bit-repeat stress
-CFN_PWF_SPLIT=2 python $R/tools/pwfs_bench.py 2>&1 | grep -v "$FILT" > $O/pwfs_bench.txt
+{ CFN_PWF_SPLIT=2 python $R/tools/pwfs_bench.py; L3=1 python $R/tools/pwfs_bench.py; L1=1 python $R/tools/pwfs_bench.py; echo '## layer-3 variant, knock-outs (CFN_PWFS_DBG: 1 weight gradient, 2 data gradient, 8 stores)'; for d in 1 2 3 11; do echo -n "dbg=$d  "; L3=1 CFN_PWFS_DBG=$d python $R/tools/pwfs_bench.py | grep fused; done; } 2>&1 | grep -v "$FILT" > $O/pwfs_bench.txt
 CFN_PWF_SPLIT=2 bash $R/tools/pwfs_knockouts.sh 2>&1 | grep -v "$FILT" > $O/pwfs_knockouts.txt
 RUNS=200 python $R/tools/pwfs_stress.py 2>&1 | grep -v "$FILT" > $O/pwfs_stress.txt
-{ for i in 1 2; do for v in 0 1 2; do echo -n "CFN_PWF_SPLIT=$v  "; CFN_PWF_SPLIT=$v python $R/bench.py --no-cpu-baseline --no-coarse-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms/step', d['value'], 'clips/s  figure A', d['roofline']['frac'])"; done; done; } > $O/pwfs_step_ab.txt
+{ for i in 1 2; do for v in "0 1" "1 0" "1 1" "2 1"; do set -- $v; echo -n "CFN_PWF_SPLIT=$1 CFN_PWF_L3=$2  "; CFN_PWF_SPLIT=$1 CFN_PWF_L3=$2 python $R/bench.py --no-cpu-baseline --no-coarse-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms/step', d['value'], 'clips/s  figure A', d['roofline']['frac'])"; done; done; } > $O/pwfs_step_ab.txt
 { echo "# one profiled step at the benchmarked shape (8 clips x 256 frames):"; FRAMES=256 python $R/tools/glue_profile_coarse.py 8 2>&1 | grep "in the step"
   echo "# 2 clips x 64 frames, with the call sites:"; python $R/tools/glue_profile_coarse.py 2 2>&1 | grep -v "$FILT\|Warn\|_warn_once\|ROCTracer"; } > $O/glue_coarse.txt
 python $R/tools/sync_debug.py 2>&1 | grep -v "$FILT" > $O/sync_debug.txt
