@@ -708,7 +708,9 @@ static int pf3_try_launch(const float* gy, const float* y, const double* gsum, c
     a.N = N; a.M = Cout; a.K = Cin; a.Q = (int)Ql;
     { const char* e = getenv("CFN_PWFS_DBG"); a.dbg = e ? atoi(e) : 0; }
     const long nst = cfn_cdiv(Ql, PF3_PT);
-    static const int wgs = getenv("CFN_PWFS_WGS") ? atoi(getenv("CFN_PWFS_WGS")) : 1024;
+    // ONE whole round of the chip (one workgroup per CU is resident): every workgroup pays the W^T load and 20.7 k fp64 atomics once; measured 8 clips x 256 frames:
+    // 256 / 512 / 1024 workgroups = 0.301 / 0.333 / 0.395 ms, 320 / 384 (partial rounds) 0.416 / 0.376
+    static const int wgs = getenv("CFN_PWF3_WGS") ? atoi(getenv("CFN_PWF3_WGS")) : 256;
     long want = wgs / N;
     if (want < 1) want = 1;
     long stages = cfn_cdiv(nst, want);
@@ -761,8 +763,9 @@ int pwfs_try_launch(const float* gy, const float* y, const double* gsum, const d
     a.N = N; a.M = Cout; a.K = Cin; a.Q = (int)Ql;
     { const char* e = getenv("CFN_PWFS_DBG"); a.dbg = e ? atoi(e) : 0; }
     const long nst = cfn_cdiv(Ql, PFS_PT);
-    // one workgroup per CU is resident: 1024 workgroups = 4 whole rounds of the chip
-    static const int wgs = getenv("CFN_PWFS_WGS") ? atoi(getenv("CFN_PWFS_WGS")) : 1024;
+    // one workgroup per CU is resident: whole rounds of the chip, and few of them (a workgroup splits W^T once and ends with M x K fp64 atomics): measured, 48 -> 108 at
+    // 8 clips x 256 frames: 256 / 512 / 768 / 1024 / 2048 workgroups = 0.495 / 0.471-0.481 / 0.491 / 0.504 / 0.553 ms; 320 (1.25 rounds) 0.619
+    static const int wgs = getenv("CFN_PWFS_WGS") ? atoi(getenv("CFN_PWFS_WGS")) : 512;
     long want = wgs / N;
     if (want < 1) want = 1;
     long stages = cfn_cdiv(nst, want);
