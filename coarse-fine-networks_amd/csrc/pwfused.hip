@@ -334,7 +334,8 @@ extern "C" int cfn_pwconv_bwd_fused(const float* gy, const float* y, const doubl
     // whole rounds of the chip: 2 workgroups per CU are resident with a prologue (3 without), so 1024 (1536) workgroups
     // are 2 full rounds; 640 (= 1.25 rounds) cost 4.56 instead of 3.83 ms on 24->54 @112
     const bool epi = A != nullptr;
-    long want = (epi ? 1024 : 1536) / N;
+    static const int wgs_env = getenv("CFN_PWF_WGS") ? atoi(getenv("CFN_PWF_WGS")) : 0;      // (measurement switch: workgroups per launch)
+    long want = (wgs_env > 0 ? wgs_env : (epi ? 1024 : 1536)) / N;
     if (want < 1) want = 1;
     long stages = cfn_cdiv(nst, want);
     if (stages < 4) stages = 4;
