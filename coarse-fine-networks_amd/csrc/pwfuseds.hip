@@ -679,6 +679,271 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split3_kernel(const Pf3Ar
     }
 }
 
+// ---- layer 3, conv3 (216 -> 96 with the BN2 + swish prologue in front): the same budget with the roles of the sides exchanged.  G' has 96 rows (3 row tiles), x 216 (7 column
+// tiles = 14 channel tiles of the data gradient); W^T pre-split is [3][224][104] bf16.  Waves 0-3 stage everything (G': 3 passes x 2 tensors, x: 7 passes) and own the column
+// tiles w, w + 4 x all three row tiles (every x element goes through the prologue once); waves 4-7 own the data gradient of channel tiles 4 d .. 4 d + 3 for all 32
+// positions with THEIR part of W^T resident (4 tiles x 3 k-steps x 3 terms: 144 registers), the act' epilogue and the statistics of those channels (no cross-wave sum).
+struct Pf3eArgs {
+    const float* gy; const float* y; const double* gs; const double* gq; const double* gsc;
+    const float* x; const double* pa; const double* pb; const unsigned* wsplit;
+    float* gx; double* gA; double* gB; double* gw;
+    int N, M, K, Q, nstrips, stages;
+};
+
+template <int MT, int NT, int ACT>
+__global__ __launch_bounds__(512, 1) void pw_bwd_fused_split3e_kernel(const Pf3eArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BM = 32 * MT, BN = 32 * NT, BMP = BM + 8;
+    constexpr int NG = BM / 32, NX = BN / 32;                    // float4 per staging thread and stage: 32 rows x 8 float4 per pass of 256 threads
+    constexpr int NT16 = BN / 16, KS = BM / 32;
+    constexpr int NC = (NT + 3) / 4;                              // column tiles per weight-gradient wave (j = w + 4 n)
+    constexpr int ND = 4;                                         // channel tiles per data-gradient wave
+    static_assert(NT16 <= 4 * ND, "four data-gradient waves x four channel tiles");
+    const int tid = threadIdx.x, wave = cfn_uni((int)(tid >> 6)), lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int m16 = lane & 15, kq = lane >> 4;
+    unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
+    const int strip = L % a.nstrips;
+    const int n = L / a.nstrips;
+    const int M = a.M, K = a.K, Q = a.Q;
+    constexpr int IMG = (BM + BN) * PF3_PITCH;
+    float* img0 = smem;
+    float* sCx = smem + 2 * IMG;                                  // [BN][2] (A, B) of the epilogue
+    constexpr int OOB = 0x7ffffff0;
+    const int qbeg = strip * a.stages * PF3_PT;
+    const int nst = min(a.stages, (Q - qbeg + PF3_PT - 1) / PF3_PT);
+    for (int k = tid; k < BN; k += 512) {
+        const bool ok = k < K;
+        sCx[2 * k] = ok ? (float)a.pa[(long)n * K + k] : 1.0f;
+        sCx[2 * k + 1] = ok ? (float)a.pb[(long)n * K + k] : 0.0f;
+    }
+
+    if (wave < 4) {
+        // ================= waves 0-3: stage G' and x; weight gradient of the column tiles j = w, w + 4 (x all row tiles) over all 32 positions =================
+        const int lrow = tid >> 3, c4 = (tid & 7) * 4;
+        __amdgpu_buffer_rsrc_t rg = cfn_rsrc(const_cast<float*>(a.gy + (long)n * M * Q), (unsigned)((long)M * Q * 4));
+        __amdgpu_buffer_rsrc_t ry = cfn_rsrc(const_cast<float*>((a.y ? a.y : a.gy) + (long)n * M * Q), a.y ? (unsigned)((long)M * Q * 4) : 0u);
+        __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<float*>(a.x + (long)n * K * Q), (unsigned)((long)K * Q * 4));
+        pf4 pg[NG], py[NG], px[NX];
+        int vog[NG], vox[NX];
+        float rcs[NG], rcq[NG], rcz[NG];                             // (gs, 2 gq, gsc) of this thread's G' rows: registers
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            const int row = it * 32 + lrow;
+            const bool ok = row < M;
+            rcs[it] = (ok && a.gs) ? (float)a.gs[(long)n * M + row] : 0.0f;
+            rcq[it] = (ok && a.gq && a.y) ? 2.0f * (float)a.gq[(long)n * M + row] : 0.0f;
+            rcz[it] = (ok && a.gsc) ? (float)a.gsc[(long)n * M + row] : 1.0f;
+            vog[it] = ok ? (row * Q + c4) * 4 : OOB;
+        }
+#pragma unroll
+        for (int it = 0; it < NX; ++it) vox[it] = (it * 32 + lrow) < K ? ((it * 32 + lrow) * Q + c4) * 4 : OOB;
+        auto prefetch = [&](int q0) {
+            const bool inq = q0 + c4 < Q;
+#pragma unroll
+            for (int it = 0; it < NG; ++it) {
+                const int vo = inq ? vog[it] : OOB;
+                pg[it] = __builtin_bit_cast(pf4, __builtin_amdgcn_raw_buffer_load_b128(rg, vo, q0 * 4, 0));
+                py[it] = __builtin_bit_cast(pf4, __builtin_amdgcn_raw_buffer_load_b128(ry, vo, q0 * 4, 0));
+            }
+#pragma unroll
+            for (int it = 0; it < NX; ++it)
+                px[it] = __builtin_bit_cast(pf4, __builtin_amdgcn_raw_buffer_load_b128(rx, inq ? vox[it] : OOB, q0 * 4, 0));
+        };
+        auto stage = [&](int q0, float* sG, float* sX) {
+            const bool inq = q0 + c4 < Q;
+#pragma unroll
+            for (int it = 0; it < NG; ++it) {
+                const int row = it * 32 + lrow;
+                const float cs = rcs[it], cq = rcq[it], cz = rcz[it];
+                const bool ok = inq && (row < M);
+                float* d = sG + row * PF3_PITCH + c4;
+                d[0] = ok ? fmaf(py[it].x, cq, fmaf(pg[it].x, cz, cs)) : 0.0f;
+                d[1] = ok ? fmaf(py[it].y, cq, fmaf(pg[it].y, cz, cs)) : 0.0f;
+                d[2] = ok ? fmaf(py[it].z, cq, fmaf(pg[it].z, cz, cs)) : 0.0f;
+                d[3] = ok ? fmaf(py[it].w, cq, fmaf(pg[it].w, cz, cs)) : 0.0f;
+            }
+#pragma unroll
+            for (int it = 0; it < NX; ++it) {
+                float* d = sX + (it * 32 + lrow) * PF3_PITCH + c4;
+                d[0] = px[it].x; d[1] = px[it].y; d[2] = px[it].z; d[3] = px[it].w;
+            }
+        };
+        if (nst > 0) {
+            prefetch(qbeg);
+            stage(qbeg, img0, img0 + BM * PF3_PITCH);
+            if (nst > 1) prefetch(qbeg + PF3_PT);
+        }
+        float ca[NC], cb[NC];                                        // prologue coefficients of this lane's x rows (row (w + 4 c) * 32 + col)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int k = (wave + 4 * c) * 32 + col;
+            const bool ok = k < K;
+            ca[c] = ok ? (float)a.pa[(long)n * K + k] : 1.0f;
+            cb[c] = ok ? (float)a.pb[(long)n * K + k] : 0.0f;
+        }
+        __syncthreads();
+        f16v acc[NC][MT];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.0f;
+        for (int st = 0; st < nst; ++st) {
+            const int q0 = qbeg + st * PF3_PT;
+            float* cur = img0 + (st & 1) * IMG;
+            float* nxt = img0 + ((st + 1) & 1) * IMG;
+            if (st + 1 < nst) {
+                stage(q0 + PF3_PT, nxt, nxt + BM * PF3_PITCH);
+                if (st + 2 < nst) prefetch(q0 + 2 * PF3_PT);
+            }
+            const float* sG = cur;
+            const float* sX = cur + BM * PF3_PITCH;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int p0 = 16 * kb + 8 * half;
+                pfs_u4 Bf[NC][3];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const int j = wave + 4 * c;
+                    if (j < NT) {                                    // wave uniform
+                        const float* r = sX + (j * 32 + col) * PF3_PITCH + p0;
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) {
+                            const float x0 = cfn_act<ACT>(fmaf(r[2 * h], ca[c], cb[c])), x1 = cfn_act<ACT>(fmaf(r[2 * h + 1], ca[c], cb[c]));
+                            unsigned p[3];
+                            pfs_split3(x0, x1, p);
+#pragma unroll
+                            for (int s = 0; s < 3; ++s) Bf[c][s][h] = p[s];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    pfs_u4 Af[3];
+                    const float* r = sG + (i * 32 + col) * PF3_PITCH + p0;
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        unsigned p[3];
+                        pfs_split3(r[2 * h], r[2 * h + 1], p);
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) Af[s][h] = p[s];
+                    }
+#define PF3E_WG(SA, SB)                                                                                                                        \
+                    _Pragma("unroll") for (int c = 0; c < NC; ++c)                                                                              \
+                        if (wave + 4 * c < NT)                                                                                                  \
+                            acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pfs_bf8, Af[SA]), __builtin_bit_cast(pfs_bf8, Bf[c][SB]), acc[c][i], 0, 0, 0);
+                    PFS_TERMS(PF3E_WG)
+#undef PF3E_WG
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = wave + 4 * c;
+            if (j < NT) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int gm = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, gk = j * 32 + col;
+                        const float v = acc[c][i][r];
+                        if (gm < M && gk < K) cfn_add64(&a.gw[(long)gm * K + gk], (double)v);
+                    }
+            }
+        }
+    } else {
+        // ================= waves 4-7: data gradient of the channel tiles 4 d .. 4 d + 3 for all 32 positions; W^T resident; act' epilogue; statistics =================
+        const int d = wave - 4;
+        const int tb = ND * d, tn = ND;                               // channel tiles 4 d .. 4 d + 3 (the last wave's tiles 14, 15 do not exist: zero weights, dropped stores)
+        __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + (long)n * K * Q, (unsigned)((long)K * Q * 4));
+        __amdgpu_buffer_rsrc_t rw = cfn_rsrc(const_cast<unsigned*>(a.wsplit), (unsigned)((size_t)3 * BN * (BMP / 2) * 4));
+        const int wlane = ((m16 * BMP + 8 * kq) / 2) * 4;
+        pfs_u4 Wr[ND][KS][3];
+#pragma unroll
+        for (int t = 0; t < ND; ++t)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    Wr[t][s][u] = (t < tn && tb + t < NT16) ? __builtin_bit_cast(pfs_u4, __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, cfn_uni((((u * BN + (tb + t) * 16) * BMP + 32 * s) / 2) * 4), 0))
+                                                      : (pfs_u4){0u, 0u, 0u, 0u};
+        float sa[ND][4], sb[ND][4];                                  // per-lane partial statistics of rows (4 d + t) * 16 + 4 kq + r
+#pragma unroll
+        for (int t = 0; t < ND; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sa[t][r] = 0.0f; sb[t][r] = 0.0f; }
+        __syncthreads();
+        for (int st = 0; st < nst; ++st) {
+            const int q0 = qbeg + st * PF3_PT;
+            const float* sG = img0 + (st & 1) * IMG;
+            const float* sX = sG + BM * PF3_PITCH;
+            pf4 da[2][ND];
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int t = 0; t < ND; ++t) da[pb][t] = (pf4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    const float* r = sG + (32 * s + 8 * kq) * PF3_PITCH + 16 * pb + m16;
+                    pfs_u4 Gf[3];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        unsigned p[3];
+                        pfs_split3(r[(2 * h) * PF3_PITCH], r[(2 * h + 1) * PF3_PITCH], p);
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) Gf[u][h] = p[u];
+                    }
+#define PF3E_DG(SA, SB)                                                                                                                        \
+                    _Pragma("unroll") for (int t = 0; t < ND; ++t)                                                                              \
+                        da[pb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pfs_bf8, Wr[t][s][SA]), __builtin_bit_cast(pfs_bf8, Gf[SB]), da[pb][t], 0, 0, 0);
+                    PFS_TERMS(PF3E_DG)
+#undef PF3E_DG
+                }
+            }
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const int q = q0 + 16 * pb + m16;
+                const int gvo = q < Q ? (4 * kq * Q + 16 * pb + m16) * 4 : OOB;
+#pragma unroll
+                for (int t = 0; t < ND; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ci = (tb + t) * 16 + 4 * kq + r;
+                        const float v = da[pb][t][r];                // exactly 0 for positions >= Q and rows >= K
+                        const float xr = sX[ci * PF3_PITCH + 16 * pb + m16];
+                        const float2 pab = cfn_settle(*reinterpret_cast<const float2*>(sCx + 2 * ci));
+                        const float dz = v * cfn_act_grad<ACT>(fmaf(xr, pab.x, pab.y));
+                        sa[t][r] = fmaf(dz, xr, sa[t][r]);
+                        sb[t][r] += dz;
+                        const float o = dz * pab.x;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rd, gvo, (q0 + ((tb + t) * 16 + r) * Q) * 4, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+        }
+        // every channel has ONE owner wave: reduce over the 16 position lanes, one fp64 atomic per channel and workgroup
+#pragma unroll
+        for (int t = 0; t < ND; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = sa[t][r], v = sb[t][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { u += __shfl_xor(u, o, 64); v += __shfl_xor(v, o, 64); }
+                const int ci = (tb + t) * 16 + 4 * kq + r;
+                if (m16 == 0 && t < tn && ci < K) {
+                    cfn_add64(&a.gA[(long)n * K + ci], (double)u);
+                    cfn_add64(&a.gB[(long)n * K + ci], (double)v);
+                }
+            }
+    }
+}
+
 static unsigned* pf3_workspace(size_t bytes, hipStream_t st) {
     // one grow-only buffer per (device, stream), never freed (a captured graph may hold the address); none is allocated while the stream is being captured
     static std::mutex mu;
@@ -726,6 +991,41 @@ static int pf3_try_launch(const float* gy, const float* y, const double* gsum, c
     return cfn_check_launch("pwconv_bwd_fused (split bf16, layer 3)");
 }
 
+static int pf3e_try_launch(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w, const float* x, const double* A, const double* B,
+                           int act, float* gx, double* gA, double* gB, double* gw, int N, int Cin, int Cout, long Ql, const double* gscale, hipStream_t st) {
+    constexpr int MT = 3, NT = 7, BM = 32 * MT, BN = 32 * NT, BMP = BM + 8;
+    const size_t wbytes = (size_t)3 * BN * (BMP / 2) * 4;
+    unsigned* ws = pf3_workspace(wbytes, st);
+    if (!ws) return -1;
+    hipLaunchKernelGGL((pf3_presplit_kernel<MT, NT>), dim3((BN * (BMP / 2) + 255) / 256), dim3(256), 0, st, w, Cout, Cin, ws);
+    Pf3eArgs a = {};
+    a.gy = gy; a.y = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.gsc = gscale; a.x = x; a.pa = A; a.pb = B; a.wsplit = ws;
+    a.gx = gx; a.gA = gA; a.gB = gB; a.gw = gw;
+    a.N = N; a.M = Cout; a.K = Cin; a.Q = (int)Ql;
+    const long nst = cfn_cdiv(Ql, PF3_PT);
+    static const int wgs = getenv("CFN_PWF3_WGS") ? atoi(getenv("CFN_PWF3_WGS")) : 256;
+    long want = wgs / N;
+    if (want < 1) want = 1;
+    long stages = cfn_cdiv(nst, want);
+    if (stages < 4) stages = 4;
+    a.stages = (int)stages;
+    a.nstrips = (int)cfn_cdiv(nst, stages);
+    const unsigned blocks = (unsigned)((long)N * a.nstrips);
+    const size_t lds = ((size_t)2 * (BM + BN) * PF3_PITCH + 2 * BN) * sizeof(float);
+    CfnProfScope prof(CFN_K_PWCONV_BWD, st, 4.0 * N * ((double)Cout * Ql * (a.y ? 2 : 1) + (double)Cin * Ql * 2));
+#define CFN_PF3E_GO(ACTV)                                                                                       \
+    do {                                                                                                        \
+        auto k = pw_bwd_fused_split3e_kernel<MT, NT, ACTV>;                                                     \
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, st, a);                                             \
+    } while (0)
+    if (act == CFN_ACT_RELU) CFN_PF3E_GO(CFN_ACT_RELU);
+    else if (act == CFN_ACT_SWISH) CFN_PF3E_GO(CFN_ACT_SWISH);
+    else CFN_PF3E_GO(CFN_ACT_NONE);
+#undef CFN_PF3E_GO
+    return cfn_check_launch("pwconv_bwd_fused (split bf16, layer 3 conv3)");
+}
+
 // -1 = not handled (cfn_pwconv_bwd_fused goes on to its fp32 kernel / declines)
 int pwfs_try_launch(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w, const float* x, const double* A,
                     const double* B, int act, float* gx, double* gA, double* gB, double* gw, int N, int Cin, int Cout, int T, int Hi, int Wi,
@@ -747,6 +1047,15 @@ int pwfs_try_launch(const float* gy, const float* y, const double* gsum, const d
         const long Ql3 = (long)T * Hi * Wi;
         if (Ql3 % 4 == 0 && Ql3 < (1L << 30) && (long)Cout * Ql3 * 4 < 0x7ffffff0L && ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)(y ? y : gy)) & 15) == 0))
             return pf3_try_launch(gy, y, gsum, gsumsq, w, x, gx, gw, N, Cin, Cout, Ql3, gscale, st);
+    }
+    // layer 3's conv3 (216 -> 96 behind BN2 + swish): the same structure with the sides exchanged (CFN_PWF_L3E: 0 off; while it is being measured: off unless set)
+    const char* env_l3e = getenv("CFN_PWF_L3E");          // read per call (tests / A-B harnesses switch it inside one process)
+    const int l3e_on = env_l3e ? atoi(env_l3e) : 0;
+    if (on >= 1 && l3e_on && A != nullptr && acc == nullptr && Cout > 64 && Cout <= 96 && Cin > 192 && Cin <= 224) {
+        const long Ql3 = (long)T * Hi * Wi;
+        if (Ql3 % 4 == 0 && Ql3 < (1L << 30) && (long)Cin * Ql3 * 4 < 0x7ffffff0L && ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)(y ? y : gy)) & 15) == 0) &&
+            (act == CFN_ACT_NONE || act == CFN_ACT_RELU || act == CFN_ACT_SWISH))
+            return pf3e_try_launch(gy, y, gsum, gsumsq, w, x, A, B, act, gx, gA, gB, gw, N, Cin, Cout, Ql3, gscale, st);
     }
     if (!wide_m && !wide_k && !thin_k && !l1_m && !l1_k) return -1;
     if (A != nullptr && on < 2) return -1;

@@ -384,6 +384,38 @@ def test_pwconv_bwd_fused_split_layer3_matches_separate(cfg, two, monkeypatch):
         assert torch.equal(g, g2), name                # run-to-run bits
 
 
+@pytest.mark.parametrize('act', [0, 1, 2])
+@pytest.mark.parametrize('cfg', [(1, 216, 96, 3, 14, 14), (2, 216, 96, 2, 14, 14), (1, 200, 90, 1, 10, 10), (2, 196, 72, 5, 6, 6), (1, 216, 96, 16, 14, 14)])
+def test_pwconv_bwd_fused_split_layer3_conv3_matches_separate(cfg, act, monkeypatch):
+    """the conv3 side of the layer-3 one-pass backward (pw_bwd_fused_split3e_kernel: 216 -> 96 behind a prologue; act' epilogue and the statistics of 216 channels in the
+    data-gradient waves) against the separate kernels: gx, gA, gB, gw; launched twice: identical bits"""
+    import cfn_hip
+    monkeypatch.setenv('CFN_PWF_L3E', '1')
+    N, Cin, Cout, T, H, W = cfg
+    f64 = lambda seed, *shape, scale=1.0: (rnd(seed, *shape) * scale).double().to(DEV)
+    gy, y, x = rnd(1, N, Cout, T, H, W).to(DEV), rnd(2, N, Cout, T, H, W).to(DEV), rnd(3, N, Cin, T, H, W).to(DEV)
+    w = (0.3 * rnd(4, Cout, Cin)).to(DEV)
+    gs, gq, gsc = f64(5, N, Cout, scale=0.05), f64(6, N, Cout, scale=0.01), 1.0 + f64(7, N, Cout, scale=0.3)
+    A, B = 1.0 + f64(8, N, Cin, scale=0.2), f64(9, N, Cin, scale=0.2)
+
+    def run(fused):
+        gx = torch.full_like(x, float('nan'))
+        gA, gB = (torch.zeros(N, Cin, dtype=torch.float64, device=DEV) for _ in range(2))
+        gw = torch.zeros(Cout, Cin, dtype=torch.float64, device=DEV)
+        if fused:
+            ok = cfn_hip.call_try('cfn_pwconv_bwd_fused', gy, y, gs, gq, w, x, A, B, act, gx, gA, gB, gw, N, Cin, Cout, T, H, W, None, 1, gsc)
+            assert ok, 'shape should be handled by the layer-3 conv3 split fused kernel'
+        else:
+            cfn_hip.call('cfn_pwconv_bwd_data_acc', gy, y, gs, gq, w, x, A, B, act, gx, gA, gB, N, Cin, Cout, T, H, W, 1, None, 1, gsc)
+            cfn_hip.call('cfn_pwconv_bwd_weight', gy, y, gs, gq, x, A, B, act, gw, N, Cin, Cout, T, H, W, 1, gsc)
+        return gx, gA, gB, gw
+
+    ref, got, again = run(False), run(True), run(True)
+    for name, r, g, g2 in zip(('gx', 'gA', 'gB', 'gw'), ref, got, again):
+        assert relerr(g, r) <= 2e-5, (name, relerr(g, r))
+        assert torch.equal(g, g2), name
+
+
 @pytest.mark.parametrize('shortcut', ['identity', 'conv_s2', 'conv_s1'])
 @pytest.mark.parametrize('cfg', [(2, 54, 24, 4, 8, 8), (1, 108, 48, 3, 6, 6), (2, 216, 96, 2, 14, 14), (1, 20, 12, 3, 5, 7)])
 def test_linked_tail(cfg, shortcut):
