@@ -423,6 +423,7 @@ struct Pf3Args {
     const float* gy; const float* y; const double* gs; const double* gq; const double* gsc;
     const float* x; const unsigned* wsplit;          // wsplit: [3 terms][BN][BMP / 2] packed bf16 pairs (co, co + 1) of W^T (pf3_presplit_kernel)
     float* gx; double* gw;
+    const float* acc; int acc_s, acc_Ho, acc_Wo, Hi, Wi, T;      // compact shortcut gradient of a stage-first block (null otherwise), added on its stride lattice
     int N, M, K, Q, nstrips, stages;
     int dbg;                                         // knock-outs (CFN_PWFS_DBG, 0 in the product): 1 weight gradient, 2 data gradient, 8 gx stores
 };
@@ -448,7 +449,8 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split3_kernel(const Pf3Ar
     constexpr int NG = BM / 32, NX = BN / 32;                    // float4 per staging thread and stage: 32 rows x 8 float4 per pass of 256 threads
     constexpr int NT16 = BN / 16, KS = BM / 32;
     constexpr int NR = (MT + 3) / 4;                              // row tiles per weight-gradient wave (i = w + 4 n)
-    static_assert(NT16 == 6, "three data-gradient waves own two 16-channel tiles each");
+    constexpr int NDW = NT16 / 2;                                 // data-gradient waves: two 16-channel tiles each (3 at 96 input channels, 2 at 48-64)
+    static_assert(NT16 % 2 == 0 && NDW <= 3, "at most three data-gradient waves beside the staging wave");
     const int tid = threadIdx.x, wave = cfn_uni((int)(tid >> 6)), lane = tid & 63, half = lane >> 5, col = lane & 31;
     const int m16 = lane & 15, kq = lane >> 4;
     unsigned L = cfn_xcd_remap(blockIdx.x, gridDim.x);
@@ -580,8 +582,8 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split3_kernel(const Pf3Ar
                     }
             }
         }
-    } else if (wave < 7) {
-        // ================= waves 4-6: data gradient.  Wave d owns the channel tiles 2 d, 2 d + 1 (input channels 32 d .. 32 d + 31) for ALL 32 positions of a stage, and keeps
+    } else if (wave < 4 + NDW) {
+        // ================= waves 4 .. 4 + NDW - 1: data gradient.  Wave d owns the channel tiles 2 d, 2 d + 1 (input channels 32 d .. 32 d + 31) for ALL 32 positions of a stage, and keeps
         // its part of W^T -- 2 tiles x 7 k-steps x 3 terms, 168 registers -- RESIDENT: read once from the pre-split workspace, nothing but LDS reads in the stage loop =========
         const int d = wave - 4;
         __amdgpu_buffer_rsrc_t rd = cfn_rsrc(a.gx + (long)n * K * Q, (unsigned)((long)K * Q * 4));
@@ -595,10 +597,39 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split3_kernel(const Pf3Ar
 #pragma unroll
                 for (int u = 0; u < 3; ++u)
                     Wr[t][s][u] = __builtin_bit_cast(pfs_u4, __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, (((u * BN + (2 * d + t) * 16) * BMP + 32 * s) / 2) * 4, 0));
+        const int hw = a.Hi * a.Wi;
+        const int acc_pitch4 = a.T * a.acc_Ho * a.acc_Wo * 4;       // bytes per channel of the compact gradient
+        __amdgpu_buffer_rsrc_t racc = cfn_rsrc(const_cast<float*>(a.acc ? a.acc + (long)n * K * (acc_pitch4 / 4) : a.gy), a.acc ? (unsigned)((long)K * acc_pitch4) : 0u);
         __syncthreads();
         for (int st = 0; st < nst; ++st) {
             const int q0 = qbeg + st * PF3_PT;
             const float* sG = img0 + (st & 1) * IMG;
+            float av[2][2][4];                                       // the compact shortcut gradient of this lane's outputs: loads up front
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) av[pb][t][r] = 0.0f;
+            if (a.acc) {                                             // workgroup uniform
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    const int q = q0 + 16 * pb + m16;
+                    int aoff = OOB;
+                    if (q < Q) {
+                        const int tq = q / hw, rq = q - tq * hw;
+                        const int hq = rq / a.Wi, wq_ = rq - hq * a.Wi;
+                        if (hq % a.acc_s == 0 && wq_ % a.acc_s == 0) aoff = (((tq * a.acc_Ho + hq / a.acc_s) * a.acc_Wo + wq_ / a.acc_s)) * 4;
+                    }
+                    const unsigned arow = (unsigned)aoff + (unsigned)(4 * kq) * (unsigned)acc_pitch4;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            av[pb][t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                racc, (int)(aoff == OOB ? (unsigned)OOB : arow + (unsigned)r * (unsigned)acc_pitch4), (2 * d + t) * 16 * acc_pitch4, 0));
+                }
+            }
             pf4 da[2][2];                                            // [position block][tile]
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb)
@@ -633,14 +664,18 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split3_kernel(const Pf3Ar
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float v = da[pb][t][r];                // (through a scalar: __builtin_bit_cast of a vector ELEMENT took element 0 for every r)
+                        const float v = da[pb][t][r] + av[pb][t][r];  // (through a scalar: __builtin_bit_cast of a vector ELEMENT took element 0 for every r)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, gvo, (q0 + ((2 * d + t) * 16 + r) * Q) * 4, 0);
                     }
             }
             __syncthreads();
         }
+    } else if (wave < 7) {
+        // (with two data-gradient waves one wave has nothing to do but keep the barrier count)
+        __syncthreads();
+        for (int st = 0; st < nst; ++st) __syncthreads();
     } else {
-        // ================= wave 7: stages the x rows (96 rows x 8 float4 = 12 passes of 8 rows) =================
+        // ================= wave 7: stages the x rows (8 rows x 8 float4 per pass) =================
         __amdgpu_buffer_rsrc_t rx = cfn_rsrc(const_cast<float*>(a.x + (long)n * K * Q), (unsigned)((long)K * Q * 4));
         constexpr int NP = BN / 8;
         const int xrow = lane >> 3;                                  // 8 lanes per row segment
@@ -961,21 +996,27 @@ static unsigned* pf3_workspace(size_t bytes, hipStream_t st) {
     return p;
 }
 
-static int pf3_try_launch(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w, const float* x, float* gx, double* gw,
-                          int N, int Cin, int Cout, long Ql, const double* gscale, hipStream_t st) {
-    constexpr int MT = 7, NT = 3, BM = 32 * MT, BN = 32 * NT, BMP = BM + 8;
+template <int NT>
+static int pf3_launch(const float* gy, const float* y, const double* gsum, const double* gsumsq, const float* w, const float* x, float* gx, double* gw,
+                      int N, int Cin, int Cout, int T, int Hi, int Wi, const float* acc, int acc_stride, const double* gscale, hipStream_t st) {
+    constexpr int MT = 7, BM = 32 * MT, BN = 32 * NT, BMP = BM + 8;
+    const long Ql = (long)T * Hi * Wi;
     const size_t wbytes = (size_t)3 * BN * (BMP / 2) * 4;
     unsigned* ws = pf3_workspace(wbytes, st);
     if (!ws) return -1;
     hipLaunchKernelGGL((pf3_presplit_kernel<MT, NT>), dim3((BN * (BMP / 2) + 255) / 256), dim3(256), 0, st, w, Cout, Cin, ws);
     Pf3Args a = {};
     a.gy = gy; a.y = gsumsq ? y : nullptr; a.gs = gsum; a.gq = gsumsq; a.gsc = gscale; a.x = x; a.wsplit = ws; a.gx = gx; a.gw = gw;
+    a.acc = acc; a.acc_s = acc ? acc_stride : 1; a.Hi = Hi; a.Wi = Wi; a.T = T;
+    a.acc_Ho = (Hi - 1) / a.acc_s + 1; a.acc_Wo = (Wi - 1) / a.acc_s + 1;
     a.N = N; a.M = Cout; a.K = Cin; a.Q = (int)Ql;
     { const char* e = getenv("CFN_PWFS_DBG"); a.dbg = e ? atoi(e) : 0; }
     const long nst = cfn_cdiv(Ql, PF3_PT);
-    // ONE whole round of the chip (one workgroup per CU is resident): every workgroup pays the W^T load and 20.7 k fp64 atomics once; measured 8 clips x 256 frames:
-    // 256 / 512 / 1024 workgroups = 0.301 / 0.333 / 0.395 ms, 320 / 384 (partial rounds) 0.416 / 0.376
-    static const int wgs = getenv("CFN_PWF3_WGS") ? atoi(getenv("CFN_PWF3_WGS")) : 256;
+    // whole rounds of the chip (one workgroup per CU is resident) and few of them: every workgroup pays the W^T load and M x K fp64 atomics once; measured at 96 -> 216,
+    // 8 clips x 256 frames x 14 x 14: 256 / 512 / 1024 workgroups = 0.301 / 0.333 / 0.395 ms, 320 / 384 (partial rounds) 0.416 / 0.376.  One round; two where a workgroup
+    // would otherwise walk more than ~100 stages (the first block of layer 3 at 28 x 28)
+    static const int wgs_env = getenv("CFN_PWF3_WGS") ? atoi(getenv("CFN_PWF3_WGS")) : 0;
+    const long wgs = wgs_env > 0 ? wgs_env : ((long)N * nst > 256L * 100 ? 512 : 256);
     long want = wgs / N;
     if (want < 1) want = 1;
     long stages = cfn_cdiv(nst, want);
@@ -1043,10 +1084,13 @@ int pwfs_try_launch(const float* gy, const float* y, const double* gsum, const d
     const bool l1_k = on >= 3 && Cin > 32 && Cin <= 64 && Cout >= 16 && Cout <= 32;      // conv3 of layer 1: 54 -> 24
     // layer 3's conv1 (96 -> 216, no prologue, no shortcut gradient): the variant with W^T resident in the data-gradient waves' registers (CFN_PWF_L3=0 switches it off alone)
     static const int l3_on = getenv("CFN_PWF_L3") ? atoi(getenv("CFN_PWF_L3")) : 1;
-    if (on >= 1 && l3_on && A == nullptr && acc == nullptr && Cout > 192 && Cout <= 224 && Cin > 64 && Cin <= 96) {
+    if (on >= 1 && l3_on && A == nullptr && Cout > 192 && Cout <= 224 && Cin > 32 && Cin <= 96) {
         const long Ql3 = (long)T * Hi * Wi;
-        if (Ql3 % 4 == 0 && Ql3 < (1L << 30) && (long)Cout * Ql3 * 4 < 0x7ffffff0L && ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)(y ? y : gy)) & 15) == 0))
-            return pf3_try_launch(gy, y, gsum, gsumsq, w, x, gx, gw, N, Cin, Cout, Ql3, gscale, st);
+        if (Ql3 % 4 == 0 && Ql3 < (1L << 30) && (long)Cout * Ql3 * 4 < 0x7ffffff0L && ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)(y ? y : gy)) & 15) == 0) &&
+            (acc == nullptr || acc_stride >= 1)) {
+            if (Cin > 64) return pf3_launch<3>(gy, y, gsum, gsumsq, w, x, gx, gw, N, Cin, Cout, T, Hi, Wi, acc, acc_stride, gscale, st);       // 96 -> 216: the blocks of layer 3
+            return pf3_launch<2>(gy, y, gsum, gsumsq, w, x, gx, gw, N, Cin, Cout, T, Hi, Wi, acc, acc_stride, gscale, st);                      // 48 -> 216 @28: its first block
+        }
     }
     // layer 3's conv3 (216 -> 96 behind BN2 + swish): the same structure with the sides exchanged (CFN_PWF_L3E: 0 off; while it is being measured: off unless set)
     const char* env_l3e = getenv("CFN_PWF_L3E");          // read per call (tests / A-B harnesses switch it inside one process)

@@ -355,26 +355,28 @@ def test_pwconv_bwd_fused_split_matches_separate(cfg, act, monkeypatch):
 
 
 @pytest.mark.parametrize('two', [True, False])
-@pytest.mark.parametrize('cfg', [(1, 96, 216, 3, 14, 14), (2, 96, 216, 2, 14, 14), (1, 90, 200, 1, 10, 10), (2, 72, 196, 5, 6, 6), (1, 96, 216, 16, 14, 14)])
+@pytest.mark.parametrize('cfg', [(1, 96, 216, 3, 14, 14, 0), (2, 96, 216, 2, 14, 14, 0), (1, 90, 200, 1, 10, 10, 0), (2, 72, 196, 5, 6, 6, 0), (1, 96, 216, 16, 14, 14, 0),
+                                 (1, 48, 216, 3, 14, 14, 0), (2, 48, 216, 2, 28, 28, 2), (1, 40, 200, 2, 12, 12, 2), (1, 96, 216, 2, 14, 14, 2)])
 def test_pwconv_bwd_fused_split_layer3_matches_separate(cfg, two, monkeypatch):
     """the layer-3 variant of the one-pass backward (csrc/pwfuseds.hip, pw_bwd_fused_split3_kernel: W^T pre-split into a workspace and read out of L2, 6 weight-gradient
     + 2 data-gradient waves, 32-position stages) against the separate kernels; no prologue (conv1 of a block), with / without the batch-norm terms"""
     import cfn_hip
     monkeypatch.setenv('CFN_PWF_SPLIT', '1')
-    N, Cin, Cout, T, H, W = cfg
+    N, Cin, Cout, T, H, W, acc_s = cfg
     f64 = lambda seed, *shape, scale=1.0: (rnd(seed, *shape) * scale).double().to(DEV)
     gy, y, x = rnd(1, N, Cout, T, H, W).to(DEV), rnd(2, N, Cout, T, H, W).to(DEV), rnd(3, N, Cin, T, H, W).to(DEV)
     w = (0.3 * rnd(4, Cout, Cin)).to(DEV)
     gs, gq, gsc = (f64(5, N, Cout, scale=0.05), f64(6, N, Cout, scale=0.01), 1.0 + f64(7, N, Cout, scale=0.3)) if two else (None, None, None)
+    acc = rnd(10, N, Cin, T, (H - 1) // acc_s + 1, (W - 1) // acc_s + 1).to(DEV) if acc_s else None      # compact shortcut gradient of a stage-first block
 
     def run(fused):
         gx = torch.full_like(x, float('nan'))
         gw = torch.zeros(Cout, Cin, dtype=torch.float64, device=DEV)
         if fused:
-            ok = cfn_hip.call_try('cfn_pwconv_bwd_fused', gy, y, gs, gq, w, x, None, None, 0, gx, None, None, gw, N, Cin, Cout, T, H, W, None, 1, gsc)
+            ok = cfn_hip.call_try('cfn_pwconv_bwd_fused', gy, y, gs, gq, w, x, None, None, 0, gx, None, None, gw, N, Cin, Cout, T, H, W, acc, acc_s or 1, gsc)
             assert ok, 'shape should be handled by the layer-3 split fused kernel'
         else:
-            cfn_hip.call('cfn_pwconv_bwd_data_acc', gy, y, gs, gq, w, x, None, None, 0, gx, None, None, N, Cin, Cout, T, H, W, 1, None, 1, gsc)
+            cfn_hip.call('cfn_pwconv_bwd_data_acc', gy, y, gs, gq, w, x, None, None, 0, gx, None, None, N, Cin, Cout, T, H, W, 1, acc, acc_s or 1, gsc)
             cfn_hip.call('cfn_pwconv_bwd_weight', gy, y, gs, gq, x, None, None, 0, gw, N, Cin, Cout, T, H, W, 1, gsc)
         return gx, gw
 

@@ -12,7 +12,7 @@ import cfn_hip                    # noqa: E402
 DEV = 'cuda'
 N, T, H0 = int(os.environ.get('NB', '8')), int(os.environ.get('FRAMES', '256')), int(os.environ.get('HW', '28'))
 CASES = [('L1 conv1 24->54 @2H (no prologue)', 24, 54, None), ('L1 conv3 54->24 @2H (swish prologue)', 54, 24, 2), ('L1 conv1 24->54 @4H (no prologue)', 24, 54, None),
-         ] if os.environ.get('L1') else [('L3 conv1 96->216 @H/2 (no prologue)', 96, 216, None), ('L3 conv3 216->96 @H/2 (swish prologue)', 216, 96, 2)] if os.environ.get('L3') else [('conv1 48->108 (no prologue)', 48, 108, None), ('conv1 24->108 @2H (no prologue)', 24, 108, None), ('conv1 24->108 @2H + compact shortcut gradient', 24, 108, None), ('conv3 108->48 (swish prologue)', 108, 48, 2), ('conv1 48->108 (relu prologue)', 48, 108, 1)]
+         ] if os.environ.get('L1') else [('L3 conv1 96->216 @H/2 (no prologue)', 96, 216, None), ('L3.0 conv1 48->216 @H + compact shortcut gradient', 48, 216, None), ('L3 conv3 216->96 @H/2 (swish prologue)', 216, 96, 2)] if os.environ.get('L3') else [('conv1 48->108 (no prologue)', 48, 108, None), ('conv1 24->108 @2H (no prologue)', 24, 108, None), ('conv1 24->108 @2H + compact shortcut gradient', 24, 108, None), ('conv3 108->48 (swish prologue)', 108, 48, 2), ('conv1 48->108 (relu prologue)', 48, 108, 1)]
 
 
 def timeit(fn, iters=10, warm=3):

@@ -13,7 +13,7 @@ DEV = 'cuda'
 os.environ['CFN_PWF_SPLIT'] = '2'
 R = int(os.environ.get('RUNS', '200'))
 CFGS = [(1, 128, 64, 4, 28, 28, 1), (1, 108, 48, 3, 10, 10, 1), (2, 48, 108, 3, 8, 8, 1), (2, 108, 48, 8, 28, 28, 2), (2, 48, 108, 8, 28, 28, None),
-        (2, 108, 48, 8, 28, 28, 0), (4, 48, 108, 16, 28, 28, 1), (2, 24, 108, 8, 56, 56, None), (2, 96, 216, 16, 14, 14, None), (8, 96, 216, 8, 14, 14, None)]
+        (2, 108, 48, 8, 28, 28, 0), (4, 48, 108, 16, 28, 28, 1), (2, 24, 108, 8, 56, 56, None), (2, 96, 216, 16, 14, 14, None), (8, 96, 216, 8, 14, 14, None), (2, 48, 216, 8, 28, 28, None)]
 for N, Cin, Cout, T, H, W, act in CFGS:
     g = torch.Generator().manual_seed(1)
     rnd = lambda *s: torch.randn(*s, generator=g)
