@@ -418,6 +418,7 @@ static int pfs_launch(const PfsArgs& a, int act, bool epi, unsigned blocks, hipS
 //     load -> MFMA rounds per stage at two waves per SIMD.)
 #define PF3_PT 32
 #define PF3_PITCH 33
+#define PF3_TP 36          // pitch of the data-gradient waves' output tiles (floats): 16-byte rows
 
 struct Pf3Args {
     const float* gy; const float* y; const double* gs; const double* gq; const double* gsc;
@@ -656,17 +657,30 @@ __global__ __launch_bounds__(512, 1) void pw_bwd_fused_split3_kernel(const Pf3Ar
 #undef PF3_DG
                 }
             }
+            // the wave's 32 channels x 32 positions go through a wave-private LDS tile and leave as 16-byte stores: 8 lanes write one 128-byte line of a row
+            // (the C layout gives a lane one position and four ROWS: stored directly that is 16 four-byte stores per lane into 64-byte row segments)
+            float* tile = smem + 2 * IMG + d * (32 * PF3_TP);
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-                const int q = q0 + 16 * pb + m16;
-                const int gvo = (q < Q && !(a.dbg & 8)) ? (4 * kq * Q + 16 * pb + m16) * 4 : OOB;    // one lane offset; the (tile, row) part rides in the scalar offset; rows >= K fall outside the descriptor
+            for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v = da[pb][t][r] + av[pb][t][r];  // (through a scalar: __builtin_bit_cast of a vector ELEMENT took element 0 for every r)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, gvo, (q0 + ((2 * d + t) * 16 + r) * Q) * 4, 0);
+                        tile[(t * 16 + 4 * kq + r) * PF3_TP + 16 * pb + m16] = v;
                     }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {
+                const int seg = lane & 7, r0 = lane >> 3;                    // 8 lanes per row, 8 rows per pass
+                const bool inq = q0 + 4 * seg < Q && !(a.dbg & 8);           // (Q is a multiple of 4: a float4 is inside or outside as a whole)
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int row = ps * 8 + r0;
+                    const pf4 v = *reinterpret_cast<const pf4*>(tile + row * PF3_TP + 4 * seg);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pfs_u4, v), rd, inq ? (r0 * Q + 4 * seg) * 4 : OOB, (q0 + (32 * d + ps * 8) * Q) * 4, 0);
+                }
             }
             __syncthreads();
         }
@@ -1024,7 +1038,7 @@ static int pf3_launch(const float* gy, const float* y, const double* gsum, const
     a.stages = (int)stages;
     a.nstrips = (int)cfn_cdiv(nst, stages);
     const unsigned blocks = (unsigned)((long)N * a.nstrips);
-    const size_t lds = (size_t)2 * (BM + BN) * PF3_PITCH * sizeof(float);
+    const size_t lds = ((size_t)2 * (BM + BN) * PF3_PITCH + 3 * 32 * PF3_TP) * sizeof(float);      // two images + the data-gradient waves' output tiles
     CfnProfScope prof(CFN_K_PWCONV_BWD, st, 4.0 * N * ((double)Cout * Ql * (a.y ? 2 : 1) + (double)Cin * Ql * 2));
     auto k = pw_bwd_fused_split3_kernel<MT, NT>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
