@@ -418,6 +418,37 @@ def test_pwconv_bwd_fused_split_layer3_conv3_matches_separate(cfg, act, monkeypa
         assert torch.equal(g, g2), name
 
 
+@pytest.mark.parametrize('cfg', [(4, 48, 108, 16, 28, 28, 1), (2, 24, 108, 8, 56, 56, None), (8, 96, 216, 8, 14, 14, None), (2, 48, 216, 8, 28, 28, None), (2, 108, 48, 8, 28, 28, 2)])
+def test_pwconv_bwd_fused_split_bit_repeat_stress(cfg, monkeypatch):
+    """200 launches of the one-pass kernels on the same inputs: every output bit-identical to the first launch's.  (The first 8-wave build of csrc/pwfuseds.hip reproduced the
+    round-3 race here -- one G' row wrong in the rows staged by lanes 48-63 in 1-7 of 100 launches, DESIGN 4.1 -- and this is the test that would catch it again; the shapes are
+    the ones tools/pwfs_stress.py saw it on, plus the layer-3 instances.)"""
+    import cfn_hip
+    monkeypatch.setenv('CFN_PWF_SPLIT', '2')
+    N, Cin, Cout, T, H, W, act = cfg
+    f64 = lambda seed, *shape, scale=1.0: (rnd(seed, *shape) * scale).double().to(DEV)
+    gy, y, x = rnd(1, N, Cout, T, H, W).to(DEV), rnd(2, N, Cout, T, H, W).to(DEV), rnd(3, N, Cin, T, H, W).to(DEV)
+    w = (0.3 * rnd(4, Cout, Cin)).to(DEV)
+    gs, gq, gsc = f64(5, N, Cout, scale=0.05), f64(6, N, Cout, scale=0.01), 1.0 + f64(7, N, Cout, scale=0.3)
+    A = B = None
+    if act is not None:
+        A, B = 1.0 + f64(8, N, Cin, scale=0.2), f64(9, N, Cin, scale=0.2)
+
+    def run():
+        gx = torch.full_like(x, float('nan'))
+        gA = gB = None
+        if A is not None:
+            gA, gB = (torch.zeros(N, Cin, dtype=torch.float64, device=DEV) for _ in range(2))
+        gw = torch.zeros(Cout, Cin, dtype=torch.float64, device=DEV)
+        assert cfn_hip.call_try('cfn_pwconv_bwd_fused', gy, y, gs, gq, w, x, A, B, act or 0, gx, gA, gB, gw, N, Cin, Cout, T, H, W, None, 1, gsc)
+        return [v for v in (gx, gA, gB, gw) if v is not None]
+
+    ref = run()
+    for i in range(200):
+        for a_, b_ in zip(run(), ref):
+            assert torch.equal(a_, b_), 'launch %d differs' % i
+
+
 @pytest.mark.parametrize('shortcut', ['identity', 'conv_s2', 'conv_s1'])
 @pytest.mark.parametrize('cfg', [(2, 54, 24, 4, 8, 8), (1, 108, 48, 3, 6, 6), (2, 216, 96, 2, 14, 14), (1, 20, 12, 3, 5, 7)])
 def test_linked_tail(cfg, shortcut):
